@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- FAD hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], "C3"): two synthetic float16 embedding matrices of
+[100000 x 512] per GPU, RESIDENT IN HBM when the timed region starts.  One *step* is one pass of the
+hot path over that batch:
+
+    moments(A) ; moments(B)           hand-written HIP, fp16 MFMA E^T E + column sums  -> (n, sum x, sum xxT)
+    [N>1]  one all-reduce (RCCL/xGMI) of the packed float64 statistics of both sets
+    frechet(A, B)                     finalise (mu, Sigma) x2 + Newton-Schulz sqrt(S1 S2) in fp64 MFMA
+
+i.e. exactly one FAD score over the union of all ranks' rows.  With N GPUs every rank holds its own
+100k-row shard of both sets (weak scaling: rows grow with N), so `value` is reported in
+config-3-sized score workloads per second:  value = N * K / seconds  (at N=1: plain FAD scores/s).
+
+Rank 0 prints ONE JSON line with the driver's fields plus
+  roofline      dominant kernel (moments tile kernel): achieved TFLOP/s from ALGORITHMIC flops
+                2*N*D^2 per launch / mean launch duration (HIP events on the launch stream,
+                recorded inside the timed region by the library), vs the dense fp16 MFMA peak
+  cpu_baseline  the numpy/scipy oracle (a line-by-line restatement of fadtk's CPU path, both
+                sqrtm and eig as in fad.py:88-92) timed on this node's host cores, rank 0, N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_ROWS = 100_000
+DIM = 512
+MFMA_F16_PEAK_TFLOPS = 2500.0          # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def make_sets(torch, device, rank):
+    """C3 recipe: A ~ N(0,1), B ~ 1.02 N(0,1) + 0.01, float16, generated on device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(10 + 1000 * rank)
+    a = torch.randn((N_ROWS, DIM), generator=g, device=device, dtype=torch.float32).to(torch.float16)
+    g.manual_seed(11 + 1000 * rank)
+    b = (1.02 * torch.randn((N_ROWS, DIM), generator=g, device=device, dtype=torch.float32) + 0.01).to(torch.float16)
+    return a, b
+
+
+def cpu_baseline(a_host, b_host):
+    """Reference CPU path (oracle port), best of 3 after one warm-up, same arrays as the GPU run."""
+    from oracle import fad_oracle as O
+    threads = os.cpu_count()
+    blas = "unknown"
+    try:
+        from threadpoolctl import threadpool_info
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if info:
+            threads = info[0].get("num_threads", threads)
+            blas = f"{info[0].get('internal_api')} {info[0].get('version')}"
+    except Exception:       # noqa: BLE001
+        pass
+    times, fad = [], None
+    for it in range(4):
+        t0 = time.perf_counter()
+        fad = O.fad_between(a_host, b_host)
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    import scipy
+    return {"value": 1.0 / min(times), "unit": "FAD scores/s", "cores": int(threads), "kind": "port",
+            "sample": f"full config-3 workload (2 x [{N_ROWS}x{DIM}] fp16 -> 1 score), best of 3 after 1 warm-up; "
+                      f"{os.cpu_count()} logical CPUs, BLAS {blas}, numpy {np.__version__}, scipy {scipy.__version__}",
+            "seconds_best": min(times)}, float(fad)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fadtk_amd import hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    a, b = make_sets(torch, device, rank)
+    ma, mb = hip.Moments(DIM, local_rank), hip.Moments(DIM, local_rank)
+    plen = ma.packed_len
+    packed = torch.empty(2 * plen, dtype=torch.float64, device=device)
+
+    def step():
+        ma.reset(); mb.reset()
+        ma.update(a); mb.update(b)
+        if distributed:                       # the ONE exchange of the path: sum-reducible sufficient statistics
+            ma.export_to(packed[:plen]); mb.export_to(packed[plen:])
+            dist.all_reduce(packed)
+            ma.import_(packed[:plen]); mb.import_(packed[plen:])
+        return hip.frechet_from_moments(ma, mb)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ma.set_timing(True); mb.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fad, diag = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ka, ra_, variant = ma.last_timing()
+    kb_, rb_, _ = mb.last_timing()
+    kernel_ms = 0.5 * (ka + kb_)
+    reduce_ms = 0.5 * (ra_ + rb_)
+    ma.set_timing(False); mb.set_timing(False)
+
+    # ---- untimed breakdown (torch events on the same stream: stream 0 is torch's current stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    bm, bf = [], []
+    for _ in range(5):
+        ma.reset(); mb.reset()
+        ev[0].record(); ma.update(a); mb.update(b); ev[1].record()
+        hip.frechet_from_moments(ma, mb); ev[2].record()
+        torch.cuda.synchronize()
+        bm.append(ev[0].elapsed_time(ev[1])); bf.append(ev[1].elapsed_time(ev[2]))
+
+    if rank != 0:
+        if distributed:
+            dist.destroy_process_group()
+        return
+
+    n_gpus = world
+    flops = 2.0 * N_ROWS * DIM * DIM                       # algorithmic, per launch
+    achieved = flops / (kernel_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = ROOT / "profiles" / "moments_traffic.json"     # measured in a separate rocprofv3 --pmc pass
+    if tpath.exists():
+        try:
+            traffic = json.loads(tpath.read_text()).get("hbm_bytes_per_launch")
+        except Exception:       # noqa: BLE001
+            traffic = None
+    out = {
+        "metric": "FAD scores/sec + cov-GEMM TFLOP/s (% MFMA peak), N=100k D=512",
+        "value": n_gpus * args.steps / elapsed,
+        "unit": "FAD scores/s (config-3-sized: 2 x [100000 x 512] fp16 frames per score per GPU)",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 in, f32 MFMA accumulate (moments); f64 (Frechet)", "data": "synthetic",
+        "config": {"workload": "C3: CLAP-sized embeddings N=100000 D=512 fp16 per set per GPU, "
+                               "moments x2 + Newton-Schulz Frechet, inputs resident in HBM",
+                   "rows_per_set_per_gpu": N_ROWS, "dim": DIM,
+                   "sharding": "rows sharded over ranks; one all-reduce of packed (n, sum x, sum xxT) fp64 "
+                               f"[{2 * plen} doubles] per step" if distributed else "single GPU, no collective"},
+        "fad": fad, "newton_schulz_iters": diag["iters"], "ns_converged": diag["converged"],
+        "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,
+        "breakdown_ms": {"moments_x2": float(np.median(bm)), "frechet": float(np.median(bf)),
+                         "moments_reduce_kernels": reduce_ms},
+        "roofline": {"kernel": "moments_tile_h16<f16>" if variant == 0 else "moments_tile_f64",
+                     "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+                     "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                     "algorithmic_bytes_per_launch": N_ROWS * DIM * 2,
+                     "hbm_GBps_algorithmic": N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
+                     "hbm_frac_of_8TBps": N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        base, fad_cpu = cpu_baseline(a.cpu().numpy(), b.cpu().numpy())
+        out["cpu_baseline"] = base
+        out["speedup_vs_cpu"] = out["value"] / base["value"]
+        # parity on the very same inputs; the device route keeps float64 means, the reference rounds
+        # them to float16 first, so compare both the raw value and the root-only part
+        mu1, _, _ = ma.finalize(); mu2, _, _ = mb.finalize()
+        gap = mu1.astype(np.float32).astype(np.float16) - mu2.astype(np.float32).astype(np.float16)
+        fad_compat = float(gap.dot(gap)) + diag["tr1"] + diag["tr2"] - 2.0 * diag["tr_sqrt"]
+        out["parity_rel_err_vs_cpu"] = abs(fad_compat - fad_cpu) / abs(fad_cpu)
+        out["parity_rel_err_vs_cpu_f64_means"] = abs(fad - fad_cpu) / abs(fad_cpu)
+        out["fad_cpu"] = fad_cpu
+    print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

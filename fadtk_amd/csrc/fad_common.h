@@ -1,0 +1,84 @@
+// Internal helpers shared by the HIP translation units of libfad_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/fad_hip.h"
+
+namespace fad {
+
+// ---- thread-local error text -------------------------------------------------------------
+char* err_buf();
+int set_error(int code, const char* fmt, ...);
+
+#define FAD_HIP_TRY(expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return ::fad::set_error(FAD_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                                    hipGetErrorString(e_), __FILE__, __LINE__);            \
+    } while (0)
+
+#define FAD_TRY(expr)                 \
+    do {                              \
+        int s_ = (expr);              \
+        if (s_ != FAD_OK) return s_;  \
+    } while (0)
+
+int check_device(int device);         // FAD_OK if `device` is a gfx950 GPU
+int num_cus(int device);
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t dtype_size(int dt) {
+    switch (dt) { case FAD_F16: case FAD_BF16: return 2; case FAD_F32: return 4; case FAD_F64: return 8; }
+    return 0;
+}
+
+// RAII device switch (the caller's current device is restored on scope exit).
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// Growable device buffer owned by a handle.
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+};
+
+// ---- fp64 GEMM on v_mfma_f64_16x16x4_f64 (gemm_f64.hip) ------------------------------------
+// One launch = `ntypes` (1 or 2) GEMM shapes x `batch` independent problems:
+//   C = alpha * A * B + beta_eye * I,  operands of problem b at base + b * stride (stride 0 = shared),
+// optional per-workgroup partial sums of (C - gamma I)^2 at partials[b][slot], and an optional
+// per-problem skip flag (skip[b * skip_stride] != 0 -> that problem's workgroups exit at once).
+struct GemmType {
+    const double* A; int64_t sa;
+    const double* B; int64_t sb;
+    double* C; int64_t sc;
+    double alpha, beta_eye, gamma;
+    double* partials;
+};
+// returns the number of partial slots per problem (>0) or a negative fad_status
+int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, const int* skip, int skip_stride,
+                    hipStream_t stream, int device);
+int gemm_f64_slots(int d, int ntypes, int64_t batch, int device);
+int gemm_f64_slots_max(int d);
+
+// ---- Newton-Schulz trace-sqrt driver (frechet.hip) ---------------------------------------
+struct NsWorkspace {
+    DevBuf mats;      // 6 * d*d doubles: A, Y0, Y1, Z0, Z1, T
+    DevBuf small;     // partials, per-iteration stats, flags
+    DevBuf stage;     // host->device staging of mu/cov
+    void* pinned = nullptr; size_t pinned_cap = 0;
+    void release();
+};
+
+}  // namespace fad

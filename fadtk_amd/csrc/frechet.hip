@@ -1,0 +1,684 @@
+// Frechet distance between Gaussians on the GPU (gfx950): single pair and batched per-song.
+//
+// Replaces calc_frechet_distance, fadtk/fad.py:51-120:
+//     FAD = ||mu1 - mu2||^2 + tr C1 + tr C2 - 2 tr sqrt(C1 C2)
+// and the per-song loop of score_individual, fadtk/fad.py:373-387.
+//
+// The reference returns tr sqrt through scipy.linalg.eig (sum of sqrt of the eigenvalues of
+// C1 C2, fad.py:91-92) and also runs scipy.linalg.sqrtm for a diagnostic (fad.py:88).  Here
+// tr sqrt(A), A = C1 C2, comes from the coupled Newton-Schulz iteration
+//     Y0 = A / c, Z0 = I;   T = (3 I - Z Y) / 2;   Y <- Y T;   Z <- T Z;     Y -> sqrt(A / c)
+// entirely in fp64 on MFMA tiles (gemm_f64.hip).  c >= rho(A) is the smallest of ||A||_F,
+// ||A||_1, ||A||_inf.  Stopping is decided ON DEVICE per problem, so the host enqueues iterations
+// blindly and syncs once per chunk:
+//   1  ||I - Z Y||_F <= tol                       (full-rank product)
+//   2  trace(Y) stagnates to 1e-13 relative        (rank-deficient product: null directions never
+//                                                   converge but add nothing to the trace; stopping
+//                                                   here also keeps Z from blowing up)
+//   0  max_iter
+// A non-finite residual triggers the reference's eps fallback (fad.py:94-99) once (single-pair API).
+//
+// Two-frame songs (Whisper) never need a matrix root: with d = x1 - x2,
+// Sigma_s = d d^T / 2 is rank one and tr sqrt(Sigma_b Sigma_s) = sqrt(d^T Sigma_b d / 2).
+#include "fad_common.h"
+
+#include <algorithm>
+#include <vector>
+
+struct fad_moments;
+namespace fad {
+const double* moments_packed(const fad_moments* h);
+int moments_device(const fad_moments* h);
+int moments_dim(const fad_moments* h);
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxIter = 64;
+
+struct NsState {
+    double c, tr1, tr2, mean_term;
+    double res_last, tr_last;
+    int done, final_iter, conv, nonfinite, too_few, pad;
+    double res[kMaxIter];
+    double tr[kMaxIter];
+};
+constexpr int kStateInts = sizeof(NsState) / sizeof(int);
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// ---- |row| sums, |col| sums, row sums of squares of A[b]; grid (d, B) ----------------------
+__global__ __launch_bounds__(256) void ns_rowstats(const double* __restrict__ Aall, int d,
+                                                   double* __restrict__ stats_all, const NsState* __restrict__ st) {
+    __shared__ double red[3][4];
+    const int b = blockIdx.y;
+    if (st[b].done) return;
+    const double* A = Aall + (int64_t)b * d * d;
+    double* stats = stats_all + (int64_t)b * 3 * d;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    double ra = 0.0, ca = 0.0, rs = 0.0;
+    for (int j = tid; j < d; j += 256) {
+        const double v = A[(int64_t)r * d + j];
+        ra += fabs(v); rs += v * v;
+        ca += fabs(A[(int64_t)j * d + r]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ra += __shfl_xor(ra, off); ca += __shfl_xor(ca, off); rs += __shfl_xor(rs, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = ra; red[1][tid >> 6] = ca; red[2][tid >> 6] = rs; }
+    __syncthreads();
+    if (tid == 0) {
+        stats[r] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        stats[d + r] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        stats[2 * d + r] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+}
+
+// one block per problem: scale c, traces, mean term; arms the iteration state
+__global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ stats_all, int d,
+                                                  const double* __restrict__ cov1, int64_t s1,
+                                                  const double* __restrict__ cov2, int64_t s2,
+                                                  const double* __restrict__ mu1, int64_t m1,
+                                                  const double* __restrict__ mu2, int64_t m2,
+                                                  NsState* __restrict__ st_all) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    NsState* st = st_all + b;
+    if (st->done) return;
+    const double* stats = stats_all + (int64_t)b * 3 * d;
+    cov1 += b * s1; cov2 += b * s2; mu1 += b * m1; mu2 += b * m2;
+    double mr = 0.0, mc = 0.0, sq = 0.0, t1 = 0.0, t2 = 0.0, mt = 0.0;
+    for (int i = tid; i < d; i += 256) {
+        mr = fmax(mr, stats[i]); mc = fmax(mc, stats[d + i]); sq += stats[2 * d + i];
+        t1 += cov1[(int64_t)i * d + i]; t2 += cov2[(int64_t)i * d + i];
+        const double df = mu1[i] - mu2[i];
+        mt += df * df;
+    }
+    const double inf_norm = block_max(mr, red);
+    const double one_norm = block_max(mc, red);
+    const double fro2 = block_sum(sq, red);          // NaNs/Infs propagate through the sums
+    const double tr1 = block_sum(t1, red), tr2 = block_sum(t2, red), mean_term = block_sum(mt, red);
+    if (tid == 0) {
+        double c = sqrt(fro2);
+        if (inf_norm < c) c = inf_norm;
+        if (one_norm < c) c = one_norm;
+        const bool bad = !(fro2 == fro2) || isinf(fro2) || !(tr1 == tr1) || !(tr2 == tr2) || isinf(tr1) ||
+                         isinf(tr2) || !(mean_term == mean_term) || isinf(mean_term);
+        st->c = c; st->tr1 = tr1; st->tr2 = tr2; st->mean_term = mean_term;
+        st->res_last = 0.0; st->tr_last = 0.0;
+        st->final_iter = -1; st->conv = 0;
+        st->nonfinite = bad ? 1 : 0;
+        st->done = bad ? 1 : 0;
+        if (!bad && !(c > 0.0)) {            // A == 0: its root is 0, nothing to iterate
+            st->done = 1; st->conv = 1; st->final_iter = 0; st->c = 1.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ns_scale(const double* __restrict__ Aall, int d, const NsState* __restrict__ st,
+                                                double* __restrict__ Yall, double* __restrict__ Zall, int64_t stride) {
+    const int b = blockIdx.y;
+    if (st[b].done) return;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (int64_t)d * d) return;
+    const double inv = 1.0 / st[b].c;
+    const int r = (int)(g / d), c = (int)(g - (int64_t)r * d);
+    Yall[b * stride + g] = Aall[(int64_t)b * d * d + g] * inv;
+    Zall[b * stride + g] = (r == c) ? 1.0 : 0.0;
+}
+
+// one block per problem per iteration: reduce the residual partials, trace(Y), decide
+__global__ __launch_bounds__(256) void ns_check(int k, int max_iter, NsState* __restrict__ st_all,
+                                                const double* __restrict__ partials_all, int nslots,
+                                                const double* __restrict__ Yall, int64_t stride, int d,
+                                                double tol_res, double tol_tr) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    NsState* st = st_all + b;
+    if (st->done) return;
+    const double* partials = partials_all + (int64_t)b * nslots;
+    const double* Y = Yall + b * stride;
+    const int tid = threadIdx.x;
+    double s = 0.0, t = 0.0;
+    for (int i = tid; i < nslots; i += 256) s += partials[i];
+    for (int i = tid; i < d; i += 256) t += Y[(int64_t)i * d + i];
+    const double sumsq = block_sum(s, red);
+    const double tr = block_sum(t, red);
+    if (tid != 0) return;
+    const double res = 2.0 * sqrt(sumsq);           // ||I - ZY||_F = 2 ||T - I||_F
+    st->res[k] = res; st->tr[k] = tr;
+    const bool finite = (res == res) && !isinf(res) && (tr == tr) && !isinf(tr);
+    if (!finite) { st->done = 1; st->nonfinite = 1; return; }
+    const double tr_prev = st->tr_last;
+    st->res_last = res; st->tr_last = tr; st->final_iter = k;
+    if (res <= tol_res) { st->done = 1; st->conv = 1; }
+    else if (k > 0 && fabs(tr - tr_prev) <= tol_tr * fabs(tr)) { st->done = 1; st->conv = 2; }
+    else if (k + 1 >= max_iter) { st->done = 1; st->conv = 0; }
+}
+
+__global__ __launch_bounds__(256) void add_diag(double* __restrict__ M, int d, double eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d) M[(int64_t)i * d + i] += eps;
+}
+
+// packed moments -> mu, cov (same formula as moments_finalize_kernel) + the n >= 2 check
+__global__ __launch_bounds__(256) void finalize_for_frechet(const double* __restrict__ acc, int d, int ddof,
+                                                            double* __restrict__ mu, double* __restrict__ cov,
+                                                            NsState* __restrict__ st) {
+    const double n = acc[0];
+    const double* sum = acc + 1;
+    const double* M = acc + 1 + d;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0 && n < 2.0) st->too_few = 1;
+    if (g < d) mu[g] = sum[g] / n;
+    if (g >= (int64_t)d * d) return;
+    const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
+    cov[g] = (M[g] - sum[a] * (sum[b] / n)) / (n - (double)ddof);
+}
+
+__global__ void clear_states(NsState* st, int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b < B) { st[b].too_few = 0; st[b].done = 0; st[b].nonfinite = 0; st[b].conv = 0; st[b].final_iter = -1; }
+}
+
+// ------------------------------------------------------------------------------------------
+struct Workspace : NsWorkspace {
+    int device = -1;
+    DevBuf rows, offs, songbuf, songmat;     // per-song path
+};
+
+static Workspace& thread_ws(int device) {
+    static thread_local Workspace ws[8];
+    Workspace& w = ws[device & 7];
+    if (w.device != device) {
+        if (w.device >= 0) { w.release(); w.rows.release(); w.offs.release(); w.songbuf.release(); w.songmat.release(); }
+        w.device = device;
+    }
+    return w;
+}
+
+struct NsProblem {                  // B problems of dimension d; strides in elements (0 = shared)
+    int d; int64_t B;
+    const double* cov1; int64_t s_cov1;
+    const double* cov2; int64_t s_cov2;
+    const double* mu1; int64_t s_mu1;
+    const double* mu2; int64_t s_mu2;
+};
+
+static size_t ns_small_bytes(int d, int64_t B) {
+    return (size_t)B * (sizeof(NsState) + ((size_t)gemm_f64_slots_max(d) + 3 * (size_t)d) * sizeof(double)) + 256;
+}
+
+// Enqueue + run the batched iteration.  On return host_states (pinned, B entries) holds the final
+// per-problem state; the caller turns it into scores.  States must have been cleared by the caller
+// (so that pre-kernels like finalize_for_frechet can raise too_few).
+static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_t stream, Workspace& ws,
+                  NsState** host_states) {
+    const int d = pb.d;
+    const int64_t B = pb.B, dd = (int64_t)d * d;
+    if (max_iter <= 0) max_iter = 64;
+    if (max_iter > kMaxIter) max_iter = kMaxIter;
+    const double tol_res = (tol > 0.0) ? tol : 1e-13 * d;
+    const double tol_tr = 1e-13;
+
+    FAD_TRY(ws.mats.reserve((size_t)(6 * dd * B) * sizeof(double)));
+    double* A = static_cast<double*>(ws.mats.p);
+    double* Y[2] = {A + dd * B, A + 2 * dd * B};
+    double* Z[2] = {A + 3 * dd * B, A + 4 * dd * B};
+    double* T = A + 5 * dd * B;
+    NsState* dstates = static_cast<NsState*>(ws.small.p);
+    double* partials = reinterpret_cast<double*>(dstates + B);
+    double* rowstats = partials + (size_t)B * gemm_f64_slots_max(d);
+    const int* skip = &dstates[0].done;
+
+    const size_t hbytes = (size_t)B * sizeof(NsState);
+    if (!ws.pinned || ws.pinned_cap < hbytes) {
+        if (ws.pinned) (void)hipHostFree(ws.pinned);
+        ws.pinned = nullptr; ws.pinned_cap = 0;
+        FAD_HIP_TRY(hipHostMalloc(&ws.pinned, hbytes + 4096, hipHostMallocDefault));
+        ws.pinned_cap = hbytes + 4096;
+    }
+    NsState* hs = static_cast<NsState*>(ws.pinned);
+    *host_states = hs;
+
+    GemmType g[2];
+    g[0] = {pb.cov1, pb.s_cov1, pb.cov2, pb.s_cov2, A, dd, 1.0, 0.0, 0.0, nullptr};
+    int rc = gemm_f64_launch(d, g, 1, B, skip, kStateInts, stream, device);
+    if (rc < 0) return rc;
+    hipLaunchKernelGGL(ns_rowstats, dim3(d, (unsigned)B), dim3(256), 0, stream, A, d, rowstats, dstates);
+    hipLaunchKernelGGL(ns_prepare, dim3((unsigned)B), dim3(256), 0, stream, rowstats, d, pb.cov1, pb.s_cov1, pb.cov2,
+                       pb.s_cov2, pb.mu1, pb.s_mu1, pb.mu2, pb.s_mu2, dstates);
+    hipLaunchKernelGGL(ns_scale, dim3((unsigned)cdiv(dd, 256), (unsigned)B), dim3(256), 0, stream, A, d, dstates, Y[0],
+                       Z[0], dd);
+
+    int cur = 0, k = 0, chunk = 8;
+    bool all_done = false;
+    while (!all_done && k < max_iter) {
+        const int stop = (k + chunk < max_iter) ? k + chunk : max_iter;
+        for (; k < stop; ++k) {
+            g[0] = {Z[cur], dd, Y[cur], dd, T, dd, -0.5, 1.5, 1.0, partials};
+            const int nslots = gemm_f64_launch(d, g, 1, B, skip, kStateInts, stream, device);
+            if (nslots < 0) return nslots;
+            hipLaunchKernelGGL(ns_check, dim3((unsigned)B), dim3(256), 0, stream, k, max_iter, dstates, partials, nslots,
+                               Y[cur], dd, d, tol_res, tol_tr);
+            g[0] = {Y[cur], dd, T, dd, Y[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
+            g[1] = {T, dd, Z[cur], dd, Z[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
+            rc = gemm_f64_launch(d, g, 2, B, skip, kStateInts, stream, device);
+            if (rc < 0) return rc;
+            cur ^= 1;
+        }
+        FAD_HIP_TRY(hipMemcpyAsync(hs, dstates, hbytes, hipMemcpyDeviceToHost, stream));
+        FAD_HIP_TRY(hipStreamSynchronize(stream));
+        all_done = true;
+        for (int64_t b = 0; b < B; ++b) if (!hs[b].done) { all_done = false; break; }
+        chunk = 4;
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
+// single pair, with the reference's eps fallback; cov/mu are DEVICE pointers
+static int frechet_single(int d, const double* cov1, const double* cov2, const double* mu1, const double* mu2,
+                          double eps, int max_iter, double tol, int device, hipStream_t stream, Workspace& ws,
+                          double* out_fad, fad_diag_t* diag, bool check_few) {
+    const int64_t dd = (int64_t)d * d;
+    NsState* hs = nullptr;
+    NsProblem pb{d, 1, cov1, 0, cov2, 0, mu1, 0, mu2, 0};
+    FAD_TRY(run_ns(pb, max_iter, tol, device, stream, ws, &hs));
+    if (check_few && hs->too_few)
+        return set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
+    bool used_eps = false;
+    if (hs->nonfinite && eps > 0.0) {
+        // fad.py:94-99: add eps to both diagonals and take the root again
+        FAD_TRY(ws.stage.reserve((size_t)(4 * dd + 2 * d) * sizeof(double)));     // keeps the first 2dd+2d intact
+        double* E1 = static_cast<double*>(ws.stage.p) + 2 * dd + 2 * d;
+        double* E2 = E1 + dd;
+        FAD_HIP_TRY(hipMemcpyAsync(E1, cov1, dd * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        FAD_HIP_TRY(hipMemcpyAsync(E2, cov2, dd * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(add_diag, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, stream, E1, d, eps);
+        hipLaunchKernelGGL(add_diag, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, stream, E2, d, eps);
+        hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, stream, static_cast<NsState*>(ws.small.p), (int64_t)1);
+        NsProblem pe{d, 1, E1, 0, E2, 0, mu1, 0, mu2, 0};
+        FAD_TRY(run_ns(pe, max_iter, tol, device, stream, ws, &hs));
+        used_eps = true;
+    }
+    if (hs->nonfinite) {
+        if (diag) { memset(diag, 0, sizeof(*diag)); diag->used_eps = used_eps; diag->residual = hs->res_last; }
+        return set_error(FAD_ERR_NOT_FINITE,
+                         "sqrt(C1 C2) did not stay finite (NaN/Inf input or a product with negative eigenvalues)");
+    }
+    const double tr_sqrt = sqrt(hs->c) * hs->tr_last;
+    double tr1 = hs->tr1, tr2 = hs->tr2;          // traces refer to the caller's inputs (fad.py:119-120)
+    if (used_eps) { tr1 -= eps * d; tr2 -= eps * d; }
+    if (out_fad) *out_fad = hs->mean_term + tr1 + tr2 - 2.0 * tr_sqrt;
+    if (diag) {
+        diag->iters = hs->final_iter + 1; diag->converged = hs->conv; diag->used_eps = used_eps ? 1 : 0;
+        diag->reserved = 0; diag->residual = hs->res_last; diag->scale = hs->c;
+        diag->mean_term = hs->mean_term; diag->tr1 = tr1; diag->tr2 = tr2; diag->tr_sqrt = tr_sqrt;
+    }
+    if (hs->conv == 0)
+        return set_error(FAD_ERR_NOT_CONVERGED, "Newton-Schulz stopped at max_iter with residual %.3e", hs->res_last);
+    return FAD_OK;
+}
+
+// ==========================================================================================
+// per-song kernels
+// ==========================================================================================
+template <typename TIn> __device__ __forceinline__ double ld_f64(const TIn* p, int64_t i);
+struct r_f16 { uint16_t b; };
+struct r_bf16 { uint16_t b; };
+template <> __device__ __forceinline__ double ld_f64<double>(const double* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ double ld_f64<float>(const float* p, int64_t i) { return (double)p[i]; }
+template <> __device__ __forceinline__ double ld_f64<r_f16>(const r_f16* p, int64_t i) {
+    _Float16 h; uint16_t s = p[i].b; __builtin_memcpy(&h, &s, 2); return (double)(float)h;
+}
+template <> __device__ __forceinline__ double ld_f64<r_bf16>(const r_bf16* p, int64_t i) {
+    return (double)__uint_as_float(((uint32_t)p[i].b) << 16);
+}
+
+// numpy's mean of an fp16 / bf16 / fp32 matrix is rounded to that dtype
+template <typename TIn> __device__ __forceinline__ double round_like_input(double v) { return v; }
+template <> __device__ __forceinline__ double round_like_input<float>(double v) { return (double)(float)v; }
+template <> __device__ __forceinline__ double round_like_input<r_f16>(double v) { return (double)(float)(_Float16)(float)v; }
+template <> __device__ __forceinline__ double round_like_input<r_bf16>(double v) {
+    uint32_t u = __float_as_uint((float)v);
+    u += 0x7fffu + ((u >> 16) & 1u);              // round to nearest even
+    return (double)__uint_as_float(u & 0xffff0000u);
+}
+
+// One workgroup per song: exact fp64 mean, mean as the reference sees it, ||mu_b - mean||^2,
+// tr Sigma_s = sum ||x - mean||^2 / (n - 1), and for two-frame songs the difference row d = x1 - x2.
+template <typename TIn>
+__global__ __launch_bounds__(256) void song_stats(const TIn* __restrict__ rows, int64_t ld, int d,
+                                                  const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
+                                                  int mean_mode, double* __restrict__ mean_exact,
+                                                  double* __restrict__ mean_ref, double* __restrict__ scal /*[S][2]*/) {
+    __shared__ double red[4];
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = offsets[s], r1 = offsets[s + 1];
+    const int64_t n = r1 - r0;
+    double mt = 0.0, ts = 0.0;
+    for (int a = threadIdx.x; a < d; a += 256) {
+        double sum = 0.0;
+        for (int64_t r = r0; r < r1; ++r) sum += ld_f64<TIn>(rows, r * ld + a);
+        const double m = (n > 0) ? sum / (double)n : 0.0;
+        const double mr = mean_mode ? round_like_input<TIn>(m) : m;
+        mean_exact[s * d + a] = m;
+        mean_ref[s * d + a] = mr;
+        double sq = 0.0;
+        for (int64_t r = r0; r < r1; ++r) { const double c = ld_f64<TIn>(rows, r * ld + a) - m; sq += c * c; }
+        ts += sq;
+        const double df = mu_b[a] - mr;
+        mt += df * df;
+    }
+    mt = block_sum(mt, red);
+    ts = block_sum(ts, red);
+    if (threadIdx.x == 0) { scal[2 * s] = mt; scal[2 * s + 1] = (n > 1) ? ts / (double)(n - 1) : 0.0; }
+}
+
+// Sigma_s = Xc^T Xc / (n-1) with the exact fp64 mean (np.cov), 16x16 threads per 16x16 tile; grid (t, t, songs)
+template <typename TIn>
+__global__ __launch_bounds__(256) void song_cov(const TIn* __restrict__ rows, int64_t ld, int d,
+                                                const int64_t* __restrict__ offsets, const int64_t* __restrict__ song_ids,
+                                                const double* __restrict__ mean_exact, double* __restrict__ cov_out) {
+    const int64_t slot = blockIdx.z;
+    const int64_t s = song_ids[slot];
+    const int a = blockIdx.y * 16 + (threadIdx.x >> 4), b = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (a >= d || b >= d) return;
+    const int64_t r0 = offsets[s], r1 = offsets[s + 1];
+    const double ma = mean_exact[s * d + a], mb = mean_exact[s * d + b];
+    double acc = 0.0;
+    for (int64_t r = r0; r < r1; ++r)
+        acc += (ld_f64<TIn>(rows, r * ld + a) - ma) * (ld_f64<TIn>(rows, r * ld + b) - mb);
+    cov_out[slot * (int64_t)d * d + (int64_t)a * d + b] = acc / (double)(r1 - r0 - 1);
+}
+
+// Two-frame songs: q_s = d_s^T Sigma_b d_s with d_s = x1 - x2, 16 songs per workgroup on
+// v_mfma_f64_16x16x4_f64.  The 16 difference rows are staged in LDS (k-chunks of <= 1024, pitch
+// KC+2 doubles: conflict-free ds_read_b64 for the A fragment); per column block of 16,
+//   W[16 songs x 16 cols] = Dm[16 x KC] Sigma_b[KC x 16 cols],  q += sum_col W .* Dm[:, col].
+// Sigma_b is read straight from L2 (shared by every workgroup, 128-byte row segments).
+constexpr int PQ_KC = 1024;
+template <typename TIn>
+__global__ __launch_bounds__(256) void pair_quadform(const TIn* __restrict__ rows, int64_t ld, int d,
+                                                     const int64_t* __restrict__ offsets,
+                                                     const int64_t* __restrict__ song_ids, int64_t n_pairs,
+                                                     const double* __restrict__ cov_b, int kc_len,
+                                                     double* __restrict__ q_out) {
+    extern __shared__ __attribute__((aligned(16))) double sD[];      // [16][kc_len + 2] then red[4][16]
+    const int P = kc_len + 2;
+    double* red = sD + 16 * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t slot0 = (int64_t)blockIdx.x * 16;
+    double qacc[4] = {0.0, 0.0, 0.0, 0.0};            // rows lk + 4*reg of W
+    int64_t rW[4]; bool okW[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t sl = slot0 + lk + 4 * reg;
+        okW[reg] = sl < n_pairs;
+        rW[reg] = okW[reg] ? offsets[song_ids[sl]] : 0;
+    }
+    const int ncb = (d + 15) / 16;
+    for (int kc0 = 0; kc0 < d; kc0 += kc_len) {
+        const int len = (d - kc0 < kc_len) ? d - kc0 : kc_len;
+        const int len4 = (len + 3) & ~3;
+        __syncthreads();
+        for (int sg = 0; sg < 16; ++sg) {
+            const int64_t sl = slot0 + sg;
+            const bool ok = sl < n_pairs;
+            const int64_t r = ok ? offsets[song_ids[sl]] : 0;
+            for (int k = tid; k < len4; k += 256) {
+                double v = 0.0;
+                if (ok && k < len) v = ld_f64<TIn>(rows, r * ld + kc0 + k) - ld_f64<TIn>(rows, (r + 1) * ld + kc0 + k);
+                sD[sg * P + k] = v;
+            }
+        }
+        __syncthreads();
+        for (int cb = wave; cb < ncb; cb += 4) {
+            const int col = cb * 16 + li;
+            const bool col_ok = col < d;
+            f64x4 w = (f64x4){0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < len4; k0 += 4) {
+                const int k = k0 + lk;
+                const double a = sD[li * P + k];
+                const double b = (col_ok && k < len) ? cov_b[(int64_t)(kc0 + k) * d + col] : 0.0;
+                w = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, w, 0, 0, 0);
+            }
+            if (col_ok) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (okW[reg]) {
+                        const double dv = ld_f64<TIn>(rows, rW[reg] * ld + col) - ld_f64<TIn>(rows, (rW[reg] + 1) * ld + col);
+                        qacc[reg] += w[reg] * dv;
+                    }
+            }
+        }
+    }
+    // reduce over the 16 column lanes, then over the 4 waves (fixed order)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) qacc[reg] += __shfl_xor(qacc[reg], off);
+        if (li == 0) red[wave * 16 + lk + 4 * reg] = qacc[reg];
+    }
+    __syncthreads();
+    if (tid < 16 && slot0 + tid < n_pairs)
+        q_out[slot0 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+}
+
+}  // namespace fad
+
+using namespace fad;
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2, const double* cov2,
+                double eps, int max_iter, double tol, int on_device, int device, void* stream,
+                double* out_fad, fad_diag_t* diag) {
+    if (d < 1 || d > 16384) return set_error(FAD_ERR_INVALID, "d=%d out of range", d);
+    if (!mu1 || !mu2 || !cov1 || !cov2 || !out_fad) return set_error(FAD_ERR_INVALID, "NULL argument");
+    FAD_TRY(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return set_error(FAD_ERR_HIP, "cannot select device %d", device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace& ws = thread_ws(device);
+    FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
+    hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, st, static_cast<NsState*>(ws.small.p), (int64_t)1);
+    const int64_t dd = (int64_t)d * d;
+    const double *dc1 = cov1, *dc2 = cov2, *dm1 = mu1, *dm2 = mu2;
+    if (!on_device) {
+        FAD_TRY(ws.stage.reserve((size_t)(4 * dd + 2 * d) * sizeof(double)));
+        double* s = static_cast<double*>(ws.stage.p);
+        FAD_HIP_TRY(hipMemcpyAsync(s, cov1, dd * sizeof(double), hipMemcpyHostToDevice, st));
+        FAD_HIP_TRY(hipMemcpyAsync(s + dd, cov2, dd * sizeof(double), hipMemcpyHostToDevice, st));
+        FAD_HIP_TRY(hipMemcpyAsync(s + 2 * dd, mu1, d * sizeof(double), hipMemcpyHostToDevice, st));
+        FAD_HIP_TRY(hipMemcpyAsync(s + 2 * dd + d, mu2, d * sizeof(double), hipMemcpyHostToDevice, st));
+        dc1 = s; dc2 = s + dd; dm1 = s + 2 * dd; dm2 = s + 2 * dd + d;
+    }
+    return frechet_single(d, dc1, dc2, dm1, dm2, eps, max_iter, tol, device, st, ws, out_fad, diag, false);
+}
+
+int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
+                             int max_iter, double tol, void* stream, double* out_fad, fad_diag_t* diag) {
+    if (!h1 || !h2 || !out_fad) return set_error(FAD_ERR_INVALID, "NULL argument");
+    const int d = moments_dim(h1), device = moments_device(h1);
+    if (moments_dim(h2) != d)
+        return set_error(FAD_ERR_SHAPE, "Training and test covariances have different dimensions (%d vs %d)", d, moments_dim(h2));
+    if (moments_device(h2) != device) return set_error(FAD_ERR_INVALID, "handles live on different devices");
+    DeviceGuard g(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace& ws = thread_ws(device);
+    FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
+    NsState* dstate = static_cast<NsState*>(ws.small.p);
+    hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, st, dstate, (int64_t)1);
+    const int64_t dd = (int64_t)d * d;
+    FAD_TRY(ws.stage.reserve((size_t)(4 * dd + 2 * d) * sizeof(double)));
+    double* s = static_cast<double*>(ws.stage.p);
+    const unsigned eg = (unsigned)cdiv(dd, 256);
+    hipLaunchKernelGGL(finalize_for_frechet, dim3(eg), dim3(256), 0, st, moments_packed(h1), d, ddof, s + 2 * dd, s, dstate);
+    hipLaunchKernelGGL(finalize_for_frechet, dim3(eg), dim3(256), 0, st, moments_packed(h2), d, ddof, s + 2 * dd + d, s + dd, dstate);
+    return frechet_single(d, s, s + dd, s + 2 * dd, s + 2 * dd + d, eps, max_iter, tol, device, st, ws, out_fad, diag, true);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+namespace fad {
+
+template <typename TIn>
+static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const TIn* drows, int64_t ld,
+                        const int64_t* h_off, const int64_t* d_off, int64_t n_songs, int mean_mode, int device,
+                        hipStream_t st, Workspace& ws, double* out_scores, int32_t* out_status) {
+    const int64_t dd = (int64_t)d * d;
+    // ---- per-song scalars and means
+    // songbuf: mean_exact [S*d] | mean_ref [S*d] | scal [S*2] | q [S] | ids (int64) [S]
+    const size_t sb_doubles = (size_t)n_songs * (2 * d + 3);
+    FAD_TRY(ws.songbuf.reserve(sb_doubles * sizeof(double) + (size_t)n_songs * sizeof(int64_t) + 64));
+    double* mean_exact = static_cast<double*>(ws.songbuf.p);
+    double* mean_ref = mean_exact + (size_t)n_songs * d;
+    double* scal = mean_ref + (size_t)n_songs * d;
+    double* qdev = scal + 2 * (size_t)n_songs;
+    int64_t* ids_dev = reinterpret_cast<int64_t*>(qdev + n_songs);
+    hipLaunchKernelGGL((song_stats<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
+                       mean_mode, mean_exact, mean_ref, scal);
+
+    // baseline trace (fp64, on device via a 1-problem prepare would be overkill): small D2H of the diagonal
+    std::vector<int64_t> pairs, general;
+    for (int64_t s = 0; s < n_songs; ++s) {
+        const int64_t n = h_off[s + 1] - h_off[s];
+        if (n < 2) { out_status[s] = FAD_ERR_TOO_FEW_ROWS; out_scores[s] = __builtin_nan(""); }
+        else if (n == 2) { out_status[s] = FAD_OK; pairs.push_back(s); }
+        else { out_status[s] = FAD_OK; general.push_back(s); }
+    }
+    std::vector<double> h_scal((size_t)2 * n_songs), h_diag((size_t)d);
+    FAD_HIP_TRY(hipMemcpy2DAsync(h_diag.data(), sizeof(double), dcov_b, (size_t)(d + 1) * sizeof(double), sizeof(double), d,
+                                 hipMemcpyDeviceToHost, st));
+    FAD_HIP_TRY(hipMemcpyAsync(h_scal.data(), scal, h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+
+    // ---- two-frame songs: closed form
+    std::vector<double> h_q(pairs.size());
+    if (!pairs.empty()) {
+        FAD_HIP_TRY(hipMemcpyAsync(ids_dev, pairs.data(), pairs.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        const int kc_len = (int)std::min<int64_t>(PQ_KC, cdiv(d, 32) * 32);
+        const size_t lds = ((size_t)16 * (kc_len + 2) + 64) * sizeof(double);
+        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_quadform<TIn>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((pair_quadform<TIn>), dim3((unsigned)cdiv((int64_t)pairs.size(), 16)), dim3(256), lds, st,
+                           drows, ld, d, d_off, ids_dev, (int64_t)pairs.size(), dcov_b, kc_len, qdev);
+        FAD_HIP_TRY(hipMemcpyAsync(h_q.data(), qdev, pairs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    FAD_HIP_TRY(hipStreamSynchronize(st));
+    double tr_b = 0.0;
+    for (int i = 0; i < d; ++i) tr_b += h_diag[i];
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        const int64_t s = pairs[i];
+        const double q = h_q[i];
+        if (!(q == q) || !(tr_b == tr_b)) { out_status[s] = FAD_ERR_NOT_FINITE; out_scores[s] = __builtin_nan(""); continue; }
+        const double root = q > 0.0 ? sqrt(0.5 * q) : 0.0;
+        out_scores[s] = h_scal[2 * s] + tr_b + h_scal[2 * s + 1] - 2.0 * root;
+    }
+
+    // ---- songs with >= 3 frames: batched D x D Newton-Schulz against the shared baseline
+    if (!general.empty()) {
+        size_t budget = (size_t)3 << 30;                         // bytes of matrices per sub-batch
+        int64_t sub = (int64_t)(budget / ((size_t)7 * dd * sizeof(double)));
+        if (sub < 1) sub = 1;
+        if (sub > 4096) sub = 4096;
+        if (sub > (int64_t)general.size()) sub = (int64_t)general.size();
+        FAD_TRY(ws.songmat.reserve((size_t)sub * dd * sizeof(double)));
+        FAD_TRY(ws.small.reserve(ns_small_bytes(d, sub)));
+        double* covs = static_cast<double*>(ws.songmat.p);
+        const unsigned t16 = (unsigned)cdiv(d, 16);
+        for (size_t g0 = 0; g0 < general.size(); g0 += (size_t)sub) {
+            const int64_t B = (int64_t)std::min<size_t>((size_t)sub, general.size() - g0);
+            FAD_HIP_TRY(hipMemcpyAsync(ids_dev, general.data() + g0, B * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((song_cov<TIn>), dim3(t16, t16, (unsigned)B), dim3(256), 0, st, drows, ld, d, d_off,
+                               ids_dev, mean_exact, covs);
+            // gather the reference-rounded means of this sub-batch contiguously: reuse q area? keep simple:
+            // mean_ref rows of the sub-batch are not contiguous, so run NS with mu2 = mu_b (mean term = 0)
+            // and take the mean term from song_stats instead.
+            NsState* dstates = static_cast<NsState*>(ws.small.p);
+            hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, dstates, B);
+            NsState* hs = nullptr;
+            NsProblem pb{d, B, dcov_b, 0, covs, dd, dmu_b, 0, dmu_b, 0};
+            FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));
+            for (int64_t b = 0; b < B; ++b) {
+                const int64_t s = general[g0 + b];
+                if (hs[b].nonfinite) { out_status[s] = FAD_ERR_NOT_FINITE; out_scores[s] = __builtin_nan(""); continue; }
+                const double tr_sqrt = sqrt(hs[b].c) * hs[b].tr_last;
+                out_scores[s] = h_scal[2 * s] + hs[b].tr1 + hs[b].tr2 - 2.0 * tr_sqrt;
+                if (hs[b].conv == 0) out_status[s] = FAD_ERR_NOT_CONVERGED;
+            }
+        }
+    }
+    return FAD_OK;
+}
+
+}  // namespace fad
+
+extern "C" int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const double* cov_b,
+                                               const void* rows, int64_t n_rows, int64_t ld, int dtype,
+                                               const int64_t* offsets, int64_t n_songs, int mean_mode,
+                                               int on_device, int device, void* stream,
+                                               double* out_scores, int32_t* out_status) {
+    if (d < 1 || d > 16384) return set_error(FAD_ERR_INVALID, "d=%d out of range", d);
+    if (!mu_b || !cov_b || !offsets || !out_scores || !out_status || n_songs < 0 || n_rows < 0)
+        return set_error(FAD_ERR_INVALID, "NULL or negative argument");
+    if (ld < d) return set_error(FAD_ERR_SHAPE, "ld=%lld < d=%d", (long long)ld, d);
+    if (dtype_size(dtype) == 0) return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+    for (int64_t s = 0; s < n_songs; ++s)
+        if (offsets[s] > offsets[s + 1] || offsets[s] < 0 || offsets[s + 1] > n_rows)
+            return set_error(FAD_ERR_INVALID, "offsets must be non-decreasing within [0, n_rows]");
+    if (n_songs == 0) return FAD_OK;
+    if (!rows && n_rows > 0) return set_error(FAD_ERR_INVALID, "rows is NULL");
+    FAD_TRY(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return set_error(FAD_ERR_HIP, "cannot select device %d", device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace& ws = thread_ws(device);
+    const int64_t dd = (int64_t)d * d;
+    const size_t es = dtype_size(dtype);
+
+    const double* dmu = mu_b; const double* dcov = cov_b; const void* drows = rows; int64_t dld = ld;
+    if (!on_device) {
+        FAD_TRY(ws.stage.reserve((size_t)(4 * dd + 2 * d) * sizeof(double)));
+        double* s = static_cast<double*>(ws.stage.p);
+        FAD_HIP_TRY(hipMemcpyAsync(s, cov_b, dd * sizeof(double), hipMemcpyHostToDevice, st));
+        FAD_HIP_TRY(hipMemcpyAsync(s + dd, mu_b, d * sizeof(double), hipMemcpyHostToDevice, st));
+        dcov = s; dmu = s + dd;
+        const int64_t row_bytes = (int64_t)d * es;
+        FAD_TRY(ws.rows.reserve((size_t)(n_rows > 0 ? n_rows : 1) * row_bytes + 16));
+        if (n_rows > 0)
+            FAD_HIP_TRY(hipMemcpy2DAsync(ws.rows.p, row_bytes, rows, ld * es, row_bytes, n_rows, hipMemcpyHostToDevice, st));
+        drows = ws.rows.p; dld = d;
+    }
+    FAD_TRY(ws.offs.reserve((size_t)(n_songs + 1) * sizeof(int64_t)));
+    FAD_HIP_TRY(hipMemcpyAsync(ws.offs.p, offsets, (size_t)(n_songs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    const int64_t* d_off = static_cast<const int64_t*>(ws.offs.p);
+
+    switch (dtype) {
+        case FAD_F16: return batched_impl<r_f16>(d, dmu, dcov, static_cast<const r_f16*>(drows), dld, offsets, d_off, n_songs, mean_mode, device, st, ws, out_scores, out_status);
+        case FAD_BF16: return batched_impl<r_bf16>(d, dmu, dcov, static_cast<const r_bf16*>(drows), dld, offsets, d_off, n_songs, mean_mode, device, st, ws, out_scores, out_status);
+        case FAD_F32: return batched_impl<float>(d, dmu, dcov, static_cast<const float*>(drows), dld, offsets, d_off, n_songs, mean_mode, device, st, ws, out_scores, out_status);
+        default: return batched_impl<double>(d, dmu, dcov, static_cast<const double*>(drows), dld, offsets, d_off, n_songs, mean_mode, device, st, ws, out_scores, out_status);
+    }
+}

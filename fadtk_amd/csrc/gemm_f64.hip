@@ -1,0 +1,174 @@
+// Batched fp64 GEMM  C = alpha * A * B + beta_eye * I  on v_mfma_f64_16x16x4_f64 (gfx950).
+//
+// The Newton-Schulz square-root iteration of the Frechet distance is three of these per step
+// (replaces scipy.linalg.sqrtm / eig of fadtk/fad.py:88-92).  fp64 is required: the distance is a
+// cancellation and fp32 iterations miss the 1e-4 bar at N=100k, D=512.
+//
+// 256 threads = 4 waves as 2x2; workgroup tile BT x BT (32 or 64), 16-deep k stages, double
+// buffered LDS, A stored [row][k] with pitch 18 and B [k][col] with pitch BT+16 -- both
+// conflict-free for ds_read_b64.  MFMA fragment maps (f64 differs from the f32 maps):
+//   A: lane l holds A[i = l&15][k = l>>4]     B: lane l holds B[k = l>>4][j = l&15]
+//   D: col = l&15, row = (l>>4) + 4*reg       (reg = 0..3)
+// Optional epilogue: per-workgroup sum of (C - gamma I)^2 written to a partial slot
+// (deterministic two-level reduction; no atomics).
+#include "fad_common.h"
+
+namespace fad {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// blockIdx.z = batch_index * ntypes + type.  Each "type" is one GEMM shape of the iteration (e.g.
+// Y' = Y T and Z' = T Z share a launch); each batch index is one independent problem (one song).
+struct GemmArgs {
+    const double* A[2]; const double* B[2]; double* C[2];
+    int64_t sa[2], sb[2], sc[2];         // per-batch-index strides (elements); 0 = shared operand
+    double alpha[2], beta_eye[2], gamma[2];
+    double* partials[2];                 // [batch][slots] or nullptr
+    const int* skip;                     // skip[batch_index * skip_stride] != 0 -> problem is finished
+    int skip_stride;
+    int ntypes;
+};
+
+constexpr int KB = 16;
+constexpr int PA = 18;
+
+template <int BT>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
+    constexpr int MT = BT / 32;              // MFMA tiles per wave per side
+    constexpr int PB = BT + 16;
+    constexpr int NA = BT * KB / 256;        // staged elements per thread per operand
+    __shared__ double sA[2][BT * PA];
+    __shared__ double sB[2][KB * PB];
+    __shared__ double red[4];
+
+    const int zi = (g.ntypes == 2) ? (blockIdx.z & 1) : 0;
+    const int64_t zb = (g.ntypes == 2) ? (blockIdx.z >> 1) : blockIdx.z;
+    if (g.skip && g.skip[zb * g.skip_stride] != 0) return;
+    const double* A = g.A[zi] + zb * g.sa[zi];
+    const double* B = g.B[zi] + zb * g.sb[zi];
+    double* C = g.C[zi] + zb * g.sc[zi];
+    const double alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int row0 = blockIdx.y * BT, col0 = blockIdx.x * BT;
+
+    double ra[NA], rb[NA];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int e = tid + q * 256;
+            const int ai = e >> 4, ak = e & 15;                 // A tile [BT][16]
+            const int r = row0 + ai, k = k0 + ak;
+            ra[q] = (r < d && k < d) ? A[(int64_t)r * d + k] : 0.0;
+            const int bk = e / BT, bj = e % BT;                 // B tile [16][BT]
+            const int kk = k0 + bk, c = col0 + bj;
+            rb[q] = (kk < d && c < d) ? B[(int64_t)kk * d + c] : 0.0;
+        }
+    };
+
+    f64x4 acc[MT][MT];
+#pragma unroll
+    for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int y = 0; y < MT; ++y) acc[x][y] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+    const int nkb = (d + KB - 1) / KB;
+    fetch(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int e = tid + q * 256;
+            sA[buf][(e >> 4) * PA + (e & 15)] = ra[q];
+            sB[buf][(e / BT) * PB + (e % BT)] = rb[q];
+        }
+        __syncthreads();
+        if (kb + 1 < nkb) fetch((kb + 1) * KB);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + lk;
+            double a[MT], b[MT];
+#pragma unroll
+            for (int f = 0; f < MT; ++f) {
+                a[f] = sA[buf][(wr * (BT / 2) + 16 * f + li) * PA + k];
+                b[f] = sB[buf][k * PB + wc * (BT / 2) + 16 * f + li];
+            }
+#pragma unroll
+            for (int fa = 0; fa < MT; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < MT; ++fb)
+                    acc[fa][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fa], b[fb], acc[fa][fb], 0, 0, 0);
+        }
+    }
+
+    double ss = 0.0;
+#pragma unroll
+    for (int fa = 0; fa < MT; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < MT; ++fb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = row0 + wr * (BT / 2) + 16 * fa + lk + 4 * reg;
+                const int c = col0 + wc * (BT / 2) + 16 * fb + li;
+                if (r < d && c < d) {
+                    const double v = alpha * acc[fa][fb][reg] + (r == c ? beta_eye : 0.0);
+                    C[(int64_t)r * d + c] = v;
+                    const double e = v - (r == c ? gamma : 0.0);
+                    ss += e * e;
+                }
+            }
+    double* partials = g.partials[zi];
+    if (partials) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (tid == 0)
+            partials[zb * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+static int pick_bt(int d, int64_t count, int device) {
+    const int64_t t64 = cdiv(d, 64) * cdiv(d, 64) * count;
+    return (t64 >= num_cus(device)) ? 64 : 32;
+}
+
+int gemm_f64_slots(int d, int ntypes, int64_t batch, int device) {
+    const int64_t t = cdiv(d, pick_bt(d, (int64_t)ntypes * batch, device));
+    return (int)(t * t);
+}
+
+int gemm_f64_slots_max(int d) { const int64_t t = cdiv(d, 32); return (int)(t * t); }
+
+int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, const int* skip, int skip_stride,
+                    hipStream_t stream, int device) {
+    if (ntypes < 1 || ntypes > 2 || batch < 1) return set_error(FAD_ERR_INVALID, "gemm: ntypes=%d batch=%lld", ntypes, (long long)batch);
+    const int bt = pick_bt(d, (int64_t)ntypes * batch, device);
+    const int64_t t = cdiv(d, bt);
+    const int64_t slots = t * t;
+    const int64_t max_b = 65535 / ntypes;
+    for (int64_t done = 0; done < batch; done += max_b) {
+        const int64_t m = (batch - done < max_b) ? batch - done : max_b;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        for (int i = 0; i < ntypes; ++i) {
+            g.A[i] = types[i].A + done * types[i].sa; g.B[i] = types[i].B + done * types[i].sb;
+            g.C[i] = types[i].C + done * types[i].sc;
+            g.sa[i] = types[i].sa; g.sb[i] = types[i].sb; g.sc[i] = types[i].sc;
+            g.alpha[i] = types[i].alpha; g.beta_eye[i] = types[i].beta_eye; g.gamma[i] = types[i].gamma;
+            g.partials[i] = types[i].partials ? types[i].partials + done * slots : nullptr;
+        }
+        g.skip = skip ? skip + done * skip_stride : nullptr;
+        g.skip_stride = skip_stride; g.ntypes = ntypes;
+        dim3 grid((unsigned)t, (unsigned)t, (unsigned)(m * ntypes));
+        if (bt == 64) hipLaunchKernelGGL((gemm_f64_kernel<64>), grid, dim3(256), 0, stream, d, g);
+        else hipLaunchKernelGGL((gemm_f64_kernel<32>), grid, dim3(256), 0, stream, d, g);
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    return (int)slots;
+}
+
+}  // namespace fad

@@ -1,0 +1,783 @@
+// Running (n, sum x, sum x x^T) of frame matrices E[N x D]  -- gfx950 / CDNA4 only.
+//
+// Replaces np.mean + np.cov of fadtk/fad.py:48 and the per-file np.cov + merge loop of
+// fadtk/utils.py:13-45 by ONE pass over E that accumulates raw moments (sum-reducible).
+//
+// Kernels
+//   moments_tile_h16   fp16/bf16 rows -> fp32 partial tiles of E^T E with
+//                      v_mfma_f32_32x32x16_{f16,bf16}.  fp16 x fp16 products are exact in fp32;
+//                      each workgroup sums a bounded run of rows in fp32 and the partials are
+//                      combined in fp64.  Only upper-triangular 128x128 tiles are computed
+//                      (E^T E is symmetric).  Column sums ride along on the diagonal tiles.
+//   moments_tile_f64   any dtype / any alignment -> fp64 partial tiles with
+//                      v_mfma_f64_16x16x4_f64 (products and sums in fp64, like np.cov).
+//   moments_reduce     partials (fp32|fp64) -> += packed fp64 accumulator, mirrored.
+//   moments_finalize   (n, sum, sumsq) -> mu, cov with ddof.
+//
+// Data layout in HBM
+//   E            row-major [N x ld], one frame per row (the layout of fadtk's .npy files)
+//   accumulator  packed fp64 [ n | sum_x[D] | sum_xxT[D*D] ]
+//   partials     [split][tile][BT][BT]   (BT = 128 fp32 | 64 fp64)
+//   colpart      [split][nt*BT] fp64
+#include "fad_common.h"
+
+namespace fad {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kXcd = 8;
+
+// Workgroup id -> work item such that consecutive items land on the SAME XCD (block b runs on
+// XCD b % 8): the tiles of one row-split then share that XCD's L2 for their slabs of E.
+__device__ __forceinline__ int xcd_contiguous(int b, int nwg) {
+    const int xcd = b % kXcd, idx = b / kXcd;
+    const int q = nwg / kXcd, r = nwg % kXcd;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void tile_coords(int tile, int nt, int& ta, int& tb) {
+    int a = 0, t = tile;
+    while (t >= nt - a) { t -= nt - a; ++a; }
+    ta = a; tb = a + t;
+}
+
+template <int KIND> __device__ __forceinline__ float h16_to_f32(uint32_t bits16) {
+    if constexpr (KIND == FAD_F16) {
+        _Float16 h; unsigned short s = (unsigned short)bits16; __builtin_memcpy(&h, &s, 2); return (float)h;
+    } else {
+        return __uint_as_float(bits16 << 16);
+    }
+}
+
+template <int KIND> __device__ __forceinline__ float sum8(const uint4& v) {
+    float s = 0.f;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s += h16_to_f32<KIND>(w[q] & 0xffffu); s += h16_to_f32<KIND>(w[q] >> 16); }
+    return s;
+}
+
+template <int KIND> __device__ __forceinline__ f32x16 mfma_h16(const uint4& a, const uint4& b, const f32x16& c) {
+    if constexpr (KIND == FAD_F16) {
+        f16x8 va, vb; __builtin_memcpy(&va, &a, 16); __builtin_memcpy(&vb, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(va, vb, c, 0, 0, 0);
+    } else {
+        bf16x8 va, vb; __builtin_memcpy(&va, &a, 16); __builtin_memcpy(&vb, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, c, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp16 / bf16 tile kernel.  256 threads = 4 waves as 2x2; workgroup tile 128 x 128 of E^T E,
+// wave tile 64 x 64 = 2x2 MFMA 32x32 tiles; 32 rows of E per LDS stage (double buffered).
+//
+// Fragment trick: an MFMA operand wants 8 consecutive k (rows of E) of ONE column per lane, but E
+// is row-major.  The sum over k is order-free and the column<->lane assignment is ours to pick,
+// so lane i reads the 32-bit word holding columns (2i, 2i+1) of 8 rows and two v_perm_b32 per row
+// pair split them into the fragment of the "even" 32x32 tile (columns 2i) and of the "odd" one
+// (columns 2i+1).  Output element (fa, reg, fb) of lane l is then
+//   a = 64*wr + 2*row(reg, l>>5) + fa,  b = 64*wc + 2*(l&31) + fb,
+// i.e. the two fb values are adjacent columns: one 8-byte store.
+// ------------------------------------------------------------------------------------------
+constexpr int H_BT = 128;     // tile edge
+constexpr int H_KB = 32;      // rows per stage
+
+template <int KIND>
+__global__ __launch_bounds__(256) void moments_tile_h16(
+    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
+    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart) {
+    __shared__ uint4 smem[2][2][H_KB * 16];     // [buffer][A|B][row*16 + 16B-chunk]  = 32 KiB
+
+    const int w = xcd_contiguous(blockIdx.x, S * T);
+    const int split = w / T, tile = w - split * T;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const bool diag = (ta == tb);
+    const int ca = ta * H_BT, cb = tb * H_BT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, kg = lane >> 5;
+
+    const int64_t k_begin = (int64_t)split * rows_per_split;
+    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
+
+    // staging: thread -> (row r, r+16 ; 16-byte chunk c) of each slab
+    const int sr = tid >> 4, sc = tid & 15;
+    const bool col_ok_a = (ca + sc * 8) < d;        // d % 8 == 0 on this path: chunk all-in or all-out
+    const bool col_ok_b = (cb + sc * 8) < d;
+    const uint16_t* ga = E + ca + sc * 8;
+    const uint16_t* gb = E + cb + sc * 8;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    uint4 ra[2], rb[2];
+    auto fetch = [&](int kb) {
+        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t r = r0 + 16 * h;
+            const bool ok = r < k_end;
+            ra[h] = (ok && col_ok_a) ? *reinterpret_cast<const uint4*>(ga + r * ld) : zero4;
+            if (!diag) rb[h] = (ok && col_ok_b) ? *reinterpret_cast<const uint4*>(gb + r * ld) : zero4;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
+    double csum[2] = {0.0, 0.0};
+    const bool do_colsum = diag && (wr == 0);
+
+    if (nkb > 0) fetch(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        smem[buf][0][sr * 16 + sc] = ra[0];
+        smem[buf][0][(sr + 16) * 16 + sc] = ra[1];
+        if (!diag) { smem[buf][1][sr * 16 + sc] = rb[0]; smem[buf][1][(sr + 16) * 16 + sc] = rb[1]; }
+        __syncthreads();
+        if (kb + 1 < nkb) fetch(kb + 1);
+
+        const uint32_t* sA = reinterpret_cast<const uint32_t*>(smem[buf][0]);
+        const uint32_t* sB = reinterpret_cast<const uint32_t*>(smem[buf][diag ? 0 : 1]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rbase = ks * 16 + kg * 8;
+            uint32_t wa[8], wb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                wa[e] = sA[(rbase + e) * 64 + 32 * wr + li];
+                wb[e] = sB[(rbase + e) * 64 + 32 * wc + li];
+            }
+            uint4 a0, a1, b0, b1;
+            // even columns: low halves of consecutive rows; odd columns: high halves
+            a0.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x05040100u); a1.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x07060302u);
+            a0.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x05040100u); a1.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x07060302u);
+            a0.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x05040100u); a1.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x07060302u);
+            a0.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x05040100u); a1.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x07060302u);
+            b0.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x05040100u); b1.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u);
+            b0.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x05040100u); b1.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u);
+            b0.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x05040100u); b1.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x07060302u);
+            b0.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x05040100u); b1.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x07060302u);
+
+            acc[0][0] = mfma_h16<KIND>(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_h16<KIND>(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_h16<KIND>(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_h16<KIND>(a1, b1, acc[1][1]);
+            if (do_colsum) {     // wave-uniform; 8-term fp32 sums of 16-bit values, then fp64
+                csum[0] += (double)sum8<KIND>(b0);
+                csum[1] += (double)sum8<KIND>(b1);
+            }
+        }
+    }
+
+    // ---- epilogue: fp32 partial tile, two adjacent columns per store
+    float* out = partials + ((int64_t)split * T + tile) * (H_BT * H_BT);
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;       // C/D row of the 32x32 tile
+            const int a_local = 64 * wr + 2 * row32 + fa;
+            const int b_local = 64 * wc + 2 * li;
+            float2 v = make_float2(acc[fa][0][reg], acc[fa][1][reg]);
+            *reinterpret_cast<float2*>(out + a_local * H_BT + b_local) = v;
+        }
+    }
+    if (do_colsum) {
+        // lanes l and l+32 hold the two k-halves of the same column
+        csum[0] += __shfl_xor(csum[0], 32);
+        csum[1] += __shfl_xor(csum[1], 32);
+        if (kg == 0) {
+            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + 2 * li;
+            cp[0] = csum[0]; cp[1] = csum[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic tile kernel: any input dtype, any pitch/alignment.  Everything in fp64 on
+// v_mfma_f64_16x16x4_f64 (A: lane l holds A[i=l&15][k=l>>4]; B[k=l>>4][j=l&15];
+// D: col = l&15, row = (l>>4) + 4*reg).  Workgroup tile 64x64, wave tile 32x32, 16 rows/stage.
+// ------------------------------------------------------------------------------------------
+constexpr int G_BT = 64;
+constexpr int G_KB = 16;
+constexpr int G_LDS = 80;     // padded row pitch (doubles): consecutive k rows hit the other bank half
+
+template <typename TIn> __device__ __forceinline__ double to_f64(TIn v);
+template <> __device__ __forceinline__ double to_f64<double>(double v) { return v; }
+template <> __device__ __forceinline__ double to_f64<float>(float v) { return (double)v; }
+struct raw_f16 { uint16_t b; };
+struct raw_bf16 { uint16_t b; };
+template <> __device__ __forceinline__ double to_f64<raw_f16>(raw_f16 v) { return (double)h16_to_f32<FAD_F16>(v.b); }
+template <> __device__ __forceinline__ double to_f64<raw_bf16>(raw_bf16 v) { return (double)h16_to_f32<FAD_BF16>(v.b); }
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void moments_tile_f64(
+    const TIn* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
+    int64_t rows_per_split, double* __restrict__ partials, double* __restrict__ colpart) {
+    __shared__ double smem[2][2][G_KB * G_LDS];      // 40 KiB
+
+    const int w = xcd_contiguous(blockIdx.x, S * T);
+    const int split = w / T, tile = w - split * T;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const bool diag = (ta == tb);
+    const int ca = ta * G_BT, cb = tb * G_BT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+
+    const int64_t k_begin = (int64_t)split * rows_per_split;
+    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    const int nkb = (int)((k_end - k_begin + G_KB - 1) / G_KB);
+
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+    double ra[4], rb[4];
+    auto fetch = [&](int kb) {
+        const int64_t r = k_begin + (int64_t)kb * G_KB + sr;
+        const bool ok = r < k_end;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int colA = ca + sc4 + q, colB = cb + sc4 + q;
+            ra[q] = (ok && colA < d) ? to_f64<TIn>(E[r * ld + colA]) : 0.0;
+            if (!diag) rb[q] = (ok && colB < d) ? to_f64<TIn>(E[r * ld + colB]) : 0.0;
+        }
+    };
+
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double csum[2] = {0.0, 0.0};
+    const bool do_colsum = diag && (wr == 0);
+
+    if (nkb > 0) fetch(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            smem[buf][0][sr * G_LDS + sc4 + q] = ra[q];
+            if (!diag) smem[buf][1][sr * G_LDS + sc4 + q] = rb[q];
+        }
+        __syncthreads();
+        if (kb + 1 < nkb) fetch(kb + 1);
+        const double* sA = smem[buf][0];
+        const double* sB = smem[buf][diag ? 0 : 1];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + lk;
+            double a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = sA[k * G_LDS + 32 * wr + 16 * f + li];
+                b[f] = sB[k * G_LDS + 32 * wc + 16 * f + li];
+            }
+#pragma unroll
+            for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+                    acc[fa][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fa], b[fb], acc[fa][fb], 0, 0, 0);
+            if (do_colsum) { csum[0] += b[0]; csum[1] += b[1]; }
+        }
+    }
+
+    double* out = partials + ((int64_t)split * T + tile) * (G_BT * G_BT);
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int a_local = 32 * wr + 16 * fa + lk + 4 * reg;
+                const int b_local = 32 * wc + 16 * fb + li;
+                out[a_local * G_BT + b_local] = acc[fa][fb][reg];
+            }
+    if (do_colsum) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            csum[f] += __shfl_xor(csum[f], 16);
+            csum[f] += __shfl_xor(csum[f], 32);
+        }
+        if (lk == 0) {
+            double* cp = colpart + (int64_t)split * (nt * G_BT) + cb + 32 * wc + li;
+            cp[0] = csum[0]; cp[16] = csum[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// partials -> packed fp64 accumulator (sum over splits in fp64, fixed order => deterministic).
+// One thread per 4 adjacent columns of one tile row.
+// ------------------------------------------------------------------------------------------
+template <typename PT, int BT>
+__global__ __launch_bounds__(256) void moments_reduce(
+    const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed) {
+    const int per_tile = BT * BT / 4;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (int64_t)T * per_tile) return;
+    const int tile = (int)(g / per_tile), e = (int)(g - (int64_t)tile * per_tile);
+    const int a_local = e / (BT / 4), b_local = (e % (BT / 4)) * 4;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const int a = ta * BT + a_local, b0 = tb * BT + b_local;
+    if (a >= d || b0 >= d) return;
+
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const PT* p = partials + (int64_t)tile * BT * BT + a_local * BT + b_local;
+    const int64_t stride = (int64_t)T * BT * BT;
+    for (int sp = 0; sp < S; ++sp) {
+        if constexpr (sizeof(PT) == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
+            s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+        } else {
+            const double2 v0 = *reinterpret_cast<const double2*>(p + sp * stride);
+            const double2 v1 = *reinterpret_cast<const double2*>(p + sp * stride + 2);
+            s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+        }
+    }
+    double* M = acc_packed + 1 + d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = b0 + q;
+        if (b >= d) break;
+        if (ta != tb) {
+            M[(int64_t)a * d + b] += s[q];
+            M[(int64_t)b * d + a] += s[q];
+        } else if (a <= b) {            // diagonal tile: upper triangle is authoritative
+            M[(int64_t)a * d + b] += s[q];
+            if (a != b) M[(int64_t)b * d + a] += s[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void moments_reduce_cols(
+    const double* __restrict__ colpart, int S, int dpad, int d, double n_add,
+    double* __restrict__ acc_packed) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a == 0) acc_packed[0] += n_add;
+    if (a >= d) return;
+    double s = 0.0;
+    for (int sp = 0; sp < S; ++sp) s += colpart[(int64_t)sp * dpad + a];
+    acc_packed[1 + a] += s;
+}
+
+// per-segment column sums: seg_sums[s][a] = sum over rows of segment s of E[r][a]   (fp64)
+template <typename TIn>
+__global__ __launch_bounds__(128) void segment_colsums(
+    const TIn* __restrict__ E, int64_t ld, int d, const int64_t* __restrict__ offsets,
+    double* __restrict__ seg_sums) {
+    const int64_t seg = blockIdx.x;
+    const int a = blockIdx.y * 128 + threadIdx.x;
+    if (a >= d) return;
+    const int64_t r0 = offsets[seg], r1 = offsets[seg + 1];
+    double s0 = 0.0, s1 = 0.0;
+    int64_t r = r0;
+    for (; r + 1 < r1; r += 2) { s0 += to_f64<TIn>(E[r * ld + a]); s1 += to_f64<TIn>(E[(r + 1) * ld + a]); }
+    if (r < r1) s0 += to_f64<TIn>(E[r * ld + a]);
+    seg_sums[seg * d + a] = s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void packed_axpy(double* __restrict__ dst, const double* __restrict__ src,
+                                                   int64_t len) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < len) dst[g] += src[g];
+}
+
+// mu = sum/n ; cov = (M - sum sum^T / n) / (n - ddof)
+__global__ __launch_bounds__(256) void moments_finalize_kernel(
+    const double* __restrict__ acc_packed, int d, int ddof, double* __restrict__ mu,
+    double* __restrict__ cov) {
+    const double n = acc_packed[0];
+    const double* sum = acc_packed + 1;
+    const double* M = acc_packed + 1 + d;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < d && mu) mu[g] = sum[g] / n;
+    if (g >= (int64_t)d * d) return;
+    const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
+    cov[g] = (M[g] - sum[a] * (sum[b] / n)) / (n - (double)ddof);
+}
+
+}  // namespace fad
+
+// ==========================================================================================
+// handle + host side
+// ==========================================================================================
+struct fad_moments {
+    int d = 0, device = 0;
+    double* acc = nullptr;                 // packed [1 + d + d*d]
+    fad::DevBuf partials, colpart, stage, seg_off, seg_out, scratch;
+    // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
+    // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
+    static constexpr int kRing = 256;
+    bool timing = false;
+    hipEvent_t* ev = nullptr;              // [kRing][3]
+    int ev_count = 0;                      // entries recorded since the last query
+    int last_variant = -1;                 // 0: h16 MFMA tile kernel, 1: generic fp64 kernel
+    int n_cu = 256;
+};
+
+namespace fad {
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return FAD_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        p = nullptr;
+        return set_error(FAD_ERR_ALLOC, "hipMalloc of %zu bytes failed", want);
+    }
+    cap = want;
+    return FAD_OK;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+static int64_t packed_len(int d) { return 1 + (int64_t)d + (int64_t)d * d; }
+
+struct SplitPlan { int nt, T, S; int64_t rows_per_split; };
+
+static SplitPlan plan_splits(int64_t n, int d, int bt, int kb, int n_cu, int wg_per_cu, int64_t min_rows) {
+    SplitPlan p;
+    p.nt = (int)cdiv(d, bt);
+    p.T = p.nt * (p.nt + 1) / 2;
+    int64_t want = cdiv((int64_t)n_cu * wg_per_cu, p.T);
+    int64_t max_by_rows = cdiv(n, min_rows);
+    int64_t s = want < max_by_rows ? want : max_by_rows;
+    if (s < 1) s = 1;
+    int64_t rps = cdiv(cdiv(n, s), kb) * kb;
+    p.rows_per_split = rps;
+    p.S = (int)cdiv(n, rps);
+    return p;
+}
+
+template <typename TIn>
+static void launch_generic(const void* rows, int64_t n, int64_t ld, int d, const SplitPlan& p,
+                           double* partials, double* colpart, hipStream_t st) {
+    hipLaunchKernelGGL((moments_tile_f64<TIn>), dim3(p.S * p.T), dim3(256), 0, st,
+                       reinterpret_cast<const TIn*>(rows), n, ld, d, p.nt, p.T, p.S, p.rows_per_split,
+                       partials, colpart);
+}
+
+// rows must be a DEVICE pointer here.
+static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld, int dtype, hipStream_t st) {
+    const int d = h->d;
+    const bool is16 = (dtype == FAD_F16 || dtype == FAD_BF16);
+    const bool aligned = is16 && (d % 8 == 0) && (ld % 8 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(rows) & 15u) == 0);
+    const char* force = getenv("FAD_MOMENTS_FORCE_GENERIC");
+    const bool use_h16 = aligned && !(force && force[0] == '1');
+
+    hipEvent_t* ev = nullptr;
+    if (h->timing) {
+        if (!h->ev) {
+            h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3];
+            if (!h->ev) return set_error(FAD_ERR_ALLOC, "out of host memory");
+            for (int i = 0; i < fad_moments::kRing * 3; ++i) FAD_HIP_TRY(hipEventCreate(&h->ev[i]));
+        }
+        ev = h->ev + 3 * (h->ev_count % fad_moments::kRing);
+        h->ev_count++;
+    }
+    if (use_h16) {
+        SplitPlan p = plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256);
+        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_BT * H_BT * sizeof(float)));
+        FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
+        float* part = static_cast<float*>(h->partials.p);
+        double* colp = static_cast<double*>(h->colpart.p);
+        if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
+        if (dtype == FAD_F16)
+            hipLaunchKernelGGL((moments_tile_h16<FAD_F16>), dim3(p.S * p.T), dim3(256), 0, st,
+                               static_cast<const uint16_t*>(rows), n, ld, d, p.nt, p.T, p.S,
+                               p.rows_per_split, part, colp);
+        else
+            hipLaunchKernelGGL((moments_tile_h16<FAD_BF16>), dim3(p.S * p.T), dim3(256), 0, st,
+                               static_cast<const uint16_t*>(rows), n, ld, d, p.nt, p.T, p.S,
+                               p.rows_per_split, part, colp);
+        if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
+        const int64_t groups = (int64_t)p.T * (H_BT * H_BT / 4);
+        hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, st,
+                           part, p.S, p.T, p.nt, d, h->acc);
+        hipLaunchKernelGGL(moments_reduce_cols, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st,
+                           colp, p.S, p.nt * H_BT, d, (double)n, h->acc);
+        if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
+        h->last_variant = 0;
+    } else {
+        SplitPlan p = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
+        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * G_BT * G_BT * sizeof(double)));
+        FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * G_BT * sizeof(double)));
+        double* part = static_cast<double*>(h->partials.p);
+        double* colp = static_cast<double*>(h->colpart.p);
+        if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
+        switch (dtype) {
+            case FAD_F16: launch_generic<raw_f16>(rows, n, ld, d, p, part, colp, st); break;
+            case FAD_BF16: launch_generic<raw_bf16>(rows, n, ld, d, p, part, colp, st); break;
+            case FAD_F32: launch_generic<float>(rows, n, ld, d, p, part, colp, st); break;
+            case FAD_F64: launch_generic<double>(rows, n, ld, d, p, part, colp, st); break;
+            default: return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+        }
+        if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
+        const int64_t groups = (int64_t)p.T * (G_BT * G_BT / 4);
+        hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, st,
+                           part, p.S, p.T, p.nt, d, h->acc);
+        hipLaunchKernelGGL(moments_reduce_cols, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st,
+                           colp, p.S, p.nt * G_BT, d, (double)n, h->acc);
+        if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
+        h->last_variant = 1;
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
+// Host rows -> staged through h->stage in bounded chunks (PCIe), then update_device.
+static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, int dtype, int on_device,
+                      hipStream_t st) {
+    if (on_device) return update_device(h, rows, n, ld, dtype, st);
+    const size_t es = dtype_size(dtype);
+    const int64_t row_bytes = (int64_t)h->d * es;
+    int64_t chunk_rows = ((int64_t)1 << 30) / (row_bytes > 0 ? row_bytes : 1);
+    if (chunk_rows < 1024) chunk_rows = 1024;
+    chunk_rows = (chunk_rows / 32) * 32;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const int64_t m = (n - r0 < chunk_rows) ? n - r0 : chunk_rows;
+        FAD_TRY(h->stage.reserve((size_t)m * row_bytes + 16));
+        const char* src = static_cast<const char*>(rows) + r0 * ld * es;
+        FAD_HIP_TRY(hipMemcpy2DAsync(h->stage.p, row_bytes, src, ld * es, row_bytes, m,
+                                     hipMemcpyHostToDevice, st));
+        FAD_TRY(update_device(h, h->stage.p, m, h->d, dtype, st));
+        // the staging buffer is reused by the next chunk: wait for the kernels that read it
+        if (r0 + m < n) FAD_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return FAD_OK;
+}
+
+}  // namespace fad
+
+using namespace fad;
+
+extern "C" {
+
+int fad_moments_create(int d, int device, fad_moments_t** out) {
+    if (!out) return set_error(FAD_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (d < 1 || d > 16384) return set_error(FAD_ERR_INVALID, "d=%d out of range [1, 16384]", d);
+    FAD_TRY(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return set_error(FAD_ERR_HIP, "cannot select device %d", device);
+    fad_moments* h = new (std::nothrow) fad_moments();
+    if (!h) return set_error(FAD_ERR_ALLOC, "out of host memory");
+    h->d = d; h->device = device; h->n_cu = num_cus(device);
+    const size_t bytes = (size_t)packed_len(d) * sizeof(double);
+    if (hipMalloc(reinterpret_cast<void**>(&h->acc), bytes) != hipSuccess) {
+        delete h;
+        return set_error(FAD_ERR_ALLOC, "hipMalloc of %zu bytes failed", bytes);
+    }
+    if (hipMemset(h->acc, 0, bytes) != hipSuccess) {
+        (void)hipFree(h->acc); delete h;
+        return set_error(FAD_ERR_HIP, "hipMemset failed");
+    }
+    *out = h;
+    return FAD_OK;
+}
+
+int fad_moments_destroy(fad_moments_t* h) {
+    if (!h) return FAD_OK;
+    DeviceGuard g(h->device);
+    if (h->acc) (void)hipFree(h->acc);
+    h->partials.release(); h->colpart.release(); h->stage.release();
+    h->seg_off.release(); h->seg_out.release(); h->scratch.release();
+    if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
+    delete h;
+    return FAD_OK;
+}
+
+int fad_moments_reset(fad_moments_t* h, void* stream) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    DeviceGuard g(h->device);
+    FAD_HIP_TRY(hipMemsetAsync(h->acc, 0, (size_t)packed_len(h->d) * sizeof(double),
+                               static_cast<hipStream_t>(stream)));
+    return FAD_OK;
+}
+
+int fad_moments_dim(const fad_moments_t* h) { return h ? h->d : set_error(FAD_ERR_INVALID, "handle is NULL"); }
+int64_t fad_moments_packed_len(const fad_moments_t* h) {
+    return h ? packed_len(h->d) : (int64_t)set_error(FAD_ERR_INVALID, "handle is NULL");
+}
+
+int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                       int on_device, void* stream) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    if (n < 0 || ld < h->d) return set_error(FAD_ERR_SHAPE, "n=%lld ld=%lld d=%d", (long long)n, (long long)ld, h->d);
+    if (dtype_size(dtype) == 0) return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+    if (n == 0) return FAD_OK;
+    if (!rows) return set_error(FAD_ERR_INVALID, "rows is NULL");
+    DeviceGuard g(h->device);
+    return update_any(h, rows, n, ld, dtype, on_device, static_cast<hipStream_t>(stream));
+}
+
+int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                                 const int64_t* offsets, int64_t n_segments, double* seg_sums,
+                                 int on_device, void* stream) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    if (n < 0 || ld < h->d) return set_error(FAD_ERR_SHAPE, "n=%lld ld=%lld d=%d", (long long)n, (long long)ld, h->d);
+    if (dtype_size(dtype) == 0) return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+    if (n_segments < 0 || (n_segments > 0 && !offsets)) return set_error(FAD_ERR_INVALID, "bad segment list");
+    for (int64_t s = 0; s < n_segments; ++s)
+        if (offsets[s] > offsets[s + 1] || offsets[s] < 0 || offsets[s + 1] > n)
+            return set_error(FAD_ERR_INVALID, "offsets must be non-decreasing within [0, n]");
+    if (n == 0) return FAD_OK;
+    if (!rows) return set_error(FAD_ERR_INVALID, "rows is NULL");
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t es = dtype_size(dtype);
+    const void* drows = rows;
+    int64_t dld = ld;
+    if (!on_device) {      // one staged copy serves both kernels (bounded by caller: host blocks are per-batch)
+        const int64_t row_bytes = (int64_t)h->d * es;
+        FAD_TRY(h->stage.reserve((size_t)n * row_bytes + 16));
+        FAD_HIP_TRY(hipMemcpy2DAsync(h->stage.p, row_bytes, rows, ld * es, row_bytes, n, hipMemcpyHostToDevice, st));
+        drows = h->stage.p; dld = h->d;
+    }
+    FAD_TRY(update_device(h, drows, n, dld, dtype, st));
+    if (seg_sums && n_segments > 0) {
+        FAD_TRY(h->seg_off.reserve((size_t)(n_segments + 1) * sizeof(int64_t)));
+        FAD_HIP_TRY(hipMemcpyAsync(h->seg_off.p, offsets, (size_t)(n_segments + 1) * sizeof(int64_t),
+                                   hipMemcpyHostToDevice, st));
+        double* dout = seg_sums;
+        if (!on_device) {
+            FAD_TRY(h->seg_out.reserve((size_t)n_segments * h->d * sizeof(double)));
+            dout = static_cast<double*>(h->seg_out.p);
+        }
+        const dim3 grid((unsigned)n_segments, (unsigned)cdiv(h->d, 128));
+        const int64_t* doff = static_cast<const int64_t*>(h->seg_off.p);
+        switch (dtype) {
+            case FAD_F16: hipLaunchKernelGGL((segment_colsums<raw_f16>), grid, dim3(128), 0, st, static_cast<const raw_f16*>(drows), dld, h->d, doff, dout); break;
+            case FAD_BF16: hipLaunchKernelGGL((segment_colsums<raw_bf16>), grid, dim3(128), 0, st, static_cast<const raw_bf16*>(drows), dld, h->d, doff, dout); break;
+            case FAD_F32: hipLaunchKernelGGL((segment_colsums<float>), grid, dim3(128), 0, st, static_cast<const float*>(drows), dld, h->d, doff, dout); break;
+            default: hipLaunchKernelGGL((segment_colsums<double>), grid, dim3(128), 0, st, static_cast<const double*>(drows), dld, h->d, doff, dout); break;
+        }
+        FAD_HIP_TRY(hipGetLastError());
+        if (!on_device) {
+            FAD_HIP_TRY(hipMemcpyAsync(seg_sums, dout, (size_t)n_segments * h->d * sizeof(double),
+                                       hipMemcpyDeviceToHost, st));
+        }
+    }
+    if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
+    return FAD_OK;
+}
+
+int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream) {
+    if (!dst || !src) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    if (dst->d != src->d) return set_error(FAD_ERR_SHAPE, "d mismatch %d vs %d", dst->d, src->d);
+    if (dst->device != src->device) return set_error(FAD_ERR_INVALID, "handles live on different devices; export/import instead");
+    DeviceGuard g(dst->device);
+    const int64_t len = packed_len(dst->d);
+    hipLaunchKernelGGL(packed_axpy, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dst->acc, src->acc, len);
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
+int fad_moments_export(const fad_moments_t* h, double* packed, int on_device, void* stream) {
+    if (!h || !packed) return set_error(FAD_ERR_INVALID, "NULL argument");
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t bytes = (size_t)packed_len(h->d) * sizeof(double);
+    FAD_HIP_TRY(hipMemcpyAsync(packed, h->acc, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
+    return FAD_OK;
+}
+
+int fad_moments_import(fad_moments_t* h, const double* packed, int on_device, void* stream) {
+    if (!h || !packed) return set_error(FAD_ERR_INVALID, "NULL argument");
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t bytes = (size_t)packed_len(h->d) * sizeof(double);
+    FAD_HIP_TRY(hipMemcpyAsync(h->acc, packed, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
+    return FAD_OK;
+}
+
+int fad_moments_count(const fad_moments_t* h, int64_t* n, void* stream) {
+    if (!h || !n) return set_error(FAD_ERR_INVALID, "NULL argument");
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double v = 0.0;
+    FAD_HIP_TRY(hipMemcpyAsync(&v, h->acc, sizeof(double), hipMemcpyDeviceToHost, st));
+    FAD_HIP_TRY(hipStreamSynchronize(st));
+    *n = (int64_t)(v + 0.5);
+    return FAD_OK;
+}
+
+int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* cov, int64_t* n_out,
+                         int on_device, void* stream) {
+    if (!h || !cov) return set_error(FAD_ERR_INVALID, "NULL argument");
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int64_t n = 0;
+    FAD_TRY(fad_moments_count(h, &n, stream));
+    if (n_out) *n_out = n;
+    if (n < 2) return set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames, you have %lld", (long long)n);
+    const int d = h->d;
+    fad_moments* hm = const_cast<fad_moments*>(h);
+    double* dmu = mu; double* dcov = cov;
+    if (!on_device) {
+        FAD_TRY(hm->scratch.reserve(((size_t)d * d + d) * sizeof(double)));
+        dcov = static_cast<double*>(hm->scratch.p);
+        dmu = dcov + (size_t)d * d;
+    }
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3((unsigned)cdiv((int64_t)d * d, 256)), dim3(256), 0, st,
+                       h->acc, d, ddof, dmu, dcov);
+    FAD_HIP_TRY(hipGetLastError());
+    if (!on_device) {
+        FAD_HIP_TRY(hipMemcpyAsync(cov, dcov, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (mu) FAD_HIP_TRY(hipMemcpyAsync(mu, dmu, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+        FAD_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return FAD_OK;
+}
+
+int fad_moments_set_timing(fad_moments_t* h, int enabled) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    h->timing = enabled != 0;
+    h->ev_count = 0;
+    return FAD_OK;
+}
+
+// Average duration of the tile kernel and of the reduce kernels over every update recorded since
+// timing was enabled / last queried (at most the last 256).  Synchronises on the newest event.
+int fad_moments_last_timing(fad_moments_t* h, float* ms_main, float* ms_reduce, int* variant) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    if (!h->timing || !h->ev || h->ev_count == 0)
+        return set_error(FAD_ERR_INVALID, "timing was not enabled before the update");
+    DeviceGuard g(h->device);
+    const int total = h->ev_count;
+    const int m = total < fad_moments::kRing ? total : fad_moments::kRing;
+    FAD_HIP_TRY(hipEventSynchronize(h->ev[3 * ((total - 1) % fad_moments::kRing) + 2]));
+    double a = 0.0, b = 0.0;
+    for (int i = total - m; i < total; ++i) {
+        hipEvent_t* e = h->ev + 3 * (i % fad_moments::kRing);
+        float x = 0.f, y = 0.f;
+        FAD_HIP_TRY(hipEventElapsedTime(&x, e[0], e[1]));
+        FAD_HIP_TRY(hipEventElapsedTime(&y, e[1], e[2]));
+        a += x; b += y;
+    }
+    if (ms_main) *ms_main = (float)(a / m);
+    if (ms_reduce) *ms_reduce = (float)(b / m);
+    if (variant) *variant = h->last_variant;
+    h->ev_count = 0;
+    return FAD_OK;
+}
+
+}  // extern "C"
+
+// accessors for the other translation units (frechet.hip)
+namespace fad {
+const double* moments_packed(const fad_moments* h) { return h->acc; }
+int moments_device(const fad_moments* h) { return h->device; }
+int moments_dim(const fad_moments* h) { return h->d; }
+}

@@ -1,0 +1,293 @@
+"""FAD math and orchestration -- host-side mirror of fadtk/fad.py on top of libfad_hip.so.
+
+Same public names, argument meaning, return dtypes and error behaviour as the reference
+(`calc_embd_statistics`, `calc_frechet_distance`, `FrechetAudioDistance`, `FADInfResults`), so
+callers and tests written against fadtk read the same.  All reductions over frames and the matrix
+square root run on the GPU; numpy only carries host buffers and O(D) glue (dtype casts, traces).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import traceback
+from pathlib import Path
+from typing import NamedTuple, Union
+
+import numpy as np
+
+from . import hip
+from .utils import PathLike, calculate_embd_statistics_online, find_sox_formats, get_cache_embedding_path, tmap, tq, write
+
+log = logging.getLogger("fadtk_amd")
+sox_path = os.environ.get("SOX_PATH", "sox")
+ffmpeg_path = os.environ.get("FFMPEG_PATH", "ffmpeg")
+
+
+class FADInfResults(NamedTuple):
+    score: float
+    slope: float
+    r2: float
+    points: list
+
+
+def _mean_dtype(dtype: np.dtype) -> np.dtype:
+    """dtype of ``np.mean(x, axis=0)``: float16/32 stay, everything else is float64."""
+    return dtype if dtype in (np.float16, np.float32) else np.dtype(np.float64)
+
+
+def calc_embd_statistics(embd_lst, device: int = 0):
+    """Mean and covariance of a frame matrix [N x D] (fadtk/fad.py:42-48), computed on the GPU.
+
+    Returns (mu, cov) with numpy's dtypes: mu in the input's float dtype (float16 embeddings give a
+    float16 mean, rounded from an exact float64 column sum), cov float64 with ddof = 1.
+    """
+    n = embd_lst.shape[0]
+    assert n >= 2, (f"FAD requires at least two embedding window frames, you have {tuple(embd_lst.shape)}."
+                    " (This probably means that your audio is too short)")
+    with hip.Moments(int(embd_lst.shape[1]), device) as acc:
+        acc.update(embd_lst)
+        mu, cov, _ = acc.finalize(ddof=1)
+    try:
+        in_dtype = embd_lst.dtype if isinstance(embd_lst, np.ndarray) else \
+            np.dtype(str(embd_lst.dtype).replace("torch.", ""))
+    except TypeError:                                  # torch.bfloat16 has no numpy twin
+        in_dtype = np.dtype(np.float32)
+    out_dtype = _mean_dtype(in_dtype) if in_dtype.kind == "f" else np.dtype(np.float64)
+    if out_dtype == np.float16:
+        mu = mu.astype(np.float32).astype(np.float16)      # numpy sums fp16 in fp32, then casts
+    elif out_dtype == np.float32:
+        mu = mu.astype(np.float32)
+    return mu, cov
+
+
+def calc_frechet_distance(mu1, cov1, mu2, cov2, eps: float = 1e-6, device: int = 0):
+    """Frechet distance between N(mu1, cov1) and N(mu2, cov2) (fadtk/fad.py:51-120).
+
+        d^2 = ||mu1 - mu2||^2 + Tr(cov1) + Tr(cov2) - 2 Tr sqrt(cov1 cov2)
+
+    Tr sqrt(cov1 cov2) comes from the GPU (Newton-Schulz in float64, see csrc/frechet.hip); the
+    O(D) terms are formed here with numpy so that the reference's dtype behaviour carries over
+    (float16 means give a float16 ``diff.dot(diff)``).  Returns ``np.float64``.
+    Raises AssertionError on shape mismatch (fad.py:78-81) and ValueError when the product has no
+    real root / is not finite (fad.py:102-106).
+    """
+    mu1 = np.atleast_1d(mu1)
+    mu2 = np.atleast_1d(mu2)
+    cov1 = np.atleast_2d(cov1)
+    cov2 = np.atleast_2d(cov2)
+    assert mu1.shape == mu2.shape, \
+        f"Training and test mean vectors have different lengths ({mu1.shape} vs {mu2.shape})"
+    assert cov1.shape == cov2.shape, \
+        f"Training and test covariances have different dimensions ({cov1.shape} vs {cov2.shape})"
+    assert cov1.shape == (mu1.shape[0], mu1.shape[0]), \
+        f"Covariance shape {cov1.shape} does not match the mean length {mu1.shape[0]}"
+
+    gap = mu1 - mu2
+    _, diag = hip.frechet(mu1, cov1, mu2, cov2, eps=eps, device=device)
+    if diag["used_eps"]:
+        log.info("fid calculation produces singular product; adding %s to diagonal of cov estimates", eps)
+    return np.float64(gap.dot(gap) + np.trace(cov1) + np.trace(cov2) - 2 * diag["tr_sqrt"])
+
+
+class FrechetAudioDistance:
+    """Drop-in for fadtk.FrechetAudioDistance (fadtk/fad.py:123-395)."""
+    loaded = False
+
+    def __init__(self, ml, audio_load_worker: int = 8, load_model: bool = True, device: int = 0):
+        self.ml = ml
+        self.audio_load_worker = audio_load_worker
+        self.sox_formats = find_sox_formats(sox_path)
+        self.device_index = device
+        if load_model:
+            self.ml.load_model()
+            self.loaded = True
+        try:
+            import torch
+            torch.autograd.set_grad_enabled(False)
+        except Exception:       # noqa: BLE001
+            pass
+
+    # ------------------------------------------------------------------ audio -> embeddings
+    def load_audio(self, f: PathLike):
+        """Normalise one audio file to mono PCM16 WAV at the model's rate, cached under
+        <dir>/convert/<sr>/<stem>.wav (fad.py:139-186), and hand it to the loader."""
+        from .audio import convert_to_model_rate
+        f = Path(f)
+        cache_dir = f.parent / "convert" / str(self.ml.sr)
+        new = (cache_dir / f.name).with_suffix(".wav")
+        if not new.exists():
+            cache_dir.mkdir(parents=True, exist_ok=True)
+            convert_to_model_rate(f, new, self.ml.sr)
+        return self.ml.load_wav(new)
+
+    def cache_embedding_file(self, audio_dir: PathLike):
+        """Embed one audio file and store <dir>/embeddings/<model>/<stem>.npy (fad.py:188-201)."""
+        cache = get_cache_embedding_path(self.ml.name, audio_dir)
+        if cache.exists():
+            return
+        wav = self.load_audio(audio_dir)
+        embd = self.ml.get_embedding(wav)
+        cache.parent.mkdir(parents=True, exist_ok=True)
+        np.save(cache, embd)
+
+    def read_embedding_file(self, audio_dir: PathLike):
+        cache = get_cache_embedding_path(self.ml.name, audio_dir)
+        assert cache.exists(), f"Embedding file {cache} does not exist, please run cache_embedding_file first."
+        return np.load(cache)
+
+    def load_embeddings(self, dir: PathLike, max_count: int = -1, concat: bool = True):
+        files = list(Path(dir).glob("*.*"))
+        log.info(f"Loading {len(files)} audio files from {dir}...")
+        return self._load_embeddings(files, max_count=max_count, concat=concat)
+
+    def _load_embeddings(self, files, max_count: int = -1, concat: bool = True):
+        if len(files) == 0:
+            raise ValueError("No files provided")
+        if max_count == -1:
+            embd_lst = tmap(self.read_embedding_file, files, desc="Loading audio files...",
+                            max_workers=self.audio_load_worker)
+        else:                                        # stop once more than max_count frames are in (fad.py:231-237)
+            embd_lst, seen = [], 0
+            for f in tq(files, "Loading files"):
+                embd_lst.append(self.read_embedding_file(f))
+                seen += embd_lst[-1].shape[0]
+                if seen > max_count:
+                    break
+        if concat:
+            return np.concatenate(embd_lst, axis=0)
+        return embd_lst, files
+
+    # ------------------------------------------------------------------ statistics
+    def load_stats(self, path: PathLike):
+        """Resolve a dataset spec to (mu, cov) in the reference's order (fad.py:245-290):
+        bundled ``stats/<name>.npz`` -> an .npz file with ``<model>.mu/.cov`` -> the cached
+        ``<dir>/stats/<model>/{mu,cov}.npy`` -> compute from ``<dir>/embeddings/<model>/*.npy``
+        on the GPU and write that cache (float64)."""
+        if isinstance(path, str):
+            bundled = Path(__file__).parent / "stats" / (path.lower() + ".npz")
+            if bundled.exists():
+                path = bundled
+        path = Path(path)
+
+        if path.is_file():
+            log.info(f"Loading embedding statistics from {path}...")
+            with np.load(path) as data:
+                k_mu, k_cov = f"{self.ml.name}.mu", f"{self.ml.name}.cov"
+                if k_mu not in data or k_cov not in data:
+                    raise ValueError(f"FAD statistics file {path} doesn't contain data for model {self.ml.name}")
+                return data[k_mu], data[k_cov]
+
+        cache_dir = path / "stats" / self.ml.name
+        emb_dir = path / "embeddings" / self.ml.name
+        if cache_dir.exists():
+            log.info(f"Embedding statistics is already cached for {path}, loading...")
+            return np.load(cache_dir / "mu.npy"), np.load(cache_dir / "cov.npy")
+
+        if not path.is_dir():
+            log.error(f"The dataset you want to use ({path}) is not a directory nor a file.")
+            exit(1)
+
+        log.info(f"Loading embedding files from {path}...")
+        mu, cov = calculate_embd_statistics_online(list(emb_dir.glob("*.npy")), device=self.device_index,
+                                                   workers=self.audio_load_worker)
+        log.info("> Embeddings statistics calculated.")
+        cache_dir.mkdir(parents=True, exist_ok=True)
+        np.save(cache_dir / "mu.npy", mu)
+        np.save(cache_dir / "cov.npy", cov)
+        return mu, cov
+
+    # ------------------------------------------------------------------ scores
+    def score(self, baseline: PathLike, eval: PathLike):
+        """One FAD value between a baseline and an eval set (fad.py:292-302)."""
+        mu_bg, cov_bg = self.load_stats(baseline)
+        mu_eval, cov_eval = self.load_stats(eval)
+        return calc_frechet_distance(mu_bg, cov_bg, mu_eval, cov_eval, device=self.device_index)
+
+    def score_inf(self, baseline: PathLike, eval_files, steps: int = 25, min_n: int = 500, raw: bool = False):
+        """FAD-infinity: FAD at ``steps`` resampled sizes, extrapolated to 1/n -> 0 (fad.py:304-351).
+        Resampling uses numpy's global RNG exactly like the reference (seed it to reproduce)."""
+        log.info(f"Calculating FAD-inf for {self.ml.name}...")
+        mu_base, cov_base = self.load_stats(baseline)
+        if all(Path(f).suffix == ".npy" for f in eval_files):
+            embeds = np.concatenate([np.load(f) for f in eval_files], axis=0)
+        else:
+            embeds = self._load_embeddings(eval_files, concat=True)
+        max_n = len(embeds)
+        ns = [int(n) for n in np.linspace(min_n, max_n, steps)]
+
+        gpu_rows = None
+        try:                                         # keep the frame matrix resident in HBM and gather there
+            import torch
+            if torch.cuda.is_available() and embeds.dtype in (np.float16, np.float32, np.float64):
+                gpu_rows = torch.from_numpy(embeds).to(f"cuda:{self.device_index}")
+        except Exception:       # noqa: BLE001
+            gpu_rows = None
+
+        results = []
+        for n in tq(ns, desc="Calculating FAD-inf"):
+            indices = np.random.choice(embeds.shape[0], size=n, replace=True)
+            if gpu_rows is not None:
+                import torch
+                picked = gpu_rows.index_select(0, torch.from_numpy(indices).to(gpu_rows.device))
+                with hip.Moments(embeds.shape[1], self.device_index) as acc:
+                    acc.update(picked)
+                    mu64, cov_eval, _ = acc.finalize()
+                mu_eval = mu64.astype(np.float32).astype(embeds.dtype) if embeds.dtype != np.float64 else mu64
+            else:
+                mu_eval, cov_eval = calc_embd_statistics(embeds[indices], device=self.device_index)
+            results.append([n, calc_frechet_distance(mu_base, cov_base, mu_eval, cov_eval, device=self.device_index)])
+
+        ys = np.array(results)
+        xs = 1 / np.array(ns)
+        slope, intercept = np.polyfit(xs, ys[:, 1], 1)
+        fit = slope * xs + intercept
+        r2 = 1 - np.sum((ys[:, 1] - fit) ** 2) / np.sum((ys[:, 1] - np.mean(ys[:, 1])) ** 2)
+        return FADInfResults(score=intercept, slope=slope, r2=r2, points=results)
+
+    def score_individual(self, baseline: PathLike, eval_dir: PathLike, csv_name: Union[Path, str]) -> Path:
+        """Per-file FAD against the baseline, written as ``path,score`` lines sorted by |score|
+        (fad.py:353-395).  All songs are scored in one batched GPU call; files whose embedding is
+        missing, unreadable or shorter than two frames are logged and dropped like the reference."""
+        csv = Path(csv_name)
+        if isinstance(csv_name, str):
+            csv = Path("data") / "fad-individual" / self.ml.name / csv_name
+        if csv.exists():
+            log.info(f"CSV file {csv} already exists, exiting...")
+            return csv
+
+        mu, cov = self.load_stats(baseline)
+        _files = list(Path(eval_dir).glob("*.*"))
+
+        def _read(f):
+            try:
+                return self.read_embedding_file(f)
+            except Exception as e:      # noqa: BLE001
+                traceback.print_exc()
+                log.error(f"An error occurred calculating individual FAD using model {self.ml.name} on file {f}")
+                log.error(e)
+                return None
+
+        embds = tmap(_read, _files, desc="Loading embeddings", max_workers=self.audio_load_worker)
+        scores = [None] * len(_files)
+        ok = [i for i, e in enumerate(embds) if e is not None and e.ndim == 2 and e.shape[1] == np.shape(mu)[-1]]
+        for i, e in enumerate(embds):
+            if e is not None and i not in set(ok):
+                log.error(f"Embedding of {_files[i]} has shape {e.shape}; expected [*, {np.shape(mu)[-1]}]")
+        if ok:
+            dtypes = {embds[i].dtype for i in ok}
+            cast = (lambda a: a) if len(dtypes) == 1 else (lambda a: a.astype(np.float64))
+            rows = np.concatenate([cast(embds[i]) for i in ok], axis=0)
+            offs = np.concatenate([[0], np.cumsum([embds[i].shape[0] for i in ok])])
+            vals, status = hip.frechet_batched(mu, cov, rows, offs, mean_mode=1, device=self.device_index)
+            for j, i in enumerate(ok):
+                if status[j] == 0 or status[j] == -8:
+                    scores[i] = np.float64(vals[j])
+                else:
+                    log.error(f"An error occurred calculating individual FAD using model {self.ml.name} on file "
+                              f"{_files[i]} (status {status[j]}: "
+                              f"{'fewer than two frames' if status[j] == -6 else 'non-finite result'})")
+
+        pairs = [p for p in zip(_files, scores) if p[1] is not None]
+        pairs = sorted(pairs, key=lambda x: np.abs(x[1]))
+        write(csv, "\n".join(",".join(str(x).replace(",", "_") for x in row) for row in pairs))
+        return csv

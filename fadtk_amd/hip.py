@@ -1,0 +1,205 @@
+"""Thin object layer over the C ABI: running moments, Frechet distance, batched per-song FAD.
+
+Everything here forwards to libfad_hip.so; numpy is only used to own host buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi as K
+
+
+class Moments:
+    """Running (n, sum x, sum x x^T) of frames in float64 HBM (``fad_moments_*``).
+
+    Replaces ``np.mean``/``np.cov`` of fadtk/fad.py:48 and the per-file merge of
+    fadtk/utils.py:13-45.  ``update`` accepts numpy arrays (host, staged over PCIe by the library)
+    or torch CUDA tensors (used in place, on torch's current stream).
+    """
+
+    def __init__(self, d: int, device: int = 0):
+        self._lib = K.load_library()
+        K.require_gpu(device)
+        self.d = int(d)
+        self.device = int(device)
+        h = C.c_void_p()
+        K.check(self._lib.fad_moments_create(self.d, self.device, C.byref(h)), "fad_moments_create")
+        self._h = h
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fad_moments_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _stream(self) -> int:
+        return K.current_stream_ptr(self.device)
+
+    # -- accumulation
+    def reset(self):
+        K.check(self._lib.fad_moments_reset(self._h, self._stream()), "fad_moments_reset")
+
+    def update(self, rows) -> "Moments":
+        ptr, n, d, ld, code, on_dev, keep = K.rows_view(rows)
+        if d != self.d:
+            raise AssertionError(f"frame matrix has {d} features, accumulator has {self.d}")
+        K.check(self._lib.fad_moments_update(self._h, ptr, n, ld, code, on_dev, self._stream()), "fad_moments_update")
+        if on_dev:
+            self._keep = keep          # torch tensor must outlive the enqueued kernels
+        return self
+
+    def update_segmented(self, rows, offsets: Sequence[int], want_sums: bool = True):
+        """Feed files/songs stored back to back; returns per-segment column sums [S x D] (float64, host)."""
+        ptr, n, d, ld, code, on_dev, keep = K.rows_view(rows)
+        if d != self.d:
+            raise AssertionError(f"frame matrix has {d} features, accumulator has {self.d}")
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+        n_seg = off.shape[0] - 1
+        sums = None
+        sums_ptr = None
+        sums_dev = None
+        if want_sums and n_seg > 0:
+            if on_dev:
+                import torch
+                sums_dev = torch.empty((n_seg, self.d), dtype=torch.float64, device=keep.device)
+                sums_ptr = sums_dev.data_ptr()
+            else:
+                sums = np.empty((n_seg, self.d), dtype=np.float64)
+                sums_ptr = sums.ctypes.data
+        K.check(self._lib.fad_moments_update_segmented(
+            self._h, ptr, n, ld, code, off.ctypes.data_as(C.POINTER(C.c_int64)), n_seg, sums_ptr, on_dev,
+            self._stream()), "fad_moments_update_segmented")
+        if sums_dev is not None:
+            sums = sums_dev.cpu().numpy()
+        return sums
+
+    def merge(self, other: "Moments") -> "Moments":
+        K.check(self._lib.fad_moments_merge(self._h, other._h, self._stream()), "fad_moments_merge")
+        return self
+
+    # -- packed statistics (what an RCCL all-reduce runs over)
+    @property
+    def packed_len(self) -> int:
+        return 1 + self.d + self.d * self.d
+
+    def export(self) -> np.ndarray:
+        out = np.empty(self.packed_len, dtype=np.float64)
+        K.check(self._lib.fad_moments_export(self._h, out.ctypes.data, 0, self._stream()), "fad_moments_export")
+        return out
+
+    def export_to(self, tensor):
+        """Copy the packed statistics into a float64 torch CUDA tensor of ``packed_len`` elements."""
+        assert tensor.is_cuda and tensor.numel() == self.packed_len and tensor.is_contiguous()
+        K.check(self._lib.fad_moments_export(self._h, tensor.data_ptr(), 1, self._stream()), "fad_moments_export")
+        return tensor
+
+    def import_(self, packed) -> "Moments":
+        if K._is_torch(packed) and packed.is_cuda:
+            assert packed.numel() == self.packed_len and packed.is_contiguous()
+            K.check(self._lib.fad_moments_import(self._h, packed.data_ptr(), 1, self._stream()), "fad_moments_import")
+        else:
+            a = K.f64_host(packed, (self.packed_len,))
+            K.check(self._lib.fad_moments_import(self._h, a.ctypes.data, 0, self._stream()), "fad_moments_import")
+        return self
+
+    @property
+    def count(self) -> int:
+        n = C.c_int64()
+        K.check(self._lib.fad_moments_count(self._h, C.byref(n), self._stream()), "fad_moments_count")
+        return int(n.value)
+
+    def finalize(self, ddof: int = 1) -> Tuple[np.ndarray, np.ndarray, int]:
+        """-> (mu [D] float64, cov [D x D] float64, n).  n < 2 raises AssertionError (fad.py:46-47)."""
+        mu = np.empty(self.d, dtype=np.float64)
+        cov = np.empty((self.d, self.d), dtype=np.float64)
+        n = C.c_int64()
+        K.check(self._lib.fad_moments_finalize(self._h, int(ddof), mu.ctypes.data, cov.ctypes.data, C.byref(n), 0,
+                                               self._stream()), "fad_moments_finalize")
+        return mu, cov, int(n.value)
+
+    # -- timing of the dominant kernel (bench.py)
+    def set_timing(self, on: bool = True):
+        K.check(self._lib.fad_moments_set_timing(self._h, 1 if on else 0))
+
+    def last_timing(self):
+        a, b, v = C.c_float(), C.c_float(), C.c_int()
+        K.check(self._lib.fad_moments_last_timing(self._h, C.byref(a), C.byref(b), C.byref(v)))
+        return float(a.value), float(b.value), int(v.value)
+
+
+def frechet(mu1, cov1, mu2, cov2, eps: float = 1e-6, max_iter: int = 0, tol: float = 0.0, device: int = 0):
+    """``fad_frechet`` on host float64 arrays -> (fad, diag dict).  Shapes are checked by the caller."""
+    lib = K.load_library()
+    K.require_gpu(device)
+    mu1 = K.f64_host(mu1)
+    mu2 = K.f64_host(mu2)
+    d = mu1.shape[0]
+    cov1 = K.f64_host(cov1, (d, d))
+    cov2 = K.f64_host(cov2, (d, d))
+    out = C.c_double()
+    diag = K.FadDiag()
+    st = lib.fad_frechet(d, mu1.ctypes.data, cov1.ctypes.data, mu2.ctypes.data, cov2.ctypes.data, float(eps),
+                         int(max_iter), float(tol), 0, int(device), K.current_stream_ptr(device), C.byref(out),
+                         C.byref(diag))
+    K.check(st, "fad_frechet")
+    return float(out.value), diag.as_dict()
+
+
+def frechet_from_moments(m1: Moments, m2: Moments, ddof: int = 1, eps: float = 1e-6, max_iter: int = 0,
+                         tol: float = 0.0):
+    """FAD straight from two accumulators, all in HBM (``fad_frechet_from_moments``)."""
+    lib = K.load_library()
+    out = C.c_double()
+    diag = K.FadDiag()
+    st = lib.fad_frechet_from_moments(m1._h, m2._h, int(ddof), float(eps), int(max_iter), float(tol),
+                                      K.current_stream_ptr(m1.device), C.byref(out), C.byref(diag))
+    K.check(st, "fad_frechet_from_moments")
+    return float(out.value), diag.as_dict()
+
+
+def frechet_batched(mu_b, cov_b, rows, offsets: Sequence[int], mean_mode: int = 1, device: int = 0):
+    """Per-song FAD against one baseline (``fad_frechet_batched_vs_baseline``).
+
+    -> (scores float64 [S], status int32 [S]); songs with < 2 frames get NaN and FAD_ERR_TOO_FEW_ROWS.
+    """
+    lib = K.load_library()
+    K.require_gpu(device)
+    mu_b = K.f64_host(mu_b)
+    d = mu_b.shape[0]
+    cov_b = K.f64_host(cov_b, (d, d))
+    ptr, n, dd, ld, code, on_dev, keep = K.rows_view(rows)
+    if n > 0 and dd != d:
+        raise AssertionError(f"songs have {dd} features, baseline has {d}")
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    n_songs = off.shape[0] - 1
+    scores = np.full(max(n_songs, 0), np.nan, dtype=np.float64)
+    status = np.zeros(max(n_songs, 0), dtype=np.int32)
+    if on_dev:
+        # baseline must live where the rows live
+        import torch
+        mu_t = torch.from_numpy(mu_b).to(keep.device)
+        cov_t = torch.from_numpy(cov_b).to(keep.device)
+        mu_p, cov_p = mu_t.data_ptr(), cov_t.data_ptr()
+    else:
+        mu_p, cov_p = mu_b.ctypes.data, cov_b.ctypes.data
+    st = lib.fad_frechet_batched_vs_baseline(d, mu_p, cov_p, ptr, n, max(ld, d), code,
+                                             off.ctypes.data_as(C.POINTER(C.c_int64)), n_songs, int(mean_mode),
+                                             on_dev, int(device), K.current_stream_ptr(device),
+                                             scores.ctypes.data, status.ctypes.data)
+    K.check(st, "fad_frechet_batched_vs_baseline")
+    return scores, status

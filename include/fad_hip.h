@@ -1,0 +1,146 @@
+/*
+ * fad_hip.h -- C ABI of libfad_hip.so, the MI355X (gfx950) implementation of the FAD hot path.
+ *
+ * The reference (microsoft/fadtk v1.1.0) is pure Python and has no FFI for this path; each
+ * entry point below replaces the numpy/scipy call(s) cited next to it (paths relative to the
+ * reference root).  A maintainer binds these with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns FAD_OK (0) or a negative fad_status; nothing throws across the ABI;
+ *     fad_last_error() gives a thread-local message for the last failure on the calling thread.
+ *   - `on_device` != 0 means the data pointers are device (HBM) pointers on the handle's GPU;
+ *     0 means host pointers (the library stages them over PCIe itself).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is enqueued on
+ *     that stream; functions that return results to HOST memory synchronise it before returning.
+ *   - row-major everywhere; `ld` is the row pitch in ELEMENTS.
+ *   - distinct handles are independent; handle-less functions are re-entrant; one handle must not
+ *     be used from two threads at once.
+ *   - there is NO CPU fallback: without a usable GPU every compute entry returns
+ *     FAD_ERR_NO_DEVICE.
+ */
+#ifndef FAD_HIP_H
+#define FAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAD_ABI_VERSION 1
+
+typedef enum fad_status {
+    FAD_OK = 0,
+    FAD_ERR_INVALID = -1,       /* bad argument (NULL, negative size, unknown dtype ...)        */
+    FAD_ERR_NO_DEVICE = -2,     /* no HIP device / wrong architecture                            */
+    FAD_ERR_HIP = -3,           /* a HIP runtime call failed (message has the hipError string)   */
+    FAD_ERR_ALLOC = -4,         /* device or host allocation failed                              */
+    FAD_ERR_SHAPE = -5,         /* dimension mismatch (fad.py:78-81 AssertionError)              */
+    FAD_ERR_TOO_FEW_ROWS = -6,  /* N < 2 frames (fad.py:46-47 AssertionError)                    */
+    FAD_ERR_NOT_FINITE = -7,    /* NaN/Inf in the inputs or a diverged root (fad.py:102-106 ValueError) */
+    FAD_ERR_NOT_CONVERGED = -8  /* iteration hit max_iter (result still written; see fad_diag_t) */
+} fad_status;
+
+typedef enum fad_dtype { FAD_F16 = 0, FAD_BF16 = 1, FAD_F32 = 2, FAD_F64 = 3 } fad_dtype;
+
+/* ------------------------------------------------------------------ library / device */
+int fad_version(void);                       /* FAD_ABI_VERSION                                   */
+int fad_device_count(void);                  /* number of gfx950 devices visible (0 if none)      */
+const char* fad_last_error(void);            /* thread-local, never NULL                          */
+const char* fad_device_arch(int device);     /* e.g. "gfx950:sramecc+:xnack-"; "" on failure      */
+
+/* ------------------------------------------------------------------ running moments
+ * Replaces calc_embd_statistics (fadtk/fad.py:42-48), _process_file (fadtk/utils.py:13-16) and
+ * the merge loop of calculate_embd_statistics_online (fadtk/utils.py:36-45).
+ *
+ * A handle accumulates the sufficient statistics (n, sum x, sum x x^T) of all rows fed so far,
+ * in float64 in HBM, packed as [n | sum_x (D) | sum_xxT (D*D, row-major, symmetric)] =
+ * 1 + D + D*D doubles.  Raw moments are sum-reducible, so merging datasets or GPUs is an
+ * element-wise add of packed buffers (one RCCL all-reduce across ranks).
+ */
+typedef struct fad_moments fad_moments_t;
+
+int fad_moments_create(int d, int device, fad_moments_t** out);
+int fad_moments_destroy(fad_moments_t* h);
+int fad_moments_reset(fad_moments_t* h, void* stream);
+int fad_moments_dim(const fad_moments_t* h);                 /* D, or <0 on error                */
+int64_t fad_moments_packed_len(const fad_moments_t* h);      /* 1 + D + D*D                      */
+
+/* Feed a block of `n` frames (rows) of `d` features.  n == 0 is a no-op. */
+int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                       int on_device, void* stream);
+
+/* Same, for `n_segments` files/songs stored back to back: segment s owns rows
+ * [offsets[s], offsets[s+1]) (offsets is a HOST array of n_segments+1 entries).  If
+ * seg_sums != NULL it receives the per-segment column sums, [n_segments x D] float64 (host or
+ * device per on_device): the per-file means of utils.py:16 and the per-song means of
+ * fad.py:377 are seg_sums / segment length. */
+int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                                 const int64_t* offsets, int64_t n_segments, double* seg_sums,
+                                 int on_device, void* stream);
+
+int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream);   /* dst += src */
+/* Copy the packed float64 statistics out / in (the buffer an RCCL all-reduce runs over). */
+int fad_moments_export(const fad_moments_t* h, double* packed, int on_device, void* stream);
+int fad_moments_import(fad_moments_t* h, const double* packed, int on_device, void* stream);
+int fad_moments_count(const fad_moments_t* h, int64_t* n, void* stream);
+
+/* mu = sum_x / n ; cov = (sum_xxT - n mu mu^T) / (n - ddof)   (np.mean / np.cov, fad.py:48).
+ * mu [D], cov [D*D] float64.  n < 2 -> FAD_ERR_TOO_FEW_ROWS (fad.py:46-47). */
+int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* cov, int64_t* n,
+                         int on_device, void* stream);
+
+/* Opt-in HIP-event timing (bench.py's roofline): while enabled every update records events around
+ * its tile kernel on the caller's stream (no synchronisation); last_timing() returns the AVERAGE
+ * duration in ms of the tile kernel and of the reduce kernels over the updates recorded since the
+ * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA, 1 = generic fp64). */
+int fad_moments_set_timing(fad_moments_t* h, int enabled);
+int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_reduce_kernel,
+                            int* kernel_variant);
+
+/* ------------------------------------------------------------------ Frechet distance
+ * Replaces calc_frechet_distance (fadtk/fad.py:51-120):
+ *   ||mu1-mu2||^2 + tr C1 + tr C2 - 2 tr sqrt(C1 C2)
+ * tr sqrt(C1 C2) = sum_i sqrt(lambda_i(C1 C2)) -- the value the reference returns through
+ * scipy.linalg.eig (fad.py:91-92) -- is computed with a coupled Newton-Schulz iteration in
+ * float64 on MFMA tiles.  eps: added to both diagonals for a retry when the first attempt
+ * diverges (fad.py:94-99).  max_iter <= 0 -> default (64); tol <= 0 -> default.
+ */
+typedef struct fad_diag {
+    int32_t iters;          /* Newton-Schulz iterations executed                                 */
+    int32_t converged;      /* 1: residual < tol, 2: trace stagnated (rank-deficient product), 0: max_iter */
+    int32_t used_eps;       /* 1 if the eps-regularised retry produced the result                */
+    int32_t reserved;
+    double residual;        /* ||I - Z Y||_F at the last iteration                               */
+    double scale;           /* c with Y0 = C1 C2 / c                                             */
+    double mean_term;       /* ||mu1 - mu2||^2 in float64                                        */
+    double tr1, tr2;        /* tr C1, tr C2                                                      */
+    double tr_sqrt;         /* tr sqrt(C1 C2)                                                    */
+} fad_diag_t;
+
+int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2, const double* cov2,
+                double eps, int max_iter, double tol, int on_device, int device, void* stream,
+                double* out_fad, fad_diag_t* diag);
+
+/* Same, straight from two moment handles (no host round trip of mu/cov). */
+int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
+                             int max_iter, double tol, void* stream, double* out_fad, fad_diag_t* diag);
+
+/* ------------------------------------------------------------------ per-song FAD (--indiv)
+ * Replaces the loop of score_individual (fadtk/fad.py:373-387): for every song s (rows
+ * [offsets[s], offsets[s+1]) of `rows`), FAD between the baseline (mu_b, cov_b) and that song's
+ * own (mu_s, cov_s).  Songs with fewer than 2 frames get status FAD_ERR_TOO_FEW_ROWS and a NaN
+ * score (the reference drops them, fad.py:380-391).
+ * mean_mode: 0 = song mean in float64; 1 = round the song mean to the input dtype first, as
+ * np.mean does for float16 (model_loader.py:47-48 + fad.py:48).
+ */
+int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const double* cov_b,
+                                    const void* rows, int64_t n_rows, int64_t ld, int dtype,
+                                    const int64_t* offsets, int64_t n_songs, int mean_mode,
+                                    int on_device, int device, void* stream,
+                                    double* out_scores, int32_t* out_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAD_HIP_H */

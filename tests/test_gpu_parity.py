@@ -1,0 +1,406 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
+
+Bar (BASELINE.json north_star): |FAD_gpu - FAD_ref| / |FAD_ref| <= 1e-4.  The checks below are
+tighter wherever the arithmetic allows, so a regression shows long before the bar is hit.
+"""
+import logging
+
+import numpy as np
+import pytest
+
+import recipes as R
+from oracle import fad_oracle as O
+
+pytestmark = pytest.mark.gpu
+logging.getLogger("fad_oracle").setLevel(logging.CRITICAL)
+
+FAD_BAR = 1e-4
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fadtk_amd
+    from fadtk_amd import _capi
+    _capi.require_gpu(0)
+    return fadtk_amd
+
+
+def structured_rows(seed, n, d, dtype):
+    """Column-dependent gains, shifts and cross-correlations: any column permutation or transposition
+    in the kernel's fragment/epilogue maps changes the expected covariance."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d))
+    gains = 0.5 + np.arange(d) / d
+    x = x * gains + 0.3 * np.sin(np.arange(d))
+    x[:, 1:] += 0.25 * x[:, :-1]                    # asymmetric neighbour coupling
+    return x.astype(dtype)
+
+
+# --------------------------------------------------------------------------------- moments
+@pytest.mark.parametrize("n,d", [(2, 8), (257, 16), (1024, 128), (3000, 512), (777, 200), (4099, 136), (50, 768)])
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64])
+def test_moments_match_np_cov(F, n, d, dtype):
+    x = structured_rows(n * 7 + d, n, d, dtype)
+    mu, cov = F.calc_embd_statistics(x)
+    mu_o, cov_o = O.embd_statistics(x)
+    assert mu.dtype == mu_o.dtype and cov.dtype == np.float64
+    scale = np.abs(cov_o).max()
+    tol = 2e-6 if dtype == np.float16 else 1e-11            # fp16 path sums bounded runs in fp32
+    np.testing.assert_allclose(cov, cov_o, rtol=0, atol=tol * scale)
+    np.testing.assert_array_equal(cov, cov.T)                # exactly symmetric, like dsyrk
+    if dtype == np.float64:
+        np.testing.assert_allclose(mu, mu_o, rtol=1e-13, atol=1e-15)
+    else:                                                    # <= 1 ulp of the rounded dtype (numpy sums in fp32)
+        ulp = np.spacing(np.abs(mu_o).astype(mu_o.dtype)).astype(np.float64)
+        assert np.all(np.abs(mu.astype(np.float64) - mu_o.astype(np.float64)) <= ulp)
+        assert np.mean(mu == mu_o) > 0.95
+
+
+def test_moments_golden_g1(F, golden, golden_dir):
+    z = np.load(golden_dir / "g1_stats.npz")
+    for c in golden["g1"]:
+        x = R.normal_rows(c["seed"], c["n"], c["d"], c["scale"], c["shift"], dtype=np.dtype(c["dtype"]))
+        mu, cov = F.calc_embd_statistics(x)
+        assert str(mu.dtype) == c["mu_dtype"]
+        ref = z[f"cov{c['id']}"]
+        np.testing.assert_allclose(cov, ref, rtol=0, atol=(2e-6 if c["dtype"] == "float16" else 1e-11) * np.abs(ref).max())
+
+
+def test_moments_alignment_and_pitch_fallbacks(F):
+    from fadtk_amd.hip import Moments
+    big = structured_rows(5, 600, 136, np.float16)
+    views = {"pitched": big[:, :128],            # ld=136 > d=128, 16-B aligned rows -> MFMA kernel
+             "odd_offset": big[:, 1:129],        # rows start 2 B off a 16-B boundary -> generic kernel
+             "odd_width": big[:, :131]}          # d % 8 != 0 -> generic kernel
+    for name, v in views.items():
+        with Moments(v.shape[1]) as m:
+            m.update(v)
+            mu, cov, n = m.finalize()
+        mu_o, cov_o = O.embd_statistics(np.ascontiguousarray(v))
+        assert n == 600
+        np.testing.assert_allclose(cov, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max(), err_msg=name)
+        np.testing.assert_allclose(mu, mu_o.astype(np.float64), rtol=0, atol=1e-3, err_msg=name)
+
+
+def test_moments_mfma_and_generic_kernels_agree(F, monkeypatch):
+    from fadtk_amd.hip import Moments
+    x = structured_rows(9, 5000, 256, np.float16)
+    with Moments(256) as m:
+        m.set_timing(True)
+        m.update(x)
+        _, _, variant = m.last_timing()
+        p_mfma = m.export()
+    assert variant == 0
+    monkeypatch.setenv("FAD_MOMENTS_FORCE_GENERIC", "1")
+    with Moments(256) as m:
+        m.set_timing(True)
+        m.update(x)
+        _, _, variant = m.last_timing()
+        p_gen = m.export()
+    assert variant == 1
+    x64 = x.astype(np.float64)
+    exact = x64.T @ x64
+    d = 256
+    np.testing.assert_allclose(p_gen[1 + d:].reshape(d, d), exact, rtol=1e-12)
+    np.testing.assert_allclose(p_mfma[1 + d:].reshape(d, d), exact, rtol=0, atol=1e-6 * np.abs(exact).max())
+    np.testing.assert_allclose(p_mfma[1:1 + d], x64.sum(0), rtol=1e-12, atol=1e-9)   # column sums are fp64-exact
+    assert p_mfma[0] == 5000 and p_gen[0] == 5000
+
+
+def test_moments_streaming_merge_export_import(F):
+    """Sufficient statistics are additive: chunked updates, merged handles and an export/import
+    round trip (the multi-GPU reduce) all give the statistics of the whole set."""
+    from fadtk_amd.hip import Moments
+    x = structured_rows(11, 9000, 128, np.float16)
+    with Moments(128) as whole, Moments(128) as parts, Moments(128) as a, Moments(128) as b, Moments(128) as c:
+        whole.update(x)
+        for lo, hi in ((0, 1), (1, 4000), (4000, 4000), (4000, 9000)):      # includes an empty block
+            parts.update(x[lo:hi])
+        a.update(x[:2500]); b.update(x[2500:])
+        a.merge(b)
+        c.import_(a.export())
+        pw, pp, pa, pc = whole.export(), parts.export(), a.export(), c.export()
+        assert whole.count == 9000 and parts.count == 9000 and c.count == 9000
+    np.testing.assert_array_equal(pa, pc)
+    scale = np.abs(pw).max()
+    np.testing.assert_allclose(pp, pw, rtol=0, atol=1e-6 * scale)
+    np.testing.assert_allclose(pa, pw, rtol=0, atol=1e-6 * scale)
+
+
+def test_moments_torch_device_tensors(F):
+    import torch
+    from fadtk_amd.hip import Moments
+    x = structured_rows(13, 2048, 256, np.float32)
+    for tdt in (torch.float16, torch.bfloat16, torch.float32, torch.float64):
+        xt = torch.from_numpy(x).to("cuda").to(tdt)
+        with Moments(256) as m:
+            m.update(xt)
+            torch.cuda.synchronize()
+            mu, cov, n = m.finalize()
+        ref = xt.to(torch.float64).cpu().numpy()
+        mu_o, cov_o = ref.mean(0), np.cov(ref, rowvar=False)
+        np.testing.assert_allclose(cov, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+        np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-9)
+
+
+def test_moments_edge_cases(F):
+    from fadtk_amd.hip import Moments
+    with pytest.raises(AssertionError):
+        F.calc_embd_statistics(np.zeros((1, 8), np.float16))
+    with Moments(8) as m:
+        m.update(np.zeros((0, 8), np.float16))
+        assert m.count == 0
+        with pytest.raises(AssertionError):
+            m.finalize()
+        with pytest.raises(AssertionError):
+            m.update(np.zeros((4, 9), np.float16))
+        m.update(np.ones((1, 8), np.float32))
+        with pytest.raises(AssertionError):
+            m.finalize()
+        m.update(3 * np.ones((1, 8), np.float32))
+        mu, cov, n = m.finalize()
+        assert n == 2 and np.allclose(mu, 2.0) and np.allclose(cov, 2.0)
+        m.reset()
+        assert m.count == 0
+
+
+# --------------------------------------------------------------------------------- frechet
+def _pair_stats(a, b):
+    m1, c1 = O.embd_statistics(a)
+    m2, c2 = O.embd_statistics(b)
+    return m1, c1, m2, c2
+
+
+@pytest.mark.parametrize("case", ["c1_iid", "c1_iid_f32", "c1_iid_f64", "shifted"])
+def test_frechet_golden_pairs(F, golden, case):
+    g = golden["g2"][case]
+    a, b = {"c1_iid": R.c1_pair, "c1_iid_f32": lambda: R.c1_pair(np.float32),
+            "c1_iid_f64": lambda: R.c1_pair(np.float64), "shifted": R.shifted_pair}[case]()
+    fad = F.calc_frechet_distance(*_pair_stats(a, b))
+    assert isinstance(fad, np.float64)
+    assert abs(fad - g["fad"]) / abs(g["fad"]) < 1e-9
+    # and with the statistics from the GPU as well (the whole path)
+    m1, c1 = F.calc_embd_statistics(a)
+    m2, c2 = F.calc_embd_statistics(b)
+    fad2 = F.calc_frechet_distance(m1, c1, m2, c2)
+    assert abs(fad2 - g["fad"]) / abs(g["fad"]) < FAD_BAR / 10
+
+
+def test_frechet_identical_sets_is_zero(F, golden):
+    a, _ = R.c1_pair()
+    fad = F.calc_frechet_distance(*_pair_stats(a, a))
+    assert abs(fad) < 1e-8 * golden["g2"]["identical"]["tr1"]
+
+
+@pytest.mark.parametrize("d", [64, 512])
+def test_frechet_decaying_spectrum(F, golden, d):
+    x1 = R.decaying_rows(30, 4 * d, d, basis_seed=40)
+    x2 = R.decaying_rows(31, 4 * d, d, basis_seed=40, gain=1.1)
+    x3 = R.decaying_rows(32, 4 * d, d, basis_seed=41)
+    for other, key in ((x2, f"decay_same_basis_d{d}"), (x3, f"decay_diff_basis_d{d}")):
+        fad = F.calc_frechet_distance(*_pair_stats(x1, other))
+        assert abs(fad - golden["g2"][key]["fad"]) / abs(golden["g2"][key]["fad"]) < 1e-6, key
+
+
+@pytest.mark.parametrize("d,rows", [(128, 2), (128, 10), (128, 50), (768, 2), (768, 10)])
+def test_frechet_rank_deficient(F, golden, d, rows):
+    g = golden["g2"][f"rankdef_d{d}_n{rows}"]
+    mu_b, cov_b = R.baseline_stats(50 + d, 4 * d, d)
+    s = R.songs(60 + rows, 1, rows, d)[0]
+    mu_s, cov_s = O.embd_statistics(s)
+    fad = F.calc_frechet_distance(mu_b, cov_b, mu_s, cov_s)
+    assert abs(fad - g["fad"]) / abs(g["fad"]) < 1e-6
+
+
+def test_frechet_properties(F):
+    """Size-independent properties: symmetry in its arguments and quadratic scaling."""
+    a = structured_rows(21, 3000, 96, np.float32)
+    b = structured_rows(22, 2500, 96, np.float32) * 1.1 + 0.05
+    m1, c1, m2, c2 = _pair_stats(a, b)
+    f12 = F.calc_frechet_distance(m1, c1, m2, c2)
+    f21 = F.calc_frechet_distance(m2, c2, m1, c1)
+    assert abs(f12 - f21) < 1e-9 * abs(f12)
+    f_scaled = F.calc_frechet_distance(3 * m1, 9 * c1, 3 * m2, 9 * c2)
+    assert abs(f_scaled - 9 * f12) < 1e-9 * abs(9 * f12)
+    assert abs(f12 - O.frechet_distance(m1, c1, m2, c2, run_sqrtm=False)) < 1e-9 * abs(f12)
+
+
+def test_frechet_errors(F):
+    e8, e9 = np.eye(8), np.eye(9)
+    with pytest.raises(AssertionError):
+        F.calc_frechet_distance(np.zeros(8), e8, np.zeros(9), e9)
+    with pytest.raises(AssertionError):
+        F.calc_frechet_distance(np.zeros(8), e8, np.zeros(8), e9)
+    bad = e8.copy(); bad[0, 0] = np.nan
+    with pytest.raises(ValueError):
+        F.calc_frechet_distance(np.zeros(8), bad, np.zeros(8), e8)
+    neg = -e8                                              # product with negative eigenvalues: no real root
+    with pytest.raises(ValueError):
+        F.calc_frechet_distance(np.zeros(8), neg, np.zeros(8), e8)
+    # zero covariance: root is zero, distance is the mean term + traces
+    assert F.calc_frechet_distance(np.ones(8), np.zeros((8, 8)), np.zeros(8), e8) == pytest.approx(16.0)
+
+
+def test_frechet_from_moments_matches_host_route(F):
+    from fadtk_amd import hip
+    a, b = R.c1_pair()
+    with hip.Moments(128) as ma, hip.Moments(128) as mb:
+        ma.update(a); mb.update(b)
+        fad, diag = hip.frechet_from_moments(ma, mb)
+        mu1, c1, _ = ma.finalize(); mu2, c2, _ = mb.finalize()
+    fad_host, _ = hip.frechet(mu1, c1, mu2, c2)
+    assert abs(fad - fad_host) < 1e-12 * abs(fad_host)
+    assert diag["converged"] == 1 and diag["iters"] < 20
+    with hip.Moments(128) as ma, hip.Moments(128) as mb:
+        ma.update(a); mb.update(b[:1])
+        with pytest.raises(AssertionError):
+            hip.frechet_from_moments(ma, mb)
+
+
+def test_config3_full_size(F, golden):
+    """BASELINE config 3: N=100000, D=512 fp16, whole path on the GPU vs the reference's scalar."""
+    g = golden["g7"]
+    a, b = R.c3_pair()
+    assert R.checksum(a) == pytest.approx(g["in_checksum"][0], rel=1e-12)
+    m1, c1 = F.calc_embd_statistics(a)
+    m2, c2 = F.calc_embd_statistics(b)
+    assert m1.dtype == np.float16
+    assert np.trace(c1) == pytest.approx(g["tr1"], rel=1e-7)
+    assert np.trace(c2) == pytest.approx(g["tr2"], rel=1e-7)
+    d = m1 - m2
+    assert float(d.dot(d)) == pytest.approx(g["mean_term"], rel=2e-3)      # fp16 scalar in the reference too
+    fad = F.calc_frechet_distance(m1, c1, m2, c2)
+    assert abs(fad - g["fad"]) / g["fad"] < FAD_BAR
+    # device-resident route (what bench.py times)
+    import torch
+    from fadtk_amd import hip
+    with hip.Moments(512) as ma, hip.Moments(512) as mb:
+        ma.update(torch.from_numpy(a).cuda()); mb.update(torch.from_numpy(b).cuda())
+        fad_dev, diag = hip.frechet_from_moments(ma, mb)
+    # this route keeps the means in float64 (no fp16 rounding of mu): compare the root, not the mean term
+    assert diag["tr_sqrt"] == pytest.approx(g["tr_sqrt"], rel=2e-7)
+    assert abs((fad_dev - diag["mean_term"]) - (g["fad"] - g["mean_term"])) / g["fad"] < FAD_BAR
+
+
+# --------------------------------------------------------------------------------- online statistics
+def test_online_statistics_golden_g3(F, golden, golden_dir, tmp_path):
+    g = golden["g3"]
+    z = np.load(golden_dir / "g3_online.npz")
+    blocks = R.ragged_files(g["seed"], g["n_files"], g["d"])
+    files = []
+    for i, blk in enumerate(blocks):
+        np.save(tmp_path / f"f{i:03d}.npy", blk)
+        files.append(tmp_path / f"f{i:03d}.npy")
+    mu, cov = F.calculate_embd_statistics_online(files)
+    assert mu.dtype == np.float64 and cov.dtype == np.float64
+    np.testing.assert_allclose(mu, z["mu"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(cov, z["cov"], rtol=0, atol=2e-6 * np.abs(z["cov"]).max())
+    mu_i, cov_i = F.dataset_statistics(blocks, compat=False)            # plain raw-moment estimate
+    allrows = np.concatenate(blocks).astype(np.float64)
+    np.testing.assert_allclose(cov_i, np.cov(allrows, rowvar=False), rtol=0, atol=2e-6 * np.abs(cov_i).max())
+    # Q5: a one-row file poisons the covariance, not the mean
+    np.save(tmp_path / "one.npy", blocks[0][:1])
+    mu_n, cov_n = F.calculate_embd_statistics_online(files[:3] + [tmp_path / "one.npy"])
+    assert np.isnan(cov_n).all() and g["cov_nan_all"]
+    np.testing.assert_allclose(mu_n, z["mu_nan"], rtol=1e-12)
+
+
+# --------------------------------------------------------------------------------- per-song
+class _Toy:
+    def __init__(self, name):
+        self.name = name
+        self.sr = 16000
+
+    def load_model(self):
+        raise AssertionError("not needed")
+
+
+def test_score_individual_golden_g4_and_load_stats_g5(F, golden, golden_dir, tmp_path):
+    g = golden["g4"]
+    model, d = g["model"], g["d"]
+    evald = tmp_path / "evalset"
+    (evald / "embeddings" / model).mkdir(parents=True)
+    from pathlib import Path
+    for nm, rows in zip(g["names"], R.songs(g["songs_seed"], len(g["names"]), g["rows"], d)):
+        (evald / nm).write_bytes(b"")
+        np.save(evald / "embeddings" / model / (Path(nm).stem + ".npy"), rows)
+    mu_b, cov_b = R.baseline_stats(g["base_seed"], g["base_n"], d)
+    np.savez(tmp_path / "base.npz", **{f"{model}.mu": mu_b, f"{model}.cov": cov_b})
+    fad = F.FrechetAudioDistance(_Toy(model), audio_load_worker=2, load_model=False)
+    out = fad.score_individual(str(tmp_path / "base.npz"), evald, tmp_path / "indiv.csv")
+    got = [ln.rsplit(",", 1) for ln in out.read_text().replace(str(tmp_path), "{ROOT}").split("\n")]
+    want = [ln.rsplit(",", 1) for ln in g["csv"].split("\n")]
+    assert [a for a, _ in got] == [a for a, _ in want]                    # order, dropped 1-frame song, ','->'_'
+    np.testing.assert_allclose([float(b) for _, b in got], [float(b) for _, b in want], rtol=1e-6)
+    assert fad.score_individual(str(tmp_path / "base.npz"), evald, tmp_path / "indiv.csv") == out   # resume-by-cache
+
+    g5 = golden["g5"]
+    clean = tmp_path / "clean"
+    (clean / "embeddings" / model).mkdir(parents=True)
+    for i, blk in enumerate(R.ragged_files(g5["seed"], g5["n_files"], d)):
+        np.save(clean / "embeddings" / model / f"c{i}.npy", blk)
+    mu_c, cov_c = fad.load_stats(clean)
+    z = np.load(golden_dir / "g5_stats.npz")
+    np.testing.assert_allclose(mu_c, z["mu"], rtol=1e-10, atol=1e-12)    # merge order differs: glob order is fs-dependent
+    np.testing.assert_allclose(cov_c, z["cov"], rtol=0, atol=2e-6 * np.abs(z["cov"]).max())
+    assert sorted(p.name for p in (clean / "stats" / model).glob("*")) == g5["cache_files"]
+    assert str(np.load(clean / "stats" / model / "mu.npy").dtype) == g5["mu_dtype"]
+    assert str(np.load(clean / "stats" / model / "cov.npy").dtype) == g5["cov_dtype"]
+    mu_again, cov_again = fad.load_stats(clean)
+    assert np.array_equal(mu_c, mu_again) and np.array_equal(cov_c, cov_again)
+    mu_n, cov_n = fad.load_stats(str(tmp_path / "base.npz"))
+    assert np.array_equal(mu_n, mu_b) and np.array_equal(cov_n, cov_b)
+    with pytest.raises(ValueError):
+        F.FrechetAudioDistance(_Toy("other-model"), load_model=False).load_stats(str(tmp_path / "base.npz"))
+    score = fad.score(str(tmp_path / "base.npz"), clean)
+    assert abs(score - g5["fad_clean_vs_npz"]) / g5["fad_clean_vs_npz"] < 1e-6
+
+
+def test_two_frame_songs_config5_shape_g8(F, golden):
+    from fadtk_amd import hip
+    g = golden["g8"]
+    d = g["d"]
+    mu_b, cov_b = R.baseline_stats(g["base_seed"], g["base_n"], d)
+    sg = R.songs(g["songs_seed"], g["n_songs"], g["rows"], d)
+    rows = np.concatenate(sg)
+    offs = np.arange(0, 2 * g["n_songs"] + 1, 2)
+    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+    assert (status == 0).all()
+    np.testing.assert_allclose(scores, g["scores"], rtol=1e-6)
+    import torch
+    scores_dev, _ = hip.frechet_batched(mu_b, cov_b, torch.from_numpy(rows).cuda(), offs, mean_mode=1)
+    np.testing.assert_allclose(scores_dev, scores, rtol=1e-12)
+
+
+def test_multi_frame_songs_g8(F, golden):
+    from fadtk_amd import hip
+    m = golden["g8"]["multi"]
+    d = m["d"]
+    mu_b, cov_b = R.baseline_stats(m["base_seed"], m["base_n"], d)
+    sg = R.songs(m["songs_seed"], m["n_songs"], m["rows"], d)
+    sg_with_bad = sg[:3] + [sg[0][:1], sg[0][:0]] + sg[3:]                  # 1-frame and empty songs in the middle
+    rows = np.concatenate(sg_with_bad)
+    offs = np.concatenate([[0], np.cumsum([s.shape[0] for s in sg_with_bad])])
+    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+    assert status[3] == -6 and status[4] == -6 and np.isnan(scores[3]) and np.isnan(scores[4])
+    keep = [i for i in range(len(sg_with_bad)) if i not in (3, 4)]
+    assert (status[keep] == 0).all()
+    np.testing.assert_allclose(scores[keep], m["scores"], rtol=1e-6)
+
+
+def test_score_inf_golden_g6(F, golden, tmp_path):
+    g = golden["g6"]
+    mu_b, cov_b = R.baseline_stats(g["base_seed"], g["base_n"], g["d"])
+    rows = R.normal_rows(g["rows_seed"], g["n"], g["d"], 1.1, 0.05)
+    np.savez(tmp_path / "b.npz", **{"toy.mu": mu_b, "toy.cov": cov_b})
+    files = []
+    for i in range(4):
+        np.save(tmp_path / f"e{i}.npy", rows[i * 500:(i + 1) * 500])
+        files.append(tmp_path / f"e{i}.npy")
+    fad = F.FrechetAudioDistance(_Toy("toy"), load_model=False)
+    np.random.seed(0)
+    res = fad.score_inf(str(tmp_path / "b.npz"), files)
+    assert [p[0] for p in res.points] == [p[0] for p in g["points"]]
+    np.testing.assert_allclose([p[1] for p in res.points], [p[1] for p in g["points"]], rtol=FAD_BAR / 10)
+    assert res.score == pytest.approx(g["score"], rel=FAD_BAR)
+    assert res.r2 == pytest.approx(g["r2"], rel=1e-3)
