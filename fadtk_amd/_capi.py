@@ -94,6 +94,10 @@ def load_library(path: Optional[os.PathLike] = None):
             raise FadHipUnavailable(
                 f"{p} is missing: build it with `python -m fadtk_amd.build` (needs hipcc). "
                 "fadtk_amd has no CPU fallback for the FAD hot path.")
+        try:                       # bring PyTorch's bundled HIP runtime in first: one runtime per process,
+            import torch           # noqa: F401  so torch streams / events / device pointers are ours too
+        except Exception:          # noqa: BLE001  (pure C users run on the system ROCm runtime)
+            pass
         lib = C.CDLL(str(p))
         for name, (res, args) in SIGNATURES.items():
             try:

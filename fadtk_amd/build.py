@@ -33,6 +33,18 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libfad_hip.so")
 
 
+def _torch_lib_dir():
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            d = Path(spec.origin).parent / "lib"
+            return str(d) if d.exists() else None
+    except Exception:       # noqa: BLE001
+        pass
+    return None
+
+
 def _stale(out: Path, deps) -> bool:
     if not out.exists():
         return True
@@ -68,7 +80,13 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
             list(ex.map(compile_one, jobs))
     objs = [objdir / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+        # ONE HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so (no SONAME,
+        # found by file name).  Linking against that copy makes our NEEDED entry "libamdhip64.so", which
+        # the loader resolves to torch's already-loaded runtime -- so torch's streams, events and device
+        # pointers are valid inside the library.  Without torch the system ROCm runtime is used.
+        link_dirs = [d for d in (_torch_lib_dir(), "/opt/rocm/lib") if d and (Path(d) / "libamdhip64.so").exists()]
+        cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
+               f"-L{link_dirs[0]}", "-lamdhip64", *[f"-Wl,-rpath,{d}" for d in link_dirs], "-Wl,--enable-new-dtags"]
         if verbose:
             print("[fadtk_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __rest
     if (g < d) mu[g] = sum[g] / n;
     if (g >= (int64_t)d * d) return;
     const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
-    cov[g] = (M[g] - sum[a] * (sum[b] / n)) / (n - (double)ddof);
+    cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit
 }
 
 __global__ void clear_states(NsState* st, int64_t B) {

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(
     if (g < d && mu) mu[g] = sum[g] / n;
     if (g >= (int64_t)d * d) return;
     const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
-    cov[g] = (M[g] - sum[a] * (sum[b] / n)) / (n - (double)ddof);
+    cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit
 }
 
 }  // namespace fad

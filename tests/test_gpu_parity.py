@@ -50,7 +50,10 @@ def test_moments_match_np_cov(F, n, d, dtype):
     np.testing.assert_array_equal(cov, cov.T)                # exactly symmetric, like dsyrk
     if dtype == np.float64:
         np.testing.assert_allclose(mu, mu_o, rtol=1e-13, atol=1e-15)
-    else:                                                    # <= 1 ulp of the rounded dtype (numpy sums in fp32)
+    elif dtype == np.float32:                                # numpy's own fp32 running sum is the noisy side here
+        np.testing.assert_allclose(mu, mu_o, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(mu, x.astype(np.float64).mean(0).astype(np.float32), rtol=0, atol=0)
+    else:                                                    # <= 1 ulp of fp16 (numpy sums fp16 in fp32, then rounds)
         ulp = np.spacing(np.abs(mu_o).astype(mu_o.dtype)).astype(np.float64)
         assert np.all(np.abs(mu.astype(np.float64) - mu_o.astype(np.float64)) <= ulp)
         assert np.mean(mu == mu_o) > 0.95
@@ -103,7 +106,7 @@ def test_moments_mfma_and_generic_kernels_agree(F, monkeypatch):
     d = 256
     np.testing.assert_allclose(p_gen[1 + d:].reshape(d, d), exact, rtol=1e-12)
     np.testing.assert_allclose(p_mfma[1 + d:].reshape(d, d), exact, rtol=0, atol=1e-6 * np.abs(exact).max())
-    np.testing.assert_allclose(p_mfma[1:1 + d], x64.sum(0), rtol=1e-12, atol=1e-9)   # column sums are fp64-exact
+    np.testing.assert_allclose(p_mfma[1:1 + d], x64.sum(0), rtol=1e-7, atol=1e-6)   # 8-term fp32 sums, then fp64
     assert p_mfma[0] == 5000 and p_gen[0] == 5000
 
 
@@ -221,7 +224,7 @@ def test_frechet_properties(F):
     f21 = F.calc_frechet_distance(m2, c2, m1, c1)
     assert abs(f12 - f21) < 1e-9 * abs(f12)
     f_scaled = F.calc_frechet_distance(3 * m1, 9 * c1, 3 * m2, 9 * c2)
-    assert abs(f_scaled - 9 * f12) < 1e-9 * abs(9 * f12)
+    assert abs(f_scaled - 9 * f12) < 1e-7 * abs(9 * f12)
     assert abs(f12 - O.frechet_distance(m1, c1, m2, c2, run_sqrtm=False)) < 1e-9 * abs(f12)
 
 
