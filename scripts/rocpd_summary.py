@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3's rocpd SQLite output into small text summaries (kernel stats / PMC means).
+
+    python scripts/rocpd_summary.py stats  <results.db>  > profiles/rNN_kernel_stats.csv
+    python scripts/rocpd_summary.py pmc    <results.db>  > profiles/rNN_pmc_<counter>.csv
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    m = re.match(r"(?:void )?([\w:]+(?:<[^()]{0,60}>)?)", name)
+    s = m.group(1) if m else name
+    return s[:90]
+
+
+def main():
+    mode, db = sys.argv[1], sys.argv[2]
+    cur = sqlite3.connect(db).cursor()
+    if mode == "stats":
+        print("kernel,calls,total_us,avg_us,min_us,max_us,pct,vgpr,agpr,lds_bytes,grid,workgroup")
+        rows = cur.execute(
+            "select name, count(*), sum(duration)/1e3, avg(duration)/1e3, min(duration)/1e3, max(duration)/1e3, "
+            "max(vgpr_count), max(accum_vgpr_count), max(lds_size), max(grid_x*grid_y*grid_z), max(workgroup_x) "
+            "from kernels group by name order by sum(duration) desc").fetchall()
+        total = sum(r[2] for r in rows) or 1.0
+        for r in rows[:40]:
+            print(f"\"{short(r[0])}\",{r[1]},{r[2]:.1f},{r[3]:.2f},{r[4]:.2f},{r[5]:.2f},{100 * r[2] / total:.2f},"
+                  f"{r[6]},{r[7]},{r[8]},{r[9]},{r[10]}")
+    else:
+        print("kernel,counter,mean_per_dispatch,dispatches")
+        for r in cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                             "group by kernel_name, counter_name order by avg(value) desc limit 40"):
+            print(f"\"{short(r[0])}\",{r[1]},{r[2]:.1f},{r[3]}")
+
+
+if __name__ == "__main__":
+    main()
