@@ -202,6 +202,152 @@ __global__ __launch_bounds__(256) void moments_tile_h16(
 }
 
 // ------------------------------------------------------------------------------------------
+// v2 of the fp16/bf16 tile kernel: same tiling and fragment trick, but the slabs of E go
+// HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip)
+// through a ring of NST stages, so each workgroup keeps NST-1 stages (up to 48 KiB) of loads in
+// flight instead of one.  v1 was latency-bound: one 16 KiB stage in flight per workgroup gave
+// 0.9 TB/s.  Waits are counted (s_waitcnt vmcnt(N), never 0 in steady state) and the barrier is a
+// raw s_barrier so that younger stages stay in flight across it.
+// Out-of-range rows / columns are redirected per lane to a 16-byte block of zeros.
+// ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KIND, int NST, bool DIAG>
+__device__ __forceinline__ void tile_h16_glds_body(
+    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
+    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
+    uint4* smem) {
+    constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
+    constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, kg = lane >> 5;
+    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
+
+    const int sr = tid >> 4, sc = tid & 15;
+    const bool col_ok_a = (ca + sc * 8) < d;
+    const bool col_ok_b = (cb + sc * 8) < d;
+    const uint16_t* ga = E + ca + sc * 8;
+    const uint16_t* gb = E + cb + sc * 8;
+    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
+
+    auto issue = [&](int kb) {
+        uint4* st = smem + (kb % NST) * STAGE;
+        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t r = r0 + 16 * h;
+            const bool ok = r < k_end;
+            // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
+            uint4* dstA = st + 256 * h + 64 * wave;
+            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)dstA, 16, 0, 0);
+            if (!DIAG) {
+                const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
+    double csum[2] = {0.0, 0.0};
+    const bool do_colsum = DIAG && (wr == 0);
+
+    for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        // stage kb must have landed; up to NST-2 younger stages may stay in flight
+        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
+        if (ahead >= 2) wait_vmcnt<2 * LPS>();
+        else if (ahead == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // every wave's pieces of stage kb are in LDS; stage kb-1 is free
+        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+
+        const uint32_t* sA = reinterpret_cast<const uint32_t*>(smem + (kb % NST) * STAGE);
+        const uint32_t* sB = DIAG ? sA : sA + H_KB * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rbase = ks * 16 + kg * 8;
+            uint32_t wa[8], wb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                wa[e] = sA[(rbase + e) * 64 + 32 * wr + li];
+                wb[e] = sB[(rbase + e) * 64 + 32 * wc + li];
+            }
+            uint4 a0, a1, b0, b1;
+            a0.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x05040100u); a1.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x07060302u);
+            a0.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x05040100u); a1.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x07060302u);
+            a0.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x05040100u); a1.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x07060302u);
+            a0.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x05040100u); a1.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x07060302u);
+            b0.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x05040100u); b1.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u);
+            b0.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x05040100u); b1.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u);
+            b0.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x05040100u); b1.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x07060302u);
+            b0.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x05040100u); b1.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x07060302u);
+            acc[0][0] = mfma_h16<KIND>(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_h16<KIND>(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_h16<KIND>(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_h16<KIND>(a1, b1, acc[1][1]);
+            if (do_colsum) {
+                csum[0] += (double)sum8<KIND>(b0);
+                csum[1] += (double)sum8<KIND>(b1);
+            }
+        }
+    }
+
+    float* out = partials + ((int64_t)split * T + tile) * (H_BT * H_BT);
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+            const int a_local = 64 * wr + 2 * row32 + fa;
+            const int b_local = 64 * wc + 2 * li;
+            *reinterpret_cast<float2*>(out + a_local * H_BT + b_local) = make_float2(acc[fa][0][reg], acc[fa][1][reg]);
+        }
+    }
+    if (do_colsum) {
+        csum[0] += __shfl_xor(csum[0], 32);
+        csum[1] += __shfl_xor(csum[1], 32);
+        if (kg == 0) {
+            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + 2 * li;
+            cp[0] = csum[0]; cp[1] = csum[1];
+        }
+    }
+}
+
+template <int KIND, int NST>
+__global__ __launch_bounds__(256) void moments_tile_h16_glds(
+    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
+    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
+    const int w = xcd_contiguous(blockIdx.x, S * T);
+    const int split = w / T, tile = w - split * T;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const int64_t k_begin = (int64_t)split * rows_per_split;
+    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    if (ta == tb)
+        tile_h16_glds_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+                                            partials, colpart, smem_dyn);
+    else
+        tile_h16_glds_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+                                             partials, colpart, smem_dyn);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic tile kernel: any input dtype, any pitch/alignment.  Everything in fp64 on
 // v_mfma_f64_16x16x4_f64 (A: lane l holds A[i=l&15][k=l>>4]; B[k=l>>4][j=l&15];
 // D: col = l&15, row = (l>>4) + 4*reg).  Workgroup tile 64x64, wave tile 32x32, 16 rows/stage.
@@ -319,8 +465,21 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
 // ------------------------------------------------------------------------------------------
 template <typename PT, int BT>
 __global__ __launch_bounds__(256) void moments_reduce(
-    const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed) {
+    const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed,
+    const double* __restrict__ colpart, double n_add, int tile_blocks) {
     const int per_tile = BT * BT / 4;
+    if ((int)blockIdx.x >= tile_blocks) {          // trailing blocks: column sums and the row count
+        const int a = ((int)blockIdx.x - tile_blocks) * 256 + threadIdx.x;
+        if (a == 0) acc_packed[0] += n_add;
+        if (a >= d) return;
+        const int dpad = nt * BT;
+        double s0 = 0.0, s1 = 0.0;
+        int sp = 0;
+        for (; sp + 1 < S; sp += 2) { s0 += colpart[(int64_t)sp * dpad + a]; s1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
+        if (sp < S) s0 += colpart[(int64_t)sp * dpad + a];
+        acc_packed[1 + a] += s0 + s1;
+        return;
+    }
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= (int64_t)T * per_tile) return;
     const int tile = (int)(g / per_tile), e = (int)(g - (int64_t)tile * per_tile);
@@ -355,17 +514,6 @@ __global__ __launch_bounds__(256) void moments_reduce(
             if (a != b) M[(int64_t)b * d + a] += s[q];
         }
     }
-}
-
-__global__ __launch_bounds__(256) void moments_reduce_cols(
-    const double* __restrict__ colpart, int S, int dpad, int d, double n_add,
-    double* __restrict__ acc_packed) {
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a == 0) acc_packed[0] += n_add;
-    if (a >= d) return;
-    double s = 0.0;
-    for (int sp = 0; sp < S; ++sp) s += colpart[(int64_t)sp * dpad + a];
-    acc_packed[1 + a] += s;
 }
 
 // per-segment column sums: seg_sums[s][a] = sum over rows of segment s of E[r][a]   (fp64)
@@ -446,7 +594,7 @@ static SplitPlan plan_splits(int64_t n, int d, int bt, int kb, int n_cu, int wg_
     SplitPlan p;
     p.nt = (int)cdiv(d, bt);
     p.T = p.nt * (p.nt + 1) / 2;
-    int64_t want = cdiv((int64_t)n_cu * wg_per_cu, p.T);
+    int64_t want = ((int64_t)n_cu * wg_per_cu) / p.T;      // floor: never more workgroups than resident slots
     int64_t max_by_rows = cdiv(n, min_rows);
     int64_t s = want < max_by_rows ? want : max_by_rows;
     if (s < 1) s = 1;
@@ -484,28 +632,45 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         h->ev_count++;
     }
     if (use_h16) {
+        const char* var = getenv("FAD_MOMENTS_VARIANT");
+        const int variant = (var && var[0] == '1') ? 1 : 2;
+        constexpr int NST = 4;
         SplitPlan p = plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256);
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_BT * H_BT * sizeof(float)));
         FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
         float* part = static_cast<float*>(h->partials.p);
         double* colp = static_cast<double*>(h->colpart.p);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-        if (dtype == FAD_F16)
-            hipLaunchKernelGGL((moments_tile_h16<FAD_F16>), dim3(p.S * p.T), dim3(256), 0, st,
-                               static_cast<const uint16_t*>(rows), n, ld, d, p.nt, p.T, p.S,
-                               p.rows_per_split, part, colp);
-        else
-            hipLaunchKernelGGL((moments_tile_h16<FAD_BF16>), dim3(p.S * p.T), dim3(256), 0, st,
-                               static_cast<const uint16_t*>(rows), n, ld, d, p.nt, p.T, p.S,
-                               p.rows_per_split, part, colp);
+        const uint16_t* e16 = static_cast<const uint16_t*>(rows);
+        if (variant == 2) {
+            const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
+            static bool attr_set = false;
+            if (!attr_set) {
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_glds<FAD_F16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_glds<FAD_BF16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            if (dtype == FAD_F16)
+                hipLaunchKernelGGL((moments_tile_h16_glds<FAD_F16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld,
+                                   d, p.nt, p.T, p.S, p.rows_per_split, part, colp);
+            else
+                hipLaunchKernelGGL((moments_tile_h16_glds<FAD_BF16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n,
+                                   ld, d, p.nt, p.T, p.S, p.rows_per_split, part, colp);
+        } else if (dtype == FAD_F16) {
+            hipLaunchKernelGGL((moments_tile_h16<FAD_F16>), dim3(p.S * p.T), dim3(256), 0, st, e16, n, ld, d, p.nt, p.T,
+                               p.S, p.rows_per_split, part, colp);
+        } else {
+            hipLaunchKernelGGL((moments_tile_h16<FAD_BF16>), dim3(p.S * p.T), dim3(256), 0, st, e16, n, ld, d, p.nt, p.T,
+                               p.S, p.rows_per_split, part, colp);
+        }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
-        const int64_t groups = (int64_t)p.T * (H_BT * H_BT / 4);
-        hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc);
-        hipLaunchKernelGGL(moments_reduce_cols, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st,
-                           colp, p.S, p.nt * H_BT, d, (double)n, h->acc);
+        const int tile_blocks = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
+        hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
+                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
-        h->last_variant = 0;
+        h->last_variant = (variant == 2) ? 0 : 2;
     } else {
         SplitPlan p = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * G_BT * G_BT * sizeof(double)));
@@ -521,11 +686,9 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             default: return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
-        const int64_t groups = (int64_t)p.T * (G_BT * G_BT / 4);
-        hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc);
-        hipLaunchKernelGGL(moments_reduce_cols, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st,
-                           colp, p.S, p.nt * G_BT, d, (double)n, h->acc);
+        const int tile_blocks = (int)cdiv((int64_t)p.T * (G_BT * G_BT / 4), 256);
+        hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
+                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = 1;
     }
