@@ -4,9 +4,9 @@
 // (replaces scipy.linalg.sqrtm / eig of fadtk/fad.py:88-92).  fp64 is required: the distance is a
 // cancellation and fp32 iterations miss the 1e-4 bar at N=100k, D=512.
 //
-// 256 threads = 4 waves as 2x2; workgroup tile BT x BT (32 or 64), 16-deep k stages, double
-// buffered LDS, A stored [row][k] with pitch 18 and B [k][col] with pitch BT+16 -- both
-// conflict-free for ds_read_b64.  MFMA fragment maps (f64 differs from the f32 maps):
+// 256 threads = 4 waves as 2x2; workgroup tile BT x BT (32 or 64), 64-deep k stages, register
+// prefetch of the next stage, A stored [row][k] with pitch 66 and B [k][col] with pitch BT+16 --
+// both conflict-free for ds_read_b64.  MFMA fragment maps (f64 differs from the f32 maps):
 //   A: lane l holds A[i = l&15][k = l>>4]     B: lane l holds B[k = l>>4][j = l&15]
 //   D: col = l&15, row = (l>>4) + 4*reg       (reg = 0..3)
 // Optional epilogue: per-workgroup sum of (C - gamma I)^2 written to a partial slot
@@ -29,17 +29,23 @@ struct GemmArgs {
     int ntypes;
 };
 
-constexpr int KB = 16;
-constexpr int PA = 18;
+constexpr int KB = 64;                 // k depth of one LDS stage
+constexpr int PA = KB + 2;             // A pitch (doubles): rows i..i+15 land on distinct bank pairs
 
+// One stage = A[BT x 64] and B[64 x BT] in LDS (single buffer); the next stage is prefetched into
+// registers as 16-byte loads while the current one feeds the MFMAs, so every thread keeps
+// BT*64*2/256 doubles (32 or 64 KiB per workgroup) of loads in flight -- the first version staged
+// 16-deep slices and was latency-bound at ~20 % of the fp64 MFMA rate.
 template <int BT>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     constexpr int MT = BT / 32;              // MFMA tiles per wave per side
     constexpr int PB = BT + 16;
-    constexpr int NA = BT * KB / 256;        // staged elements per thread per operand
-    __shared__ double sA[2][BT * PA];
-    __shared__ double sB[2][KB * PB];
-    __shared__ double red[4];
+    constexpr int NV = BT * KB / 2 / 256;    // double2 loads per thread per operand per stage
+    constexpr int BV = BT / 2;               // double2 per B row
+    __shared__ __attribute__((aligned(16))) double smem[BT * PA + KB * PB + 8];
+    double* sA = smem;
+    double* sB = smem + BT * PA;
+    double* red = smem + BT * PA + KB * PB;
 
     const int zi = (g.ntypes == 2) ? (blockIdx.z & 1) : 0;
     const int64_t zb = (g.ntypes == 2) ? (blockIdx.z >> 1) : blockIdx.z;
@@ -53,18 +59,26 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.y * BT, col0 = blockIdx.x * BT;
+    const bool vec = ((d & 1) == 0);         // 16-byte loads need even d (row starts stay 16-B aligned)
 
-    double ra[NA], rb[NA];
+    double2 ra[NV], rb[NV];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
+        for (int q = 0; q < NV; ++q) {
             const int e = tid + q * 256;
-            const int ai = e >> 4, ak = e & 15;                 // A tile [BT][16]
+            const int ai = e / (KB / 2), ak = (e % (KB / 2)) * 2;        // A tile [BT][64], pairs along k
             const int r = row0 + ai, k = k0 + ak;
-            ra[q] = (r < d && k < d) ? A[(int64_t)r * d + k] : 0.0;
-            const int bk = e / BT, bj = e % BT;                 // B tile [16][BT]
+            const int bk = e / BV, bj = (e % BV) * 2;                    // B tile [64][BT], pairs along j
             const int kk = k0 + bk, c = col0 + bj;
-            rb[q] = (kk < d && c < d) ? B[(int64_t)kk * d + c] : 0.0;
+            if (vec) {
+                ra[q] = (r < d && k < d) ? *reinterpret_cast<const double2*>(A + (int64_t)r * d + k) : make_double2(0.0, 0.0);
+                rb[q] = (kk < d && c < d) ? *reinterpret_cast<const double2*>(B + (int64_t)kk * d + c) : make_double2(0.0, 0.0);
+            } else {
+                ra[q].x = (r < d && k < d) ? A[(int64_t)r * d + k] : 0.0;
+                ra[q].y = (r < d && k + 1 < d) ? A[(int64_t)r * d + k + 1] : 0.0;
+                rb[q].x = (kk < d && c < d) ? B[(int64_t)kk * d + c] : 0.0;
+                rb[q].y = (kk < d && c + 1 < d) ? B[(int64_t)kk * d + c + 1] : 0.0;
+            }
         }
     };
 
@@ -77,23 +91,23 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     const int nkb = (d + KB - 1) / KB;
     fetch(0);
     for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
+        if (kb) __syncthreads();                 // everyone is done reading the previous stage
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
+        for (int q = 0; q < NV; ++q) {
             const int e = tid + q * 256;
-            sA[buf][(e >> 4) * PA + (e & 15)] = ra[q];
-            sB[buf][(e / BT) * PB + (e % BT)] = rb[q];
+            *reinterpret_cast<double2*>(sA + (e / (KB / 2)) * PA + (e % (KB / 2)) * 2) = ra[q];
+            *reinterpret_cast<double2*>(sB + (e / BV) * PB + (e % BV) * 2) = rb[q];
         }
         __syncthreads();
         if (kb + 1 < nkb) fetch((kb + 1) * KB);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll 4
+        for (int ks = 0; ks < KB / 4; ++ks) {
             const int k = ks * 4 + lk;
             double a[MT], b[MT];
 #pragma unroll
             for (int f = 0; f < MT; ++f) {
-                a[f] = sA[buf][(wr * (BT / 2) + 16 * f + li) * PA + k];
-                b[f] = sB[buf][k * PB + wc * (BT / 2) + 16 * f + li];
+                a[f] = sA[(wr * (BT / 2) + 16 * f + li) * PA + k];
+                b[f] = sB[k * PB + wc * (BT / 2) + 16 * f + li];
             }
 #pragma unroll
             for (int fa = 0; fa < MT; ++fa)
@@ -123,6 +137,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     if (partials) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        __syncthreads();
         if (lane == 0) red[wave] = ss;
         __syncthreads();
         if (tid == 0)
