@@ -203,3 +203,76 @@ def frechet_batched(mu_b, cov_b, rows, offsets: Sequence[int], mean_mode: int = 
                                              scores.ctypes.data, status.ctypes.data)
     K.check(st, "fad_frechet_batched_vs_baseline")
     return scores, status
+
+
+# ---------------------------------------------------------------------------------------------
+# log-mel front ends (csrc/logmel.hip)
+# ---------------------------------------------------------------------------------------------
+def _clips_view(clips, device: int):
+    """list of 1-D arrays (numpy / torch) or one 1-D array -> (ptr, offsets int64[n+1], on_device, keepalive)."""
+    if not isinstance(clips, (list, tuple)):
+        clips = [clips]
+    if len(clips) and K._is_torch(clips[0]) and clips[0].is_cuda:
+        import torch
+        flat = torch.cat([c.reshape(-1).to(torch.float32) for c in clips]) if len(clips) > 1 else \
+            clips[0].reshape(-1).to(torch.float32).contiguous()
+        lens = [int(c.numel()) for c in clips]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        return flat.data_ptr(), off, 1, flat
+    arrs = [np.asarray(c.cpu().numpy() if K._is_torch(c) else c, dtype=np.float32).reshape(-1) for c in clips]
+    flat = np.ascontiguousarray(np.concatenate(arrs)) if arrs else np.zeros(0, np.float32)
+    off = np.concatenate([[0], np.cumsum([len(a) for a in arrs])]).astype(np.int64)
+    return flat.ctypes.data, off, 0, flat
+
+
+def _out_buffer(shape, on_dev: int, like):
+    if on_dev:
+        import torch
+        t = torch.empty(shape, dtype=torch.float32, device=like.device)
+        return t, t.data_ptr()
+    a = np.empty(shape, dtype=np.float32)
+    return a, a.ctypes.data
+
+
+def vggish_num_examples(n_samples: int) -> int:
+    return int(K.load_library().fad_logmel_vggish_num_examples(int(n_samples)))
+
+
+def logmel_vggish(clips, device: int = 0):
+    """16 kHz mono clips -> (examples [E, 96, 64] float32, example_offsets int64 [n_clips + 1])."""
+    lib = K.load_library()
+    K.require_gpu(device)
+    ptr, off, on_dev, keep = _clips_view(clips, device)
+    n = len(off) - 1
+    total = sum(vggish_num_examples(int(off[i + 1] - off[i])) for i in range(n))
+    out, optr = _out_buffer((total, 96, 64), on_dev, keep)
+    ex_off = np.zeros(n + 1, dtype=np.int64)
+    K.check(lib.fad_logmel_vggish(ptr, off.ctypes.data_as(C.POINTER(C.c_int64)), n, optr, total,
+                                  ex_off.ctypes.data_as(C.POINTER(C.c_int64)), on_dev, device,
+                                  K.current_stream_ptr(device)), "fad_logmel_vggish")
+    return out, ex_off
+
+
+def logmel_whisper(clips, n_mels: int = 80, device: int = 0):
+    """16 kHz mono clips -> [n_clips, n_mels, 3000] float32 (each clip padded / cut to 30 s)."""
+    lib = K.load_library()
+    K.require_gpu(device)
+    ptr, off, on_dev, keep = _clips_view(clips, device)
+    n = len(off) - 1
+    out, optr = _out_buffer((n, n_mels, 3000), on_dev, keep)
+    K.check(lib.fad_logmel_whisper(ptr, off.ctypes.data_as(C.POINTER(C.c_int64)), n, int(n_mels), optr, on_dev, device,
+                                   K.current_stream_ptr(device)), "fad_logmel_whisper")
+    return out
+
+
+def logmel_htsat(clips, device: int = 0):
+    """48 kHz mono clips of ONE common length -> [n_clips, 1 + n/480, 64] float32 (dB log-mel)."""
+    lib = K.load_library()
+    K.require_gpu(device)
+    ptr, off, on_dev, keep = _clips_view(clips, device)
+    n = len(off) - 1
+    frames = 1 + int(off[1] - off[0]) // 480 if n else 1
+    out, optr = _out_buffer((n, frames, 64), on_dev, keep)
+    K.check(lib.fad_logmel_htsat(ptr, off.ctypes.data_as(C.POINTER(C.c_int64)), n, frames, optr, on_dev, device,
+                                 K.current_stream_ptr(device)), "fad_logmel_htsat")
+    return out

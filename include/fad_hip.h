@@ -140,6 +140,33 @@ int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const double* cov
                                     int on_device, int device, void* stream,
                                     double* out_scores, int32_t* out_status);
 
+/* ------------------------------------------------------------------ log-mel front ends
+ * Replace the third-party feature extraction that runs inside ModelLoader._get_embedding
+ * (fadtk/model_loader.py:99,108 VGGish / torchvggish mel_features; :661,666 Whisper /
+ * transformers WhisperFeatureExtractor; :385,406 CLAP-HTSAT / torchlibrosa).
+ * wav: float32 mono samples of n_clips clips stored back to back, clip c = wav[offsets[c] ..
+ * offsets[c+1]) (offsets: HOST array of n_clips+1).  wav/out are host or device per on_device.
+ *
+ * VGGish  (16 kHz): periodic-Hann 400 / hop 160 / FFT 512 magnitude, 64 HTK mels 125-7500 Hz,
+ *          log(mel + 0.01), non-overlapping examples of 96 frames, incomplete tail dropped.
+ *          out [total_examples][96][64]; example_offsets (host, n_clips+1, may be NULL) receives the
+ *          first example of each clip.
+ * Whisper (16 kHz): clip zero-padded / cut to 480000 samples, centred reflect STFT 400 / hop 160,
+ *          power, n_mels (80 or 128) Slaney mels 0-8 kHz, log10(max(.,1e-10)), clamp to
+ *          (clip max - 8), (x + 4) / 4.   out [n_clips][n_mels][3000].
+ * HTSAT   (48 kHz): centred reflect STFT 1024 / hop 480, power, 64 Slaney mels 50-14000 Hz,
+ *          10 log10(max(.,1e-10)).  Every clip must give n_frames_out = 1 + n_samples/480 frames.
+ *          out [n_clips][n_frames_out][64].
+ */
+int64_t fad_logmel_vggish_num_examples(int64_t n_samples);
+int fad_logmel_vggish(const float* wav, const int64_t* offsets, int64_t n_clips, float* out,
+                      int64_t out_capacity_examples, int64_t* example_offsets, int on_device, int device,
+                      void* stream);
+int fad_logmel_whisper(const float* wav, const int64_t* offsets, int64_t n_clips, int n_mels, float* out,
+                       int on_device, int device, void* stream);
+int fad_logmel_htsat(const float* wav, const int64_t* offsets, int64_t n_clips, int64_t n_frames_out,
+                     float* out, int on_device, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

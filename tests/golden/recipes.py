@@ -89,3 +89,13 @@ def checksum(a: np.ndarray) -> float:
     """Order-independent fingerprint of an input array (guards against RNG drift)."""
     a64 = np.asarray(a, dtype=np.float64)
     return float(a64.sum() + 3.0 * np.abs(a64).sum())
+
+
+def audio_clip(seed: int, n: int, sr: int) -> np.ndarray:
+    """Synthetic mono audio: white noise plus three sinusoids, float32 in about [-0.6, 0.6]."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / sr
+    x = 0.1 * rng.standard_normal(n)
+    for f, a in ((220.0, 0.2), (1760.0, 0.1), (5200.0, 0.05)):
+        x += a * np.sin(2 * np.pi * f * t + rng.random() * 6.28)
+    return x.astype(np.float32)
