@@ -1,0 +1,72 @@
+"""End to end on the GPU: synthetic audio -> HIP front end + PyTorch-ROCm forward -> fp16 embedding cache
+-> HIP moments / Frechet -> score, checked against the oracle run on the very same cached embeddings
+(BASELINE config 2 shape, scaled down; weights are seeded random: no checkpoints exist offline)."""
+import logging
+
+import numpy as np
+import pytest
+
+import recipes as R
+from oracle import fad_oracle as O
+
+pytestmark = pytest.mark.gpu
+logging.getLogger("fad_oracle").setLevel(logging.CRITICAL)
+
+
+def _make_set(root, n_files, seconds, sr, seed0, gain=1.0):
+    from fadtk_amd import audio
+    root.mkdir(parents=True)
+    for i in range(n_files):
+        audio.write_pcm16(root / f"clip{i:03d}.wav", gain * R.audio_clip(seed0 + i, int(seconds * sr), sr), sr)
+    return root
+
+
+def test_vggish_directory_score_matches_oracle(tmp_path, monkeypatch):
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    import fadtk_amd
+    from fadtk_amd.fad_batch import cache_embedding_files
+    from fadtk_amd.model_loader import VGGishModel
+    base = _make_set(tmp_path / "base", 12, 10.0, 16000, 500)
+    evl = _make_set(tmp_path / "eval", 9, 10.0, 16000, 600, gain=0.7)
+    ml = VGGishModel()
+    for d in (base, evl):
+        cache_embedding_files(d, ml, workers=4)
+    embs = sorted((base / "embeddings" / "vggish").glob("*.npy"))
+    assert len(embs) == 12
+    e0 = np.load(embs[0])
+    assert e0.shape == (10, 128) and e0.dtype == np.float16          # 10 s -> 10 examples of 0.96 s
+    assert (base / "convert" / "16000" / "clip000.wav").exists()     # normalised-audio cache
+    cache_embedding_files(base, ml, workers=4)                        # second call: everything cached
+
+    fad = fadtk_amd.FrechetAudioDistance(ml, load_model=False)
+    score = fad.score(base, evl)
+    blocks_b = [np.load(p) for p in (base / "embeddings" / "vggish").glob("*.npy")]
+    blocks_e = [np.load(p) for p in (evl / "embeddings" / "vggish").glob("*.npy")]
+    want = O.frechet_distance(*O.statistics_online(blocks_b), *O.statistics_online(blocks_e), run_sqrtm=False)
+    assert abs(score - want) / abs(want) < 1e-4
+    assert (base / "stats" / "vggish" / "mu.npy").exists()
+
+    out = fad.score_individual(base, evl, tmp_path / "indiv.csv")
+    lines = out.read_text().split("\n")
+    assert len(lines) == 9
+    mu_b, cov_b = fad.load_stats(base)
+    by_name = {ln.rsplit(",", 1)[0]: float(ln.rsplit(",", 1)[1]) for ln in lines}
+    for p in sorted(evl.glob("*.wav"))[:3]:
+        e = np.load(evl / "embeddings" / "vggish" / (p.stem + ".npy"))
+        ref = O.frechet_distance(mu_b, cov_b, *O.embd_statistics(e), run_sqrtm=False)
+        assert abs(by_name[str(p)] - ref) / abs(ref) < 1e-4
+
+
+@pytest.mark.parametrize("which", ["whisper-tiny", "encodec-emb", "clap-laion-audio"])
+def test_loader_shapes_on_gpu(which, monkeypatch, tmp_path):
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    from fadtk_amd import audio
+    from fadtk_amd.model_loader import get_all_models
+    ml = {m.name: m for m in get_all_models()}[which]
+    ml.load_model()
+    secs = 3
+    audio.write_pcm16(tmp_path / "x.wav", R.audio_clip(700, secs * ml.sr, ml.sr), ml.sr)
+    emb = ml.get_embedding(ml.load_wav(tmp_path / "x.wav"))
+    assert emb.dtype == np.float16 and emb.ndim == 2 and emb.shape[1] == ml.num_features and np.isfinite(emb).all()
+    expect = {"whisper-tiny": 2, "encodec-emb": 75 * secs, "clap-laion-audio": secs}[which]
+    assert emb.shape[0] == expect

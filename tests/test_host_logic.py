@@ -1,0 +1,95 @@
+"""CPU-only checks of the host-side mirror: plugin surface, cache layout, audio plumbing, CLI parsing."""
+import subprocess
+import sys
+import wave
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import recipes as R
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_cache_path_layout():
+    from fadtk_amd import get_cache_embedding_path
+    assert get_cache_embedding_path("vggish", "/data/set/song.one.flac") == Path("/data/set/embeddings/vggish/song.one.npy")
+    assert get_cache_embedding_path("clap-laion-audio", Path("rel/a.wav")) == Path("rel/embeddings/clap-laion-audio/a.npy")
+
+
+def test_registry_names_and_plugin_contract():
+    from fadtk_amd.model_loader import ModelLoader, get_all_models
+    import pickle
+    models = get_all_models()
+    names = [m.name for m in models]
+    assert names == ["clap-laion-audio", "clap-laion-music", "vggish", "encodec-emb", "encodec-emb-48k",
+                     "whisper-tiny", "whisper-small", "whisper-base", "whisper-medium", "whisper-large"]
+    dims = {m.name: (m.num_features, m.sr) for m in models}
+    assert dims["vggish"] == (128, 16000) and dims["encodec-emb"] == (128, 24000)
+    assert dims["clap-laion-audio"] == (512, 48000) and dims["whisper-small"] == (768, 16000)
+    for m in models:                                   # loaders cross process boundaries before load_model()
+        assert pickle.loads(pickle.dumps(m)).name == m.name and m.model is None
+
+    class Custom(ModelLoader):                         # README-style plugin
+        def __init__(self):
+            super().__init__("my-model", 7, 8000, min_len=2)
+
+        def load_model(self):
+            self.model = "ready"
+
+        def _get_embedding(self, audio):
+            import torch
+            return torch.ones((3, 7), dtype=torch.float32) * float(len(audio))
+
+    c = Custom()
+    assert c.enforce_min_len(np.zeros(10)).shape == (16000,)        # padded to min_len * sr
+    e = c.get_embedding(np.zeros(5))
+    assert e.dtype == np.float16 and e.shape == (3, 7) and (e == 5).all()
+
+
+def test_wav_roundtrip_load_wav_and_resampler(tmp_path):
+    from fadtk_amd import audio
+    from fadtk_amd.model_loader import VGGishModel
+    sr = 16000
+    x = R.audio_clip(400, sr // 2, sr)
+    audio.write_pcm16(tmp_path / "a.wav", x, sr)
+    with wave.open(str(tmp_path / "a.wav")) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, sr, sr // 2)
+    pcm, fs = audio.read_pcm16(tmp_path / "a.wav")
+    assert fs == sr and pcm.dtype == np.int16
+    np.testing.assert_array_equal(pcm, np.clip(np.rint(x.astype(np.float64) * 32768), -32768, 32767).astype(np.int16))
+    wav = VGGishModel().load_wav(tmp_path / "a.wav")              # int16 / 32768, zero padded to 1 s
+    assert wav.dtype == np.float64 and wav.shape == (sr,) and np.all(wav[sr // 2:] == 0)
+    np.testing.assert_array_equal(wav[: sr // 2], pcm / 32768.0)
+
+    # resampler: a 1 kHz tone survives 48k -> 16k with its amplitude, an above-Nyquist tone is removed
+    t = np.arange(48000) / 48000.0
+    low, high = np.sin(2 * np.pi * 1000 * t), np.sin(2 * np.pi * 15000 * t)
+    y = audio.resample_kaiser((low + high).astype(np.float32), 48000, 16000, device="cpu")
+    assert y.shape == (16000,)
+    ref = np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)
+    assert np.abs(y[500:-500] - ref[500:-500]).max() < 2e-3
+    assert audio.resample_kaiser(low.astype(np.float32), 16000, 16000) is not None
+    audio.convert_to_model_rate(tmp_path / "a.wav", tmp_path / "convert" / "8000" / "a.wav", 8000)
+    assert audio.read_pcm16(tmp_path / "convert" / "8000" / "a.wav")[1] == 8000
+
+
+def test_cli_surface():
+    out = subprocess.run([sys.executable, "-m", "fadtk", "--help"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0
+    for flag in ("--workers", "--sox-path", "--inf", "--indiv", "baseline", "eval", "csv"):
+        assert flag in out.stdout
+    out = subprocess.run([sys.executable, "-m", "fadtk.embeds", "--help"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "--models" in out.stdout and "--dirs" in out.stdout
+    bad = subprocess.run([sys.executable, "-m", "fadtk", "not-a-model", "a", "b"], capture_output=True, text=True, cwd=ROOT)
+    assert bad.returncode == 2 and "invalid choice" in bad.stderr
+
+
+def test_shard_matches_array_split():
+    from fadtk_amd import dist
+    items = list(range(23))
+    for w in (1, 2, 3, 8, 30):
+        got = [dist.shard(items, r, w) for r in range(w)]
+        want = [list(a) for a in np.array_split(items, w)]
+        assert got == want
