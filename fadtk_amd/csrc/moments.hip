@@ -348,6 +348,35 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
 }
 
 // ------------------------------------------------------------------------------------------
+// Shift guard.  The fp16 pass sums exact products in fp32 over bounded runs; that is accurate
+// relative to sum x^2, not to the variance.  For a column with |mean| >> std (constant-ish features,
+// outlier dimensions of transformer states) the covariance is a small difference of large sums, so
+// the update is REDONE exactly (fp64 products and sums, like np.cov's centred dsyrk) when any column
+// of this block has mean^2 > 64 var.  The test uses what the fp16 pass just produced (column sums and
+// the diagonal of its partial tiles); no host round trip: the fp64 kernels are launched
+// unconditionally and exit at once when the flag is clear.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moments_detect_shift(
+    const float* __restrict__ partials, const double* __restrict__ colpart, int S, int T, int nt, int d,
+    double n_rows, int* __restrict__ flag) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    if (a < d) {
+        const int ta = a / H_BT, al = a - ta * H_BT;
+        const int tile = ta * nt - ta * (ta - 1) / 2;            // index of diagonal tile (ta, ta)
+        double s1 = 0.0, s2 = 0.0;
+        for (int sp = 0; sp < S; ++sp) {
+            s1 += colpart[(int64_t)sp * (nt * H_BT) + a];
+            s2 += (double)partials[((int64_t)sp * T + tile) * (H_BT * H_BT) + al * H_BT + al];
+        }
+        const double mean = s1 / n_rows, var = s2 / n_rows - mean * mean;
+        hit = !(mean * mean <= 64.0 * var);                       // also catches var <= 0 and NaN
+        if (mean == 0.0 && s2 == 0.0) hit = false;                // all-zero column: nothing to cancel
+    }
+    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic tile kernel: any input dtype, any pitch/alignment.  Everything in fp64 on
 // v_mfma_f64_16x16x4_f64 (A: lane l holds A[i=l&15][k=l>>4]; B[k=l>>4][j=l&15];
 // D: col = l&15, row = (l>>4) + 4*reg).  Workgroup tile 64x64, wave tile 32x32, 16 rows/stage.
@@ -367,8 +396,10 @@ template <> __device__ __forceinline__ double to_f64<raw_bf16>(raw_bf16 v) { ret
 template <typename TIn>
 __global__ __launch_bounds__(256) void moments_tile_f64(
     const TIn* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, double* __restrict__ partials, double* __restrict__ colpart) {
+    int64_t rows_per_split, double* __restrict__ partials, double* __restrict__ colpart,
+    const int* __restrict__ gate) {
     __shared__ double smem[2][2][G_KB * G_LDS];      // 40 KiB
+    if (gate && *gate == 0) return;                  // shift guard: only runs when the fp16 pass flagged the block
 
     const int w = xcd_contiguous(blockIdx.x, S * T);
     const int split = w / T, tile = w - split * T;
@@ -466,8 +497,9 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
 template <typename PT, int BT>
 __global__ __launch_bounds__(256) void moments_reduce(
     const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed,
-    const double* __restrict__ colpart, double n_add, int tile_blocks) {
+    const double* __restrict__ colpart, double n_add, int tile_blocks, const int* __restrict__ gate, int gate_want) {
     const int per_tile = BT * BT / 4;
+    if (gate && (*gate != 0) != (gate_want != 0)) return;     // exactly one of the two reduces of an update runs
     if ((int)blockIdx.x >= tile_blocks) {          // trailing blocks: column sums and the row count
         const int a = ((int)blockIdx.x - tile_blocks) * 256 + threadIdx.x;
         if (a == 0) acc_packed[0] += n_add;
@@ -561,6 +593,9 @@ struct fad_moments {
     int d = 0, device = 0;
     double* acc = nullptr;                 // packed [1 + d + d*d]
     fad::DevBuf partials, colpart, stage, seg_off, seg_out, scratch;
+    fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
+    int* shift_flag = nullptr;             // device int, set by moments_detect_shift
+    int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0)
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
     // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
     static constexpr int kRing = 256;
@@ -606,10 +641,10 @@ static SplitPlan plan_splits(int64_t n, int d, int bt, int kb, int n_cu, int wg_
 
 template <typename TIn>
 static void launch_generic(const void* rows, int64_t n, int64_t ld, int d, const SplitPlan& p,
-                           double* partials, double* colpart, hipStream_t st) {
+                           double* partials, double* colpart, hipStream_t st, const int* gate = nullptr) {
     hipLaunchKernelGGL((moments_tile_f64<TIn>), dim3(p.S * p.T), dim3(256), 0, st,
                        reinterpret_cast<const TIn*>(rows), n, ld, d, p.nt, p.T, p.S, p.rows_per_split,
-                       partials, colpart);
+                       partials, colpart, gate);
 }
 
 // rows must be a DEVICE pointer here.
@@ -667,8 +702,25 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
         const int tile_blocks = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
+        const int* gate = nullptr;
+        if (h->guard) {
+            FAD_HIP_TRY(hipMemsetAsync(h->shift_flag, 0, sizeof(int), st));
+            hipLaunchKernelGGL(moments_detect_shift, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part, colp, p.S, p.T,
+                               p.nt, d, (double)n, h->shift_flag);
+            gate = h->shift_flag;
+            SplitPlan q = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
+            FAD_TRY(h->partials64.reserve((size_t)q.S * q.T * G_BT * G_BT * sizeof(double)));
+            FAD_TRY(h->colpart64.reserve((size_t)q.S * q.nt * G_BT * sizeof(double)));
+            double* part64 = static_cast<double*>(h->partials64.p);
+            double* colp64 = static_cast<double*>(h->colpart64.p);
+            if (dtype == FAD_F16) launch_generic<raw_f16>(rows, n, ld, d, q, part64, colp64, st, gate);
+            else launch_generic<raw_bf16>(rows, n, ld, d, q, part64, colp64, st, gate);
+            const int tb64 = (int)cdiv((int64_t)q.T * (G_BT * G_BT / 4), 256);
+            hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)(tb64 + cdiv(d, 256))), dim3(256), 0, st,
+                               part64, q.S, q.T, q.nt, d, h->acc, colp64, (double)n, tb64, gate, 1);
+        }
         hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks);
+                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, gate, 0);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = (variant == 2) ? 0 : 2;
     } else {
@@ -688,7 +740,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
         const int tile_blocks = (int)cdiv((int64_t)p.T * (G_BT * G_BT / 4), 256);
         hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks);
+                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, (const int*)nullptr, 0);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = 1;
     }
@@ -739,10 +791,12 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
         delete h;
         return set_error(FAD_ERR_ALLOC, "hipMalloc of %zu bytes failed", bytes);
     }
-    if (hipMemset(h->acc, 0, bytes) != hipSuccess) {
+    if (hipMemset(h->acc, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&h->shift_flag), sizeof(int)) != hipSuccess) {
         (void)hipFree(h->acc); delete h;
-        return set_error(FAD_ERR_HIP, "hipMemset failed");
+        return set_error(FAD_ERR_HIP, "hipMemset / hipMalloc failed");
     }
+    const char* gs = getenv("FAD_MOMENTS_SHIFT_GUARD");
+    h->guard = !(gs && gs[0] == '0');
     *out = h;
     return FAD_OK;
 }
@@ -751,6 +805,8 @@ int fad_moments_destroy(fad_moments_t* h) {
     if (!h) return FAD_OK;
     DeviceGuard g(h->device);
     if (h->acc) (void)hipFree(h->acc);
+    if (h->shift_flag) (void)hipFree(h->shift_flag);
+    h->partials64.release(); h->colpart64.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
     h->seg_off.release(); h->seg_out.release(); h->scratch.release();
     if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }

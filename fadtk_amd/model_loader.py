@@ -141,9 +141,12 @@ class VGGishModel(ModelLoader):
         elif _allow_random(self.random_init):
             log.warning("vggish: no local checkpoint, using seeded random weights (synthetic runs only)")
             g = torch.Generator().manual_seed(self._seed())
-            with torch.no_grad():
+            with torch.no_grad():                      # He initialisation: activations keep their scale through the stack
                 for p in self.model.parameters():
-                    p.copy_(torch.randn(p.shape, generator=g) * (0.5 / max(1, p[0].numel()) ** 0.5 if p.dim() > 1 else 0.01))
+                    if p.dim() > 1:
+                        p.copy_(torch.randn(p.shape, generator=g) * (2.0 / p[0].numel()) ** 0.5)
+                    else:
+                        p.copy_(0.05 * torch.randn(p.shape, generator=g))
         else:
             raise FileNotFoundError("vggish checkpoint not found (set FADTK_AMD_CHECKPOINTS or FADTK_AMD_RANDOM_WEIGHTS=1)")
         self.model.eval().to(self.device)

@@ -110,6 +110,29 @@ def test_moments_mfma_and_generic_kernels_agree(F, monkeypatch):
     assert p_mfma[0] == 5000 and p_gen[0] == 5000
 
 
+def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
+    """|mean| >> std: the covariance is a tiny difference of huge raw moments.  The guard must notice
+    and redo the block in fp64 so that the result matches np.cov's centred computation."""
+    from fadtk_amd.hip import Moments
+    rng = np.random.default_rng(77)
+    n, d = 6000, 256
+    x = rng.standard_normal((n, d))
+    x[:, :64] = 40.0 + 0.05 * x[:, :64]            # outlier dimensions: mean/std ~ 800 (fp16 grid is 0.03 there)
+    x[:, 64] = 3.0                                 # a constant column
+    x = x.astype(np.float16)
+    _, cov_o = O.embd_statistics(x)
+    mu, cov = F.calc_embd_statistics(x)
+    assert np.abs(cov - cov_o).max() <= 1e-9 * np.abs(cov_o).max() + 1e-12
+    assert abs(cov[64, 64]) < 1e-12 and np.abs(cov[:64, :64] - cov_o[:64, :64]).max() < 1e-10
+    with Moments(d) as m:                          # guard decisions are per update: a benign block stays on the MFMA path
+        m.set_timing(True)
+        m.update(x[:, 128:].repeat(2, axis=1)[:, :d].copy())
+        assert m.last_timing()[2] == 0
+    monkeypatch.setenv("FAD_MOMENTS_SHIFT_GUARD", "0")     # without the guard the fp32 partial sums show
+    _, cov_fast = F.calc_embd_statistics(x)
+    assert np.abs(cov_fast[:64, :64] - cov_o[:64, :64]).max() > 1e-7
+
+
 def test_moments_streaming_merge_export_import(F):
     """Sufficient statistics are additive: chunked updates, merged handles and an export/import
     round trip (the multi-GPU reduce) all give the statistics of the whole set."""
