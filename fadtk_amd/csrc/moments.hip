@@ -60,6 +60,17 @@ template <int KIND> __device__ __forceinline__ float sum8(const uint4& v) {
     return s;
 }
 
+template <int KIND> __device__ __forceinline__ float sumsq8(const uint4& v) {
+    float s = 0.f;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float lo = h16_to_f32<KIND>(w[q] & 0xffffu), hi = h16_to_f32<KIND>(w[q] >> 16);
+        s = fmaf(lo, lo, s); s = fmaf(hi, hi, s);
+    }
+    return s;
+}
+
 template <int KIND> __device__ __forceinline__ f32x16 mfma_h16(const uint4& a, const uint4& b, const f32x16& c) {
     if constexpr (KIND == FAD_F16) {
         f16x8 va, vb; __builtin_memcpy(&va, &a, 16); __builtin_memcpy(&vb, &b, 16);
@@ -223,7 +234,7 @@ template <int KIND, int NST, bool DIAG>
 __device__ __forceinline__ void tile_h16_glds_body(
     const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
-    uint4* smem) {
+    uint4* smem, int* __restrict__ shift_flag) {
     constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
     constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,7 +274,7 @@ __device__ __forceinline__ void tile_h16_glds_body(
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
-    double csum[2] = {0.0, 0.0};
+    double csum[2] = {0.0, 0.0}, csq[2] = {0.0, 0.0};
     const bool do_colsum = DIAG && (wr == 0);
 
     for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
@@ -304,6 +315,8 @@ __device__ __forceinline__ void tile_h16_glds_body(
             if (do_colsum) {
                 csum[0] += (double)sum8<KIND>(b0);
                 csum[1] += (double)sum8<KIND>(b1);
+                csq[0] += (double)sumsq8<KIND>(b0);
+                csq[1] += (double)sumsq8<KIND>(b1);
             }
         }
     }
@@ -322,6 +335,20 @@ __device__ __forceinline__ void tile_h16_glds_body(
     if (do_colsum) {
         csum[0] += __shfl_xor(csum[0], 32);
         csum[1] += __shfl_xor(csum[1], 32);
+        if (shift_flag) {
+            // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?
+            // Then fp32 partial sums of x^2 cannot resolve the variance and the block is redone in fp64.
+            const double nr = (double)(k_end - k_begin);
+            bool hit = false;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const double s2 = csq[f] + __shfl_xor(csq[f], 32);
+                const double mean = csum[f] / nr, var = s2 / nr - mean * mean;
+                const bool col_in = (cb + 64 * wc + 2 * li + f) < d;
+                if (col_in && !(mean * mean <= 64.0 * var) && !(csum[f] == 0.0 && s2 == 0.0)) hit = true;
+            }
+            if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
+        }
         if (kg == 0) {
             double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + 2 * li;
             cp[0] = csum[0]; cp[1] = csum[1];
@@ -332,7 +359,8 @@ __device__ __forceinline__ void tile_h16_glds_body(
 template <int KIND, int NST>
 __global__ __launch_bounds__(256) void moments_tile_h16_glds(
     const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart) {
+    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
+    int* __restrict__ shift_flag) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
     const int w = xcd_contiguous(blockIdx.x, S * T);
     const int split = w / T, tile = w - split * T;
@@ -341,10 +369,10 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
     const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
     if (ta == tb)
         tile_h16_glds_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                            partials, colpart, smem_dyn);
+                                            partials, colpart, smem_dyn, shift_flag);
     else
         tile_h16_glds_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                             partials, colpart, smem_dyn);
+                                             partials, colpart, smem_dyn, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -352,29 +380,12 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
 // relative to sum x^2, not to the variance.  For a column with |mean| >> std (constant-ish features,
 // outlier dimensions of transformer states) the covariance is a small difference of large sums, so
 // the update is REDONE exactly (fp64 products and sums, like np.cov's centred dsyrk) when any column
-// of this block has mean^2 > 64 var.  The test uses what the fp16 pass just produced (column sums and
-// the diagonal of its partial tiles); no host round trip: the fp64 kernels are launched
-// unconditionally and exit at once when the flag is clear.
+// has mean^2 > 64 var within some workgroup's run of rows.  No host round trip: the fp64 tile kernel
+// is launched unconditionally and exits at once when the flag is clear; one reduce launch serves both
+// sources.  Two flags alternate between updates so that the reduce of update k can clear the flag of
+// update k+1 without a memset.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void moments_detect_shift(
-    const float* __restrict__ partials, const double* __restrict__ colpart, int S, int T, int nt, int d,
-    double n_rows, int* __restrict__ flag) {
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    bool hit = false;
-    if (a < d) {
-        const int ta = a / H_BT, al = a - ta * H_BT;
-        const int tile = ta * nt - ta * (ta - 1) / 2;            // index of diagonal tile (ta, ta)
-        double s1 = 0.0, s2 = 0.0;
-        for (int sp = 0; sp < S; ++sp) {
-            s1 += colpart[(int64_t)sp * (nt * H_BT) + a];
-            s2 += (double)partials[((int64_t)sp * T + tile) * (H_BT * H_BT) + al * H_BT + al];
-        }
-        const double mean = s1 / n_rows, var = s2 / n_rows - mean * mean;
-        hit = !(mean * mean <= 64.0 * var);                       // also catches var <= 0 and NaN
-        if (mean == 0.0 && s2 == 0.0) hit = false;                // all-zero column: nothing to cancel
-    }
-    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
+// (the test itself lives in the epilogue of the diagonal-tile workgroups of moments_tile_h16_glds)
 
 // ------------------------------------------------------------------------------------------
 // Generic tile kernel: any input dtype, any pitch/alignment.  Everything in fp64 on
@@ -497,8 +508,10 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
 template <typename PT, int BT>
 __global__ __launch_bounds__(256) void moments_reduce(
     const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed,
-    const double* __restrict__ colpart, double n_add, int tile_blocks, const int* __restrict__ gate, int gate_want) {
+    const double* __restrict__ colpart, double n_add, int tile_blocks, const int* __restrict__ gate, int gate_want,
+    int* __restrict__ clear_flag) {
     const int per_tile = BT * BT / 4;
+    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;     // next update's flag
     if (gate && (*gate != 0) != (gate_want != 0)) return;     // exactly one of the two reduces of an update runs
     if ((int)blockIdx.x >= tile_blocks) {          // trailing blocks: column sums and the row count
         const int a = ((int)blockIdx.x - tile_blocks) * 256 + threadIdx.x;
@@ -594,7 +607,8 @@ struct fad_moments {
     double* acc = nullptr;                 // packed [1 + d + d*d]
     fad::DevBuf partials, colpart, stage, seg_off, seg_out, scratch;
     fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
-    int* shift_flag = nullptr;             // device int, set by moments_detect_shift
+    int* shift_flag = nullptr;             // device int[2], ping-pong between updates
+    unsigned update_seq = 0;
     int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0)
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
     // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
@@ -677,6 +691,12 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         double* colp = static_cast<double*>(h->colpart.p);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
         const uint16_t* e16 = static_cast<const uint16_t*>(rows);
+        int* flag_now = nullptr; int* flag_next = nullptr;
+        if (h->guard && variant == 2) {
+            flag_now = h->shift_flag + (h->update_seq & 1u);
+            flag_next = h->shift_flag + ((h->update_seq + 1u) & 1u);
+            h->update_seq++;
+        }
         if (variant == 2) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
             static bool attr_set = false;
@@ -689,10 +709,10 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             }
             if (dtype == FAD_F16)
                 hipLaunchKernelGGL((moments_tile_h16_glds<FAD_F16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld,
-                                   d, p.nt, p.T, p.S, p.rows_per_split, part, colp);
+                                   d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
             else
                 hipLaunchKernelGGL((moments_tile_h16_glds<FAD_BF16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n,
-                                   ld, d, p.nt, p.T, p.S, p.rows_per_split, part, colp);
+                                   ld, d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
         } else if (dtype == FAD_F16) {
             hipLaunchKernelGGL((moments_tile_h16<FAD_F16>), dim3(p.S * p.T), dim3(256), 0, st, e16, n, ld, d, p.nt, p.T,
                                p.S, p.rows_per_split, part, colp);
@@ -702,25 +722,21 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
         const int tile_blocks = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
-        const int* gate = nullptr;
-        if (h->guard) {
-            FAD_HIP_TRY(hipMemsetAsync(h->shift_flag, 0, sizeof(int), st));
-            hipLaunchKernelGGL(moments_detect_shift, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part, colp, p.S, p.T,
-                               p.nt, d, (double)n, h->shift_flag);
-            gate = h->shift_flag;
+        if (flag_now) {
             SplitPlan q = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
             FAD_TRY(h->partials64.reserve((size_t)q.S * q.T * G_BT * G_BT * sizeof(double)));
             FAD_TRY(h->colpart64.reserve((size_t)q.S * q.nt * G_BT * sizeof(double)));
             double* part64 = static_cast<double*>(h->partials64.p);
             double* colp64 = static_cast<double*>(h->colpart64.p);
-            if (dtype == FAD_F16) launch_generic<raw_f16>(rows, n, ld, d, q, part64, colp64, st, gate);
-            else launch_generic<raw_bf16>(rows, n, ld, d, q, part64, colp64, st, gate);
+            if (dtype == FAD_F16) launch_generic<raw_f16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
+            else launch_generic<raw_bf16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
             const int tb64 = (int)cdiv((int64_t)q.T * (G_BT * G_BT / 4), 256);
             hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)(tb64 + cdiv(d, 256))), dim3(256), 0, st,
-                               part64, q.S, q.T, q.nt, d, h->acc, colp64, (double)n, tb64, gate, 1);
+                               part64, q.S, q.T, q.nt, d, h->acc, colp64, (double)n, tb64, (const int*)flag_now, 1,
+                               (int*)nullptr);
         }
         hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, gate, 0);
+                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, (const int*)flag_now, 0, flag_next);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = (variant == 2) ? 0 : 2;
     } else {
@@ -740,7 +756,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
         const int tile_blocks = (int)cdiv((int64_t)p.T * (G_BT * G_BT / 4), 256);
         hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, (const int*)nullptr, 0);
+                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, (const int*)nullptr, 0, (int*)nullptr);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = 1;
     }
@@ -791,7 +807,8 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
         delete h;
         return set_error(FAD_ERR_ALLOC, "hipMalloc of %zu bytes failed", bytes);
     }
-    if (hipMemset(h->acc, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&h->shift_flag), sizeof(int)) != hipSuccess) {
+    if (hipMemset(h->acc, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&h->shift_flag), 2 * sizeof(int)) != hipSuccess ||
+        hipMemset(h->shift_flag, 0, 2 * sizeof(int)) != hipSuccess) {
         (void)hipFree(h->acc); delete h;
         return set_error(FAD_ERR_HIP, "hipMemset / hipMalloc failed");
     }
