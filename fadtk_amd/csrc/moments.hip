@@ -274,8 +274,8 @@ __device__ __forceinline__ void tile_h16_glds_body(
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
-    double csum[2] = {0.0, 0.0}, csq[2] = {0.0, 0.0};
-    const bool do_colsum = DIAG && (wr == 0);
+    double csum[2] = {0.0, 0.0};
+    const bool do_colsum = DIAG && (wr == wc);     // the diagonal waves also hold sum x^2 (diagonal of acc)
 
     for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
 
@@ -315,8 +315,6 @@ __device__ __forceinline__ void tile_h16_glds_body(
             if (do_colsum) {
                 csum[0] += (double)sum8<KIND>(b0);
                 csum[1] += (double)sum8<KIND>(b1);
-                csq[0] += (double)sumsq8<KIND>(b0);
-                csq[1] += (double)sumsq8<KIND>(b1);
             }
         }
     }
@@ -338,11 +336,19 @@ __device__ __forceinline__ void tile_h16_glds_body(
         if (shift_flag) {
             // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?
             // Then fp32 partial sums of x^2 cannot resolve the variance and the block is redone in fp64.
+            // sum x^2 of column (2 li + f) is the diagonal element acc[f][f][reg] of the lane whose C/D row
+            // (reg&3) + 8 (reg>>2) + 4 kg equals li: kg = (li>>2)&1, reg = (li&3) + 4 (li>>3).
             const double nr = (double)(k_end - k_begin);
+            const int myreg = (li & 3) + 4 * (li >> 3);
+            const bool own = kg == ((li >> 2) & 1);
             bool hit = false;
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                const double s2 = csq[f] + __shfl_xor(csq[f], 32);
+                float dsel = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsel = (r == myreg) ? acc[f][f][r] : dsel;
+                double s2 = own ? (double)dsel : 0.0;
+                s2 += __shfl_xor(s2, 32);
                 const double mean = csum[f] / nr, var = s2 / nr - mean * mean;
                 const bool col_in = (cb + 64 * wc + 2 * li + f) < d;
                 if (col_in && !(mean * mean <= 64.0 * var) && !(csum[f] == 0.0 && s2 == 0.0)) hit = true;
