@@ -32,11 +32,14 @@ struct GemmArgs {
 constexpr int KB = 64;                 // k depth of one LDS stage
 constexpr int PA = KB + 2;             // A pitch (doubles): rows i..i+15 land on distinct bank pairs
 
-// One stage = A[BT x 64] and B[64 x BT] in LDS (single buffer); the next stage is prefetched into
-// registers as 16-byte loads while the current one feeds the MFMAs, so every thread keeps
-// BT*64*2/256 doubles (32 or 64 KiB per workgroup) of loads in flight -- the first version staged
-// 16-deep slices and was latency-bound at ~20 % of the fp64 MFMA rate.
-template <int BT>
+// The operands of a D=512 iteration are 2 MB matrices that the PREVIOUS kernel wrote from all 8 XCDs, so
+// every first touch is an L2 miss served by the Infinity Cache / HBM (~1-2 us), and each panel is wanted by
+// 16 workgroups.  Two measures (the first version ran at ~20 % of the fp64 MFMA rate, latency-bound):
+//   * prefetch DEPTH stages ahead into registers (16-byte loads), so a thread has DEPTH x 64 k of both
+//     operands in flight while the MFMAs chew on the LDS-resident stage;
+//   * XCD-aware tile map: workgroup b runs on XCD b % 8; XCD (ex, ey) of a 2 x 4 grid owns a contiguous
+//     block of output tiles, so each private L2 fetches 1/2 of A's rows and 1/4 of B's columns once.
+template <int BT, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     constexpr int MT = BT / 32;              // MFMA tiles per wave per side
     constexpr int PB = BT + 16;
@@ -55,14 +58,29 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     double* C = g.C[zi] + zb * g.sc[zi];
     const double alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
 
+    // ---- tile coordinates (XCD-aware when the tile grid splits evenly into 2 x 4 blocks)
+    int ty = blockIdx.y, tx = blockIdx.x;
+    const int t = gridDim.x;
+    if ((t & 3) == 0) {
+        const int b = blockIdx.y * t + blockIdx.x;
+        const int xcd = b & 7, idx = b >> 3;
+        const int R = t >> 1, Cc = t >> 2;
+        ty = (xcd >> 2) * R + idx / Cc;
+        tx = (xcd & 3) * Cc + idx % Cc;
+    }
+    const int slot = ty * t + tx;
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
-    const int row0 = blockIdx.y * BT, col0 = blockIdx.x * BT;
+    const int row0 = ty * BT, col0 = tx * BT;
     const bool vec = ((d & 1) == 0);         // 16-byte loads need even d (row starts stay 16-B aligned)
+    const int nkb = (d + KB - 1) / KB;
 
-    double2 ra[NV], rb[NV];
-    auto fetch = [&](int k0) {
+    double2 ra[DEPTH][NV], rb[DEPTH][NV];
+    auto fetch = [&](double2 (&pa)[NV], double2 (&pb)[NV], int kb) {
+        if (kb >= nkb) return;
+        const int k0 = kb * KB;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int e = tid + q * 256;
@@ -71,13 +89,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
             const int bk = e / BV, bj = (e % BV) * 2;                    // B tile [64][BT], pairs along j
             const int kk = k0 + bk, c = col0 + bj;
             if (vec) {
-                ra[q] = (r < d && k < d) ? *reinterpret_cast<const double2*>(A + (int64_t)r * d + k) : make_double2(0.0, 0.0);
-                rb[q] = (kk < d && c < d) ? *reinterpret_cast<const double2*>(B + (int64_t)kk * d + c) : make_double2(0.0, 0.0);
+                pa[q] = (r < d && k < d) ? *reinterpret_cast<const double2*>(A + (int64_t)r * d + k) : make_double2(0.0, 0.0);
+                pb[q] = (kk < d && c < d) ? *reinterpret_cast<const double2*>(B + (int64_t)kk * d + c) : make_double2(0.0, 0.0);
             } else {
-                ra[q].x = (r < d && k < d) ? A[(int64_t)r * d + k] : 0.0;
-                ra[q].y = (r < d && k + 1 < d) ? A[(int64_t)r * d + k + 1] : 0.0;
-                rb[q].x = (kk < d && c < d) ? B[(int64_t)kk * d + c] : 0.0;
-                rb[q].y = (kk < d && c + 1 < d) ? B[(int64_t)kk * d + c + 1] : 0.0;
+                pa[q].x = (r < d && k < d) ? A[(int64_t)r * d + k] : 0.0;
+                pa[q].y = (r < d && k + 1 < d) ? A[(int64_t)r * d + k + 1] : 0.0;
+                pb[q].x = (kk < d && c < d) ? B[(int64_t)kk * d + c] : 0.0;
+                pb[q].y = (kk < d && c + 1 < d) ? B[(int64_t)kk * d + c + 1] : 0.0;
             }
         }
     };
@@ -88,18 +106,18 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
 #pragma unroll
         for (int y = 0; y < MT; ++y) acc[x][y] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-    const int nkb = (d + KB - 1) / KB;
-    fetch(0);
-    for (int kb = 0; kb < nkb; ++kb) {
+    // one stage: registers -> LDS, refill the same registers DEPTH stages ahead, MFMAs from LDS
+    auto stage = [&](double2 (&pa)[NV], double2 (&pb)[NV], int kb) {
+        if (kb >= nkb) return;
         if (kb) __syncthreads();                 // everyone is done reading the previous stage
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int e = tid + q * 256;
-            *reinterpret_cast<double2*>(sA + (e / (KB / 2)) * PA + (e % (KB / 2)) * 2) = ra[q];
-            *reinterpret_cast<double2*>(sB + (e / BV) * PB + (e % BV) * 2) = rb[q];
+            *reinterpret_cast<double2*>(sA + (e / (KB / 2)) * PA + (e % (KB / 2)) * 2) = pa[q];
+            *reinterpret_cast<double2*>(sB + (e / BV) * PB + (e % BV) * 2) = pb[q];
         }
         __syncthreads();
-        if (kb + 1 < nkb) fetch((kb + 1) * KB);
+        fetch(pa, pb, kb + DEPTH);
 #pragma unroll 4
         for (int ks = 0; ks < KB / 4; ++ks) {
             const int k = ks * 4 + lk;
@@ -115,6 +133,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
                 for (int fb = 0; fb < MT; ++fb)
                     acc[fa][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fa], b[fb], acc[fa][fb], 0, 0, 0);
         }
+    };
+
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) fetch(ra[s], rb[s], s);
+    for (int kb = 0; kb < nkb; kb += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) stage(ra[s], rb[s], kb + s);
     }
 
     double ss = 0.0;
@@ -140,9 +165,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
         __syncthreads();
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        if (tid == 0)
-            partials[zb * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
-                (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) partials[zb * (gridDim.x * gridDim.y) + slot] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -179,8 +202,8 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
         g.skip = skip ? skip + done * skip_stride : nullptr;
         g.skip_stride = skip_stride; g.ntypes = ntypes;
         dim3 grid((unsigned)t, (unsigned)t, (unsigned)(m * ntypes));
-        if (bt == 64) hipLaunchKernelGGL((gemm_f64_kernel<64>), grid, dim3(256), 0, stream, d, g);
-        else hipLaunchKernelGGL((gemm_f64_kernel<32>), grid, dim3(256), 0, stream, d, g);
+        if (bt == 64) hipLaunchKernelGGL((gemm_f64_kernel<64, 2>), grid, dim3(256), 0, stream, d, g);
+        else hipLaunchKernelGGL((gemm_f64_kernel<32, 3>), grid, dim3(256), 0, stream, d, g);
     }
     FAD_HIP_TRY(hipGetLastError());
     return (int)slots;
