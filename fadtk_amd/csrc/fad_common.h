@@ -68,7 +68,7 @@ struct GemmType {
 };
 // returns the number of partial slots per problem (>0) or a negative fad_status
 int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, const int* skip, int skip_stride,
-                    hipStream_t stream, int device);
+                    hipStream_t stream, int device, int partial_stride = 0);
 int gemm_f64_slots(int d, int ntypes, int64_t batch, int device);
 int gemm_f64_slots_max(int d);
 

@@ -38,7 +38,9 @@ constexpr int kMaxIter = 64;
 struct NsState {
     double c, tr1, tr2, mean_term;
     double res_last, tr_last;
-    int done, final_iter, conv, nonfinite, too_few, pad;
+    int done;          // no more T GEMMs / residual checks for this problem
+    int final_iter, conv, nonfinite, too_few;
+    int finished;      // no more update GEMMs either: tr_last is final (also the host's "all done" test)
     double res[kMaxIter];
     double tr[kMaxIter];
 };
@@ -124,51 +126,84 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
         st->final_iter = -1; st->conv = 0;
         st->nonfinite = bad ? 1 : 0;
         st->done = bad ? 1 : 0;
+        st->finished = bad ? 1 : 0;
         if (!bad && !(c > 0.0)) {            // A == 0: its root is 0, nothing to iterate
-            st->done = 1; st->conv = 1; st->final_iter = 0; st->c = 1.0;
+            st->done = 1; st->finished = 1; st->conv = 1; st->final_iter = 0; st->c = 1.0;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void ns_scale(const double* __restrict__ Aall, int d, const NsState* __restrict__ st,
-                                                double* __restrict__ Yall, double* __restrict__ Zall, int64_t stride) {
+// Iteration 0 needs no GEMM for T and Z: with Z0 = I,  T0 = (3I - Y0)/2 and Z1 = T0.  This kernel writes
+// Y0 = A/c, T0 (twice: as T and as Z1) and the per-block partial sums of (T0 - I)^2, i.e. the residual of
+// iteration 0 in the same form the T GEMM produces it.  grid (ceil(d*d/256), B).
+__global__ __launch_bounds__(256) void ns_first(const double* __restrict__ Aall, int d, const NsState* __restrict__ st,
+                                                double* __restrict__ Y0, double* __restrict__ T, double* __restrict__ Z1,
+                                                int64_t stride, double* __restrict__ partials_all, int nslots) {
+    __shared__ double red[4];
     const int b = blockIdx.y;
     if (st[b].done) return;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= (int64_t)d * d) return;
-    const double inv = 1.0 / st[b].c;
-    const int r = (int)(g / d), c = (int)(g - (int64_t)r * d);
-    Yall[b * stride + g] = Aall[(int64_t)b * d * d + g] * inv;
-    Zall[b * stride + g] = (r == c) ? 1.0 : 0.0;
+    double e2 = 0.0;
+    if (g < (int64_t)d * d) {
+        const double inv = 1.0 / st[b].c;
+        const int r = (int)(g / d), c = (int)(g - (int64_t)r * d);
+        const double y = Aall[(int64_t)b * d * d + g] * inv;
+        const double t = (r == c ? 1.5 : 0.0) - 0.5 * y;
+        Y0[b * stride + g] = y;
+        T[b * stride + g] = t;
+        Z1[b * stride + g] = t;
+        const double e = t - (r == c ? 1.0 : 0.0);
+        e2 = e * e;
+    }
+    const double s = block_sum(e2, red);
+    if (threadIdx.x == 0) partials_all[(int64_t)b * nslots + blockIdx.x] = s;
 }
 
 // one block per problem per iteration: reduce the residual partials, trace(Y), decide
 __global__ __launch_bounds__(256) void ns_check(int k, int max_iter, NsState* __restrict__ st_all,
-                                                const double* __restrict__ partials_all, int nslots,
+                                                const double* __restrict__ partials_all, int nslots, int pstride,
                                                 const double* __restrict__ Yall, int64_t stride, int d,
-                                                double tol_res, double tol_tr) {
+                                                double tol_res, double tol_tr, int finalize_only) {
     __shared__ double red[4];
     const int b = blockIdx.x;
     NsState* st = st_all + b;
-    if (st->done) return;
-    const double* partials = partials_all + (int64_t)b * nslots;
+    if (st->finished) return;
+    if (finalize_only && !st->done) return;
     const double* Y = Yall + b * stride;
     const int tid = threadIdx.x;
-    double s = 0.0, t = 0.0;
-    for (int i = tid; i < nslots; i += 256) s += partials[i];
+    double t = 0.0;
     for (int i = tid; i < d; i += 256) t += Y[(int64_t)i * d + i];
-    const double sumsq = block_sum(s, red);
     const double tr = block_sum(t, red);
+    if (st->done) {
+        // the previous check predicted convergence after one more update: Y is that final iterate
+        if (tid == 0) {
+            st->tr[k] = tr; st->res[k] = st->res_last;
+            const bool finite = (tr == tr) && !isinf(tr);
+            if (!finite) st->nonfinite = 1;
+            st->tr_last = tr; st->final_iter = k; st->finished = 1;
+        }
+        return;
+    }
+    const double* partials = partials_all + (int64_t)b * pstride;
+    double s = 0.0;
+    for (int i = tid; i < nslots; i += 256) s += partials[i];
+    const double sumsq = block_sum(s, red);
     if (tid != 0) return;
     const double res = 2.0 * sqrt(sumsq);           // ||I - ZY||_F = 2 ||T - I||_F
     st->res[k] = res; st->tr[k] = tr;
     const bool finite = (res == res) && !isinf(res) && (tr == tr) && !isinf(tr);
-    if (!finite) { st->done = 1; st->nonfinite = 1; return; }
+    if (!finite) { st->done = 1; st->finished = 1; st->nonfinite = 1; return; }
     const double tr_prev = st->tr_last;
     st->res_last = res; st->tr_last = tr; st->final_iter = k;
-    if (res <= tol_res) { st->done = 1; st->conv = 1; }
-    else if (k > 0 && fabs(tr - tr_prev) <= tol_tr * fabs(tr)) { st->done = 1; st->conv = 2; }
-    else if (k + 1 >= max_iter) { st->done = 1; st->conv = 0; }
+    if (res <= tol_res) { st->done = 1; st->finished = 1; st->conv = 1; }
+    else if (k > 0 && fabs(tr - tr_prev) <= tol_tr * fabs(tr)) { st->done = 1; st->finished = 1; st->conv = 2; }
+    else if (k + 1 >= max_iter) { st->done = 1; st->finished = 1; st->conv = 0; }
+    else {
+        // E_{k+1} = (3 E_k^2 + E_k^3) / 4 for E = I - ZY, hence ||E_{k+1}||_F <= 3/4 res^2 + 1/4 res^3: when that
+        // bound is already below the tolerance the NEXT iterate is converged -- apply the update, skip its T GEMM
+        const double bound = 0.75 * res * res + 0.25 * res * res * res;
+        if (bound <= tol_res) { st->done = 1; st->conv = 1; st->res_last = bound; }
+    }
 }
 
 __global__ __launch_bounds__(256) void add_diag(double* __restrict__ M, int d, double eps) {
@@ -177,9 +212,13 @@ __global__ __launch_bounds__(256) void add_diag(double* __restrict__ M, int d, d
 }
 
 // packed moments -> mu, cov (same formula as moments_finalize_kernel) + the n >= 2 check
-__global__ __launch_bounds__(256) void finalize_for_frechet(const double* __restrict__ acc, int d, int ddof,
-                                                            double* __restrict__ mu, double* __restrict__ cov,
+__global__ __launch_bounds__(256) void finalize_for_frechet(const double* __restrict__ acc1,
+                                                            const double* __restrict__ acc2, int d, int ddof,
+                                                            double* __restrict__ mus, double* __restrict__ covs,
                                                             NsState* __restrict__ st) {
+    const double* acc = blockIdx.y ? acc2 : acc1;
+    double* mu = mus + (int64_t)blockIdx.y * d;
+    double* cov = covs + (int64_t)blockIdx.y * d * d;
     const double n = acc[0];
     const double* sum = acc + 1;
     const double* M = acc + 1 + d;
@@ -193,7 +232,7 @@ __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __rest
 
 __global__ void clear_states(NsState* st, int64_t B) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (b < B) { st[b].too_few = 0; st[b].done = 0; st[b].nonfinite = 0; st[b].conv = 0; st[b].final_iter = -1; }
+    if (b < B) { st[b].too_few = 0; st[b].done = 0; st[b].finished = 0; st[b].nonfinite = 0; st[b].conv = 0; st[b].final_iter = -1; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -220,8 +259,12 @@ struct NsProblem {                  // B problems of dimension d; strides in ele
     const double* mu2; int64_t s_mu2;
 };
 
+static int ns_pstride(int d) {                       // partial slots per problem: GEMM tiles or ns_first blocks
+    const int64_t a = gemm_f64_slots_max(d), b = cdiv((int64_t)d * d, 256);
+    return (int)(a > b ? a : b);
+}
 static size_t ns_small_bytes(int d, int64_t B) {
-    return (size_t)B * (sizeof(NsState) + ((size_t)gemm_f64_slots_max(d) + 3 * (size_t)d) * sizeof(double)) + 256;
+    return (size_t)B * (sizeof(NsState) + ((size_t)ns_pstride(d) + 3 * (size_t)d) * sizeof(double)) + 256;
 }
 
 // Enqueue + run the batched iteration.  On return host_states (pinned, B entries) holds the final
@@ -243,8 +286,10 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     double* T = A + 5 * dd * B;
     NsState* dstates = static_cast<NsState*>(ws.small.p);
     double* partials = reinterpret_cast<double*>(dstates + B);
-    double* rowstats = partials + (size_t)B * gemm_f64_slots_max(d);
-    const int* skip = &dstates[0].done;
+    const int pstride = ns_pstride(d);
+    double* rowstats = partials + (size_t)B * pstride;
+    const int* skip_t = &dstates[0].done;            // T GEMMs stop once convergence is known or predicted
+    const int* skip_u = &dstates[0].finished;        // update GEMMs stop once the final iterate exists
 
     const size_t hbytes = (size_t)B * sizeof(NsState);
     if (!ws.pinned || ws.pinned_cap < hbytes) {
@@ -258,34 +303,42 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
 
     GemmType g[2];
     g[0] = {pb.cov1, pb.s_cov1, pb.cov2, pb.s_cov2, A, dd, 1.0, 0.0, 0.0, nullptr};
-    int rc = gemm_f64_launch(d, g, 1, B, skip, kStateInts, stream, device);
+    int rc = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device);
     if (rc < 0) return rc;
     hipLaunchKernelGGL(ns_rowstats, dim3(d, (unsigned)B), dim3(256), 0, stream, A, d, rowstats, dstates);
     hipLaunchKernelGGL(ns_prepare, dim3((unsigned)B), dim3(256), 0, stream, rowstats, d, pb.cov1, pb.s_cov1, pb.cov2,
                        pb.s_cov2, pb.mu1, pb.s_mu1, pb.mu2, pb.s_mu2, dstates);
-    hipLaunchKernelGGL(ns_scale, dim3((unsigned)cdiv(dd, 256), (unsigned)B), dim3(256), 0, stream, A, d, dstates, Y[0],
-                       Z[0], dd);
+    // iteration 0 without GEMMs for T and Z (Z0 = I): Y0, T0, Z1 = T0, residual partials
+    const int nslots0 = (int)cdiv(dd, 256);
+    hipLaunchKernelGGL(ns_first, dim3((unsigned)nslots0, (unsigned)B), dim3(256), 0, stream, A, d, dstates, Y[0], T, Z[1],
+                       dd, partials, pstride);
 
     int cur = 0, k = 0, chunk = 8;
     bool all_done = false;
     while (!all_done && k < max_iter) {
         const int stop = (k + chunk < max_iter) ? k + chunk : max_iter;
         for (; k < stop; ++k) {
-            g[0] = {Z[cur], dd, Y[cur], dd, T, dd, -0.5, 1.5, 1.0, partials};
-            const int nslots = gemm_f64_launch(d, g, 1, B, skip, kStateInts, stream, device);
-            if (nslots < 0) return nslots;
+            int nslots = nslots0;
+            if (k > 0) {
+                g[0] = {Z[cur], dd, Y[cur], dd, T, dd, -0.5, 1.5, 1.0, partials};
+                nslots = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device, pstride);
+                if (nslots < 0) return nslots;
+            }
             hipLaunchKernelGGL(ns_check, dim3((unsigned)B), dim3(256), 0, stream, k, max_iter, dstates, partials, nslots,
-                               Y[cur], dd, d, tol_res, tol_tr);
+                               pstride, Y[cur], dd, d, tol_res, tol_tr, 0);
             g[0] = {Y[cur], dd, T, dd, Y[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
             g[1] = {T, dd, Z[cur], dd, Z[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
-            rc = gemm_f64_launch(d, g, 2, B, skip, kStateInts, stream, device);
+            rc = gemm_f64_launch(d, g, k == 0 ? 1 : 2, B, skip_u, kStateInts, stream, device);      // Z1 = T0 is in place
             if (rc < 0) return rc;
             cur ^= 1;
         }
+        // a problem whose convergence was PREDICTED is finalised by the check that follows its last update
+        hipLaunchKernelGGL(ns_check, dim3((unsigned)B), dim3(256), 0, stream, k < kMaxIter ? k : kMaxIter - 1, max_iter,
+                           dstates, partials, 0, pstride, Y[cur], dd, d, tol_res, tol_tr, 1);
         FAD_HIP_TRY(hipMemcpyAsync(hs, dstates, hbytes, hipMemcpyDeviceToHost, stream));
         FAD_HIP_TRY(hipStreamSynchronize(stream));
         all_done = true;
-        for (int64_t b = 0; b < B; ++b) if (!hs[b].done) { all_done = false; break; }
+        for (int64_t b = 0; b < B; ++b) if (!hs[b].finished) { all_done = false; break; }
         chunk = 4;
     }
     FAD_HIP_TRY(hipGetLastError());
@@ -534,8 +587,8 @@ int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, i
     FAD_TRY(ws.stage.reserve((size_t)(4 * dd + 2 * d) * sizeof(double)));
     double* s = static_cast<double*>(ws.stage.p);
     const unsigned eg = (unsigned)cdiv(dd, 256);
-    hipLaunchKernelGGL(finalize_for_frechet, dim3(eg), dim3(256), 0, st, moments_packed(h1), d, ddof, s + 2 * dd, s, dstate);
-    hipLaunchKernelGGL(finalize_for_frechet, dim3(eg), dim3(256), 0, st, moments_packed(h2), d, ddof, s + 2 * dd + d, s + dd, dstate);
+    hipLaunchKernelGGL(finalize_for_frechet, dim3(eg, 2), dim3(256), 0, st, moments_packed(h1), moments_packed(h2), d, ddof,
+                       s + 2 * dd, s, dstate);
     return frechet_single(d, s, s + dd, s + 2 * dd, s + 2 * dd + d, eps, max_iter, tol, device, st, ws, out_fad, diag, true);
 }
 

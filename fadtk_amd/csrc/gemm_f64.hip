@@ -13,9 +13,12 @@
 // (deterministic two-level reduction; no atomics).
 #include "fad_common.h"
 
+#include <cstdlib>
+
 namespace fad {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 // blockIdx.z = batch_index * ntypes + type.  Each "type" is one GEMM shape of the iteration (e.g.
 // Y' = Y T and Z' = T Z share a launch); each batch index is one independent problem (one song).
@@ -27,6 +30,8 @@ struct GemmArgs {
     const int* skip;                     // skip[batch_index * skip_stride] != 0 -> problem is finished
     int skip_stride;
     int ntypes;
+    int remap;                           // XCD-aware tile map on/off
+    int pstride;                         // partial slots reserved per problem
 };
 
 constexpr int KB = 64;                 // k depth of one LDS stage
@@ -39,9 +44,13 @@ constexpr int PA = KB + 2;             // A pitch (doubles): rows i..i+15 land o
 //     operands in flight while the MFMAs chew on the LDS-resident stage;
 //   * XCD-aware tile map: workgroup b runs on XCD b % 8; XCD (ex, ey) of a 2 x 4 grid owns a contiguous
 //     block of output tiles, so each private L2 fetches 1/2 of A's rows and 1/4 of B's columns once.
-template <int BT, int DEPTH>
+// KSPLIT (used for the 32 x 32 tile): every wave owns the WHOLE tile as 2 x 2 MFMA tiles but only every
+// 4th k-step; the four partial tiles are summed through LDS at the end.  A wave then carries four
+// independent accumulators instead of one 128-long dependent chain: measured, the dependent
+// v_mfma_f64_16x16x4_f64 chain (not the loads) was what held the first versions at ~20 % of peak.
+template <int BT, int DEPTH, bool KSPLIT, bool FULL>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
-    constexpr int MT = BT / 32;              // MFMA tiles per wave per side
+    constexpr int MT = KSPLIT ? 2 : BT / 32; // MFMA tiles per wave per side
     constexpr int PB = BT + 16;
     constexpr int NV = BT * KB / 2 / 256;    // double2 loads per thread per operand per stage
     constexpr int BV = BT / 2;               // double2 per B row
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     // ---- tile coordinates (XCD-aware when the tile grid splits evenly into 2 x 4 blocks)
     int ty = blockIdx.y, tx = blockIdx.x;
     const int t = gridDim.x;
-    if ((t & 3) == 0) {
+    if (g.remap && (t & 3) == 0) {
         const int b = blockIdx.y * t + blockIdx.x;
         const int xcd = b & 7, idx = b >> 3;
         const int R = t >> 1, Cc = t >> 2;
@@ -70,15 +79,18 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     }
     const int slot = ty * t + tx;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: plain k-loop, no exec masking
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
     const int row0 = ty * BT, col0 = tx * BT;
     const bool vec = ((d & 1) == 0);         // 16-byte loads need even d (row starts stay 16-B aligned)
     const int nkb = (d + KB - 1) / KB;
 
-    double2 ra[DEPTH][NV], rb[DEPTH][NV];
-    auto fetch = [&](double2 (&pa)[NV], double2 (&pb)[NV], int kb) {
+    // three named register sets (an array of arrays indexed in a loop ends up in scratch memory, which
+    // forces a wait on every prefetch right after it is issued)
+    d2 ra0[NV], rb0[NV], ra1[NV], rb1[NV], ra2[NV], rb2[NV];
+    auto fetch = [&](d2 (&pa)[NV], d2 (&pb)[NV], int kb) {
         if (kb >= nkb) return;
         const int k0 = kb * KB;
 #pragma unroll
@@ -88,9 +100,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
             const int r = row0 + ai, k = k0 + ak;
             const int bk = e / BV, bj = (e % BV) * 2;                    // B tile [64][BT], pairs along j
             const int kk = k0 + bk, c = col0 + bj;
-            if (vec) {
-                pa[q] = (r < d && k < d) ? *reinterpret_cast<const double2*>(A + (int64_t)r * d + k) : make_double2(0.0, 0.0);
-                pb[q] = (kk < d && c < d) ? *reinterpret_cast<const double2*>(B + (int64_t)kk * d + c) : make_double2(0.0, 0.0);
+            if constexpr (FULL) {      // d % 64 == 0: no bounds, no branches -- hipcc otherwise wraps EVERY guarded load in an exec
+                             // branch with its own s_waitcnt vmcnt(0), which serialises the whole prefetch
+                pa[q] = *reinterpret_cast<const d2*>(A + (int64_t)r * d + k);
+                pb[q] = *reinterpret_cast<const d2*>(B + (int64_t)kk * d + c);
+            } else if (vec) {
+                pa[q] = (r < d && k < d) ? *reinterpret_cast<const d2*>(A + (int64_t)r * d + k) : (d2){0.0, 0.0};
+                pb[q] = (kk < d && c < d) ? *reinterpret_cast<const d2*>(B + (int64_t)kk * d + c) : (d2){0.0, 0.0};
             } else {
                 pa[q].x = (r < d && k < d) ? A[(int64_t)r * d + k] : 0.0;
                 pa[q].y = (r < d && k + 1 < d) ? A[(int64_t)r * d + k + 1] : 0.0;
@@ -107,25 +123,25 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
         for (int y = 0; y < MT; ++y) acc[x][y] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
     // one stage: registers -> LDS, refill the same registers DEPTH stages ahead, MFMAs from LDS
-    auto stage = [&](double2 (&pa)[NV], double2 (&pb)[NV], int kb) {
+    auto stage = [&](d2 (&pa)[NV], d2 (&pb)[NV], int kb) {
         if (kb >= nkb) return;
         if (kb) __syncthreads();                 // everyone is done reading the previous stage
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int e = tid + q * 256;
-            *reinterpret_cast<double2*>(sA + (e / (KB / 2)) * PA + (e % (KB / 2)) * 2) = pa[q];
-            *reinterpret_cast<double2*>(sB + (e / BV) * PB + (e % BV) * 2) = pb[q];
+            *reinterpret_cast<d2*>(sA + (e / (KB / 2)) * PA + (e % (KB / 2)) * 2) = pa[q];
+            *reinterpret_cast<d2*>(sB + (e / BV) * PB + (e % BV) * 2) = pb[q];
         }
         __syncthreads();
         fetch(pa, pb, kb + DEPTH);
 #pragma unroll 4
-        for (int ks = 0; ks < KB / 4; ++ks) {
+        for (int ks = (KSPLIT ? wave : 0); ks < KB / 4; ks += (KSPLIT ? 4 : 1)) {
             const int k = ks * 4 + lk;
             double a[MT], b[MT];
 #pragma unroll
             for (int f = 0; f < MT; ++f) {
-                a[f] = sA[(wr * (BT / 2) + 16 * f + li) * PA + k];
-                b[f] = sB[k * PB + wc * (BT / 2) + 16 * f + li];
+                a[f] = sA[((KSPLIT ? 0 : wr * (BT / 2)) + 16 * f + li) * PA + k];
+                b[f] = sB[k * PB + (KSPLIT ? 0 : wc * (BT / 2)) + 16 * f + li];
             }
 #pragma unroll
             for (int fa = 0; fa < MT; ++fa)
@@ -135,29 +151,58 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
         }
     };
 
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s) fetch(ra[s], rb[s], s);
+    fetch(ra0, rb0, 0);
+    if (DEPTH > 1) fetch(ra1, rb1, 1);
+    if (DEPTH > 2) fetch(ra2, rb2, 2);
     for (int kb = 0; kb < nkb; kb += DEPTH) {
-#pragma unroll
-        for (int s = 0; s < DEPTH; ++s) stage(ra[s], rb[s], kb + s);
+        stage(ra0, rb0, kb);
+        if (DEPTH > 1) stage(ra1, rb1, kb + 1);
+        if (DEPTH > 2) stage(ra2, rb2, kb + 2);
     }
 
     double ss = 0.0;
+    if constexpr (KSPLIT) {
+        // sum the four waves' partial tiles through LDS, then a row-major (coalesced) store of C
+        __syncthreads();
+        double* part = smem;                                   // [4][32][33]
 #pragma unroll
-    for (int fa = 0; fa < MT; ++fa)
+        for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
-        for (int fb = 0; fb < MT; ++fb)
+            for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = row0 + wr * (BT / 2) + 16 * fa + lk + 4 * reg;
-                const int c = col0 + wc * (BT / 2) + 16 * fb + li;
-                if (r < d && c < d) {
-                    const double v = alpha * acc[fa][fb][reg] + (r == c ? beta_eye : 0.0);
-                    C[(int64_t)r * d + c] = v;
-                    const double e = v - (r == c ? gamma : 0.0);
-                    ss += e * e;
-                }
+                for (int reg = 0; reg < 4; ++reg)
+                    part[wave * (32 * 33) + (16 * fa + lk + 4 * reg) * 33 + 16 * fb + li] = acc[fa][fb][reg];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256, rr = e >> 5, cc = e & 31;
+            const int r = row0 + rr, c = col0 + cc;
+            const double sum = (part[rr * 33 + cc] + part[(32 * 33) + rr * 33 + cc]) +
+                               (part[2 * (32 * 33) + rr * 33 + cc] + part[3 * (32 * 33) + rr * 33 + cc]);
+            if (r < d && c < d) {
+                const double v = alpha * sum + (r == c ? beta_eye : 0.0);
+                C[(int64_t)r * d + c] = v;
+                const double e2 = v - (r == c ? gamma : 0.0);
+                ss += e2 * e2;
             }
+        }
+    } else {
+#pragma unroll
+        for (int fa = 0; fa < MT; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < MT; ++fb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = row0 + wr * (BT / 2) + 16 * fa + lk + 4 * reg;
+                    const int c = col0 + wc * (BT / 2) + 16 * fb + li;
+                    if (r < d && c < d) {
+                        const double v = alpha * acc[fa][fb][reg] + (r == c ? beta_eye : 0.0);
+                        C[(int64_t)r * d + c] = v;
+                        const double e = v - (r == c ? gamma : 0.0);
+                        ss += e * e;
+                    }
+                }
+    }
     double* partials = g.partials[zi];
     if (partials) {
 #pragma unroll
@@ -165,7 +210,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
         __syncthreads();
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        if (tid == 0) partials[zb * (gridDim.x * gridDim.y) + slot] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) partials[zb * g.pstride + slot] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -182,7 +227,7 @@ int gemm_f64_slots(int d, int ntypes, int64_t batch, int device) {
 int gemm_f64_slots_max(int d) { const int64_t t = cdiv(d, 32); return (int)(t * t); }
 
 int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, const int* skip, int skip_stride,
-                    hipStream_t stream, int device) {
+                    hipStream_t stream, int device, int partial_stride) {
     if (ntypes < 1 || ntypes > 2 || batch < 1) return set_error(FAD_ERR_INVALID, "gemm: ntypes=%d batch=%lld", ntypes, (long long)batch);
     const int bt = pick_bt(d, (int64_t)ntypes * batch, device);
     const int64_t t = cdiv(d, bt);
@@ -197,13 +242,25 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
             g.C[i] = types[i].C + done * types[i].sc;
             g.sa[i] = types[i].sa; g.sb[i] = types[i].sb; g.sc[i] = types[i].sc;
             g.alpha[i] = types[i].alpha; g.beta_eye[i] = types[i].beta_eye; g.gamma[i] = types[i].gamma;
-            g.partials[i] = types[i].partials ? types[i].partials + done * slots : nullptr;
+            g.partials[i] = types[i].partials ? types[i].partials + done * (partial_stride > 0 ? partial_stride : slots) : nullptr;
         }
         g.skip = skip ? skip + done * skip_stride : nullptr;
         g.skip_stride = skip_stride; g.ntypes = ntypes;
+        static const int env_remap = [] { const char* e = getenv("FAD_GEMM_REMAP"); return e ? atoi(e) : 1; }();
+        static const int env_depth = [] { const char* e = getenv("FAD_GEMM_DEPTH"); return e ? atoi(e) : 1; }();
+        g.remap = env_remap;
+        g.pstride = partial_stride > 0 ? partial_stride : (int)slots;
         dim3 grid((unsigned)t, (unsigned)t, (unsigned)(m * ntypes));
-        if (bt == 64) hipLaunchKernelGGL((gemm_f64_kernel<64, 2>), grid, dim3(256), 0, stream, d, g);
-        else hipLaunchKernelGGL((gemm_f64_kernel<32, 3>), grid, dim3(256), 0, stream, d, g);
+        const bool full = (d % KB) == 0;
+        if (bt == 64) {
+            if (full) hipLaunchKernelGGL((gemm_f64_kernel<64, 2, false, true>), grid, dim3(256), 0, stream, d, g);
+            else hipLaunchKernelGGL((gemm_f64_kernel<64, 2, false, false>), grid, dim3(256), 0, stream, d, g);
+        } else {
+            if (full && env_depth == 1) hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true>), grid, dim3(256), 0, stream, d, g);
+            else if (full && env_depth == 2) hipLaunchKernelGGL((gemm_f64_kernel<32, 2, true, true>), grid, dim3(256), 0, stream, d, g);
+            else if (full) hipLaunchKernelGGL((gemm_f64_kernel<32, 3, true, true>), grid, dim3(256), 0, stream, d, g);
+            else hipLaunchKernelGGL((gemm_f64_kernel<32, 3, true, false>), grid, dim3(256), 0, stream, d, g);
+        }
     }
     FAD_HIP_TRY(hipGetLastError());
     return (int)slots;
