@@ -63,31 +63,35 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-// ---- |row| sums, |col| sums, row sums of squares of A[b]; grid (d, B) ----------------------
+constexpr int kStatRows = 5;
+// ---- per row r of A[b]: |row| sum, |col| sum, sum of squares, (row r).(col r), A[r][r]; grid (d, B) ---
 __global__ __launch_bounds__(256) void ns_rowstats(const double* __restrict__ Aall, int d,
                                                    double* __restrict__ stats_all, const NsState* __restrict__ st) {
-    __shared__ double red[3][4];
+    __shared__ double red[4][4];
     const int b = blockIdx.y;
     if (st[b].done) return;
     const double* A = Aall + (int64_t)b * d * d;
-    double* stats = stats_all + (int64_t)b * 3 * d;
+    double* stats = stats_all + (int64_t)b * kStatRows * d;
     const int r = blockIdx.x, tid = threadIdx.x;
-    double ra = 0.0, ca = 0.0, rs = 0.0;
+    double ra = 0.0, ca = 0.0, rs = 0.0, rc = 0.0;
     for (int j = tid; j < d; j += 256) {
-        const double v = A[(int64_t)r * d + j];
+        const double v = A[(int64_t)r * d + j], w = A[(int64_t)j * d + r];
         ra += fabs(v); rs += v * v;
-        ca += fabs(A[(int64_t)j * d + r]);
+        ca += fabs(w);
+        rc += v * w;                                  // row r of A times column r of A: sums to tr(A^2)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        ra += __shfl_xor(ra, off); ca += __shfl_xor(ca, off); rs += __shfl_xor(rs, off);
+        ra += __shfl_xor(ra, off); ca += __shfl_xor(ca, off); rs += __shfl_xor(rs, off); rc += __shfl_xor(rc, off);
     }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = ra; red[1][tid >> 6] = ca; red[2][tid >> 6] = rs; }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = ra; red[1][tid >> 6] = ca; red[2][tid >> 6] = rs; red[3][tid >> 6] = rc; }
     __syncthreads();
     if (tid == 0) {
         stats[r] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         stats[d + r] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         stats[2 * d + r] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        stats[3 * d + r] = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+        stats[4 * d + r] = A[(int64_t)r * d + r];
     }
 }
 
@@ -102,11 +106,12 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
     const int b = blockIdx.x, tid = threadIdx.x;
     NsState* st = st_all + b;
     if (st->done) return;
-    const double* stats = stats_all + (int64_t)b * 3 * d;
+    const double* stats = stats_all + (int64_t)b * kStatRows * d;
     cov1 += b * s1; cov2 += b * s2; mu1 += b * m1; mu2 += b * m2;
-    double mr = 0.0, mc = 0.0, sq = 0.0, t1 = 0.0, t2 = 0.0, mt = 0.0;
+    double mr = 0.0, mc = 0.0, sq = 0.0, t1 = 0.0, t2 = 0.0, mt = 0.0, ta2 = 0.0, ta = 0.0;
     for (int i = tid; i < d; i += 256) {
         mr = fmax(mr, stats[i]); mc = fmax(mc, stats[d + i]); sq += stats[2 * d + i];
+        ta2 += stats[3 * d + i]; ta += stats[4 * d + i];
         t1 += cov1[(int64_t)i * d + i]; t2 += cov2[(int64_t)i * d + i];
         const double df = mu1[i] - mu2[i];
         mt += df * df;
@@ -115,10 +120,18 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
     const double one_norm = block_max(mc, red);
     const double fro2 = block_sum(sq, red);          // NaNs/Infs propagate through the sums
     const double tr1 = block_sum(t1, red), tr2 = block_sum(t2, red), mean_term = block_sum(mt, red);
+    const double trA2 = block_sum(ta2, red), trA = block_sum(ta, red);
     if (tid == 0) {
-        double c = sqrt(fro2);
-        if (inf_norm < c) c = inf_norm;
-        if (one_norm < c) c = one_norm;
+        // Scale: the iteration needs every eigenvalue of A/c below 3 (above, Y converges to a NEGATIVE root).
+        // U = min(||A||_F, ||A||_1, ||A||_inf) >= rho(A) makes c = U/2.5 always safe; the lambda-weighted mean
+        // tr(A^2)/tr(A) <= lambda_max is where the bulk of the spectrum sits, and starting the bulk near 1 saves
+        // 1-3 iterations when U is loose (flat spectra: U ~ 2.5-3x lambda_max).  c = max of the two.
+        double u = sqrt(fro2);
+        if (inf_norm < u) u = inf_norm;
+        if (one_norm < u) u = one_norm;
+        double c = u / 2.5;
+        const double wmean = (trA > 0.0) ? trA2 / trA : 0.0;
+        if (wmean > c && wmean <= u) c = wmean;
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(tr1 == tr1) || !(tr2 == tr2) || isinf(tr1) ||
                          isinf(tr2) || !(mean_term == mean_term) || isinf(mean_term);
         st->c = c; st->tr1 = tr1; st->tr2 = tr2; st->mean_term = mean_term;
@@ -264,7 +277,7 @@ static int ns_pstride(int d) {                       // partial slots per proble
     return (int)(a > b ? a : b);
 }
 static size_t ns_small_bytes(int d, int64_t B) {
-    return (size_t)B * (sizeof(NsState) + ((size_t)ns_pstride(d) + 3 * (size_t)d) * sizeof(double)) + 256;
+    return (size_t)B * (sizeof(NsState) + ((size_t)ns_pstride(d) + kStatRows * (size_t)d) * sizeof(double)) + 256;
 }
 
 // Enqueue + run the batched iteration.  On return host_states (pinned, B entries) holds the final
