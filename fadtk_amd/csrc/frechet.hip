@@ -12,7 +12,7 @@
 // ||A||_1, ||A||_inf.  Stopping is decided ON DEVICE per problem, so the host enqueues iterations
 // blindly and syncs once per chunk:
 //   1  ||I - Z Y||_F <= tol                       (full-rank product)
-//   2  trace(Y) stagnates to 1e-13 relative        (rank-deficient product: null directions never
+//   2  trace(Y) AND the residual stand still       (rank-deficient product: null directions never
 //                                                   converge but add nothing to the trace; stopping
 //                                                   here also keeps Z from blowing up)
 //   0  max_iter
@@ -207,9 +207,14 @@ __global__ __launch_bounds__(256) void ns_check(int k, int max_iter, NsState* __
     const bool finite = (res == res) && !isinf(res) && (tr == tr) && !isinf(tr);
     if (!finite) { st->done = 1; st->finished = 1; st->nonfinite = 1; return; }
     const double tr_prev = st->tr_last;
+    const double res_prev = (k > 0) ? st->res[k - 1] : 0.0;
     st->res_last = res; st->tr_last = tr; st->final_iter = k;
+    // Stagnation = a rank-deficient product: the null directions keep the residual frozen while the trace has
+    // converged.  Both must stand still (the trace alone can pause by coincidence: with c = tr(A^2)/tr(A),
+    // tr(Y1) == tr(Y0) exactly), and not before the second iteration.
+    const bool stalled = k >= 2 && fabs(tr - tr_prev) <= tol_tr * fabs(tr) && fabs(res - res_prev) <= 1e-9 * res;
     if (res <= tol_res) { st->done = 1; st->finished = 1; st->conv = 1; }
-    else if (k > 0 && fabs(tr - tr_prev) <= tol_tr * fabs(tr)) { st->done = 1; st->finished = 1; st->conv = 2; }
+    else if (stalled) { st->done = 1; st->finished = 1; st->conv = 2; }
     else if (k + 1 >= max_iter) { st->done = 1; st->finished = 1; st->conv = 0; }
     else {
         // E_{k+1} = (3 E_k^2 + E_k^3) / 4 for E = I - ZY, hence ||E_{k+1}||_F <= 3/4 res^2 + 1/4 res^3: when that
