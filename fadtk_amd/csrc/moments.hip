@@ -382,6 +382,169 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
 }
 
 // ------------------------------------------------------------------------------------------
+// v3: same 128 x 128 tile, same LDS ring, but TWO waves per workgroup, each owning 128 (A side) x 64
+// (B side) = 4 x 2 MFMA tiles.  The A fragments come from ds_read_b64 (lane i reads columns 4i..4i+3
+// of 8 rows -> four fragments), the B fragments from ds_read_b32 as before: 16 LDS reads + 24 v_perm
+// feed 8 MFMAs instead of 16 + 16 feeding 4.  v2 saturated the LDS read port (8 waves x 16 reads per
+// 128 MFMA cycles); here a CU runs 4 such waves (2 workgroups), one per SIMD.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int NST, bool DIAG>
+__device__ __forceinline__ void tile_h16_w2_body(
+    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
+    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
+    uint4* smem, int* __restrict__ shift_flag) {
+    constexpr int LPS = DIAG ? 4 : 8;              // glds instructions per wave per stage
+    constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = B-side half
+    const int li = lane & 31, kg = lane >> 5;
+    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
+
+    const int sr = tid >> 4, sc = tid & 15;        // staging: rows sr + 8h, 16-byte chunk sc
+    const bool col_ok_a = (ca + sc * 8) < d;
+    const bool col_ok_b = (cb + sc * 8) < d;
+    const uint16_t* ga = E + ca + sc * 8;
+    const uint16_t* gb = E + cb + sc * 8;
+    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
+
+    auto issue = [&](int kb) {
+        uint4* st = smem + (kb % NST) * STAGE;
+        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int64_t r = r0 + 8 * h;
+            const bool ok = r < k_end;
+            uint4* dstA = st + (8 * h + 4 * wc) * 16;            // wave-uniform base; + lane*16 B by the hardware
+            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)dstA, 16, 0, 0);
+            if (!DIAG) {
+                const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
+    double csum[2] = {0.0, 0.0};
+
+    for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
+        if (ahead >= 2) wait_vmcnt<2 * LPS>();
+        else if (ahead == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+
+        const uint2* sA = reinterpret_cast<const uint2*>(smem + (kb % NST) * STAGE);
+        const uint32_t* sB = reinterpret_cast<const uint32_t*>(smem + (kb % NST) * STAGE + (DIAG ? 0 : H_KB * 16));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rbase = ks * 16 + kg * 8;
+            uint2 wa[8];
+            uint32_t wb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                wa[e] = sA[(rbase + e) * 32 + li];               // columns 4 li .. 4 li + 3 of row rbase + e
+                wb[e] = sB[(rbase + e) * 64 + 32 * wc + li];     // columns 64 wc + 2 li, + 1
+            }
+            uint4 a[4], b[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x0 = wa[2 * q].x, x1 = wa[2 * q + 1].x, y0 = wa[2 * q].y, y1 = wa[2 * q + 1].y;
+                const uint32_t f0 = __builtin_amdgcn_perm(x1, x0, 0x05040100u), f1 = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                const uint32_t f2 = __builtin_amdgcn_perm(y1, y0, 0x05040100u), f3 = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                const uint32_t g0 = __builtin_amdgcn_perm(wb[2 * q + 1], wb[2 * q], 0x05040100u);
+                const uint32_t g1 = __builtin_amdgcn_perm(wb[2 * q + 1], wb[2 * q], 0x07060302u);
+                if (q == 0) { a[0].x = f0; a[1].x = f1; a[2].x = f2; a[3].x = f3; b[0].x = g0; b[1].x = g1; }
+                if (q == 1) { a[0].y = f0; a[1].y = f1; a[2].y = f2; a[3].y = f3; b[0].y = g0; b[1].y = g1; }
+                if (q == 2) { a[0].z = f0; a[1].z = f1; a[2].z = f2; a[3].z = f3; b[0].z = g0; b[1].z = g1; }
+                if (q == 3) { a[0].w = f0; a[1].w = f1; a[2].w = f2; a[3].w = f3; b[0].w = g0; b[1].w = g1; }
+            }
+#pragma unroll
+            for (int fa = 0; fa < 4; ++fa) {
+                acc[fa][0] = mfma_h16<KIND>(a[fa], b[0], acc[fa][0]);
+                acc[fa][1] = mfma_h16<KIND>(a[fa], b[1], acc[fa][1]);
+            }
+            if (DIAG) {
+                csum[0] += (double)sum8<KIND>(b[0]);
+                csum[1] += (double)sum8<KIND>(b[1]);
+            }
+        }
+    }
+
+    float* out = partials + ((int64_t)split * T + tile) * (H_BT * H_BT);
+#pragma unroll
+    for (int fa = 0; fa < 4; ++fa) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+            const int a_local = 4 * row32 + fa;
+            const int b_local = 64 * wc + 2 * li;
+            *reinterpret_cast<float2*>(out + a_local * H_BT + b_local) = make_float2(acc[fa][0][reg], acc[fa][1][reg]);
+        }
+    }
+    if (DIAG) {
+        csum[0] += __shfl_xor(csum[0], 32);
+        csum[1] += __shfl_xor(csum[1], 32);
+        if (shift_flag) {
+            // sum x^2 of column b = 64 wc + 2 li + f is the accumulator element with a_local == b:
+            // fa = b & 3, C/D row r = b >> 2 = 16 wc + (li >> 1), held (for C/D column li) by kg = (r>>2)&1, reg = (r&3) + 4 (r>>3)
+            const double nr = (double)(k_end - k_begin);
+            const int r = 16 * wc + (li >> 1);
+            const int myreg = (r & 3) + 4 * (r >> 3);
+            const bool own = kg == ((r >> 2) & 1);
+            bool hit = false;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int fa_need = 2 * (li & 1) + f;
+                float dsel = 0.f;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) dsel = (x == fa_need && q == myreg) ? acc[x][f][q] : dsel;
+                double s2 = own ? (double)dsel : 0.0;
+                s2 += __shfl_xor(s2, 32);
+                const double mean = csum[f] / nr, var = s2 / nr - mean * mean;
+                const bool col_in = (cb + 64 * wc + 2 * li + f) < d;
+                if (col_in && !(mean * mean <= 64.0 * var) && !(csum[f] == 0.0 && s2 == 0.0)) hit = true;
+            }
+            if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
+        }
+        if (kg == 0) {
+            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + 2 * li;
+            cp[0] = csum[0]; cp[1] = csum[1];
+        }
+    }
+}
+
+template <int KIND, int NST>
+__global__ __launch_bounds__(128) void moments_tile_h16_w2(
+    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
+    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
+    int* __restrict__ shift_flag) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];
+    const int w = xcd_contiguous(blockIdx.x, S * T);
+    const int split = w / T, tile = w - split * T;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const int64_t k_begin = (int64_t)split * rows_per_split;
+    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    if (ta == tb)
+        tile_h16_w2_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+                                          partials, colpart, smem_dyn, shift_flag);
+    else
+        tile_h16_w2_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+                                           partials, colpart, smem_dyn, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
 // Shift guard.  The fp16 pass sums exact products in fp32 over bounded runs; that is accurate
 // relative to sum x^2, not to the variance.  For a column with |mean| >> std (constant-ish features,
 // outlier dimensions of transformer states) the covariance is a small difference of large sums, so
@@ -688,7 +851,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
     }
     if (use_h16) {
         const char* var = getenv("FAD_MOMENTS_VARIANT");
-        const int variant = (var && var[0] == '1') ? 1 : 2;
+        const int variant = (var && var[0] == '1') ? 1 : (var && var[0] == '3') ? 3 : 2;
         constexpr int NST = 4;
         SplitPlan p = plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256);
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_BT * H_BT * sizeof(float)));
@@ -698,12 +861,28 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
         const uint16_t* e16 = static_cast<const uint16_t*>(rows);
         int* flag_now = nullptr; int* flag_next = nullptr;
-        if (h->guard && variant == 2) {
+        if (h->guard && variant != 1) {
             flag_now = h->shift_flag + (h->update_seq & 1u);
             flag_next = h->shift_flag + ((h->update_seq + 1u) & 1u);
             h->update_seq++;
         }
-        if (variant == 2) {
+        if (variant == 3) {
+            const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
+            static bool attr3 = false;
+            if (!attr3) {
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_w2<FAD_F16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_w2<FAD_BF16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr3 = true;
+            }
+            if (dtype == FAD_F16)
+                hipLaunchKernelGGL((moments_tile_h16_w2<FAD_F16, NST>), dim3(p.S * p.T), dim3(128), lds, st, e16, n, ld, d,
+                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+            else
+                hipLaunchKernelGGL((moments_tile_h16_w2<FAD_BF16, NST>), dim3(p.S * p.T), dim3(128), lds, st, e16, n, ld, d,
+                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+        } else if (variant == 2) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
             static bool attr_set = false;
             if (!attr_set) {
@@ -744,7 +923,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
                            part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, (const int*)flag_now, 0, flag_next);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
-        h->last_variant = (variant == 2) ? 0 : 2;
+        h->last_variant = (variant == 1) ? 2 : 0;
     } else {
         SplitPlan p = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * G_BT * G_BT * sizeof(double)));
