@@ -96,12 +96,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
-    distributed = world > 1
+    # FAD_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, packed all-reduce) even with one rank,
+    # so that it can be exercised on a single-GPU box
+    distributed = world > 1 or os.environ.get("FAD_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     a, b = make_sets(torch, device, rank)
     ma, mb = hip.Moments(DIM, local_rank), hip.Moments(DIM, local_rank)

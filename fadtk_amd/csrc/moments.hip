@@ -674,11 +674,18 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
 // partials -> packed fp64 accumulator (sum over splits in fp64, fixed order => deterministic).
 // One thread per 4 adjacent columns of one tile row.
 // ------------------------------------------------------------------------------------------
-template <typename PT, int BT>
+struct SplitPlan { int nt, T, S; int64_t rows_per_split; };
+
+// SL "split lanes" share one output group: thread (sl, g) sums splits sl, sl+SL, ... and the SL partial
+// sums are combined through LDS in a fixed order.  With hundreds of row-splits (D = 128 uses every
+// workgroup slot for one tile) a single thread per output would walk all of them serially.
+template <typename PT, int BT, int SL>
 __global__ __launch_bounds__(256) void moments_reduce(
     const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed,
     const double* __restrict__ colpart, double n_add, int tile_blocks, const int* __restrict__ gate, int gate_want,
     int* __restrict__ clear_flag) {
+    constexpr int G = 256 / SL;                    // output groups (4 adjacent columns each) per block
+    __shared__ double red[SL > 1 ? 256 * 4 : 1];
     const int per_tile = BT * BT / 4;
     if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;     // next update's flag
     if (gate && (*gate != 0) != (gate_want != 0)) return;     // exactly one of the two reduces of an update runs
@@ -694,27 +701,44 @@ __global__ __launch_bounds__(256) void moments_reduce(
         acc_packed[1 + a] += s0 + s1;
         return;
     }
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= (int64_t)T * per_tile) return;
-    const int tile = (int)(g / per_tile), e = (int)(g - (int64_t)tile * per_tile);
-    const int a_local = e / (BT / 4), b_local = (e % (BT / 4)) * 4;
+    const int sl = threadIdx.x / G, gl = threadIdx.x % G;
+    const int64_t g = (int64_t)blockIdx.x * G + gl;
+    const bool live = g < (int64_t)T * per_tile;
+    int tile = 0, a_local = 0, b_local = 0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        tile = (int)(g / per_tile);
+        const int e = (int)(g - (int64_t)tile * per_tile);
+        a_local = e / (BT / 4); b_local = (e % (BT / 4)) * 4;
+        const PT* p = partials + (int64_t)tile * BT * BT + a_local * BT + b_local;
+        const int64_t stride = (int64_t)T * BT * BT;
+        for (int sp = sl; sp < S; sp += SL) {
+            if constexpr (sizeof(PT) == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
+                s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+            } else {
+                const double2 v0 = *reinterpret_cast<const double2*>(p + sp * stride);
+                const double2 v1 = *reinterpret_cast<const double2*>(p + sp * stride + 2);
+                s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+            }
+        }
+    }
+    if constexpr (SL > 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(sl * G + gl) * 4 + q] = s[q];
+        __syncthreads();
+        if (sl != 0) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double t = 0.0;
+            for (int l = 0; l < SL; ++l) t += red[(l * G + gl) * 4 + q];
+            s[q] = t;
+        }
+    }
+    if (!live) return;
     int ta, tb; tile_coords(tile, nt, ta, tb);
     const int a = ta * BT + a_local, b0 = tb * BT + b_local;
     if (a >= d || b0 >= d) return;
-
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    const PT* p = partials + (int64_t)tile * BT * BT + a_local * BT + b_local;
-    const int64_t stride = (int64_t)T * BT * BT;
-    for (int sp = 0; sp < S; ++sp) {
-        if constexpr (sizeof(PT) == 4) {
-            const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
-            s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
-        } else {
-            const double2 v0 = *reinterpret_cast<const double2*>(p + sp * stride);
-            const double2 v1 = *reinterpret_cast<const double2*>(p + sp * stride + 2);
-            s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
-        }
-    }
     double* M = acc_packed + 1 + d;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -727,6 +751,26 @@ __global__ __launch_bounds__(256) void moments_reduce(
             M[(int64_t)a * d + b] += s[q];
             if (a != b) M[(int64_t)b * d + a] += s[q];
         }
+    }
+}
+
+template <typename PT, int BT>
+static void launch_reduce(const PT* part, const SplitPlan& p, int d, double* acc, const double* colp, double n_add,
+                          const int* gate, int gate_want, int* clear_flag, hipStream_t st) {
+    const int64_t groups = (int64_t)p.T * (BT * BT / 4);
+    const int col_blocks = (int)cdiv(d, 256);
+    if (p.S > 64) {
+        const int tb = (int)cdiv(groups, 256 / 16);
+        hipLaunchKernelGGL((moments_reduce<PT, BT, 16>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
+                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag);
+    } else if (p.S > 8) {
+        const int tb = (int)cdiv(groups, 256 / 4);
+        hipLaunchKernelGGL((moments_reduce<PT, BT, 4>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
+                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag);
+    } else {
+        const int tb = (int)cdiv(groups, 256);
+        hipLaunchKernelGGL((moments_reduce<PT, BT, 1>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
+                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag);
     }
 }
 
@@ -806,7 +850,6 @@ void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 static int64_t packed_len(int d) { return 1 + (int64_t)d + (int64_t)d * d; }
 
-struct SplitPlan { int nt, T, S; int64_t rows_per_split; };
 
 static SplitPlan plan_splits(int64_t n, int d, int bt, int kb, int n_cu, int wg_per_cu, int64_t min_rows) {
     SplitPlan p;
@@ -906,7 +949,6 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
                                p.S, p.rows_per_split, part, colp);
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
-        const int tile_blocks = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
         if (flag_now) {
             SplitPlan q = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
             FAD_TRY(h->partials64.reserve((size_t)q.S * q.T * G_BT * G_BT * sizeof(double)));
@@ -915,13 +957,9 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             double* colp64 = static_cast<double*>(h->colpart64.p);
             if (dtype == FAD_F16) launch_generic<raw_f16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
             else launch_generic<raw_bf16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
-            const int tb64 = (int)cdiv((int64_t)q.T * (G_BT * G_BT / 4), 256);
-            hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)(tb64 + cdiv(d, 256))), dim3(256), 0, st,
-                               part64, q.S, q.T, q.nt, d, h->acc, colp64, (double)n, tb64, (const int*)flag_now, 1,
-                               (int*)nullptr);
+            launch_reduce<double, G_BT>(part64, q, d, h->acc, colp64, (double)n, flag_now, 1, nullptr, st);
         }
-        hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, (const int*)flag_now, 0, flag_next);
+        launch_reduce<float, H_BT>(part, p, d, h->acc, colp, (double)n, flag_now, 0, flag_next, st);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = (variant == 1) ? 2 : 0;
     } else {
@@ -939,9 +977,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             default: return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
-        const int tile_blocks = (int)cdiv((int64_t)p.T * (G_BT * G_BT / 4), 256);
-        hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)(tile_blocks + cdiv(d, 256))), dim3(256), 0, st,
-                           part, p.S, p.T, p.nt, d, h->acc, colp, (double)n, tile_blocks, (const int*)nullptr, 0, (int*)nullptr);
+        launch_reduce<double, G_BT>(part, p, d, h->acc, colp, (double)n, nullptr, 0, nullptr, st);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = 1;
     }

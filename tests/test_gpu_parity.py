@@ -153,6 +153,33 @@ def test_moments_streaming_merge_export_import(F):
     np.testing.assert_allclose(pa, pw, rtol=0, atol=1e-6 * scale)
 
 
+def test_moments_more_than_2_31_elements(F):
+    """16.8M x 128 fp16 = 2.15e9 elements (4.3 GB): 64-bit row offsets, 512 row-splits, HBM-bound shape."""
+    import torch
+    from fadtk_amd.hip import Moments
+    n, d = (1 << 24) + 999, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    for lo in range(0, n, 1 << 22):                       # fill in slabs to keep the fp32 temporary small
+        hi = min(n, lo + (1 << 22))
+        x[lo:hi] = (torch.randn((hi - lo, d), generator=g, device="cuda") * 0.5 + 0.25).to(torch.float16)
+    with Moments(d) as m:
+        m.update(x)
+        packed = m.export()
+    assert packed[0] == n
+    x64_sum = torch.zeros(d, dtype=torch.float64, device="cuda")
+    gram = torch.zeros((d, d), dtype=torch.float64, device="cuda")
+    for lo in range(0, n, 1 << 21):
+        blk = x[lo:lo + (1 << 21)].to(torch.float64)
+        x64_sum += blk.sum(0); gram += blk.T @ blk
+    np.testing.assert_allclose(packed[1:1 + d], x64_sum.cpu().numpy(), rtol=1e-9)
+    np.testing.assert_allclose(packed[1 + d:].reshape(d, d), gram.cpu().numpy(), rtol=2e-7)
+    last = x[-3:].to(torch.float64).cpu().numpy()        # the tail rows are in: drop them and the count/sum move
+    with Moments(d) as m2:
+        m2.update(x[:-3]); p2 = m2.export()
+    np.testing.assert_allclose(packed[1:1 + d] - p2[1:1 + d], last.sum(0), rtol=0, atol=1e-4)
+
+
 def test_moments_torch_device_tensors(F):
     import torch
     from fadtk_amd.hip import Moments
