@@ -94,6 +94,8 @@ template <int KIND> __device__ __forceinline__ f32x16 mfma_h16(const uint4& a, c
 // i.e. the two fb values are adjacent columns: one 8-byte store.
 // ------------------------------------------------------------------------------------------
 constexpr int H_BT = 128;     // tile edge
+constexpr int H_TS = H_BT * H_BT + 64;   // partial-tile stride (floats): +256 B so that the same element of
+                                         // consecutive tiles/splits does not alias onto one memory channel
 constexpr int H_KB = 32;      // rows per stage
 
 template <int KIND>
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void moments_tile_h16(
     }
 
     // ---- epilogue: fp32 partial tile, two adjacent columns per store
-    float* out = partials + ((int64_t)split * T + tile) * (H_BT * H_BT);
+    float* out = partials + ((int64_t)split * T + tile) * H_TS;
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa) {
 #pragma unroll
@@ -319,7 +321,7 @@ __device__ __forceinline__ void tile_h16_glds_body(
         }
     }
 
-    float* out = partials + ((int64_t)split * T + tile) * (H_BT * H_BT);
+    float* out = partials + ((int64_t)split * T + tile) * H_TS;
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa) {
 #pragma unroll
@@ -480,7 +482,7 @@ __device__ __forceinline__ void tile_h16_w2_body(
         }
     }
 
-    float* out = partials + ((int64_t)split * T + tile) * (H_BT * H_BT);
+    float* out = partials + ((int64_t)split * T + tile) * H_TS;
 #pragma unroll
     for (int fa = 0; fa < 4; ++fa) {
 #pragma unroll
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(128) void moments_tile_h16_w2(
 // D: col = l&15, row = (l>>4) + 4*reg).  Workgroup tile 64x64, wave tile 32x32, 16 rows/stage.
 // ------------------------------------------------------------------------------------------
 constexpr int G_BT = 64;
+constexpr int G_TS = G_BT * G_BT + 32;   // partial-tile stride (doubles), +256 B as for H_TS
 constexpr int G_KB = 16;
 constexpr int G_LDS = 80;     // padded row pitch (doubles): consecutive k rows hit the other bank half
 
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
         }
     }
 
-    double* out = partials + ((int64_t)split * T + tile) * (G_BT * G_BT);
+    double* out = partials + ((int64_t)split * T + tile) * G_TS;
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
@@ -710,8 +713,9 @@ __global__ __launch_bounds__(256) void moments_reduce(
         tile = (int)(g / per_tile);
         const int e = (int)(g - (int64_t)tile * per_tile);
         a_local = e / (BT / 4); b_local = (e % (BT / 4)) * 4;
-        const PT* p = partials + (int64_t)tile * BT * BT + a_local * BT + b_local;
-        const int64_t stride = (int64_t)T * BT * BT;
+        constexpr int TS = (sizeof(PT) == 4) ? BT * BT + 64 : BT * BT + 32;      // H_TS / G_TS
+        const PT* p = partials + (int64_t)tile * TS + a_local * BT + b_local;
+        const int64_t stride = (int64_t)T * TS;
         int sp = sl;
         if constexpr (sizeof(PT) == 4) {           // four independent loads in flight per thread
             for (; sp + 3 * SL < S; sp += 4 * SL) {
@@ -765,6 +769,55 @@ __global__ __launch_bounds__(256) void moments_reduce(
             if (a != b) M[(int64_t)b * d + a] += s[q];
         }
     }
+}
+
+// Stage 1 of the two-level reduce used when an update produced hundreds or thousands of partial tiles (long inputs
+// at small D: every run of <= 8192 rows is one split).  Block (x, c) sums the splits of chunk c for 256 output
+// groups (four loads in flight per thread) into fp64 partials laid out like moments_reduce<double, BT> expects;
+// trailing x-blocks do the same for the column partials.
+constexpr int PRESUM_CHUNK = 32;
+template <int BT>
+__global__ __launch_bounds__(256) void moments_presum(
+    const float* __restrict__ partials, const double* __restrict__ colpart, int S, int T, int nt, int group_blocks,
+    double* __restrict__ partials2, double* __restrict__ colpart2, const int* __restrict__ gate) {
+    if (gate && *gate != 0) return;                // the block is being redone in fp64: nothing to pre-sum
+    const int c = blockIdx.y;
+    const int s0 = c * PRESUM_CHUNK, s1 = (s0 + PRESUM_CHUNK < S) ? s0 + PRESUM_CHUNK : S;
+    const int dpad = nt * BT;
+    if ((int)blockIdx.x >= group_blocks) {
+        const int a = ((int)blockIdx.x - group_blocks) * 256 + threadIdx.x;
+        if (a >= dpad) return;
+        double t = 0.0;
+        for (int sp = s0; sp < s1; ++sp) t += colpart[(int64_t)sp * dpad + a];
+        colpart2[(int64_t)c * dpad + a] = t;
+        return;
+    }
+    constexpr int per_tile = BT * BT / 4;
+    constexpr int TS32 = BT * BT + 64, TS64 = BT * BT + 32;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (int64_t)T * per_tile) return;
+    const int tile = (int)(g / per_tile), e = (int)(g - (int64_t)tile * per_tile);
+    const float* p = partials + (int64_t)tile * TS32 + e * 4;
+    const int64_t stride = (int64_t)T * TS32;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    int sp = s0;
+    for (; sp + 3 < s1; sp += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + sp * stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (sp + 1) * stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (sp + 2) * stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(p + (sp + 3) * stride);
+        s[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+        s[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+        s[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+    }
+    for (; sp < s1; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
+        s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+    }
+    double* o = partials2 + ((int64_t)c * T + tile) * TS64 + e * 4;
+    *reinterpret_cast<double2*>(o) = make_double2(s[0], s[1]);
+    *reinterpret_cast<double2*>(o + 2) = make_double2(s[2], s[3]);
 }
 
 template <typename PT, int BT>
@@ -833,6 +886,7 @@ struct fad_moments {
     double* acc = nullptr;                 // packed [1 + d + d*d]
     fad::DevBuf partials, colpart, stage, seg_off, seg_out, scratch;
     fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
+    fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
     int* shift_flag = nullptr;             // device int[2], ping-pong between updates
     unsigned update_seq = 0;
     int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0)
@@ -915,7 +969,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         const int variant = (var && var[0] == '1') ? 1 : (var && var[0] == '3') ? 3 : 2;
         constexpr int NST = 4;
         SplitPlan p = plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256, 8192);
-        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_BT * H_BT * sizeof(float)));
+        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
         FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
         float* part = static_cast<float*>(h->partials.p);
         double* colp = static_cast<double*>(h->colpart.p);
@@ -969,7 +1023,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
         if (flag_now) {
             SplitPlan q = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
-            FAD_TRY(h->partials64.reserve((size_t)q.S * q.T * G_BT * G_BT * sizeof(double)));
+            FAD_TRY(h->partials64.reserve((size_t)q.S * q.T * G_TS * sizeof(double)));
             FAD_TRY(h->colpart64.reserve((size_t)q.S * q.nt * G_BT * sizeof(double)));
             double* part64 = static_cast<double*>(h->partials64.p);
             double* colp64 = static_cast<double*>(h->colpart64.p);
@@ -977,12 +1031,25 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             else launch_generic<raw_bf16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
             launch_reduce<double, G_BT>(part64, q, d, h->acc, colp64, (double)n, flag_now, 1, nullptr, st);
         }
-        launch_reduce<float, H_BT>(part, p, d, h->acc, colp, (double)n, flag_now, 0, flag_next, st);
+        if (p.S > 128) {                   // two-level: S -> ceil(S/32) fp64 partials -> accumulator
+            SplitPlan p2 = p;
+            p2.S = (int)cdiv(p.S, PRESUM_CHUNK);
+            FAD_TRY(h->presum.reserve((size_t)p2.S * p.T * (H_BT * H_BT + 32) * sizeof(double)));
+            FAD_TRY(h->presum_col.reserve((size_t)p2.S * p.nt * H_BT * sizeof(double)));
+            double* ps = static_cast<double*>(h->presum.p);
+            double* pc = static_cast<double*>(h->presum_col.p);
+            const int gb = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
+            hipLaunchKernelGGL((moments_presum<H_BT>), dim3((unsigned)(gb + cdiv(p.nt * H_BT, 256)), (unsigned)p2.S), dim3(256),
+                               0, st, part, colp, p.S, p.T, p.nt, gb, ps, pc, (const int*)flag_now);
+            launch_reduce<double, H_BT>(ps, p2, d, h->acc, pc, (double)n, flag_now, 0, flag_next, st);
+        } else {
+            launch_reduce<float, H_BT>(part, p, d, h->acc, colp, (double)n, flag_now, 0, flag_next, st);
+        }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = (variant == 1) ? 2 : 0;
     } else {
         SplitPlan p = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
-        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * G_BT * G_BT * sizeof(double)));
+        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * G_TS * sizeof(double)));
         FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * G_BT * sizeof(double)));
         double* part = static_cast<double*>(h->partials.p);
         double* colp = static_cast<double*>(h->colpart.p);
@@ -1062,7 +1129,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     DeviceGuard g(h->device);
     if (h->acc) (void)hipFree(h->acc);
     if (h->shift_flag) (void)hipFree(h->shift_flag);
-    h->partials64.release(); h->colpart64.release();
+    h->partials64.release(); h->colpart64.release(); h->presum.release(); h->presum_col.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
     h->seg_off.release(); h->seg_out.release(); h->scratch.release();
     if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
