@@ -60,8 +60,8 @@ def main():
     for d in [baseline, eval]:
         if Path(d).is_dir():
             cache_embedding_files(d, model, workers=args.workers)
-    if dist.rank() != 0:                      # scoring is one small problem: rank 0 finishes the job
-        return
+    if dist.rank() != 0 and not args.indiv:   # one score is one small problem: rank 0 finishes the job
+        return                                # (--indiv shards the songs over all ranks instead)
 
     # 2. FAD
     fad = FrechetAudioDistance(model, audio_load_worker=args.workers, load_model=False, device=dist.env_local_rank())

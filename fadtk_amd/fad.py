@@ -255,8 +255,10 @@ class FrechetAudioDistance:
             log.info(f"CSV file {csv} already exists, exiting...")
             return csv
 
+        from . import dist
         mu, cov = self.load_stats(baseline)
-        _files = list(Path(eval_dir).glob("*.*"))
+        all_files = sorted(Path(eval_dir).glob("*.*")) if dist.world_size() > 1 else list(Path(eval_dir).glob("*.*"))
+        _files = dist.shard(all_files) if dist.world_size() > 1 else all_files      # songs are independent: shard them
 
         def _read(f):
             try:
@@ -288,6 +290,10 @@ class FrechetAudioDistance:
                               f"{'fewer than two frames' if status[j] == -6 else 'non-finite result'})")
 
         pairs = [p for p in zip(_files, scores) if p[1] is not None]
+        if dist.world_size() > 1:                      # rank-ordered gather keeps the file order; rank 0 writes
+            pairs = [p for part in dist.gather_objects(pairs) for p in part]
+            if dist.rank() != 0:
+                return csv
         pairs = sorted(pairs, key=lambda x: np.abs(x[1]))
         write(csv, "\n".join(",".join(str(x).replace(",", "_") for x in row) for row in pairs))
         return csv
