@@ -384,6 +384,180 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
 }
 
 // ------------------------------------------------------------------------------------------
+// v4 = v2 with the operand fragments read by ds_read_b64_tr_b16 (LDS transpose read): in a 16-lane group lane t
+// supplies the address of 4 consecutive columns of row t>>2 and receives 4 consecutive ROWS of column t -- exactly
+// the k-contiguous fragment an MFMA wants from a row-major slab.  Two such reads per fragment replace four
+// ds_read_b32 + four v_perm_b32, at twice the LDS bytes per clock; v2's LDS read port was as busy as its MFMA pipe.
+// (Semantics verified on hardware with scripts/probes/tr_probe.hip.)  Columns map naturally: lane i <-> column i.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int KIND, int NST, bool DIAG>
+__device__ __forceinline__ void tile_h16_tr_body(
+    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
+    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
+    uint4* smem, int* __restrict__ shift_flag) {
+    constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
+    constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, kg = lane >> 5;
+    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
+
+    // LDS position (row, chunk p) holds global chunk p ^ 4*(row & 3): the transpose reads of four consecutive rows
+    // then fall into the four different 64-byte quarters of the bank space (conflict-free).  The swizzle is applied
+    // on the SOURCE address because global_load_lds writes lane-linear; rows sr and sr+16 share (row & 3).
+    const int sr = tid >> 4, sc = (tid & 15) ^ (((tid >> 4) & 3) << 2);
+    const bool col_ok_a = (ca + sc * 8) < d;
+    const bool col_ok_b = (cb + sc * 8) < d;
+    const uint16_t* ga = E + ca + sc * 8;
+    const uint16_t* gb = E + cb + sc * 8;
+    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
+    // transpose-read addressing: in each 16-lane group lane t points at (row t>>2, columns 4*(t&3)..+3) of a
+    // [4 rows][16 cols] block and receives column t of it (4 consecutive k).  Group g of the wave: rows 8*(g>>1),
+    // columns 16*(g&1) of the 32-column fragment.
+    const int t16 = lane & 15, grp = lane >> 4;
+    const int tr_row = 8 * (grp >> 1) + (t16 >> 2);                 // + ks*16 (+4 for the second read)
+    const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);              // + 32*frag + 64*wave-half, in columns
+
+    auto issue = [&](int kb) {
+        uint4* st = smem + (kb % NST) * STAGE;
+        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t r = r0 + 16 * h;
+            const bool ok = r < k_end;
+            // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
+            uint4* dstA = st + 256 * h + 64 * wave;
+            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)dstA, 16, 0, 0);
+            if (!DIAG) {
+                const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
+    double csum[2] = {0.0, 0.0};
+    const bool do_colsum = DIAG && (wr == wc);     // the diagonal waves also hold sum x^2 (diagonal of acc)
+
+    for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        // stage kb must have landed; up to NST-2 younger stages may stay in flight
+        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
+        if (ahead >= 2) wait_vmcnt<2 * LPS>();
+        else if (ahead == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // every wave's pieces of stage kb are in LDS; stage kb-1 is free
+        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+
+        const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
+        const char* sB = DIAG ? sA : sA + H_KB * 256;
+        auto frag = [&](const char* slab, int ks, int col0) -> uint4 {
+            // byte address of (row, col): row*256 + ((col/8) ^ 4*(row&3))*16 + ((col/4)&1)*8
+            const int r0 = ks * 16 + tr_row, r1 = r0 + 4, col = col0 + tr_col;
+            const int o0 = r0 * 256 + (((col >> 3) ^ ((r0 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+            const int o1 = r1 * 256 + (((col >> 3) ^ ((r1 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o1));
+            uint4 f;
+            __builtin_memcpy(&f.x, &lo, 8);
+            __builtin_memcpy(&f.z, &hi, 8);
+            return f;
+        };
+        // all 16 transpose reads of the stage are issued up front: the reads of the second k-step land while the
+        // MFMAs of the first one run (the compiler inserts the counted lgkmcnt waits)
+        uint4 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a0[ks] = frag(sA, ks, 64 * wr); a1[ks] = frag(sA, ks, 64 * wr + 32);
+            b0[ks] = frag(sB, ks, 64 * wc); b1[ks] = frag(sB, ks, 64 * wc + 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            acc[0][0] = mfma_h16<KIND>(a0[ks], b0[ks], acc[0][0]);
+            acc[0][1] = mfma_h16<KIND>(a0[ks], b1[ks], acc[0][1]);
+            acc[1][0] = mfma_h16<KIND>(a1[ks], b0[ks], acc[1][0]);
+            acc[1][1] = mfma_h16<KIND>(a1[ks], b1[ks], acc[1][1]);
+            if (do_colsum) {
+                csum[0] += (double)sum8<KIND>(b0[ks]);
+                csum[1] += (double)sum8<KIND>(b1[ks]);
+            }
+        }
+    }
+
+    float* out = partials + ((int64_t)split * T + tile) * H_TS;
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+            const int a_local = 64 * wr + 32 * fa + row32;
+            const int b_local = 64 * wc + li;
+            out[a_local * H_BT + b_local] = acc[fa][0][reg];
+            out[a_local * H_BT + b_local + 32] = acc[fa][1][reg];
+        }
+    }
+    if (do_colsum) {
+        csum[0] += __shfl_xor(csum[0], 32);
+        csum[1] += __shfl_xor(csum[1], 32);
+        if (shift_flag) {
+            // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?
+            // Then fp32 partial sums of x^2 cannot resolve the variance and the block is redone in fp64.
+            // sum x^2 of column (32 f + li) is the diagonal element acc[f][f][reg] of the lane whose C/D row
+            // (reg&3) + 8 (reg>>2) + 4 kg equals li: kg = (li>>2)&1, reg = (li&3) + 4 (li>>3).
+            const double nr = (double)(k_end - k_begin);
+            const int myreg = (li & 3) + 4 * (li >> 3);
+            const bool own = kg == ((li >> 2) & 1);
+            bool hit = false;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                float dsel = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsel = (r == myreg) ? acc[f][f][r] : dsel;
+                double s2 = own ? (double)dsel : 0.0;
+                s2 += __shfl_xor(s2, 32);
+                const double mean = csum[f] / nr, var = s2 / nr - mean * mean;
+                const bool col_in = (cb + 64 * wc + 32 * f + li) < d;
+                if (col_in && !(mean * mean <= 64.0 * var) && !(csum[f] == 0.0 && s2 == 0.0)) hit = true;
+            }
+            if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
+        }
+        if (kg == 0) {
+            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + li;
+            cp[0] = csum[0]; cp[32] = csum[1];
+        }
+    }
+}
+
+template <int KIND, int NST>
+__global__ __launch_bounds__(256) void moments_tile_h16_tr(
+    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
+    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
+    int* __restrict__ shift_flag) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
+    const int w = xcd_contiguous(blockIdx.x, S * T);
+    const int split = w / T, tile = w - split * T;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const int64_t k_begin = (int64_t)split * rows_per_split;
+    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    if (ta == tb)
+        tile_h16_tr_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+                                            partials, colpart, smem_dyn, shift_flag);
+    else
+        tile_h16_tr_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+                                             partials, colpart, smem_dyn, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
 // v3: same 128 x 128 tile, same LDS ring, but TWO waves per workgroup, each owning 128 (A side) x 64
 // (B side) = 4 x 2 MFMA tiles.  The A fragments come from ds_read_b64 (lane i reads columns 4i..4i+3
 // of 8 rows -> four fragments), the B fragments from ds_read_b32 as before: 16 LDS reads + 24 v_perm
@@ -966,7 +1140,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
     }
     if (use_h16) {
         const char* var = getenv("FAD_MOMENTS_VARIANT");
-        const int variant = (var && var[0] == '1') ? 1 : (var && var[0] == '3') ? 3 : 2;
+        const int variant = (var && var[0] >= '1' && var[0] <= '4') ? (var[0] - '0') : 4;
         constexpr int NST = 4;
         SplitPlan p = plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256, 8192);
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
@@ -996,6 +1170,22 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
                                    p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
             else
                 hipLaunchKernelGGL((moments_tile_h16_w2<FAD_BF16, NST>), dim3(p.S * p.T), dim3(128), lds, st, e16, n, ld, d,
+                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+        } else if (variant == 4) {
+            const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
+            static bool attr4 = false;
+            if (!attr4) {
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_F16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_BF16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr4 = true;
+            }
+            if (dtype == FAD_F16)
+                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_F16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
+                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+            else
+                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_BF16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
                                    p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
         } else if (variant == 2) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);

@@ -133,6 +133,21 @@ def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
     assert np.abs(cov_fast[:64, :64] - cov_o[:64, :64]).max() > 1e-7
 
 
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
+def test_moments_kernel_variants_agree(F, monkeypatch, variant):
+    """All generations of the fp16 tile kernel (register staged / LDS-DMA ring / 2-wave / transpose reads) are kept
+    selectable for A/B timing; each must produce the same statistics."""
+    from fadtk_amd.hip import Moments
+    monkeypatch.setenv("FAD_MOMENTS_VARIANT", variant)
+    x = structured_rows(31, 7001, 384, np.float16)
+    with Moments(384) as m:
+        m.update(x)
+        p = m.export()
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(p[1 + 384:].reshape(384, 384), x64.T @ x64, rtol=0, atol=1e-6 * np.abs(x64.T @ x64).max())
+    np.testing.assert_allclose(p[1:385], x64.sum(0), rtol=1e-7, atol=1e-6)
+
+
 def test_moments_streaming_merge_export_import(F):
     """Sufficient statistics are additive: chunked updates, merged handles and an export/import
     round trip (the multi-GPU reduce) all give the statistics of the whole set."""
