@@ -63,13 +63,20 @@ def score_main():
                                                 "go (default fad-individual-results.csv)"))))
     p.add_argument("--inf", action="store_true", help="FAD-infinity extrapolation")
     p.add_argument("--indiv", action="store_true", help="one score per song of the eval directory")
+    p.add_argument("--fused-stats", action="store_true",
+                   help="accumulate dataset statistics on the GPU while embedding (one all-reduce across GPUs) "
+                        "instead of re-reading the cached .npy files")
     a = p.parse_args()
     _relaunch(a.gpus, "fadtk_amd")
     model = models[a.model]
 
     for dataset in (a.baseline, a.eval):                      # 1. embeddings (file-sharded over ranks)
         if Path(dataset).is_dir():
-            cache_embedding_files(dataset, model, workers=a.workers)
+            if a.fused_stats and not (Path(dataset) / "stats" / model.name).exists():
+                from .fad_batch import embed_and_accumulate
+                embed_and_accumulate(dataset, model, workers=a.workers)
+            else:
+                cache_embedding_files(dataset, model, workers=a.workers)
     if dist.rank() != 0 and not a.indiv:                      # one score is one small problem: rank 0 finishes
         return
 

@@ -57,6 +57,25 @@ def test_vggish_directory_score_matches_oracle(tmp_path, monkeypatch):
         assert abs(by_name[str(p)] - ref) / abs(ref) < 1e-4
 
 
+def test_fused_embed_and_accumulate_matches_cache_route(tmp_path, monkeypatch):
+    """Encodec-shaped flow (config 4, scaled down): frames go straight from the model output into the HBM moments."""
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    import fadtk_amd
+    from fadtk_amd.fad_batch import embed_and_accumulate
+    from fadtk_amd.model_loader import EncodecEmbModel
+    root = _make_set(tmp_path / "set", 6, 2.0, 24000, 800)
+    ml = EncodecEmbModel("24k")
+    mu, cov = embed_and_accumulate(root, ml, workers=2)
+    blocks = [np.load(p) for p in sorted((root / "embeddings" / ml.name).glob("*.npy"))]
+    assert len(blocks) == 6 and blocks[0].shape == (150, 128) and blocks[0].dtype == np.float16
+    mu_o, cov_o = O.embd_statistics(np.concatenate(blocks).astype(np.float64))
+    np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-6 * np.abs(mu_o).max() + 1e-9)
+    np.testing.assert_allclose(cov, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+    fad = fadtk_amd.FrechetAudioDistance(ml, load_model=False)
+    mu_c, cov_c = fad.load_stats(root)                       # served from the stats cache the fused pass wrote
+    assert np.array_equal(mu_c, mu) and np.array_equal(cov_c, cov)
+
+
 @pytest.mark.parametrize("which", ["whisper-tiny", "encodec-emb", "clap-laion-audio"])
 def test_loader_shapes_on_gpu(which, monkeypatch, tmp_path):
     monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
