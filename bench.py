@@ -156,6 +156,37 @@ def main():
         torch.cuda.synchronize()
         bm.append(ev[0].elapsed_time(ev[1])); bf.append(ev[1].elapsed_time(ev[2]))
 
+    # ---- untimed side measurements (rank 0, single GPU): the HBM-bound shape of the same kernel and the per-song path
+    extra = {}
+    if rank == 0 and not distributed:
+        try:
+            n128, d128 = 4_000_000, 128                                  # config-4-like frames: D=128 is HBM-bound
+            x128 = torch.randn((n128, d128), device=device, dtype=torch.float16)
+            m128 = hip.Moments(d128, local_rank)
+            m128.update(x128); m128.set_timing(True)
+            for _ in range(5):
+                m128.update(x128)
+            k128, r128, _ = m128.last_timing()
+            extra["moments_d128_hbm_bound"] = {"rows": n128, "dim": d128, "kernel_ms": k128, "reduce_ms": r128,
+                                               "GBps_algorithmic": n128 * d128 * 2 / (k128 * 1e-3) / 1e9,
+                                               "frac_of_8TBps": n128 * d128 * 2 / (k128 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            m128.close(); del x128
+            nsongs, d5 = 10_000, 768                                     # config-5 shape: two-frame songs vs one baseline
+            g5 = torch.Generator(device=device); g5.manual_seed(5)
+            songs = torch.randn((2 * nsongs, d5), generator=g5, device=device).to(torch.float16)
+            base = torch.randn((3 * d5, d5), generator=g5, device=device, dtype=torch.float64)
+            mu5 = base.mean(0).cpu().numpy(); cov5 = torch.cov(base.T).cpu().numpy()
+            offs = np.arange(0, 2 * nsongs + 1, 2)
+            hip.frechet_batched(mu5, cov5, songs, offs)
+            torch.cuda.synchronize(); t5 = time.perf_counter()
+            for _ in range(3):
+                sc5, st5 = hip.frechet_batched(mu5, cov5, songs, offs)
+            torch.cuda.synchronize(); dt5 = (time.perf_counter() - t5) / 3
+            extra["per_song_config5_shape"] = {"songs": nsongs, "dim": d5, "frames_per_song": 2, "ms": dt5 * 1e3,
+                                               "songs_per_s": nsongs / dt5, "ok": int((st5 == 0).sum())}
+        except Exception as e:      # noqa: BLE001  side measurements must never break the bench line
+            extra["error"] = repr(e)
+
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
@@ -196,6 +227,8 @@ def main():
                      "hbm_GBps_algorithmic": N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
                      "hbm_frac_of_8TBps": N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    if extra:
+        out["extra"] = extra
     if n_gpus == 1 and not args.no_cpu_baseline:
         base, fad_cpu = cpu_baseline(a.cpu().numpy(), b.cpu().numpy())
         out["cpu_baseline"] = base

@@ -309,6 +309,32 @@ def test_frechet_errors(F):
     assert F.calc_frechet_distance(np.ones(8), np.zeros((8, 8)), np.zeros(8), e8) == pytest.approx(16.0)
 
 
+def test_thread_pool_callers_are_safe(F):
+    """fadtk drives these functions from thread pools (tmap at fad.py:229, 387): handle-less entry points keep
+    per-thread workspaces, distinct handles are independent -- concurrent calls must give the serial answers."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(5)
+    jobs = []
+    for k in range(12):
+        d = (32, 64, 96)[k % 3]
+        a = (rng.standard_normal((400 + 10 * k, d)) * (1 + 0.1 * k)).astype(np.float16)
+        b = (rng.standard_normal((300 + 7 * k, d)) + 0.05 * k).astype(np.float16)
+        jobs.append((a, b))
+
+    def one(job):
+        a, b = job
+        m1, c1 = F.calc_embd_statistics(a)
+        m2, c2 = F.calc_embd_statistics(b)
+        return float(F.calc_frechet_distance(m1, c1, m2, c2))
+
+    serial = [one(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        threaded = list(ex.map(one, jobs * 3))
+    np.testing.assert_allclose(threaded, serial * 3, rtol=1e-12)
+    want = [O.fad_between(a, b) for a, b in jobs[:3]]
+    np.testing.assert_allclose(serial[:3], want, rtol=1e-6)
+
+
 def test_frechet_from_moments_matches_host_route(F):
     from fadtk_amd import hip
     a, b = R.c1_pair()
