@@ -23,6 +23,7 @@
 #include "fad_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 struct fad_moments;
@@ -256,14 +257,14 @@ __global__ void clear_states(NsState* st, int64_t B) {
 // ------------------------------------------------------------------------------------------
 struct Workspace : NsWorkspace {
     int device = -1;
-    DevBuf rows, offs, songbuf, songmat;     // per-song path
+    DevBuf rows, offs, songbuf, songmat, rows2;     // per-song path
 };
 
 static Workspace& thread_ws(int device) {
     static thread_local Workspace ws[8];
     Workspace& w = ws[device & 7];
     if (w.device != device) {
-        if (w.device >= 0) { w.release(); w.rows.release(); w.offs.release(); w.songbuf.release(); w.songmat.release(); }
+        if (w.device >= 0) { w.release(); w.rows.release(); w.offs.release(); w.songbuf.release(); w.songmat.release(); w.rows2.release(); }
         w.device = device;
     }
     return w;
@@ -553,6 +554,116 @@ __global__ __launch_bounds__(256) void pair_quadform(const TIn* __restrict__ row
         q_out[slot0 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Songs with 3 <= n <= 64 frames (n - 1 < D): the non-zero eigenvalues of Sigma_b Sigma_s equal those of the
+// n x n Gram matrix  G = Xc Sigma_b Xc^T / (n - 1)  (Xc = centred frames), so
+//     tr sqrt(Sigma_b Sigma_s) = sum_i sqrt(lambda_i(G)).
+// W = Xc Sigma_b for ALL such songs is one batched fp64 MFMA GEMM (rows packed D at a time against the shared,
+// L2-resident Sigma_b); one workgroup per song then forms G = W Xc^T in LDS and diagonalises it with a parallel
+// cyclic Jacobi (round-robin pairs; eigenvalues only).  Replaces a D x D matrix root per song.
+// ------------------------------------------------------------------------------------------
+constexpr int GRAM_MAX = 64;
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void gram_center_rows(const TIn* __restrict__ rows, int64_t ld, int d,
+                                                        const int64_t* __restrict__ src_row, const int64_t* __restrict__ row_song,
+                                                        const double* __restrict__ mean_exact, int64_t n_rows,
+                                                        double* __restrict__ xc) {
+    const int64_t r = blockIdx.x;
+    const bool live = r < n_rows;
+    const int64_t sr = live ? src_row[r] : 0, song = live ? row_song[r] : 0;
+    for (int a = threadIdx.x; a < d; a += 256)
+        xc[r * d + a] = live ? ld_f64<TIn>(rows, sr * ld + a) - mean_exact[song * d + a] : 0.0;      // pad rows are zero
+}
+
+__global__ __launch_bounds__(256) void gram_eig(const double* __restrict__ xc, const double* __restrict__ w, int d,
+                                                const int64_t* __restrict__ first_row, const int* __restrict__ n_rows,
+                                                double* __restrict__ tr_sqrt_out) {
+    __shared__ double G[GRAM_MAX][GRAM_MAX + 1];
+    __shared__ double cs[GRAM_MAX / 2][2];
+    __shared__ int pq[GRAM_MAX / 2][2];
+    __shared__ int perm[GRAM_MAX];
+    __shared__ double red[4];
+    const int song = blockIdx.x, tid = threadIdx.x;
+    const int n = n_rows[song];
+    const int m = (n + 1) & ~1;                            // even size; an odd n gets one zero row/column
+    const int64_t r0 = first_row[song];
+    const double inv = 1.0 / (double)(n - 1);
+
+    for (int e = tid; e < m * m; e += 256) {               // G = W Xc^T / (n-1), symmetrised
+        const int i = e / m, j = e % m;
+        double acc = 0.0;
+        if (i < n && j < n) {
+            const double* wi = w + (r0 + i) * d;
+            const double* xj = xc + (r0 + j) * d;
+            const double* wj = w + (r0 + j) * d;
+            const double* xi = xc + (r0 + i) * d;
+            double a0 = 0.0, a1 = 0.0;
+            for (int k = 0; k < d; ++k) { a0 += wi[k] * xj[k]; a1 += wj[k] * xi[k]; }
+            acc = 0.5 * (a0 + a1) * inv;
+        }
+        G[i][j] = acc;
+    }
+    if (tid < m) perm[tid] = tid;
+    __syncthreads();
+
+    const int half = m / 2;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        // off-diagonal mass relative to the diagonal decides convergence
+        double off = 0.0, dia = 0.0;
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = e / m, j = e % m;
+            const double v = G[i][j];
+            if (i == j) dia += v * v; else off += v * v;
+        }
+        off = block_sum(off, red);
+        dia = block_sum(dia, red);
+        if (off <= 1e-30 * dia || off == 0.0) break;
+        for (int round = 0; round < m - 1; ++round) {
+            if (tid < half) {                              // rotation for pair (p, q) of this round
+                int p = perm[tid], q = perm[m - 1 - tid];
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double app = G[p][p], aqq = G[q][q], apq = G[p][q];
+                double c = 1.0, sn = 0.0;
+                if (fabs(apq) > 1e-300) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t); sn = t * c;
+                }
+                pq[tid][0] = p; pq[tid][1] = q; cs[tid][0] = c; cs[tid][1] = sn;
+            }
+            __syncthreads();
+            for (int e = tid; e < half * m; e += 256) {    // columns p, q of every row:  G <- G J
+                const int k = e / m, i = e % m;
+                const int p = pq[k][0], q = pq[k][1];
+                const double c = cs[k][0], sn = cs[k][1];
+                const double gip = G[i][p], giq = G[i][q];
+                G[i][p] = c * gip - sn * giq;
+                G[i][q] = sn * gip + c * giq;
+            }
+            __syncthreads();
+            for (int e = tid; e < half * m; e += 256) {    // rows p, q of every column:  G <- J^T G
+                const int k = e / m, j = e % m;
+                const int p = pq[k][0], q = pq[k][1];
+                const double c = cs[k][0], sn = cs[k][1];
+                const double gpj = G[p][j], gqj = G[q][j];
+                G[p][j] = c * gpj - sn * gqj;
+                G[q][j] = sn * gpj + c * gqj;
+            }
+            if (tid == 0) {                                // round-robin: position 0 stays, the rest rotate
+                const int last = perm[m - 1];
+                for (int k = m - 1; k > 1; --k) perm[k] = perm[k - 1];
+                perm[1] = last;
+            }
+            __syncthreads();
+        }
+    }
+    double t = 0.0;
+    for (int i = tid; i < m; i += 256) { const double lam = G[i][i]; t += lam > 0.0 ? sqrt(lam) : 0.0; }
+    t = block_sum(t, red);
+    if (tid == 0) tr_sqrt_out[song] = t;
+}
+
 }  // namespace fad
 
 using namespace fad;
@@ -633,11 +744,13 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
                        mean_mode, mean_exact, mean_ref, scal);
 
     // baseline trace (fp64, on device via a 1-problem prepare would be overkill): small D2H of the diagonal
-    std::vector<int64_t> pairs, general;
+    std::vector<int64_t> pairs, gram, general;
+    static const bool gram_on = [] { const char* e = getenv("FAD_SONG_GRAM"); return !(e && e[0] == '0'); }();
     for (int64_t s = 0; s < n_songs; ++s) {
         const int64_t n = h_off[s + 1] - h_off[s];
         if (n < 2) { out_status[s] = FAD_ERR_TOO_FEW_ROWS; out_scores[s] = __builtin_nan(""); }
         else if (n == 2) { out_status[s] = FAD_OK; pairs.push_back(s); }
+        else if (gram_on && n <= GRAM_MAX && n - 1 < d) { out_status[s] = FAD_OK; gram.push_back(s); }
         else { out_status[s] = FAD_OK; general.push_back(s); }
     }
     std::vector<double> h_scal((size_t)2 * n_songs), h_diag((size_t)d);
@@ -668,7 +781,56 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         out_scores[s] = h_scal[2 * s] + tr_b + h_scal[2 * s + 1] - 2.0 * root;
     }
 
-    // ---- songs with >= 3 frames: batched D x D Newton-Schulz against the shared baseline
+    // ---- songs with 3..64 frames: n x n Gram matrix + Jacobi eigenvalues
+    if (!gram.empty()) {
+        const int64_t budget_rows = std::max<int64_t>(d, ((int64_t)1 << 30) / ((int64_t)d * 16));     // ~1 GiB of Xc + W
+        size_t g0 = 0;
+        while (g0 < gram.size()) {
+            std::vector<int64_t> src_row, row_song, first_row;
+            std::vector<int> nrows;
+            size_t g1 = g0;
+            while (g1 < gram.size()) {
+                const int64_t sg = gram[g1], n = h_off[sg + 1] - h_off[sg];
+                if (!src_row.empty() && (int64_t)src_row.size() + n > budget_rows) break;
+                first_row.push_back((int64_t)src_row.size()); nrows.push_back((int)n);
+                for (int64_t r = 0; r < n; ++r) { src_row.push_back(h_off[sg] + r); row_song.push_back(sg); }
+                ++g1;
+            }
+            const int64_t R = (int64_t)src_row.size(), nb = cdiv(R, d), Rpad = nb * d, ns = (int64_t)(g1 - g0);
+            // device scratch: xc [Rpad*d] | w [Rpad*d] | tr [ns]   and index arrays
+            FAD_TRY(ws.songmat.reserve(((size_t)2 * Rpad * d + ns) * sizeof(double)));
+            double* xc = static_cast<double*>(ws.songmat.p);
+            double* wmat = xc + (size_t)Rpad * d;
+            double* trs = wmat + (size_t)Rpad * d;
+            FAD_TRY(ws.rows2.reserve(((size_t)2 * R + ns) * sizeof(int64_t) + (size_t)ns * sizeof(int) + 64));
+            int64_t* d_src = static_cast<int64_t*>(ws.rows2.p);
+            int64_t* d_song = d_src + R;
+            int64_t* d_first = d_song + R;
+            int* d_n = reinterpret_cast<int*>(d_first + ns);
+            FAD_HIP_TRY(hipMemcpyAsync(d_src, src_row.data(), R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipMemcpyAsync(d_song, row_song.data(), R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipMemcpyAsync(d_first, first_row.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipMemcpyAsync(d_n, nrows.data(), ns * sizeof(int), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((gram_center_rows<TIn>), dim3((unsigned)Rpad), dim3(256), 0, st, drows, ld, d, d_src, d_song,
+                               mean_exact, R, xc);
+            GemmType gt{xc, dd, dcov_b, 0, wmat, dd, 1.0, 0.0, 0.0, nullptr};          // W = Xc Sigma_b, D rows per problem
+            const int rc = gemm_f64_launch(d, &gt, 1, nb, nullptr, 0, st, device);
+            if (rc < 0) return rc;
+            hipLaunchKernelGGL(gram_eig, dim3((unsigned)ns), dim3(256), 0, st, xc, wmat, d, d_first, d_n, trs);
+            std::vector<double> h_tr((size_t)ns);
+            FAD_HIP_TRY(hipMemcpyAsync(h_tr.data(), trs, ns * sizeof(double), hipMemcpyDeviceToHost, st));
+            FAD_HIP_TRY(hipStreamSynchronize(st));         // also keeps the host index vectors alive until the copies ran
+            for (int64_t k = 0; k < ns; ++k) {
+                const int64_t sg = gram[g0 + k];
+                const double t = h_tr[k];
+                if (!(t == t) || !(tr_b == tr_b) || t > 1e300) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
+                out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * t;
+            }
+            g0 = g1;
+        }
+    }
+
+    // ---- remaining songs: batched D x D Newton-Schulz against the shared baseline
     if (!general.empty()) {
         size_t budget = (size_t)3 << 30;                         // bytes of matrices per sub-batch
         int64_t sub = (int64_t)(budget / ((size_t)7 * dd * sizeof(double)));

@@ -482,6 +482,22 @@ def test_multi_frame_songs_g8(F, golden):
     np.testing.assert_allclose(scores[keep], m["scores"], rtol=1e-6)
 
 
+def test_gram_path_matches_oracle_for_3_to_64_frames(F):
+    """3 <= n <= 64 frames: n x n Gram matrix + Jacobi eigenvalues instead of a D x D root per song."""
+    from fadtk_amd import hip
+    d = 96
+    mu_b, cov_b = R.baseline_stats(41, 5 * d, d)
+    rows_per_song = [3, 4, 7, 16, 33, 63, 64, 65, 10, 5]              # 65 frames -> the D x D iteration
+    sg = R.songs(42, len(rows_per_song), rows_per_song, d)
+    sg[3][5:] = sg[3][4]                                              # repeated frames: extra rank deficiency
+    rows = np.concatenate(sg)
+    offs = np.concatenate([[0], np.cumsum(rows_per_song)])
+    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+    assert (status == 0).all()
+    want = O.individual_scores(mu_b, cov_b, sg, run_sqrtm=False)
+    np.testing.assert_allclose(scores, want, rtol=1e-6)
+
+
 def test_score_inf_golden_g6(F, golden, tmp_path):
     g = golden["g6"]
     mu_b, cov_b = R.baseline_stats(g["base_seed"], g["base_n"], g["d"])
