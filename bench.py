@@ -87,6 +87,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Library banners (RCCL prints its version block to stdout) must not mix with the ONE JSON line: everything
+    # written to fd 1 goes to stderr until the result is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from fadtk_amd import hip
@@ -187,9 +193,9 @@ def main():
         except Exception as e:      # noqa: BLE001  side measurements must never break the bench line
             extra["error"] = repr(e)
 
+    if distributed:
+        dist.destroy_process_group()
     if rank != 0:
-        if distributed:
-            dist.destroy_process_group()
         return
 
     n_gpus = world
@@ -241,9 +247,9 @@ def main():
         out["parity_rel_err_vs_cpu"] = abs(fad_compat - fad_cpu) / abs(fad_cpu)
         out["parity_rel_err_vs_cpu_f64_means"] = abs(fad - fad_cpu) / abs(fad_cpu)
         out["fad_cpu"] = fad_cpu
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
-    if distributed:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
