@@ -23,8 +23,11 @@ if [ "$mode" = "full" ]; then
   rm -rf $out/pmc && mkdir -p $out/pmc
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$out/pmc/fetch -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1); echo "pmc fetch rc=$?"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/$out/pmc/write -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1); echo "pmc write rc=$?"
-  python scripts/summarize_pmc.py $out/pmc > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt | head -30
-  # big traces are not needed back home
+  # compact summaries (what gets copied into profiles/), then drop the big traces
+  db=$(find $out/prof -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py stats "$db" > $out/kernel_stats.csv
+  db=$(find $out/pmc/fetch -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py pmc "$db" > $out/pmc_fetch.csv
+  db=$(find $out/pmc/write -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py pmc "$db" > $out/pmc_write.csv
+  head -14 $out/kernel_stats.csv; grep -E "moments_tile|gemm" $out/pmc_fetch.csv $out/pmc_write.csv
   find $out/prof $out/pmc -name "*.db" -size +8M -delete 2>/dev/null
 fi
 echo "== done"
