@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (used under rocprofv3 "
+                                                             "so that the kernel statistics hold the config-3 launches only)")
     args = ap.parse_args()
 
     # Library banners (RCCL prints its version block to stdout) must not mix with the ONE JSON line: everything
@@ -164,7 +166,7 @@ def main():
 
     # ---- untimed side measurements (rank 0, single GPU): the HBM-bound shape of the same kernel and the per-song path
     extra = {}
-    if rank == 0 and not distributed:
+    if rank == 0 and not distributed and not args.no_extras:
         try:
             n128, d128 = 4_000_000, 128                                  # config-4-like frames: D=128 is HBM-bound
             x128 = torch.randn((n128, d128), device=device, dtype=torch.float16)

@@ -554,6 +554,30 @@ __global__ __launch_bounds__(256) void pair_quadform(const TIn* __restrict__ row
         q_out[slot0 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
 }
 
+// Two-frame songs through the batched GEMM: Dm[r] = x1 - x2 (fp64, exact), W = Dm Sigma_b (rows packed D at a
+// time, Sigma_b shared), q[r] = W[r] . Dm[r].  The 16-songs-per-workgroup kernel above (pair_quadform) re-reads all of
+// Sigma_b per workgroup and ran at ~4 TFLOP/s; kept for reference behind FAD_PAIR_GEMM=0.
+template <typename TIn>
+__global__ __launch_bounds__(256) void pair_diff_rows(const TIn* __restrict__ rows, int64_t ld, int d,
+                                                      const int64_t* __restrict__ offsets, const int64_t* __restrict__ song_ids,
+                                                      int64_t n_pairs, double* __restrict__ dm) {
+    const int64_t r = blockIdx.x;
+    const bool live = r < n_pairs;
+    const int64_t r0 = live ? offsets[song_ids[r]] : 0;
+    for (int a = threadIdx.x; a < d; a += 256)
+        dm[r * d + a] = live ? ld_f64<TIn>(rows, r0 * ld + a) - ld_f64<TIn>(rows, (r0 + 1) * ld + a) : 0.0;
+}
+
+__global__ __launch_bounds__(256) void pair_rowdot(const double* __restrict__ w, const double* __restrict__ dm, int d,
+                                                   double* __restrict__ q) {
+    __shared__ double red[4];
+    const int64_t r = blockIdx.x;
+    double t = 0.0;
+    for (int a = threadIdx.x; a < d; a += 256) t += w[r * d + a] * dm[r * d + a];
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) q[r] = t;
+}
+
 // ------------------------------------------------------------------------------------------
 // Songs with 3 <= n <= 64 frames (n - 1 < D): the non-zero eigenvalues of Sigma_b Sigma_s equal those of the
 // n x n Gram matrix  G = Xc Sigma_b Xc^T / (n - 1)  (Xc = centred frames), so
@@ -758,9 +782,30 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
                                  hipMemcpyDeviceToHost, st));
     FAD_HIP_TRY(hipMemcpyAsync(h_scal.data(), scal, h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st));
 
-    // ---- two-frame songs: closed form
+    // ---- two-frame songs: closed form  tr sqrt = sqrt(d^T Sigma_b d / 2)
     std::vector<double> h_q(pairs.size());
-    if (!pairs.empty()) {
+    static const bool pair_gemm = [] { const char* e = getenv("FAD_PAIR_GEMM"); return !(e && e[0] == '0'); }();
+    if (!pairs.empty() && pair_gemm) {
+        const int64_t budget_rows = std::max<int64_t>(d, ((int64_t)1 << 30) / ((int64_t)d * 16));
+        for (size_t p0 = 0; p0 < pairs.size(); p0 += (size_t)budget_rows) {
+            const int64_t P = (int64_t)std::min<size_t>((size_t)budget_rows, pairs.size() - p0);
+            const int64_t nb = cdiv(P, d), Ppad = nb * d;
+            FAD_TRY(ws.songmat.reserve(((size_t)2 * Ppad * d + P) * sizeof(double)));
+            double* dm = static_cast<double*>(ws.songmat.p);
+            double* wmat = dm + (size_t)Ppad * d;
+            double* qd = wmat + (size_t)Ppad * d;
+            FAD_TRY(ws.rows2.reserve((size_t)P * sizeof(int64_t)));
+            int64_t* d_ids = static_cast<int64_t*>(ws.rows2.p);
+            FAD_HIP_TRY(hipMemcpyAsync(d_ids, pairs.data() + p0, P * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((pair_diff_rows<TIn>), dim3((unsigned)Ppad), dim3(256), 0, st, drows, ld, d, d_off, d_ids, P, dm);
+            GemmType gt{dm, dd, dcov_b, 0, wmat, dd, 1.0, 0.0, 0.0, nullptr};
+            const int rc = gemm_f64_launch(d, &gt, 1, nb, nullptr, 0, st, device);
+            if (rc < 0) return rc;
+            hipLaunchKernelGGL(pair_rowdot, dim3((unsigned)P), dim3(256), 0, st, wmat, dm, d, qd);
+            FAD_HIP_TRY(hipMemcpyAsync(h_q.data() + p0, qd, P * sizeof(double), hipMemcpyDeviceToHost, st));
+            FAD_HIP_TRY(hipStreamSynchronize(st));
+        }
+    } else if (!pairs.empty()) {
         FAD_HIP_TRY(hipMemcpyAsync(ids_dev, pairs.data(), pairs.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
         const int kc_len = (int)std::min<int64_t>(PQ_KC, cdiv(d, 32) * 32);
         const size_t lds = ((size_t)16 * (kc_len + 2) + 64) * sizeof(double);

@@ -17,12 +17,12 @@ timeout 900 python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/benc
 if [ "$mode" = "full" ]; then
   echo "== rocprofv3 kernel stats"
   rm -rf $out/prof && mkdir -p $out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof_bench.json 2> $GRAFT_REPO_ROOT/$out/prof_bench.err); echo "rocprof rc=$?"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$out/prof_bench.json 2> $GRAFT_REPO_ROOT/$out/prof_bench.err); echo "rocprof rc=$?"
   find $out/prof -name "*kernel_stats*" | head; f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
   echo "== rocprofv3 pmc (HBM bytes)"
   rm -rf $out/pmc && mkdir -p $out/pmc
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$out/pmc/fetch -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1); echo "pmc fetch rc=$?"
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/$out/pmc/write -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1); echo "pmc write rc=$?"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$out/pmc/fetch -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1); echo "pmc fetch rc=$?"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/$out/pmc/write -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1); echo "pmc write rc=$?"
   # compact summaries (what gets copied into profiles/), then drop the big traces
   db=$(find $out/prof -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py stats "$db" > $out/kernel_stats.csv
   db=$(find $out/pmc/fetch -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py pmc "$db" > $out/pmc_fetch.csv
