@@ -211,6 +211,26 @@ def test_moments_torch_device_tensors(F):
         np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-9)
 
 
+def test_moments_torch_views_and_strides(F):
+    """Device tensors that are not plain contiguous matrices: row-pitched views stay in place (ld > d), transposed or
+    column-strided ones are made contiguous by the binding."""
+    import torch
+    from fadtk_amd.hip import Moments
+    base = torch.from_numpy(structured_rows(17, 1500, 160, np.float16)).cuda()
+    cases = {"pitched": base[:, :128], "rows_sliced": base[100:1300, :128], "col_strided": base[:, ::2][:, :64],
+             "transposed": base[:160, :160].T}
+    for name, v in cases.items():
+        with Moments(v.shape[1]) as m:
+            m.update(v)
+            torch.cuda.synchronize()
+            mu, cov, n = m.finalize()
+        ref = v.to(torch.float64).cpu().numpy()
+        assert n == ref.shape[0], name
+        np.testing.assert_allclose(mu, ref.mean(0), rtol=0, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(cov, np.cov(ref, rowvar=False), rtol=0, atol=2e-6 * np.abs(np.cov(ref, rowvar=False)).max(),
+                                   err_msg=name)
+
+
 def test_moments_edge_cases(F):
     from fadtk_amd.hip import Moments
     with pytest.raises(AssertionError):

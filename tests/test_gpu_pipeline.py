@@ -89,3 +89,36 @@ def test_loader_shapes_on_gpu(which, monkeypatch, tmp_path):
     assert emb.dtype == np.float16 and emb.ndim == 2 and emb.shape[1] == ml.num_features and np.isfinite(emb).all()
     expect = {"whisper-tiny": 2, "encodec-emb": 75 * secs, "clap-laion-audio": secs}[which]
     assert emb.shape[0] == expect
+
+
+def test_cli_end_to_end(tmp_path, monkeypatch):
+    """`python -m fadtk <model> <baseline> <eval> <csv>` and `--indiv`, as a user would run them."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    base = _make_set(tmp_path / "base", 5, 3.0, 16000, 900)
+    evl = _make_set(tmp_path / "eval", 4, 3.0, 16000, 950, gain=0.8)
+    env = dict(os.environ, FADTK_AMD_RANDOM_WEIGHTS="1", PYTHONPATH=str(root))
+    csv = tmp_path / "out" / "scores.csv"
+    r = subprocess.run([sys.executable, "-m", "fadtk", "vggish", str(base), str(evl), str(csv), "-w", "2", "--fused-stats"],
+                       capture_output=True, text=True, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = csv.read_text().strip().split("\n")
+    assert lines[0] == "model,baseline,eval,score,inf_r2,time" and len(lines) == 2
+    cols = lines[1].split(",")
+    assert cols[0] == "vggish" and cols[1] == str(base) and cols[4] == "None" and np.isfinite(float(cols[3]))
+    assert "The FAD vggish score between" in r.stderr
+    blocks_b = [np.load(p) for p in (base / "embeddings" / "vggish").glob("*.npy")]
+    blocks_e = [np.load(p) for p in (evl / "embeddings" / "vggish").glob("*.npy")]
+    want = O.frechet_distance(*O.embd_statistics(np.concatenate(blocks_b)), *O.embd_statistics(np.concatenate(blocks_e)),
+                              run_sqrtm=False)
+    assert abs(float(cols[3]) - want) / abs(want) < 1e-4
+    r = subprocess.run([sys.executable, "-m", "fadtk", "vggish", str(base), str(evl), str(tmp_path / "indiv.csv"), "--indiv"],
+                       capture_output=True, text=True, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = (tmp_path / "indiv.csv").read_text().strip().split("\n")
+    assert len(rows) == 4 and all(str(evl) in ln for ln in rows)
+    vals = [abs(float(ln.rsplit(",", 1)[1])) for ln in rows]
+    assert vals == sorted(vals)
