@@ -112,8 +112,9 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
     assert "The FAD vggish score between" in r.stderr
     blocks_b = [np.load(p) for p in (base / "embeddings" / "vggish").glob("*.npy")]
     blocks_e = [np.load(p) for p in (evl / "embeddings" / "vggish").glob("*.npy")]
-    want = O.frechet_distance(*O.embd_statistics(np.concatenate(blocks_b)), *O.embd_statistics(np.concatenate(blocks_e)),
-                              run_sqrtm=False)
+    # the reference CLI takes dataset statistics from its online path (float64 mu); --fused-stats skips only that
+    # path's per-file float16 rounding of the means
+    want = O.frechet_distance(*O.statistics_online(blocks_b), *O.statistics_online(blocks_e), run_sqrtm=False)
     assert abs(float(cols[3]) - want) / abs(want) < 1e-4
     r = subprocess.run([sys.executable, "-m", "fadtk", "vggish", str(base), str(evl), str(tmp_path / "indiv.csv"), "--indiv"],
                        capture_output=True, text=True, env=env, cwd=tmp_path)
