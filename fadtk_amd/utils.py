@@ -119,27 +119,56 @@ def dataset_statistics(blocks: Sequence[np.ndarray], compat: bool = True, device
             return mu, np.zeros((d, d))                                   # utils.py:42-43
         return mu, (sum_xx - np.outer(sum_x, sum_x) / n) / (n - 1)
 
-    with np.errstate(all="ignore"):
-        means = seg_sums / sizes[:, None]                                 # exact per-file means
-    means_ref = _round_like(means, dtype)                                 # what utils.py:16 returns
+    return finish_online_statistics(packed, seg_sums, sizes, dtype, device)
+
+
+def per_file_mean_terms(seg_sums: np.ndarray, sizes: np.ndarray, dtype, device: int = 0):
+    """What the reference's per-file float16 means (utils.py:16) change, as additive (sum-reducible) pieces:
+    -> (sum_f n_f m~_f  [D],  sum_f n_f m_f m_f^T  [D x D] with exact means,  sum_f n_f m~_f m~_f^T with rounded means,
+        number of files with < 2 rows, number of empty files).  The two matrices are raw moments of the rows
+    sqrt(n_f) m_f, computed by the same GPU kernel."""
+    from .hip import Moments
+    d = seg_sums.shape[1]
+    sizes = np.asarray(sizes, dtype=np.int64)
+    ok = sizes > 0
+    means = np.zeros_like(seg_sums)
+    means[ok] = seg_sums[ok] / sizes[ok, None]
+    means_ref = _round_like(means, np.dtype(dtype))
     w = sizes.astype(np.float64)
-    mu = (means_ref * w[:, None]).sum(axis=0) / total                     # utils.py:37-38, closed form
-    if total < 2:
-        return mu, np.zeros((d, d))
-    if (sizes < 2).any():
-        # np.cov of a one-row (or empty) file is NaN and poisons the merged scatter
-        if (sizes < 1).any():
-            mu = np.full(d, np.nan)
-        return mu, np.full((d, d), np.nan)
-    # sum_f n_f m_f m_f^T for exact and rounded means: two more (tiny) moment passes on the GPU
+    wsum_ref = (means_ref * w[:, None]).sum(axis=0)
     root_w = np.sqrt(w)[:, None]
+    if len(sizes) == 0:
+        z = np.zeros((d, d))
+        return wsum_ref, z, z.copy(), 0, 0
     with Moments(d, device) as a_exact, Moments(d, device) as a_ref:
         a_exact.update(np.ascontiguousarray(means * root_w))
         a_ref.update(np.ascontiguousarray(means_ref * root_w))
         within_corr = a_exact.export()[1 + d:].reshape(d, d)
         between = a_ref.export()[1 + d:].reshape(d, d)
+    return wsum_ref, within_corr, between, int((sizes < 2).sum()), int((sizes < 1).sum())
+
+
+def combine_online_statistics(packed: np.ndarray, wsum_ref, within_corr, between, n_short: int, n_empty: int):
+    """(mu, Sigma) exactly as the sequential merge of utils.py:36-45 leaves them, from sum-reducible pieces:
+    Sigma = (W + B~) / (N - 1),  W = sum xx^T - sum_f n_f m_f m_f^T (within-file scatter, exact means),
+    B~ = sum_f n_f m~_f m~_f^T - N mu~ mu~^T (between-file scatter of the float16-rounded means), mu~ = sum n_f m~_f / N."""
+    d = wsum_ref.shape[0]
+    total = int(round(packed[0]))
+    sum_xx = packed[1 + d:].reshape(d, d)
+    if total < 1:
+        return np.full(d, np.nan), np.zeros((d, d))
+    mu = wsum_ref / total
+    if total < 2:
+        return mu, np.zeros((d, d))                                     # utils.py:42-43
+    if n_short > 0:
+        # np.cov of a one-row (or empty) file is NaN and poisons the merged scatter (SURVEY.md Q5)
+        return (np.full(d, np.nan) if n_empty > 0 else mu), np.full((d, d), np.nan)
     scatter = (sum_xx - within_corr) + (between - total * np.outer(mu, mu))
     return mu, scatter / (total - 1)
+
+
+def finish_online_statistics(packed, seg_sums, sizes, dtype, device: int = 0):
+    return combine_online_statistics(packed, *per_file_mean_terms(seg_sums, sizes, dtype, device))
 
 
 def calculate_embd_statistics_online(files: List[PathLike], compat: bool = True, device: int = 0,

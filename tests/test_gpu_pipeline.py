@@ -68,9 +68,16 @@ def test_fused_embed_and_accumulate_matches_cache_route(tmp_path, monkeypatch):
     mu, cov = embed_and_accumulate(root, ml, workers=2)
     blocks = [np.load(p) for p in sorted((root / "embeddings" / ml.name).glob("*.npy"))]
     assert len(blocks) == 6 and blocks[0].shape == (150, 128) and blocks[0].dtype == np.float16
-    mu_o, cov_o = O.embd_statistics(np.concatenate(blocks).astype(np.float64))
-    np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-6 * np.abs(mu_o).max() + 1e-9)
+    mu_o, cov_o = O.statistics_online(blocks)                 # the reference's online path, float16 file means included
+    np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-9 * np.abs(mu_o).max() + 1e-12)
     np.testing.assert_allclose(cov, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+    import shutil
+    shutil.rmtree(root / "stats")
+    mu_p, cov_p = embed_and_accumulate(root, ml, workers=2, compat=False)      # plain raw moments, from the cache now
+    mu_i, cov_i = O.embd_statistics(np.concatenate(blocks).astype(np.float64))
+    np.testing.assert_allclose(mu_p, mu_i, rtol=0, atol=1e-6 * np.abs(mu_i).max() + 1e-9)
+    np.testing.assert_allclose(cov_p, cov_i, rtol=0, atol=2e-6 * np.abs(cov_i).max())
+    mu, cov = embed_and_accumulate(root, ml, workers=2)
     fad = fadtk_amd.FrechetAudioDistance(ml, load_model=False)
     mu_c, cov_c = fad.load_stats(root)                       # served from the stats cache the fused pass wrote
     assert np.array_equal(mu_c, mu) and np.array_equal(cov_c, cov)
