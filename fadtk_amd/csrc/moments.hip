@@ -20,6 +20,13 @@
 //   partials     [split][tile][BT][BT]   (BT = 128 fp32 | 64 fp64)
 //   colpart      [split][nt*BT] fp64
 #include "fad_common.h"
+#include <type_traits>
+
+// Build-time ablation switches for scripts/probe_ablate.py (never set in the product build): bit 0 drops the
+// MFMAs, bit 1 the LDS transpose reads, bit 2 the global->LDS loads, bit 3 the per-stage barrier.
+#ifndef FAD_MOM_ABLATE
+#define FAD_MOM_ABLATE 0
+#endif
 
 namespace fad {
 
@@ -53,10 +60,24 @@ template <int KIND> __device__ __forceinline__ float h16_to_f32(uint32_t bits16)
 }
 
 template <int KIND> __device__ __forceinline__ float sum8(const uint4& v) {
+    // sum of the 8 packed halfs/bfloats in fp32: four v_dot2c_f32_{f16,bf16} against (1, 1) -- the column sums
+    // ride on the diagonal tiles' waves, whose VALU time is on the kernel's critical path
     float s = 0.f;
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { s += h16_to_f32<KIND>(w[q] & 0xffffu); s += h16_to_f32<KIND>(w[q] >> 16); }
+    for (int q = 0; q < 4; ++q) {
+        if constexpr (KIND == FAD_F16) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 a; __builtin_memcpy(&a, &w[q], 4);
+            const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+            s = __builtin_amdgcn_fdot2(a, one, s, false);
+        } else {
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            b2 a, one; __builtin_memcpy(&a, &w[q], 4);
+            const uint32_t ob = 0x3f803f80u; __builtin_memcpy(&one, &ob, 4);
+            s = __builtin_amdgcn_fdot2_f32_bf16(a, one, s, false);
+        }
+    }
     return s;
 }
 
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
 // ------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int KIND, int NST, bool DIAG>
+template <int KIND, int NST, bool DIAG, int PIPE>
 __device__ __forceinline__ void tile_h16_tr_body(
     const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
@@ -421,6 +442,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);              // + 32*frag + 64*wave-half, in columns
 
     auto issue = [&](int kb) {
+        if (FAD_MOM_ABLATE & 4) return;
         uint4* st = smem + (kb % NST) * STAGE;
         const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
 #pragma unroll
@@ -450,47 +472,142 @@ __device__ __forceinline__ void tile_h16_tr_body(
 
     for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        // stage kb must have landed; up to NST-2 younger stages may stay in flight
-        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
-        if (ahead >= 2) wait_vmcnt<2 * LPS>();
-        else if (ahead == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();              // every wave's pieces of stage kb are in LDS; stage kb-1 is free
-        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
-
+    // fragment of one k-step (16 rows) of a slab: two transpose reads (rows r0..r0+3 and r0+4..r0+7 of the lane's
+    // 8-row half) give the 8 consecutive k that the 32x32x16 MFMA wants per lane
+    auto frag = [&](const char* slab, int ks, int col0, int kb) -> uint4 {
+        if (FAD_MOM_ABLATE & 2) return make_uint4(lane + ks, col0 + kb, lane, 0x3c003c00u);
+        // byte address of (row, col): row*256 + ((col/8) ^ 4*(row&3))*16 + ((col/4)&1)*8
+        const int r0 = ks * 16 + tr_row, r1 = r0 + 4, col = col0 + tr_col;
+        const int o0 = r0 * 256 + (((col >> 3) ^ ((r0 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+        const int o1 = r1 * 256 + (((col >> 3) ^ ((r1 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o1));
+        uint4 f;
+        __builtin_memcpy(&f.x, &lo, 8);
+        __builtin_memcpy(&f.z, &hi, 8);
+        return f;
+    };
+    // F[0], F[1] = the wave's two A-side fragments, F[2], F[3] = its two B-side fragments of k-step (kb, ks)
+    auto load_frags = [&](int kb, int ks, uint4 (&F)[4]) {
         const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
         const char* sB = DIAG ? sA : sA + H_KB * 256;
-        auto frag = [&](const char* slab, int ks, int col0) -> uint4 {
-            // byte address of (row, col): row*256 + ((col/8) ^ 4*(row&3))*16 + ((col/4)&1)*8
-            const int r0 = ks * 16 + tr_row, r1 = r0 + 4, col = col0 + tr_col;
-            const int o0 = r0 * 256 + (((col >> 3) ^ ((r0 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
-            const int o1 = r1 * 256 + (((col >> 3) ^ ((r1 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o0));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o1));
-            uint4 f;
-            __builtin_memcpy(&f.x, &lo, 8);
-            __builtin_memcpy(&f.z, &hi, 8);
-            return f;
-        };
-        // all 16 transpose reads of the stage are issued up front: the reads of the second k-step land while the
-        // MFMAs of the first one run (the compiler inserts the counted lgkmcnt waits)
-        uint4 a0[2], a1[2], b0[2], b1[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            a0[ks] = frag(sA, ks, 64 * wr); a1[ks] = frag(sA, ks, 64 * wr + 32);
-            b0[ks] = frag(sB, ks, 64 * wc); b1[ks] = frag(sB, ks, 64 * wc + 32);
+        F[0] = frag(sA, ks, 64 * wr, kb); F[1] = frag(sA, ks, 64 * wr + 32, kb);
+        F[2] = frag(sB, ks, 64 * wc, kb); F[3] = frag(sB, ks, 64 * wc + 32, kb);
+    };
+    auto mma_first = [&](const uint4 (&F)[4]) {
+        if (FAD_MOM_ABLATE & 1) {
+            acc[0][0][0] += (float)((F[0].x ^ F[0].y ^ F[0].z ^ F[0].w) + (F[1].x ^ F[1].y ^ F[1].z ^ F[1].w) +
+                                    (F[2].x ^ F[2].y ^ F[2].z ^ F[2].w) + (F[3].x ^ F[3].y ^ F[3].z ^ F[3].w));
+            return;
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            acc[0][0] = mfma_h16<KIND>(a0[ks], b0[ks], acc[0][0]);
-            acc[0][1] = mfma_h16<KIND>(a0[ks], b1[ks], acc[0][1]);
-            acc[1][0] = mfma_h16<KIND>(a1[ks], b0[ks], acc[1][0]);
-            acc[1][1] = mfma_h16<KIND>(a1[ks], b1[ks], acc[1][1]);
-            if (do_colsum) {
-                csum[0] += (double)sum8<KIND>(b0[ks]);
-                csum[1] += (double)sum8<KIND>(b1[ks]);
+        acc[0][0] = mfma_h16<KIND>(F[0], F[2], acc[0][0]);
+    };
+    auto mma_rest = [&](const uint4 (&F)[4]) {
+        if (FAD_MOM_ABLATE & 1) return;
+        acc[0][1] = mfma_h16<KIND>(F[0], F[3], acc[0][1]);
+        acc[1][0] = mfma_h16<KIND>(F[1], F[2], acc[1][0]);
+        acc[1][1] = mfma_h16<KIND>(F[1], F[3], acc[1][1]);
+        if (do_colsum) {
+            csum[0] += (double)sum8<KIND>(F[2]);
+            csum[1] += (double)sum8<KIND>(F[3]);
+        }
+    };
+
+    if (PIPE == 2) {
+        // Register prefetch a whole stage (2 k-steps, 16 transpose reads) ahead: the reads of stage kb+1 are issued
+        // behind the first MFMA of stage kb and have the other seven to land.  Under load (LDS-DMA bursts of the
+        // ring + 8 waves reading) an LDS read batch takes several hundred cycles; one k-step of lookahead (PIPE 1)
+        // measured no better than none.
+        uint4 Fa0[4], Fa1[4], Fb0[4], Fb1[4];
+        auto stage_step = [&](int kb, uint4 (&C0)[4], uint4 (&C1)[4], uint4 (&N0)[4], uint4 (&N1)[4]) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma_first(C0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < nkb) {
+                const int last = (nkb - 1 < kb + NST - 2) ? nkb - 1 : kb + NST - 2;     // youngest stage issued
+                if (last - (kb + 1) >= 1) wait_vmcnt<LPS>();
+                else wait_vmcnt<0>();
+                // past this barrier every wave holds stage kb in registers and is done with the slot of stage kb-1
+                if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+                if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+                load_frags(kb + 1, 0, N0);
+                load_frags(kb + 1, 1, N1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rest(C0);
+            mma_first(C1);
+            mma_rest(C1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (nkb > 0) {
+            const int ahead0 = (nkb - 1 < NST - 2) ? nkb - 1 : NST - 2;      // stages issued beyond stage 0
+            if (ahead0 >= 2) wait_vmcnt<2 * LPS>();
+            else if (ahead0 == 1) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
+            if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            load_frags(0, 0, Fa0);
+            load_frags(0, 1, Fa1);
+        }
+        for (int kb = 0; kb < nkb; kb += 2) {
+            stage_step(kb, Fa0, Fa1, Fb0, Fb1);
+            if (kb + 1 < nkb) stage_step(kb + 1, Fb0, Fb1, Fa0, Fa1);
+        }
+    } else if (PIPE) {
+        // Software-pipelined by k-step (16 rows): the 8 transpose reads of the NEXT k-step are issued right behind
+        // the first of the 4 MFMAs of the current one and land while the other three run, so a wave hides its own
+        // LDS latency.  (Two waves share a SIMD, but the issue arbiter alternates between them, they stay in phase,
+        // and without this the matrix pipe idles during every read burst -- scripts/probe_ablate.py: read, load and
+        // MFMA times simply added up.)  The compiler only ever emits s_waitcnt lgkmcnt(0) around
+        // ds_read_b64_tr_b16, so the reads sit where a full wait is what we want anyway: before the next batch.
+        uint4 F0[4], F1[4];
+        if (nkb > 0) {
+            const int ahead0 = (nkb - 1 < NST - 2) ? nkb - 1 : NST - 2;      // stages issued beyond stage 0
+            if (ahead0 >= 2) wait_vmcnt<2 * LPS>();
+            else if (ahead0 == 1) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
+            if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            load_frags(0, 0, F0);
+        }
+        for (int kb = 0; kb < nkb; ++kb) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma_first(F0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(kb, 1, F1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rest(F0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_first(F1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < nkb) {
+                // stage kb+1 must have landed; issued so far: up to stage min(nkb-1, kb+NST-2)
+                const int last = (nkb - 1 < kb + NST - 2) ? nkb - 1 : kb + NST - 2;
+                if (last - (kb + 1) >= 1) wait_vmcnt<LPS>();
+                else wait_vmcnt<0>();
+                // after this barrier every wave has consumed stage kb-1 (F1 of the previous iteration was waited
+                // for before its MFMAs), so that ring slot can be refilled
+                if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+                if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+                load_frags(kb + 1, 0, F0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rest(F1);
+        }
+    } else {
+        for (int kb = 0; kb < nkb; ++kb) {
+            // stage kb must have landed; up to NST-2 younger stages may stay in flight
+            const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
+            if (ahead >= 2) wait_vmcnt<2 * LPS>();
+            else if (ahead == 1) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
+            if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // stage kb is in LDS; stage kb-1 is free
+            if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+            // all 16 transpose reads of the stage are issued up front: the reads of the second k-step land while
+            // the MFMAs of the first one run (the compiler inserts the counted lgkmcnt waits)
+            uint4 F0[4], F1[4];
+            load_frags(kb, 0, F0);
+            load_frags(kb, 1, F1);
+            mma_first(F0); mma_rest(F0);
+            mma_first(F1); mma_rest(F1);
         }
     }
 
@@ -538,23 +655,30 @@ __device__ __forceinline__ void tile_h16_tr_body(
     }
 }
 
-template <int KIND, int NST>
+template <int KIND, int NST, int PIPE>
 __global__ __launch_bounds__(256) void moments_tile_h16_tr(
     const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
     int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
     int* __restrict__ shift_flag) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
+    long long dbg_c0 = 0, dbg_w0 = 0;
+    if (FAD_MOM_ABLATE & 16) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
     const int w = xcd_contiguous(blockIdx.x, S * T);
     const int split = w / T, tile = w - split * T;
     int ta, tb; tile_coords(tile, nt, ta, tb);
     const int64_t k_begin = (int64_t)split * rows_per_split;
     const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
     if (ta == tb)
-        tile_h16_tr_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, true, PIPE>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
                                             partials, colpart, smem_dyn, shift_flag);
     else
-        tile_h16_tr_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, false, PIPE>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
                                              partials, colpart, smem_dyn, nullptr);
+    if ((FAD_MOM_ABLATE & 16) && threadIdx.x == 0 && blockIdx.x % 97 == 0) {
+        const long long c = clock64() - dbg_c0, wt = wall_clock64() - dbg_w0;
+        printf("ablate %d pipe %d block %4d tile %d diag %d: %lld shader cycles, %lld wall ticks (100 MHz) -> %.2f GHz, %.1f us\n",
+               FAD_MOM_ABLATE, PIPE, (int)blockIdx.x, tile, (int)(ta == tb), c, wt, (double)c / (10.0 * (double)wt), (double)wt / 100.0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1140,7 +1264,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
     }
     if (use_h16) {
         const char* var = getenv("FAD_MOMENTS_VARIANT");
-        const int variant = (var && var[0] >= '1' && var[0] <= '4') ? (var[0] - '0') : 4;
+        const int variant = (var && var[0] >= '1' && var[0] <= '6') ? (var[0] - '0') : 4;
         constexpr int NST = 4;
         SplitPlan p = plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256, 8192);
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
@@ -1171,22 +1295,22 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             else
                 hipLaunchKernelGGL((moments_tile_h16_w2<FAD_BF16, NST>), dim3(p.S * p.T), dim3(128), lds, st, e16, n, ld, d,
                                    p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-        } else if (variant == 4) {
+        } else if (variant >= 4) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
+            typedef void (*tr_kernel_t)(const uint16_t*, int64_t, int64_t, int, int, int, int, int64_t, float*, double*, int*);
+            static const tr_kernel_t kern[2][3] = {
+                {&moments_tile_h16_tr<FAD_F16, NST, 0>, &moments_tile_h16_tr<FAD_F16, NST, 1>, &moments_tile_h16_tr<FAD_F16, NST, 2>},
+                {&moments_tile_h16_tr<FAD_BF16, NST, 0>, &moments_tile_h16_tr<FAD_BF16, NST, 1>, &moments_tile_h16_tr<FAD_BF16, NST, 2>}};
             static bool attr4 = false;
             if (!attr4) {
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_F16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_BF16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 3; ++b)
+                        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern[a][b]),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr4 = true;
             }
-            if (dtype == FAD_F16)
-                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_F16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
-                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-            else
-                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_BF16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
-                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+            hipLaunchKernelGGL(kern[dtype == FAD_F16 ? 0 : 1][variant - 4], dim3(p.S * p.T), dim3(256), lds, st, e16,
+                               n, ld, d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
         } else if (variant == 2) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
             static bool attr_set = false;
