@@ -67,8 +67,10 @@ struct GemmType {
     double* partials;
 };
 // returns the number of partial slots per problem (>0) or a negative fad_status
+// `check` (optional): one extra workgroup per problem runs ns_check_block (ns_check.h) beside the GEMM tiles.
+struct NsCheckArgs;
 int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, const int* skip, int skip_stride,
-                    hipStream_t stream, int device, int partial_stride = 0);
+                    hipStream_t stream, int device, int partial_stride = 0, const NsCheckArgs* check = nullptr);
 int gemm_f64_slots(int d, int ntypes, int64_t batch, int device);
 int gemm_f64_slots_max(int d);
 

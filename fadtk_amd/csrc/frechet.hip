@@ -21,6 +21,7 @@
 // Two-frame songs (Whisper) never need a matrix root: with d = x1 - x2,
 // Sigma_s = d d^T / 2 is rank one and tr sqrt(Sigma_b Sigma_s) = sqrt(d^T Sigma_b d / 2).
 #include "fad_common.h"
+#include "ns_check.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -33,36 +34,6 @@ int moments_device(const fad_moments* h);
 int moments_dim(const fad_moments* h);
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kMaxIter = 64;
-
-struct NsState {
-    double c, tr1, tr2, mean_term;
-    double res_last, tr_last;
-    int done;          // no more T GEMMs / residual checks for this problem
-    int final_iter, conv, nonfinite, too_few;
-    int finished;      // no more update GEMMs either: tr_last is final (also the host's "all done" test)
-    double res[kMaxIter];
-    double tr[kMaxIter];
-};
-constexpr int kStateInts = sizeof(NsState) / sizeof(int);
-
-__device__ __forceinline__ double block_sum(double v, double* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-__device__ __forceinline__ double block_max(double v, double* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
 
 constexpr int kStatRows = 5;
 // ---- per row r of A[b]: |row| sum, |col| sum, sum of squares, (row r).(col r), A[r][r]; grid (d, B) ---
@@ -173,56 +144,10 @@ __global__ __launch_bounds__(256) void ns_first(const double* __restrict__ Aall,
     if (threadIdx.x == 0) partials_all[(int64_t)b * nslots + blockIdx.x] = s;
 }
 
-// one block per problem per iteration: reduce the residual partials, trace(Y), decide
-__global__ __launch_bounds__(256) void ns_check(int k, int max_iter, NsState* __restrict__ st_all,
-                                                const double* __restrict__ partials_all, int nslots, int pstride,
-                                                const double* __restrict__ Yall, int64_t stride, int d,
-                                                double tol_res, double tol_tr, int finalize_only) {
+// stand-alone launch of the check (chunk ends; the per-iteration checks ride on the update GEMM launch)
+__global__ __launch_bounds__(256) void ns_check(NsCheckArgs a) {
     __shared__ double red[4];
-    const int b = blockIdx.x;
-    NsState* st = st_all + b;
-    if (st->finished) return;
-    if (finalize_only && !st->done) return;
-    const double* Y = Yall + b * stride;
-    const int tid = threadIdx.x;
-    double t = 0.0;
-    for (int i = tid; i < d; i += 256) t += Y[(int64_t)i * d + i];
-    const double tr = block_sum(t, red);
-    if (st->done) {
-        // the previous check predicted convergence after one more update: Y is that final iterate
-        if (tid == 0) {
-            st->tr[k] = tr; st->res[k] = st->res_last;
-            const bool finite = (tr == tr) && !isinf(tr);
-            if (!finite) st->nonfinite = 1;
-            st->tr_last = tr; st->final_iter = k; st->finished = 1;
-        }
-        return;
-    }
-    const double* partials = partials_all + (int64_t)b * pstride;
-    double s = 0.0;
-    for (int i = tid; i < nslots; i += 256) s += partials[i];
-    const double sumsq = block_sum(s, red);
-    if (tid != 0) return;
-    const double res = 2.0 * sqrt(sumsq);           // ||I - ZY||_F = 2 ||T - I||_F
-    st->res[k] = res; st->tr[k] = tr;
-    const bool finite = (res == res) && !isinf(res) && (tr == tr) && !isinf(tr);
-    if (!finite) { st->done = 1; st->finished = 1; st->nonfinite = 1; return; }
-    const double tr_prev = st->tr_last;
-    const double res_prev = (k > 0) ? st->res[k - 1] : 0.0;
-    st->res_last = res; st->tr_last = tr; st->final_iter = k;
-    // Stagnation = a rank-deficient product: the null directions keep the residual frozen while the trace has
-    // converged.  Both must stand still (the trace alone can pause by coincidence: with c = tr(A^2)/tr(A),
-    // tr(Y1) == tr(Y0) exactly), and not before the second iteration.
-    const bool stalled = k >= 2 && fabs(tr - tr_prev) <= tol_tr * fabs(tr) && fabs(res - res_prev) <= 1e-9 * res;
-    if (res <= tol_res) { st->done = 1; st->finished = 1; st->conv = 1; }
-    else if (stalled) { st->done = 1; st->finished = 1; st->conv = 2; }
-    else if (k + 1 >= max_iter) { st->done = 1; st->finished = 1; st->conv = 0; }
-    else {
-        // E_{k+1} = (3 E_k^2 + E_k^3) / 4 for E = I - ZY, hence ||E_{k+1}||_F <= 3/4 res^2 + 1/4 res^3: when that
-        // bound is already below the tolerance the NEXT iterate is converged -- apply the update, skip its T GEMM
-        const double bound = 0.75 * res * res + 0.25 * res * res * res;
-        if (bound <= tol_res) { st->done = 1; st->conv = 1; st->res_last = bound; }
-    }
+    ns_check_block(a, blockIdx.x, red);
 }
 
 __global__ __launch_bounds__(256) void add_diag(double* __restrict__ M, int d, double eps) {
@@ -251,7 +176,10 @@ __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __rest
 
 __global__ void clear_states(NsState* st, int64_t B) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (b < B) { st[b].too_few = 0; st[b].done = 0; st[b].finished = 0; st[b].nonfinite = 0; st[b].conv = 0; st[b].final_iter = -1; }
+    if (b < B) {
+        st[b].too_few = 0; st[b].done = 0; st[b].finished = 0; st[b].nonfinite = 0; st[b].conv = 0; st[b].final_iter = -1;
+        st[b].upd_skip[0] = 0; st[b].upd_skip[1] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -308,7 +236,6 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     const int pstride = ns_pstride(d);
     double* rowstats = partials + (size_t)B * pstride;
     const int* skip_t = &dstates[0].done;            // T GEMMs stop once convergence is known or predicted
-    const int* skip_u = &dstates[0].finished;        // update GEMMs stop once the final iterate exists
 
     const size_t hbytes = (size_t)B * sizeof(NsState);
     if (!ws.pinned || ws.pinned_cap < hbytes) {
@@ -334,6 +261,9 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
 
     int cur = 0, k = 0, chunk = 8;
     bool all_done = false;
+    NsCheckArgs chk;
+    chk.max_iter = max_iter; chk.st_all = dstates; chk.partials_all = partials; chk.pstride = pstride; chk.stride = dd;
+    chk.d = d; chk.tol_res = tol_res; chk.tol_tr = tol_tr;
     while (!all_done && k < max_iter) {
         const int stop = (k + chunk < max_iter) ? k + chunk : max_iter;
         for (; k < stop; ++k) {
@@ -343,17 +273,18 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
                 nslots = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device, pstride);
                 if (nslots < 0) return nslots;
             }
-            hipLaunchKernelGGL(ns_check, dim3((unsigned)B), dim3(256), 0, stream, k, max_iter, dstates, partials, nslots,
-                               pstride, Y[cur], dd, d, tol_res, tol_tr, 0);
+            // update GEMMs of iteration k + its convergence check as one extra workgroup per problem
+            chk.k = k; chk.nslots = nslots; chk.Yall = Y[cur]; chk.finalize_only = 0;
             g[0] = {Y[cur], dd, T, dd, Y[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
             g[1] = {T, dd, Z[cur], dd, Z[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
-            rc = gemm_f64_launch(d, g, k == 0 ? 1 : 2, B, skip_u, kStateInts, stream, device);      // Z1 = T0 is in place
+            rc = gemm_f64_launch(d, g, k == 0 ? 1 : 2, B, &dstates[0].upd_skip[k & 1], kStateInts, stream, device, 0,
+                                 &chk);                                                               // Z1 = T0 is in place
             if (rc < 0) return rc;
             cur ^= 1;
         }
         // a problem whose convergence was PREDICTED is finalised by the check that follows its last update
-        hipLaunchKernelGGL(ns_check, dim3((unsigned)B), dim3(256), 0, stream, k < kMaxIter ? k : kMaxIter - 1, max_iter,
-                           dstates, partials, 0, pstride, Y[cur], dd, d, tol_res, tol_tr, 1);
+        chk.k = k < kMaxIter ? k : kMaxIter - 1; chk.nslots = 0; chk.Yall = Y[cur]; chk.finalize_only = 1;
+        hipLaunchKernelGGL(ns_check, dim3((unsigned)B), dim3(256), 0, stream, chk);
         FAD_HIP_TRY(hipMemcpyAsync(hs, dstates, hbytes, hipMemcpyDeviceToHost, stream));
         FAD_HIP_TRY(hipStreamSynchronize(stream));
         all_done = true;

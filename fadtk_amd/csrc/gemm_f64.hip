@@ -12,6 +12,7 @@
 // Optional epilogue: per-workgroup sum of (C - gamma I)^2 written to a partial slot
 // (deterministic two-level reduction; no atomics).
 #include "fad_common.h"
+#include "ns_check.h"
 
 #include <cstdlib>
 
@@ -32,6 +33,8 @@ struct GemmArgs {
     int ntypes;
     int remap;                           // XCD-aware tile map on/off
     int pstride;                         // partial slots reserved per problem
+    int gemm_z;                          // blockIdx.z >= gemm_z: checker blocks (problem = blockIdx.z - gemm_z)
+    NsCheckArgs chk;
 };
 
 constexpr int KB = 64;                 // k depth of one LDS stage
@@ -59,6 +62,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
     double* sB = smem + BT * PA;
     double* red = smem + BT * PA + KB * PB;
 
+    if ((int)blockIdx.z >= g.gemm_z) {         // checker blocks: one live workgroup per problem
+        if (blockIdx.x == 0 && blockIdx.y == 0) ns_check_block(g.chk, (int64_t)blockIdx.z - g.gemm_z, red);
+        return;
+    }
     const int zi = (g.ntypes == 2) ? (blockIdx.z & 1) : 0;
     const int64_t zb = (g.ntypes == 2) ? (blockIdx.z >> 1) : blockIdx.z;
     if (g.skip && g.skip[zb * g.skip_stride] != 0) return;
@@ -227,12 +234,12 @@ int gemm_f64_slots(int d, int ntypes, int64_t batch, int device) {
 int gemm_f64_slots_max(int d) { const int64_t t = cdiv(d, 32); return (int)(t * t); }
 
 int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, const int* skip, int skip_stride,
-                    hipStream_t stream, int device, int partial_stride) {
+                    hipStream_t stream, int device, int partial_stride, const NsCheckArgs* check) {
     if (ntypes < 1 || ntypes > 2 || batch < 1) return set_error(FAD_ERR_INVALID, "gemm: ntypes=%d batch=%lld", ntypes, (long long)batch);
     const int bt = pick_bt(d, (int64_t)ntypes * batch, device);
     const int64_t t = cdiv(d, bt);
     const int64_t slots = t * t;
-    const int64_t max_b = 65535 / ntypes;
+    const int64_t max_b = 65535 / (ntypes + (check ? 1 : 0));
     for (int64_t done = 0; done < batch; done += max_b) {
         const int64_t m = (batch - done < max_b) ? batch - done : max_b;
         GemmArgs g;
@@ -250,7 +257,12 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
         static const int env_depth = [] { const char* e = getenv("FAD_GEMM_DEPTH"); return e ? atoi(e) : 1; }();
         g.remap = env_remap;
         g.pstride = partial_stride > 0 ? partial_stride : (int)slots;
-        dim3 grid((unsigned)t, (unsigned)t, (unsigned)(m * ntypes));
+        g.gemm_z = (int)(m * ntypes);
+        if (check) {
+            g.chk = *check;
+            g.chk.st_all += done; g.chk.partials_all += done * check->pstride; g.chk.Yall += done * check->stride;
+        }
+        dim3 grid((unsigned)t, (unsigned)t, (unsigned)(m * ntypes + (check ? m : 0)));
         const bool full = (d % KB) == 0;
         if (bt == 64) {
             if (full) hipLaunchKernelGGL((gemm_f64_kernel<64, 2, false, true>), grid, dim3(256), 0, stream, d, g);

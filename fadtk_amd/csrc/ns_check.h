@@ -1,0 +1,116 @@
+// Per-problem state of the Newton-Schulz trace-sqrt iteration and its convergence check.
+//
+// The check is a one-workgroup job (reduce the residual partials of the T GEMM, take trace(Y), decide).
+// As a kernel of its own it cost ~5 us per iteration on the critical path of a ~30 us iteration, so the
+// update-GEMM launch carries it as one extra workgroup per problem ("checker block", gemm_f64.hip): the
+// decision of iteration k is taken WHILE Y_{k+1}, Z_{k+1} are being computed and first matters to the
+// launches of iteration k+1.  Replaces the convergence logic hidden inside scipy.linalg.sqrtm
+// (fadtk/fad.py:88) -- there is no reference code for it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace fad {
+
+constexpr int kMaxIter = 64;
+
+struct NsState {
+    double c, tr1, tr2, mean_term;
+    double res_last, tr_last;
+    int done;          // no more T GEMMs / residual checks for this problem
+    int final_iter, conv, nonfinite, too_few;
+    int finished;      // tr_last is final (also the host's "all done" test)
+    // Update GEMMs of iteration k skip when upd_skip[k & 1] != 0.  Two words because the check of iteration k
+    // runs concurrently with the update GEMMs of iteration k: it only ever switches OFF the updates of
+    // iteration k+1 (the other word), never the launch it shares the grid with.
+    int upd_skip[2];
+    double res[kMaxIter];
+    double tr[kMaxIter];
+};
+constexpr int kStateInts = sizeof(NsState) / sizeof(int);
+
+struct NsCheckArgs {
+    int k, max_iter;
+    NsState* st_all;
+    const double* partials_all;      // [problem][pstride] sums of (T - I)^2 per GEMM workgroup
+    int nslots, pstride;
+    const double* Yall;              // Y_k of problem b at Yall + b * stride
+    int64_t stride;
+    int d;
+    double tol_res, tol_tr;
+    int finalize_only;               // only close problems whose convergence was predicted by the previous check
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// One workgroup (256 threads) per problem b; `red` = 4 doubles of LDS.
+__device__ __forceinline__ void ns_check_block(const NsCheckArgs& a, int64_t b, double* red) {
+    NsState* st = a.st_all + b;
+    if (st->finished) return;
+    if (a.finalize_only && !st->done) return;
+    const int k = a.k, d = a.d;
+    const double* Y = a.Yall + b * a.stride;
+    const int tid = threadIdx.x;
+    double t = 0.0;
+    for (int i = tid; i < d; i += 256) t += Y[(int64_t)i * d + i];
+    const double tr = block_sum(t, red);
+    if (st->done) {
+        // the previous check predicted convergence after one more update: Y is that final iterate
+        if (tid == 0) {
+            st->tr[k] = tr; st->res[k] = st->res_last;
+            const bool finite = (tr == tr) && !isinf(tr);
+            if (!finite) st->nonfinite = 1;
+            st->tr_last = tr; st->final_iter = k; st->finished = 1;
+            st->upd_skip[0] = 1; st->upd_skip[1] = 1;
+        }
+        return;
+    }
+    const double* partials = a.partials_all + b * a.pstride;
+    double s = 0.0;
+    for (int i = tid; i < a.nslots; i += 256) s += partials[i];
+    const double sumsq = block_sum(s, red);
+    if (tid != 0) return;
+    const double res = 2.0 * sqrt(sumsq);           // ||I - ZY||_F = 2 ||T - I||_F
+    st->res[k] = res; st->tr[k] = tr;
+    const bool finite = (res == res) && !isinf(res) && (tr == tr) && !isinf(tr);
+    const double tr_prev = st->tr_last;
+    const double res_prev = (k > 0) ? st->res[k - 1] : 0.0;
+    if (finite) { st->res_last = res; st->tr_last = tr; st->final_iter = k; }
+    // Stagnation = a rank-deficient product: the null directions keep the residual frozen while the trace has
+    // converged.  Both must stand still (the trace alone can pause by coincidence: with c = tr(A^2)/tr(A),
+    // tr(Y1) == tr(Y0) exactly), and not before the second iteration.
+    const bool stalled = k >= 2 && fabs(tr - tr_prev) <= a.tol_tr * fabs(tr) && fabs(res - res_prev) <= 1e-9 * res;
+    int finish = 0;
+    if (!finite) { st->nonfinite = 1; finish = 1; }
+    else if (res <= a.tol_res) { st->conv = 1; finish = 1; }
+    else if (stalled) { st->conv = 2; finish = 1; }
+    else if (k + 1 >= a.max_iter) { st->conv = 0; finish = 1; }
+    if (finish) {
+        // Y_k is the answer.  (The update GEMMs of iteration k may be running right now; switching their word
+        // off half way only garbles Y_{k+1}, Z_{k+1}, which nobody reads any more.)
+        st->done = 1; st->finished = 1; st->upd_skip[0] = 1; st->upd_skip[1] = 1;
+        return;
+    }
+    // E_{k+1} = (3 E_k^2 + E_k^3) / 4 for E = I - ZY, hence ||E_{k+1}||_F <= 3/4 res^2 + 1/4 res^3: when that
+    // bound is already below the tolerance the NEXT iterate is converged -- let this iteration's update finish,
+    // skip the next T GEMM and the next update; the next check closes the problem with trace(Y_{k+1}).
+    const double bound = 0.75 * res * res + 0.25 * res * res * res;
+    if (bound <= a.tol_res) { st->done = 1; st->conv = 1; st->res_last = bound; st->upd_skip[(k + 1) & 1] = 1; }
+}
+
+}  // namespace fad
