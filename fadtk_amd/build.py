@@ -21,7 +21,7 @@ LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libfad_hip.so"
 ARCH = "gfx950"
 SOURCES = ["common.cpp", "moments.hip", "gemm_f64.hip", "frechet.hip", "logmel.hip"]
-HEADERS = [CSRC / "fad_common.h", PKG.parent / "include" / "fad_hip.h"]
+HEADERS = [*sorted(CSRC.glob("*.h")), PKG.parent / "include" / "fad_hip.h"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-x", "hip"]
 

@@ -144,12 +144,6 @@ __global__ __launch_bounds__(256) void ns_first(const double* __restrict__ Aall,
     if (threadIdx.x == 0) partials_all[(int64_t)b * nslots + blockIdx.x] = s;
 }
 
-// stand-alone launch of the check (chunk ends; the per-iteration checks ride on the update GEMM launch)
-__global__ __launch_bounds__(256) void ns_check(NsCheckArgs a) {
-    __shared__ double red[4];
-    ns_check_block(a, blockIdx.x, red);
-}
-
 __global__ __launch_bounds__(256) void add_diag(double* __restrict__ M, int d, double eps) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < d) M[(int64_t)i * d + i] += eps;
@@ -259,7 +253,8 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     hipLaunchKernelGGL(ns_first, dim3((unsigned)nslots0, (unsigned)B), dim3(256), 0, stream, A, d, dstates, Y[0], T, Z[1],
                        dd, partials, pstride);
 
-    int cur = 0, k = 0, chunk = 8;
+    // launches are enqueued blind, `chunk` iterations at a time; 6 = what well-conditioned D=512 products take
+    int cur = 0, k = 0, chunk = 6;
     bool all_done = false;
     NsCheckArgs chk;
     chk.max_iter = max_iter; chk.st_all = dstates; chk.partials_all = partials; chk.pstride = pstride; chk.stride = dd;
@@ -274,7 +269,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
                 if (nslots < 0) return nslots;
             }
             // update GEMMs of iteration k + its convergence check as one extra workgroup per problem
-            chk.k = k; chk.nslots = nslots; chk.Yall = Y[cur]; chk.finalize_only = 0;
+            chk.k = k; chk.nslots = nslots; chk.Yall = Y[cur];
             g[0] = {Y[cur], dd, T, dd, Y[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
             g[1] = {T, dd, Z[cur], dd, Z[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
             rc = gemm_f64_launch(d, g, k == 0 ? 1 : 2, B, &dstates[0].upd_skip[k & 1], kStateInts, stream, device, 0,
@@ -282,9 +277,8 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
             if (rc < 0) return rc;
             cur ^= 1;
         }
-        // a problem whose convergence was PREDICTED is finalised by the check that follows its last update
-        chk.k = k < kMaxIter ? k : kMaxIter - 1; chk.nslots = 0; chk.Yall = Y[cur]; chk.finalize_only = 1;
-        hipLaunchKernelGGL(ns_check, dim3((unsigned)B), dim3(256), 0, stream, chk);
+        // (a problem whose convergence was PREDICTED by the last check of this chunk is closed by the first check
+        // of the next chunk -- its GEMMs are already switched off -- rather than by a launch of its own)
         FAD_HIP_TRY(hipMemcpyAsync(hs, dstates, hbytes, hipMemcpyDeviceToHost, stream));
         FAD_HIP_TRY(hipStreamSynchronize(stream));
         all_done = true;

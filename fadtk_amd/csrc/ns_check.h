@@ -38,7 +38,6 @@ struct NsCheckArgs {
     int64_t stride;
     int d;
     double tol_res, tol_tr;
-    int finalize_only;               // only close problems whose convergence was predicted by the previous check
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -62,7 +61,6 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 __device__ __forceinline__ void ns_check_block(const NsCheckArgs& a, int64_t b, double* red) {
     NsState* st = a.st_all + b;
     if (st->finished) return;
-    if (a.finalize_only && !st->done) return;
     const int k = a.k, d = a.d;
     const double* Y = a.Yall + b * a.stride;
     const int tid = threadIdx.x;
