@@ -27,6 +27,12 @@
 #ifndef FAD_MOM_ABLATE
 #define FAD_MOM_ABLATE 0
 #endif
+#ifndef FAD_MOM_AUX
+#define FAD_MOM_AUX 0          // cache-policy bits of the v8 LDS-DMA loads (probe knob)
+#endif
+#ifndef FAD_MOM_SPREAD
+#define FAD_MOM_SPREAD 0       // v8: issue the LDS-DMA loads between the MFMAs instead of in one burst (probe knob)
+#endif
 
 namespace fad {
 
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
 // ------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int KIND, int NST, bool DIAG, int PIPE>
+template <int KIND, int NST, bool DIAG>
 __device__ __forceinline__ void tile_h16_tr_body(
     const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
@@ -513,102 +519,21 @@ __device__ __forceinline__ void tile_h16_tr_body(
         }
     };
 
-    if (PIPE == 2) {
-        // Register prefetch a whole stage (2 k-steps, 16 transpose reads) ahead: the reads of stage kb+1 are issued
-        // behind the first MFMA of stage kb and have the other seven to land.  Under load (LDS-DMA bursts of the
-        // ring + 8 waves reading) an LDS read batch takes several hundred cycles; one k-step of lookahead (PIPE 1)
-        // measured no better than none.
-        uint4 Fa0[4], Fa1[4], Fb0[4], Fb1[4];
-        auto stage_step = [&](int kb, uint4 (&C0)[4], uint4 (&C1)[4], uint4 (&N0)[4], uint4 (&N1)[4]) {
-            __builtin_amdgcn_sched_barrier(0);
-            mma_first(C0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + 1 < nkb) {
-                const int last = (nkb - 1 < kb + NST - 2) ? nkb - 1 : kb + NST - 2;     // youngest stage issued
-                if (last - (kb + 1) >= 1) wait_vmcnt<LPS>();
-                else wait_vmcnt<0>();
-                // past this barrier every wave holds stage kb in registers and is done with the slot of stage kb-1
-                if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
-                if (kb + NST - 1 < nkb) issue(kb + NST - 1);
-                load_frags(kb + 1, 0, N0);
-                load_frags(kb + 1, 1, N1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mma_rest(C0);
-            mma_first(C1);
-            mma_rest(C1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if (nkb > 0) {
-            const int ahead0 = (nkb - 1 < NST - 2) ? nkb - 1 : NST - 2;      // stages issued beyond stage 0
-            if (ahead0 >= 2) wait_vmcnt<2 * LPS>();
-            else if (ahead0 == 1) wait_vmcnt<LPS>();
-            else wait_vmcnt<0>();
-            if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
-            load_frags(0, 0, Fa0);
-            load_frags(0, 1, Fa1);
-        }
-        for (int kb = 0; kb < nkb; kb += 2) {
-            stage_step(kb, Fa0, Fa1, Fb0, Fb1);
-            if (kb + 1 < nkb) stage_step(kb + 1, Fb0, Fb1, Fa0, Fa1);
-        }
-    } else if (PIPE) {
-        // Software-pipelined by k-step (16 rows): the 8 transpose reads of the NEXT k-step are issued right behind
-        // the first of the 4 MFMAs of the current one and land while the other three run, so a wave hides its own
-        // LDS latency.  (Two waves share a SIMD, but the issue arbiter alternates between them, they stay in phase,
-        // and without this the matrix pipe idles during every read burst -- scripts/probe_ablate.py: read, load and
-        // MFMA times simply added up.)  The compiler only ever emits s_waitcnt lgkmcnt(0) around
-        // ds_read_b64_tr_b16, so the reads sit where a full wait is what we want anyway: before the next batch.
+    for (int kb = 0; kb < nkb; ++kb) {
+        // stage kb must have landed; up to NST-2 younger stages may stay in flight
+        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
+        if (ahead >= 2) wait_vmcnt<2 * LPS>();
+        else if (ahead == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // stage kb is in LDS; stage kb-1 is free
+        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+        // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
+        // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
         uint4 F0[4], F1[4];
-        if (nkb > 0) {
-            const int ahead0 = (nkb - 1 < NST - 2) ? nkb - 1 : NST - 2;      // stages issued beyond stage 0
-            if (ahead0 >= 2) wait_vmcnt<2 * LPS>();
-            else if (ahead0 == 1) wait_vmcnt<LPS>();
-            else wait_vmcnt<0>();
-            if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
-            load_frags(0, 0, F0);
-        }
-        for (int kb = 0; kb < nkb; ++kb) {
-            __builtin_amdgcn_sched_barrier(0);
-            mma_first(F0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(kb, 1, F1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_rest(F0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_first(F1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + 1 < nkb) {
-                // stage kb+1 must have landed; issued so far: up to stage min(nkb-1, kb+NST-2)
-                const int last = (nkb - 1 < kb + NST - 2) ? nkb - 1 : kb + NST - 2;
-                if (last - (kb + 1) >= 1) wait_vmcnt<LPS>();
-                else wait_vmcnt<0>();
-                // after this barrier every wave has consumed stage kb-1 (F1 of the previous iteration was waited
-                // for before its MFMAs), so that ring slot can be refilled
-                if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();
-                if (kb + NST - 1 < nkb) issue(kb + NST - 1);
-                load_frags(kb + 1, 0, F0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mma_rest(F1);
-        }
-    } else {
-        for (int kb = 0; kb < nkb; ++kb) {
-            // stage kb must have landed; up to NST-2 younger stages may stay in flight
-            const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
-            if (ahead >= 2) wait_vmcnt<2 * LPS>();
-            else if (ahead == 1) wait_vmcnt<LPS>();
-            else wait_vmcnt<0>();
-            if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // stage kb is in LDS; stage kb-1 is free
-            if (kb + NST - 1 < nkb) issue(kb + NST - 1);
-            // all 16 transpose reads of the stage are issued up front: the reads of the second k-step land while
-            // the MFMAs of the first one run (the compiler inserts the counted lgkmcnt waits)
-            uint4 F0[4], F1[4];
-            load_frags(kb, 0, F0);
-            load_frags(kb, 1, F1);
-            mma_first(F0); mma_rest(F0);
-            mma_first(F1); mma_rest(F1);
-        }
+        load_frags(kb, 0, F0);
+        load_frags(kb, 1, F1);
+        mma_first(F0); mma_rest(F0);
+        mma_first(F1); mma_rest(F1);
     }
 
     float* out = partials + ((int64_t)split * T + tile) * H_TS;
@@ -655,7 +580,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     }
 }
 
-template <int KIND, int NST, int PIPE>
+template <int KIND, int NST>
 __global__ __launch_bounds__(256) void moments_tile_h16_tr(
     const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
     int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
@@ -669,15 +594,268 @@ __global__ __launch_bounds__(256) void moments_tile_h16_tr(
     const int64_t k_begin = (int64_t)split * rows_per_split;
     const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
     if (ta == tb)
-        tile_h16_tr_body<KIND, NST, true, PIPE>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
                                             partials, colpart, smem_dyn, shift_flag);
     else
-        tile_h16_tr_body<KIND, NST, false, PIPE>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
                                              partials, colpart, smem_dyn, nullptr);
     if ((FAD_MOM_ABLATE & 16) && threadIdx.x == 0 && blockIdx.x % 97 == 0) {
         const long long c = clock64() - dbg_c0, wt = wall_clock64() - dbg_w0;
-        printf("ablate %d pipe %d block %4d tile %d diag %d: %lld shader cycles, %lld wall ticks (100 MHz) -> %.2f GHz, %.1f us\n",
-               FAD_MOM_ABLATE, PIPE, (int)blockIdx.x, tile, (int)(ta == tb), c, wt, (double)c / (10.0 * (double)wt), (double)wt / 100.0);
+        printf("ablate %d pipe 4 block %4d tile %d diag %d: %lld shader cycles, %lld wall ticks (100 MHz) -> %.2f GHz, %.1f us\n",
+               FAD_MOM_ABLATE, (int)blockIdx.x, tile, (int)(ta == tb), c, wt, (double)c / (10.0 * (double)wt), (double)wt / 100.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// v8 ("wave tile"): every wave owns a WHOLE 128 x 128 tile in 256 accumulator registers and streams its own
+// rows; the four waves of a workgroup take the 16-row k-steps round robin and their tiles are summed once, at
+// the end, through LDS.  Why (all measured, scripts/probes + scripts/probe_ablate.py):
+//   * LDS transpose reads run at ~120 B/clk per CU.  With 64 x 64 wave tiles an MFMA needs 1 KiB of LDS reads,
+//     which makes the LDS port as busy as the matrix pipe (v4: ~590 vs 544 cycles per 32 rows), and the eight
+//     waves of a CU queue on it in lockstep.  A 128 x 128 wave tile needs 0.5 KiB per MFMA.
+//   * The partial tiles (one per workgroup) are the kernel's other big cost: 510 workgroups x 64 KiB written,
+//     then read by the reduce kernel.  One workgroup per CU halves that.
+//   * No workgroup barrier and no LDS sharing in the main loop: a wave waits only on its own LDS-DMA counter.
+// Per wave: ring of NSL slots of one k-step (16 rows x 128 columns of the A side, + the B side off the diagonal),
+// filled by global_load_lds with the same source-side XOR swizzle as v4; per k-step 16 (8) transpose reads feed
+// 16 (10 on a diagonal tile: upper blocks only) MFMAs; the reads of step i+1 are issued right behind the first
+// MFMA of step i (the compiler only emits lgkmcnt(0) around ds_read_b64_tr_b16, so that is where a full wait is
+// harmless).  Partial tile layout is fragment major: float4 index ((fa*4+fb)*4+q)*64+lane holds registers
+// 4q..4q+3 of the 32 x 32 block (fa, fb), i.e. rows 32fa + 8q + 4(lane>>5) + 0..3 of column 32fb + (lane&31).
+// ------------------------------------------------------------------------------------------
+constexpr int W_RING = 32768;                                  // LDS ring bytes per wave
+constexpr int W_LDS = 4 * W_RING + 4 * H_BT * 8 + H_BT * 8;    // + per-wave column sums + their total
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int outstanding_steps) {
+    // s_waitcnt vmcnt(outstanding_steps * N) for outstanding_steps in 0..7 (the count must be an immediate)
+    switch (outstanding_steps) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<N>(); break;
+        case 2: wait_vmcnt<2 * N>(); break;
+        case 3: wait_vmcnt<3 * N>(); break;
+        case 4: wait_vmcnt<4 * N>(); break;
+        case 5: wait_vmcnt<5 * N>(); break;
+        case 6: wait_vmcnt<6 * N>(); break;
+        default: wait_vmcnt<7 * N>(); break;
+    }
+}
+
+template <int KIND, bool DIAG>
+__device__ __forceinline__ void tile_h16_wave_body(
+    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
+    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
+    char* smem, int* __restrict__ shift_flag) {
+    constexpr int NSL = DIAG ? 8 : 4;              // ring slots (k-steps in flight + the one being read)
+    constexpr int SLOTB = DIAG ? 4096 : 8192;      // bytes per slot
+    constexpr int LPS = DIAG ? 4 : 8;              // LDS-DMA instructions per k-step
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kg = lane >> 5;
+    const int nks = (int)((k_end - k_begin + 15) / 16);
+    const int nw = (nks > wave) ? (nks - wave + 3) / 4 : 0;          // this wave's k-steps: wave, wave + 4, ...
+    char* ring = smem + wave * W_RING;
+
+    // LDS-DMA: one instruction = 4 rows x 256 B; lane -> row lane>>4, 16-byte chunk (lane&15) ^ 4*(row&3)
+    const int srow = lane >> 4, sc = (lane & 15) ^ (srow << 2);
+    const bool col_ok_a = (ca + sc * 8) < d;
+    const bool col_ok_b = (cb + sc * 8) < d;
+    const uint16_t* ga = E + ca + sc * 8;
+    const uint16_t* gb = E + cb + sc * 8;
+    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
+    // part g of the loads of own k-step i: rows 4g..4g+3 of the A slab (g < 4) or of the B slab (g >= 4)
+    auto issue_part = [&](int i, int g) {
+        if (FAD_MOM_ABLATE & 4) return;
+        char* slot = ring + (i % NSL) * SLOTB;
+        const int h = g & 3;
+        const int64_t r = k_begin + (int64_t)(wave + 4 * i) * 16 + srow + 4 * h;
+        const bool ok = r < k_end;
+        if (g < 4) {
+            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)(slot + h * 1024), 16, 0, FAD_MOM_AUX);
+        } else {
+            const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(slot + 4096 + h * 1024), 16, 0, FAD_MOM_AUX);
+        }
+    };
+    auto issue = [&](int i) {
+#pragma unroll
+        for (int g = 0; g < LPS; ++g) issue_part(i, g);
+    };
+
+    // transpose-read addressing (see v4): byte offset of the lane's first read of 32-column fragment f
+    const int t16 = lane & 15, grp = lane >> 4;
+    const int tr_row = 8 * (grp >> 1) + (t16 >> 2);
+    const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);
+    int fo[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int col = 32 * f + tr_col;
+        fo[f] = tr_row * 256 + (((col >> 3) ^ ((tr_row & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+    }
+    auto frag = [&](const char* slab, int f) -> uint4 {
+        if (FAD_MOM_ABLATE & 2) return make_uint4(lane + f, (uint32_t)(size_t)slab, lane, 0x3c003c00u);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f] + 1024));
+        uint4 v;
+        __builtin_memcpy(&v.x, &lo, 8);
+        __builtin_memcpy(&v.z, &hi, 8);
+        return v;
+    };
+    constexpr int NFR = DIAG ? 4 : 8;              // fragments per k-step: A side 0..3 (+ B side 4..7)
+    auto load_frags = [&](int i, uint4 (&F)[NFR]) {
+        const char* slot = ring + (i % NSL) * SLOTB;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) F[f] = frag(slot, f);
+        if (!DIAG) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) F[4 + f] = frag(slot + 4096, f);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
+    double csum[4] = {0.0, 0.0, 0.0, 0.0};
+
+    auto mma_first = [&](const uint4 (&F)[NFR]) {
+        if (FAD_MOM_ABLATE & 1) { acc[0][0][0] += (float)(F[0].x ^ F[1].y ^ F[2].z ^ F[3].w ^ F[NFR - 1].x); return; }
+        acc[0][0] = mfma_h16<KIND>(F[0], F[DIAG ? 0 : 4], acc[0][0]);
+    };
+    auto mma_rest = [&](const uint4 (&F)[NFR], int refill) {      // refill: own k-step whose loads ride along, or -1
+        int m = 0;
+#pragma unroll
+        for (int fa = 0; fa < 4; ++fa)
+#pragma unroll
+            for (int fb = (DIAG ? fa : 0); fb < 4; ++fb) {
+                if (fa == 0 && fb == 0) continue;
+                if (!(FAD_MOM_ABLATE & 1)) acc[fa][fb] = mfma_h16<KIND>(F[fa], F[DIAG ? fb : 4 + fb], acc[fa][fb]);
+                if (FAD_MOM_SPREAD && m < LPS) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (refill >= 0) issue_part(refill, m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ++m;
+            }
+        if (DIAG && !(FAD_MOM_ABLATE & 1)) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) csum[f] += (double)sum8<KIND>(F[f]);
+        }
+    };
+
+    const int n0 = nw < NSL ? nw : NSL;
+    for (int s = 0; s < n0; ++s) issue(s);
+    uint4 C[NFR], N[NFR];                          // fragments of the current / the next k-step
+    if (nw > 0) {
+        if (!(FAD_MOM_ABLATE & 4)) wait_vmcnt_upto<LPS>(n0 - 1);
+        load_frags(0, C);
+    }
+    for (int i = 0; i < nw; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        mma_first(C);                              // (lgkmcnt(0) before it: every read of step i has landed)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!FAD_MOM_SPREAD && i + NSL < nw) issue(i + NSL);          // ... so its slot can be refilled
+        if (i + 1 < nw) {
+            const int newest = FAD_MOM_SPREAD ? i + NSL - 1 : i + NSL;
+            const int youngest = (nw - 1 < newest) ? nw - 1 : newest;
+            if (!(FAD_MOM_ABLATE & 4)) wait_vmcnt_upto<LPS>(youngest - (i + 1));      // step i+1 is in LDS
+            load_frags(i + 1, N);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rest(C, (FAD_MOM_SPREAD && i + NSL < nw) ? i + NSL : -1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) C[f] = N[f];
+    }
+
+    // ---- epilogue: sum the four waves' tiles (fp64 sum of four fp32 values, rounded once) and store ------
+    __syncthreads();                               // every wave is done with its ring
+    float4* xch = reinterpret_cast<float4*>(smem);                   // [wave][2048] per half
+    double* colx = reinterpret_cast<double*>(smem + 4 * W_RING);     // [4][128] per-wave column sums
+    double* colt = colx + 4 * H_BT;                                  // [128] their total
+    if (DIAG) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            csum[f] += __shfl_xor(csum[f], 32);
+            if (kg == 0) colx[wave * H_BT + 32 * f + li] = csum[f];
+        }
+        __syncthreads();
+        if (tid < H_BT) {
+            const double t = (colx[tid] + colx[H_BT + tid]) + (colx[2 * H_BT + tid] + colx[3 * H_BT + tid]);
+            colt[tid] = t;
+            colpart[(int64_t)split * (nt * H_BT) + cb + tid] = t;
+        }
+    }
+    float4* out = reinterpret_cast<float4*>(partials + ((int64_t)split * T + tile) * H_TS);
+    const double nr = (double)(k_end - k_begin);
+    bool hit = false;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x16& a = acc[2 * half + fl][fb];
+                    xch[wave * 2048 + ((fl * 4 + fb) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+                }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 256 * j;
+            const float4 v0 = xch[e], v1 = xch[2048 + e], v2 = xch[4096 + e], v3 = xch[6144 + e];
+            const double s0 = ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            const double s1 = ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+            const double s2 = ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+            const double s3 = ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+            out[half * 2048 + e] = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
+            if (DIAG && shift_flag) {
+                // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?  The
+                // float4 of lane l, quad q of a diagonal block holds rows 8q + 4(l>>5) + 0..3 of column l&31: it
+                // contains the diagonal element (sum of x^2 of that column) iff (l&31)>>2 == 2q + (l>>5).
+                const int el = e & 63, eq = (e >> 6) & 3, efb = (e >> 8) & 3, efa = 2 * half + (e >> 10);
+                const int eli = el & 31;
+                if (efa == efb && (eli >> 2) == 2 * eq + (el >> 5)) {
+                    const int c = eli & 3, col = 32 * efb + eli;
+                    const double sq = (c == 0) ? s0 : (c == 1) ? s1 : (c == 2) ? s2 : s3;
+                    const double cs = colt[col];
+                    const double mean = cs / nr, var = sq / nr - mean * mean;
+                    if ((cb + col) < d && !(mean * mean <= 64.0 * var) && !(cs == 0.0 && sq == 0.0)) hit = true;
+                }
+            }
+        }
+        __syncthreads();                           // before the second half overwrites the exchange buffer
+    }
+    if (DIAG && shift_flag && hit) atomicOr(shift_flag, 1);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void moments_tile_h16_wave(
+    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
+    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
+    int* __restrict__ shift_flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem_wave[];   // the ONLY LDS object: W_LDS bytes
+    long long dbg_c0 = 0, dbg_w0 = 0;
+    if (FAD_MOM_ABLATE & 16) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
+    const int w = xcd_contiguous(blockIdx.x, S * T);
+    const int split = w / T, tile = w - split * T;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const int64_t k_begin = (int64_t)split * rows_per_split;
+    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    if (ta == tb)
+        tile_h16_wave_body<KIND, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT, partials,
+                                       colpart, smem_wave, shift_flag);
+    else
+        tile_h16_wave_body<KIND, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT, partials,
+                                        colpart, smem_wave, nullptr);
+    if ((FAD_MOM_ABLATE & 16) && threadIdx.x == 0 && blockIdx.x % 47 == 0) {
+        const long long c = clock64() - dbg_c0, wt = wall_clock64() - dbg_w0;
+        printf("ablate %d pipe 8 block %4d tile %d diag %d: %lld shader cycles, %lld wall ticks (100 MHz) -> %.2f GHz, %.1f us\n",
+               FAD_MOM_ABLATE, (int)blockIdx.x, tile, (int)(ta == tb), c, wt, (double)c / (10.0 * (double)wt), (double)wt / 100.0);
     }
 }
 
@@ -984,7 +1162,7 @@ template <typename PT, int BT, int SL>
 __global__ __launch_bounds__(256) void moments_reduce(
     const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed,
     const double* __restrict__ colpart, double n_add, int tile_blocks, const int* __restrict__ gate, int gate_want,
-    int* __restrict__ clear_flag) {
+    int* __restrict__ clear_flag, int layout) {
     constexpr int G = 256 / SL;                    // output groups (4 adjacent columns each) per block
     __shared__ double red[SL > 1 ? 256 * 4 : 1];
     const int per_tile = BT * BT / 4;
@@ -1010,9 +1188,15 @@ __global__ __launch_bounds__(256) void moments_reduce(
     if (live) {
         tile = (int)(g / per_tile);
         const int e = (int)(g - (int64_t)tile * per_tile);
-        a_local = e / (BT / 4); b_local = (e % (BT / 4)) * 4;
+        if (layout == 0) {                 // row major: 4 adjacent columns of one row
+            a_local = e / (BT / 4); b_local = (e % (BT / 4)) * 4;
+        } else {                           // fragment major (moments_tile_h16_wave): 4 adjacent ROWS of one column
+            const int el = e & 63;
+            a_local = 32 * (e >> 10) + 8 * ((e >> 6) & 3) + 4 * (el >> 5);
+            b_local = 32 * ((e >> 8) & 3) + (el & 31);
+        }
         constexpr int TS = (sizeof(PT) == 4) ? BT * BT + 64 : BT * BT + 32;      // H_TS / G_TS
-        const PT* p = partials + (int64_t)tile * TS + a_local * BT + b_local;
+        const PT* p = partials + (int64_t)tile * TS + e * 4;
         const int64_t stride = (int64_t)T * TS;
         int sp = sl;
         if constexpr (sizeof(PT) == 4) {           // four independent loads in flight per thread
@@ -1052,13 +1236,11 @@ __global__ __launch_bounds__(256) void moments_reduce(
     }
     if (!live) return;
     int ta, tb; tile_coords(tile, nt, ta, tb);
-    const int a = ta * BT + a_local, b0 = tb * BT + b_local;
-    if (a >= d || b0 >= d) return;
     double* M = acc_packed + 1 + d;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int b = b0 + q;
-        if (b >= d) break;
+        const int a = ta * BT + a_local + (layout ? q : 0), b = tb * BT + b_local + (layout ? 0 : q);
+        if (a >= d || b >= d) continue;
         if (ta != tb) {
             M[(int64_t)a * d + b] += s[q];
             M[(int64_t)b * d + a] += s[q];
@@ -1120,21 +1302,21 @@ __global__ __launch_bounds__(256) void moments_presum(
 
 template <typename PT, int BT>
 static void launch_reduce(const PT* part, const SplitPlan& p, int d, double* acc, const double* colp, double n_add,
-                          const int* gate, int gate_want, int* clear_flag, hipStream_t st) {
+                          const int* gate, int gate_want, int* clear_flag, hipStream_t st, int layout = 0) {
     const int64_t groups = (int64_t)p.T * (BT * BT / 4);
     const int col_blocks = (int)cdiv(d, 256);
     if (p.S > 64) {
         const int tb = (int)cdiv(groups, 256 / 16);
         hipLaunchKernelGGL((moments_reduce<PT, BT, 16>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
-                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag);
+                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag, layout);
     } else if (p.S > 8) {
         const int tb = (int)cdiv(groups, 256 / 4);
         hipLaunchKernelGGL((moments_reduce<PT, BT, 4>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
-                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag);
+                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag, layout);
     } else {
         const int tb = (int)cdiv(groups, 256);
         hipLaunchKernelGGL((moments_reduce<PT, BT, 1>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
-                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag);
+                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag, layout);
     }
 }
 
@@ -1264,9 +1446,18 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
     }
     if (use_h16) {
         const char* var = getenv("FAD_MOMENTS_VARIANT");
-        const int variant = (var && var[0] >= '1' && var[0] <= '6') ? (var[0] - '0') : 4;
-        constexpr int NST = 4;
-        SplitPlan p = plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256, 8192);
+        // default: v4; the one-tile-per-wave kernel (v8) wins on the HBM-bound single-tile shape (16.8M x 128: 0.80 vs
+        // 0.91 ms) and loses at D = 512 (62 vs 51 us), see DESIGN.md section 4
+        int variant = (var && var[0] >= '1' && var[0] <= '8') ? (var[0] - '0') : ((d <= H_BT && n >= (1 << 22)) ? 8 : 4);
+        if (variant >= 5 && variant <= 7) variant = 4;        // 5..7 were experiments, gone
+#ifndef FAD_MOM_NST
+#define FAD_MOM_NST 4
+#endif
+        constexpr int NST = FAD_MOM_NST;         // LDS ring depth (stages); a build-time knob for scripts/probe_ablate.py
+        // v8: one workgroup per CU, each wave sums at most 8192 rows in fp32 (4 waves per split)
+        SplitPlan p = (variant == 8) ? plan_splits(n, d, H_BT, 64, h->n_cu, 1, 256, 4 * 8192)
+                                     : plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256, 8192);
+        const int layout = (variant == 8) ? 1 : 0;
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
         FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
         float* part = static_cast<float*>(h->partials.p);
@@ -1279,7 +1470,22 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             flag_next = h->shift_flag + ((h->update_seq + 1u) & 1u);
             h->update_seq++;
         }
-        if (variant == 3) {
+        if (variant == 8) {
+            static bool attr8 = false;
+            if (!attr8) {
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_wave<FAD_F16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_wave<FAD_BF16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+                attr8 = true;
+            }
+            if (dtype == FAD_F16)
+                hipLaunchKernelGGL((moments_tile_h16_wave<FAD_F16>), dim3(p.S * p.T), dim3(256), W_LDS, st, e16, n, ld, d, p.nt,
+                                   p.T, p.S, p.rows_per_split, part, colp, flag_now);
+            else
+                hipLaunchKernelGGL((moments_tile_h16_wave<FAD_BF16>), dim3(p.S * p.T), dim3(256), W_LDS, st, e16, n, ld, d, p.nt,
+                                   p.T, p.S, p.rows_per_split, part, colp, flag_now);
+        } else if (variant == 3) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
             static bool attr3 = false;
             if (!attr3) {
@@ -1295,22 +1501,22 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             else
                 hipLaunchKernelGGL((moments_tile_h16_w2<FAD_BF16, NST>), dim3(p.S * p.T), dim3(128), lds, st, e16, n, ld, d,
                                    p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-        } else if (variant >= 4) {
+        } else if (variant == 4) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
-            typedef void (*tr_kernel_t)(const uint16_t*, int64_t, int64_t, int, int, int, int, int64_t, float*, double*, int*);
-            static const tr_kernel_t kern[2][3] = {
-                {&moments_tile_h16_tr<FAD_F16, NST, 0>, &moments_tile_h16_tr<FAD_F16, NST, 1>, &moments_tile_h16_tr<FAD_F16, NST, 2>},
-                {&moments_tile_h16_tr<FAD_BF16, NST, 0>, &moments_tile_h16_tr<FAD_BF16, NST, 1>, &moments_tile_h16_tr<FAD_BF16, NST, 2>}};
             static bool attr4 = false;
             if (!attr4) {
-                for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 3; ++b)
-                        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern[a][b]),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_F16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_BF16, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr4 = true;
             }
-            hipLaunchKernelGGL(kern[dtype == FAD_F16 ? 0 : 1][variant - 4], dim3(p.S * p.T), dim3(256), lds, st, e16,
-                               n, ld, d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+            if (dtype == FAD_F16)
+                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_F16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
+                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+            else
+                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_BF16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
+                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
         } else if (variant == 2) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
             static bool attr_set = false;
@@ -1355,9 +1561,9 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             const int gb = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
             hipLaunchKernelGGL((moments_presum<H_BT>), dim3((unsigned)(gb + cdiv(p.nt * H_BT, 256)), (unsigned)p2.S), dim3(256),
                                0, st, part, colp, p.S, p.T, p.nt, gb, ps, pc, (const int*)flag_now);
-            launch_reduce<double, H_BT>(ps, p2, d, h->acc, pc, (double)n, flag_now, 0, flag_next, st);
+            launch_reduce<double, H_BT>(ps, p2, d, h->acc, pc, (double)n, flag_now, 0, flag_next, st, layout);
         } else {
-            launch_reduce<float, H_BT>(part, p, d, h->acc, colp, (double)n, flag_now, 0, flag_next, st);
+            launch_reduce<float, H_BT>(part, p, d, h->acc, colp, (double)n, flag_now, 0, flag_next, st, layout);
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = (variant == 1) ? 2 : 0;

@@ -110,10 +110,12 @@ def test_moments_mfma_and_generic_kernels_agree(F, monkeypatch):
     assert p_mfma[0] == 5000 and p_gen[0] == 5000
 
 
-def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
+@pytest.mark.parametrize("variant", ["4", "8"])
+def test_moments_shift_guard_large_mean_small_std(F, monkeypatch, variant):
     """|mean| >> std: the covariance is a tiny difference of huge raw moments.  The guard must notice
     and redo the block in fp64 so that the result matches np.cov's centred computation."""
     from fadtk_amd.hip import Moments
+    monkeypatch.setenv("FAD_MOMENTS_VARIANT", variant)
     rng = np.random.default_rng(77)
     n, d = 6000, 256
     x = rng.standard_normal((n, d))
@@ -133,10 +135,10 @@ def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
     assert np.abs(cov_fast[:64, :64] - cov_o[:64, :64]).max() > 1e-7
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4", "8"])
 def test_moments_kernel_variants_agree(F, monkeypatch, variant):
-    """All generations of the fp16 tile kernel (register staged / LDS-DMA ring / 2-wave / transpose reads) are kept
-    selectable for A/B timing; each must produce the same statistics."""
+    """All generations of the fp16 tile kernel (register staged / LDS-DMA ring / 2-wave / transpose reads / one
+    128 x 128 tile per wave) are kept selectable for A/B timing; each must produce the same statistics."""
     from fadtk_amd.hip import Moments
     monkeypatch.setenv("FAD_MOMENTS_VARIANT", variant)
     x = structured_rows(31, 7001, 384, np.float16)
