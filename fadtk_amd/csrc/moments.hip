@@ -23,7 +23,8 @@
 #include <type_traits>
 
 // Build-time ablation switches for scripts/probe_ablate.py (never set in the product build): bit 0 drops the
-// MFMAs, bit 1 the LDS transpose reads, bit 2 the global->LDS loads, bit 3 the per-stage barrier.
+// MFMAs, bit 1 the LDS transpose reads, bit 2 the global->LDS loads, bit 3 the per-stage barrier; bit 4 prints
+// per-workgroup clocks, bit 5 makes every split of v4 read the same 256 rows (an L2-resident input).
 #ifndef FAD_MOM_ABLATE
 #define FAD_MOM_ABLATE 0
 #endif
@@ -453,8 +454,9 @@ __device__ __forceinline__ void tile_h16_tr_body(
         const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int64_t r = r0 + 16 * h;
+            int64_t r = r0 + 16 * h;
             const bool ok = r < k_end;
+            if (FAD_MOM_ABLATE & 32) r &= 255;     // probe: every split reads the same 256 rows (L2-resident)
             // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
             uint4* dstA = st + 256 * h + 64 * wave;
             const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;

@@ -21,7 +21,7 @@ def build():
     tl = B._torch_lib_dir()
     for m in MASKS:
         o = OUT / f"moments_{m}.o"
-        subprocess.run([B._hipcc(), *B.FLAGS, f"-DFAD_MOM_ABLATE={m & 31}", f"-DFAD_MOM_NST={((m >> 8) & 7) or 4}", f"-DFAD_MOM_SPREAD={(m >> 11) & 1}", f"-DFAD_MOM_AUX={(m >> 12) & 31}", "-c", str(B.CSRC / "moments.hip"), "-o", str(o)], check=True)
+        subprocess.run([B._hipcc(), *B.FLAGS, f"-DFAD_MOM_ABLATE={m & 63}", f"-DFAD_MOM_NST={((m >> 8) & 7) or 4}", f"-DFAD_MOM_SPREAD={(m >> 11) & 1}", f"-DFAD_MOM_AUX={(m >> 12) & 31}", "-c", str(B.CSRC / "moments.hip"), "-o", str(o)], check=True)
         subprocess.run(["g++", "-shared", "-fPIC", "-o", str(OUT / f"libfad_ablate_{m}.so"), str(o), *objs, f"-L{tl}", "-lamdhip64",
                         f"-Wl,-rpath,{tl}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--enable-new-dtags"], check=True)
         o.unlink()

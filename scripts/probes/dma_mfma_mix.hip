@@ -47,14 +47,16 @@ __global__ __launch_bounds__(256) void mix(const char* __restrict__ buf, int ite
         if (NG > 0 && REGSTAGE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NG) : "memory");
     }
     const long long t1 = clock64();
-    float s = (float)x; for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+    __syncthreads();
+    float s = (float)x + reinterpret_cast<float*>(smem)[tid * 37 & 16383];      // keeps the LDS writes (and their loads) alive
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
     out[blockIdx.x * 256 + tid] = s;
     if (tid == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
 template <int NG, int NL, int NM, int REGSTAGE>
-void run(const char* buf, float* out, long long* cyc) {
-    const int iters = 2000, wgs = 512;
+void run(const char* buf, float* out, long long* cyc, int wgs = 512) {
+    const int iters = 2000;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mix<NG, NL, NM, REGSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     mix<NG, NL, NM, REGSTAGE><<<wgs, 256, 65536>>>(buf, iters, out, cyc);
     hipDeviceSynchronize();
@@ -64,7 +66,7 @@ void run(const char* buf, float* out, long long* cyc) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    printf("%s glds=%d ldsrd=%d mfma=%d : %8.3f ms  %7.1f cycles/iter (wave clock)  %.2f GHz\n", REGSTAGE ? "reg-staged" : "LDS-DMA   ", NG,
+    printf("wgs=%d %s glds=%d ldsrd=%d mfma=%d : %8.3f ms  %7.1f cycles/iter (wave clock)  %.2f GHz\n", wgs, REGSTAGE ? "reg-staged" : "LDS-DMA   ", NG,
            NL, NM, ms, (double)c / iters, (double)c / (ms * 1e6));
 }
 
@@ -83,5 +85,11 @@ int main() {
     run<4, 0, 8, 1>(buf, out, cyc);
     run<4, 16, 8, 1>(buf, out, cyc);
     run<2, 16, 8, 1>(buf, out, cyc);
+    for (int wgs : {512, 256}) {
+        run<0, 0, 16, 0>(buf, out, cyc, wgs);
+        run<8, 0, 16, 0>(buf, out, cyc, wgs);
+        run<8, 0, 0, 0>(buf, out, cyc, wgs);
+        run<8, 16, 16, 0>(buf, out, cyc, wgs);
+    }
     return 0;
 }
