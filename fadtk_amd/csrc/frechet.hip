@@ -30,6 +30,7 @@
 struct fad_moments;
 namespace fad {
 const double* moments_packed(const fad_moments* h);
+int moments_settle(const fad_moments* h, hipStream_t st);      // pending reset -> zeros
 int moments_device(const fad_moments* h);
 int moments_dim(const fad_moments* h);
 
@@ -161,7 +162,15 @@ __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __rest
     const double* sum = acc + 1;
     const double* M = acc + 1 + d;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g == 0 && n < 2.0) st->too_few = 1;
+    if (g == 0) {
+        // also the per-call reset of the iteration state (clear_states), folded in to save a launch: nothing else
+        // reads these words before this kernel has finished
+        st->too_few[blockIdx.y] = (n < 2.0) ? 1 : 0;
+        if (blockIdx.y == 0) {
+            st->done = 0; st->finished = 0; st->nonfinite = 0; st->conv = 0; st->final_iter = -1;
+            st->upd_skip[0] = 0; st->upd_skip[1] = 0;
+        }
+    }
     if (g < d) mu[g] = sum[g] / n;
     if (g >= (int64_t)d * d) return;
     const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __rest
 __global__ void clear_states(NsState* st, int64_t B) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (b < B) {
-        st[b].too_few = 0; st[b].done = 0; st[b].finished = 0; st[b].nonfinite = 0; st[b].conv = 0; st[b].final_iter = -1;
+        st[b].too_few[0] = 0; st[b].too_few[1] = 0; st[b].done = 0; st[b].finished = 0; st[b].nonfinite = 0; st[b].conv = 0; st[b].final_iter = -1;
         st[b].upd_skip[0] = 0; st[b].upd_skip[1] = 0;
     }
 }
@@ -297,7 +306,7 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
     NsState* hs = nullptr;
     NsProblem pb{d, 1, cov1, 0, cov2, 0, mu1, 0, mu2, 0};
     FAD_TRY(run_ns(pb, max_iter, tol, device, stream, ws, &hs));
-    if (check_few && hs->too_few)
+    if (check_few && (hs->too_few[0] || hs->too_few[1]))
         return set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
     bool used_eps = false;
     if (hs->nonfinite && eps > 0.0) {
@@ -657,10 +666,11 @@ int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, i
     if (moments_device(h2) != device) return set_error(FAD_ERR_INVALID, "handles live on different devices");
     DeviceGuard g(device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    FAD_TRY(moments_settle(h1, st));
+    FAD_TRY(moments_settle(h2, st));
     Workspace& ws = thread_ws(device);
     FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
     NsState* dstate = static_cast<NsState*>(ws.small.p);
-    hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, st, dstate, (int64_t)1);
     const int64_t dd = (int64_t)d * d;
     FAD_TRY(ws.stage.reserve((size_t)(4 * dd + 2 * d) * sizeof(double)));
     double* s = static_cast<double*>(ws.stage.p);

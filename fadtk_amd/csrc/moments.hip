@@ -1157,40 +1157,48 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
 // ------------------------------------------------------------------------------------------
 struct SplitPlan { int nt, T, S; int64_t rows_per_split; };
 
-// SL "split lanes" share one output group: thread (sl, g) sums splits sl, sl+SL, ... and the SL partial
+// One source of partial sums for moments_reduce: `S` row-splits x `T` tiles (+ column partials).
+struct ReduceSrc {
+    const void* partials; const double* colpart;
+    int S, T, nt;
+    int tile_blocks;      // workgroups that sum tiles; the following ceil(d/256) sum the columns and the row count
+    int layout;           // 0 row major, 1 fragment major (moments_tile_h16_wave)
+    int sl;               // "split lanes" (1, 4 or 16), see below
+};
+
+// sl "split lanes" share one output group: thread (l, g) sums splits l, l+sl, ... and the sl partial
 // sums are combined through LDS in a fixed order.  With hundreds of row-splits (D = 128 uses every
 // workgroup slot for one tile) a single thread per output would walk all of them serially.
-template <typename PT, int BT, int SL>
-__global__ __launch_bounds__(256) void moments_reduce(
-    const PT* __restrict__ partials, int S, int T, int nt, int d, double* __restrict__ acc_packed,
-    const double* __restrict__ colpart, double n_add, int tile_blocks, const int* __restrict__ gate, int gate_want,
-    int* __restrict__ clear_flag, int layout) {
-    constexpr int G = 256 / SL;                    // output groups (4 adjacent columns each) per block
-    __shared__ double red[SL > 1 ? 256 * 4 : 1];
+// overwrite: the accumulator was reset since its last update -- store instead of add (saves the memset).
+template <typename PT, int BT>
+__device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* __restrict__ acc_packed, double n_add,
+                                            bool overwrite, int block, double* red) {
+    const PT* __restrict__ partials = static_cast<const PT*>(r.partials);
+    const int S = r.S, T = r.T, nt = r.nt, SL = r.sl;
+    const int G = 256 / SL;                        // output groups (4 values each) per block
     const int per_tile = BT * BT / 4;
-    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;     // next update's flag
-    if (gate && (*gate != 0) != (gate_want != 0)) return;     // exactly one of the two reduces of an update runs
-    if ((int)blockIdx.x >= tile_blocks) {          // trailing blocks: column sums and the row count
-        const int a = ((int)blockIdx.x - tile_blocks) * 256 + threadIdx.x;
-        if (a == 0) acc_packed[0] += n_add;
+    if (block >= r.tile_blocks) {                  // trailing blocks: column sums and the row count
+        const int a = (block - r.tile_blocks) * 256 + threadIdx.x;
+        if (a == 0) acc_packed[0] = overwrite ? n_add : acc_packed[0] + n_add;
         if (a >= d) return;
         const int dpad = nt * BT;
+        const double* __restrict__ colpart = r.colpart;
         double s0 = 0.0, s1 = 0.0;
         int sp = 0;
         for (; sp + 1 < S; sp += 2) { s0 += colpart[(int64_t)sp * dpad + a]; s1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
         if (sp < S) s0 += colpart[(int64_t)sp * dpad + a];
-        acc_packed[1 + a] += s0 + s1;
+        acc_packed[1 + a] = overwrite ? s0 + s1 : acc_packed[1 + a] + (s0 + s1);
         return;
     }
     const int sl = threadIdx.x / G, gl = threadIdx.x % G;
-    const int64_t g = (int64_t)blockIdx.x * G + gl;
+    const int64_t g = (int64_t)block * G + gl;
     const bool live = g < (int64_t)T * per_tile;
     int tile = 0, a_local = 0, b_local = 0;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (live) {
         tile = (int)(g / per_tile);
         const int e = (int)(g - (int64_t)tile * per_tile);
-        if (layout == 0) {                 // row major: 4 adjacent columns of one row
+        if (r.layout == 0) {               // row major: 4 adjacent columns of one row
             a_local = e / (BT / 4); b_local = (e % (BT / 4)) * 4;
         } else {                           // fragment major (moments_tile_h16_wave): 4 adjacent ROWS of one column
             const int el = e & 63;
@@ -1224,7 +1232,7 @@ __global__ __launch_bounds__(256) void moments_reduce(
             }
         }
     }
-    if constexpr (SL > 1) {
+    if (SL > 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[(sl * G + gl) * 4 + q] = s[q];
         __syncthreads();
@@ -1241,16 +1249,30 @@ __global__ __launch_bounds__(256) void moments_reduce(
     double* M = acc_packed + 1 + d;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int a = ta * BT + a_local + (layout ? q : 0), b = tb * BT + b_local + (layout ? 0 : q);
+        const int a = ta * BT + a_local + (r.layout ? q : 0), b = tb * BT + b_local + (r.layout ? 0 : q);
         if (a >= d || b >= d) continue;
+        const int64_t ab = (int64_t)a * d + b, ba = (int64_t)b * d + a;
         if (ta != tb) {
-            M[(int64_t)a * d + b] += s[q];
-            M[(int64_t)b * d + a] += s[q];
+            M[ab] = overwrite ? s[q] : M[ab] + s[q];
+            M[ba] = overwrite ? s[q] : M[ba] + s[q];
         } else if (a <= b) {            // diagonal tile: upper triangle is authoritative
-            M[(int64_t)a * d + b] += s[q];
-            if (a != b) M[(int64_t)b * d + a] += s[q];
+            M[ab] = overwrite ? s[q] : M[ab] + s[q];
+            if (a != b) M[ba] = overwrite ? s[q] : M[ba] + s[q];
         }
     }
+}
+
+// accumulator += (or =) the sum over splits of ONE of two sources: `prim` (PTA, BTA) when *gate == 0 or there is no
+// gate, else `alt` -- the fp64 redo of the block by moments_tile_f64 (shift guard).  One launch for both cases; the
+// grid is sized for the larger.
+template <typename PTA, int BTA>
+__global__ __launch_bounds__(256) void moments_reduce(ReduceSrc prim, ReduceSrc alt, int d, double* __restrict__ acc_packed,
+                                                      double n_add, const int* __restrict__ gate,
+                                                      int* __restrict__ clear_flag, int overwrite) {
+    __shared__ double red[256 * 4];
+    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;     // next update's flag
+    if (gate && *gate != 0) reduce_body<double, 64>(alt, d, acc_packed, n_add, overwrite != 0, (int)blockIdx.x, red);
+    else reduce_body<PTA, BTA>(prim, d, acc_packed, n_add, overwrite != 0, (int)blockIdx.x, red);
 }
 
 // Stage 1 of the two-level reduce used when an update produced hundreds or thousands of partial tiles (long inputs
@@ -1302,24 +1324,23 @@ __global__ __launch_bounds__(256) void moments_presum(
     *reinterpret_cast<double2*>(o + 2) = make_double2(s[2], s[3]);
 }
 
+static ReduceSrc reduce_src(const void* part, const double* colp, const SplitPlan& p, int bt, int layout) {
+    ReduceSrc r;
+    r.partials = part; r.colpart = colp; r.S = p.S; r.T = p.T; r.nt = p.nt; r.layout = layout;
+    r.sl = (p.S > 64) ? 16 : (p.S > 8) ? 4 : 1;
+    r.tile_blocks = (int)cdiv((int64_t)p.T * (bt * bt / 4), 256 / r.sl);
+    return r;
+}
+
+// prim: the update's own partials; alt (optional, with `gate`): the fp64 redo made by the shift guard
 template <typename PT, int BT>
-static void launch_reduce(const PT* part, const SplitPlan& p, int d, double* acc, const double* colp, double n_add,
-                          const int* gate, int gate_want, int* clear_flag, hipStream_t st, int layout = 0) {
-    const int64_t groups = (int64_t)p.T * (BT * BT / 4);
+static void launch_reduce(const ReduceSrc& prim, const ReduceSrc* alt, int d, double* acc, double n_add, const int* gate,
+                          int* clear_flag, bool overwrite, hipStream_t st) {
     const int col_blocks = (int)cdiv(d, 256);
-    if (p.S > 64) {
-        const int tb = (int)cdiv(groups, 256 / 16);
-        hipLaunchKernelGGL((moments_reduce<PT, BT, 16>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
-                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag, layout);
-    } else if (p.S > 8) {
-        const int tb = (int)cdiv(groups, 256 / 4);
-        hipLaunchKernelGGL((moments_reduce<PT, BT, 4>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
-                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag, layout);
-    } else {
-        const int tb = (int)cdiv(groups, 256);
-        hipLaunchKernelGGL((moments_reduce<PT, BT, 1>), dim3((unsigned)(tb + col_blocks)), dim3(256), 0, st, part, p.S, p.T,
-                           p.nt, d, acc, colp, n_add, tb, gate, gate_want, clear_flag, layout);
-    }
+    int blocks = prim.tile_blocks + col_blocks;
+    if (alt && alt->tile_blocks + col_blocks > blocks) blocks = alt->tile_blocks + col_blocks;
+    hipLaunchKernelGGL((moments_reduce<PT, BT>), dim3((unsigned)blocks), dim3(256), 0, st, prim, alt ? *alt : prim, d, acc,
+                       n_add, alt ? gate : nullptr, clear_flag, overwrite ? 1 : 0);
 }
 
 // per-segment column sums: seg_sums[s][a] = sum over rows of segment s of E[r][a]   (fp64)
@@ -1372,6 +1393,7 @@ struct fad_moments {
     int* shift_flag = nullptr;             // device int[2], ping-pong between updates
     unsigned update_seq = 0;
     int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0)
+    bool fresh = false;                    // reset since the last update: the next reduce stores instead of adding
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
     // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
     static constexpr int kRing = 256;
@@ -1543,6 +1565,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
                                p.S, p.rows_per_split, part, colp);
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
+        ReduceSrc alt; const ReduceSrc* altp = nullptr;
         if (flag_now) {
             SplitPlan q = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
             FAD_TRY(h->partials64.reserve((size_t)q.S * q.T * G_TS * sizeof(double)));
@@ -1551,8 +1574,10 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             double* colp64 = static_cast<double*>(h->colpart64.p);
             if (dtype == FAD_F16) launch_generic<raw_f16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
             else launch_generic<raw_bf16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
-            launch_reduce<double, G_BT>(part64, q, d, h->acc, colp64, (double)n, flag_now, 1, nullptr, st);
+            alt = reduce_src(part64, colp64, q, G_BT, 0);
+            altp = &alt;
         }
+        const bool overwrite = h->fresh;
         if (p.S > 128) {                   // two-level: S -> ceil(S/32) fp64 partials -> accumulator
             SplitPlan p2 = p;
             p2.S = (int)cdiv(p.S, PRESUM_CHUNK);
@@ -1563,10 +1588,13 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             const int gb = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
             hipLaunchKernelGGL((moments_presum<H_BT>), dim3((unsigned)(gb + cdiv(p.nt * H_BT, 256)), (unsigned)p2.S), dim3(256),
                                0, st, part, colp, p.S, p.T, p.nt, gb, ps, pc, (const int*)flag_now);
-            launch_reduce<double, H_BT>(ps, p2, d, h->acc, pc, (double)n, flag_now, 0, flag_next, st, layout);
+            launch_reduce<double, H_BT>(reduce_src(ps, pc, p2, H_BT, layout), altp, d, h->acc, (double)n, flag_now, flag_next,
+                                        overwrite, st);
         } else {
-            launch_reduce<float, H_BT>(part, p, d, h->acc, colp, (double)n, flag_now, 0, flag_next, st, layout);
+            launch_reduce<float, H_BT>(reduce_src(part, colp, p, H_BT, layout), altp, d, h->acc, (double)n, flag_now, flag_next,
+                                       overwrite, st);
         }
+        h->fresh = false;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = (variant == 1) ? 2 : 0;
     } else {
@@ -1584,7 +1612,8 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
             default: return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
         }
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
-        launch_reduce<double, G_BT>(part, p, d, h->acc, colp, (double)n, nullptr, 0, nullptr, st);
+        launch_reduce<double, G_BT>(reduce_src(part, colp, p, G_BT, 0), nullptr, d, h->acc, (double)n, nullptr, nullptr, h->fresh, st);
+        h->fresh = false;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
         h->last_variant = 1;
     }
@@ -1659,11 +1688,20 @@ int fad_moments_destroy(fad_moments_t* h) {
     return FAD_OK;
 }
 
+// The accumulator's memset is deferred: an update right after a reset overwrites it (saves a launch per set);
+// every other reader settles the pending zeroing first.
+static int settle(const fad_moments* hc, hipStream_t st) {
+    fad_moments* h = const_cast<fad_moments*>(hc);
+    if (!h->fresh) return FAD_OK;
+    FAD_HIP_TRY(hipMemsetAsync(h->acc, 0, (size_t)packed_len(h->d) * sizeof(double), st));
+    h->fresh = false;
+    return FAD_OK;
+}
+
 int fad_moments_reset(fad_moments_t* h, void* stream) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
-    DeviceGuard g(h->device);
-    FAD_HIP_TRY(hipMemsetAsync(h->acc, 0, (size_t)packed_len(h->d) * sizeof(double),
-                               static_cast<hipStream_t>(stream)));
+    (void)stream;
+    h->fresh = true;
     return FAD_OK;
 }
 
@@ -1740,6 +1778,8 @@ int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream
     if (dst->device != src->device) return set_error(FAD_ERR_INVALID, "handles live on different devices; export/import instead");
     DeviceGuard g(dst->device);
     const int64_t len = packed_len(dst->d);
+    FAD_TRY(settle(dst, static_cast<hipStream_t>(stream)));
+    FAD_TRY(settle(src, static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(packed_axpy, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        dst->acc, src->acc, len);
     FAD_HIP_TRY(hipGetLastError());
@@ -1751,6 +1791,7 @@ int fad_moments_export(const fad_moments_t* h, double* packed, int on_device, vo
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t bytes = (size_t)packed_len(h->d) * sizeof(double);
+    FAD_TRY(settle(h, st));
     FAD_HIP_TRY(hipMemcpyAsync(packed, h->acc, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
     return FAD_OK;
@@ -1761,6 +1802,7 @@ int fad_moments_import(fad_moments_t* h, const double* packed, int on_device, vo
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t bytes = (size_t)packed_len(h->d) * sizeof(double);
+    h->fresh = false;                              // the whole accumulator is overwritten
     FAD_HIP_TRY(hipMemcpyAsync(h->acc, packed, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
     return FAD_OK;
@@ -1771,6 +1813,7 @@ int fad_moments_count(const fad_moments_t* h, int64_t* n, void* stream) {
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double v = 0.0;
+    FAD_TRY(settle(h, st));
     FAD_HIP_TRY(hipMemcpyAsync(&v, h->acc, sizeof(double), hipMemcpyDeviceToHost, st));
     FAD_HIP_TRY(hipStreamSynchronize(st));
     *n = (int64_t)(v + 0.5);
@@ -1842,6 +1885,7 @@ int fad_moments_last_timing(fad_moments_t* h, float* ms_main, float* ms_reduce, 
 // accessors for the other translation units (frechet.hip)
 namespace fad {
 const double* moments_packed(const fad_moments* h) { return h->acc; }
+int moments_settle(const fad_moments* h, hipStream_t st) { return settle(h, st); }
 int moments_device(const fad_moments* h) { return h->device; }
 int moments_dim(const fad_moments* h) { return h->d; }
 }

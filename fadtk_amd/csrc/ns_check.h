@@ -18,7 +18,8 @@ struct NsState {
     double c, tr1, tr2, mean_term;
     double res_last, tr_last;
     int done;          // no more T GEMMs / residual checks for this problem
-    int final_iter, conv, nonfinite, too_few;
+    int final_iter, conv, nonfinite;
+    int too_few[2];    // set by finalize_for_frechet: set i has fewer than two rows
     int finished;      // tr_last is final (also the host's "all done" test)
     // Update GEMMs of iteration k skip when upd_skip[k & 1] != 0.  Two words because the check of iteration k
     // runs concurrently with the update GEMMs of iteration k: it only ever switches OFF the updates of
