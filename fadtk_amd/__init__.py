@@ -14,7 +14,8 @@ __version__ = "0.1.0"
 
 def __getattr__(name):
     # loaders and the batch driver import torch; keep `import fadtk_amd` light
-    if name in ("ModelLoader", "get_all_models", "VGGishModel", "EncodecEmbModel", "CLAPLaionModel", "WhisperModel"):
+    if name in ("ModelLoader", "get_all_models", "VGGishModel", "EncodecEmbModel", "CLAPLaionModel", "WhisperModel",
+                "W2V2Model", "HuBERTModel", "WavLMModel", "MERTModel"):
         from . import model_loader
         return getattr(model_loader, name)
     if name == "cache_embedding_files":

@@ -86,7 +86,7 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
         # pointers are valid inside the library.  Without torch the system ROCm runtime is used.
         link_dirs = [d for d in (_torch_lib_dir(), "/opt/rocm/lib") if d and (Path(d) / "libamdhip64.so").exists()]
         cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
-               f"-L{link_dirs[0]}", "-lamdhip64", *[f"-Wl,-rpath,{d}" for d in link_dirs], "-Wl,--enable-new-dtags"]
+               f"-L{link_dirs[0]}", "-lamdhip64", "-ldl", *[f"-Wl,-rpath,{d}" for d in link_dirs], "-Wl,--enable-new-dtags"]
         if verbose:
             print("[fadtk_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

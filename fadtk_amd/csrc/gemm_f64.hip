@@ -51,19 +51,25 @@ constexpr int PA = KB + 2;             // A pitch (doubles): rows i..i+15 land o
 // 4th k-step; the four partial tiles are summed through LDS at the end.  A wave then carries four
 // independent accumulators instead of one 128-long dependent chain: measured, the dependent
 // v_mfma_f64_16x16x4_f64 chain (not the loads) was what held the first versions at ~20 % of peak.
-template <int BT, int DEPTH, bool KSPLIT, bool FULL>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
+// NW = waves per workgroup (4; 8 only with KSPLIT): a single D = 512 GEMM is 256 workgroups = one per CU, and four
+// waves per CU run the fp64 MFMA at 34 TFLOP/s where eight reach 45 (scripts/probes/mfma_rate.hip).
+template <int BT, int DEPTH, bool KSPLIT, bool FULL, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
+    constexpr int NT = NW * 64;              // threads
     constexpr int MT = KSPLIT ? 2 : BT / 32; // MFMA tiles per wave per side
     constexpr int PB = BT + 16;
-    constexpr int NV = BT * KB / 2 / 256;    // double2 loads per thread per operand per stage
+    constexpr int NV = BT * KB / 2 / NT;     // double2 loads per thread per operand per stage
     constexpr int BV = BT / 2;               // double2 per B row
-    __shared__ __attribute__((aligned(16))) double smem[BT * PA + KB * PB + 8];
+    constexpr int STAGE_D = BT * PA + KB * PB;                  // doubles of one LDS stage
+    constexpr int SMEM_D = (KSPLIT && NW * 32 * 33 > STAGE_D) ? NW * 32 * 33 : STAGE_D;
+    __shared__ __attribute__((aligned(16))) double smem[SMEM_D + 8];
     double* sA = smem;
     double* sB = smem + BT * PA;
-    double* red = smem + BT * PA + KB * PB;
+    double* red = smem + SMEM_D;
 
     if ((int)blockIdx.z >= g.gemm_z) {         // checker blocks: one live workgroup per problem
-        if (blockIdx.x == 0 && blockIdx.y == 0) ns_check_block(g.chk, (int64_t)blockIdx.z - g.gemm_z, red);
+        // (the check is written for 256 threads; surplus waves leave, a finished wave no longer counts at s_barrier)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 256) ns_check_block(g.chk, (int64_t)blockIdx.z - g.gemm_z, red);
         return;
     }
     const int zi = (g.ntypes == 2) ? (blockIdx.z & 1) : 0;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
         const int k0 = kb * KB;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int e = tid + q * 256;
+            const int e = tid + q * NT;
             const int ai = e / (KB / 2), ak = (e % (KB / 2)) * 2;        // A tile [BT][64], pairs along k
             const int r = row0 + ai, k = k0 + ak;
             const int bk = e / BV, bj = (e % BV) * 2;                    // B tile [64][BT], pairs along j
@@ -135,14 +141,14 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
         if (kb) __syncthreads();                 // everyone is done reading the previous stage
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int e = tid + q * 256;
+            const int e = tid + q * NT;
             *reinterpret_cast<d2*>(sA + (e / (KB / 2)) * PA + (e % (KB / 2)) * 2) = pa[q];
             *reinterpret_cast<d2*>(sB + (e / BV) * PB + (e % BV) * 2) = pb[q];
         }
         __syncthreads();
         fetch(pa, pb, kb + DEPTH);
 #pragma unroll 4
-        for (int ks = (KSPLIT ? wave : 0); ks < KB / 4; ks += (KSPLIT ? 4 : 1)) {
+        for (int ks = (KSPLIT ? wave : 0); ks < KB / 4; ks += (KSPLIT ? NW : 1)) {
             const int k = ks * 4 + lk;
             double a[MT], b[MT];
 #pragma unroll
@@ -169,9 +175,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
 
     double ss = 0.0;
     if constexpr (KSPLIT) {
-        // sum the four waves' partial tiles through LDS, then a row-major (coalesced) store of C
+        // sum the waves' partial tiles through LDS, then a row-major (coalesced) store of C
         __syncthreads();
-        double* part = smem;                                   // [4][32][33]
+        double* part = smem;                                   // [NW][32][33]
 #pragma unroll
         for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
@@ -181,11 +187,14 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
                     part[wave * (32 * 33) + (16 * fa + lk + 4 * reg) * 33 + 16 * fb + li] = acc[fa][fb][reg];
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256, rr = e >> 5, cc = e & 31;
+        for (int q = 0; q < 1024 / NT; ++q) {
+            const int e = tid + q * NT, rr = e >> 5, cc = e & 31;
             const int r = row0 + rr, c = col0 + cc;
-            const double sum = (part[rr * 33 + cc] + part[(32 * 33) + rr * 33 + cc]) +
-                               (part[2 * (32 * 33) + rr * 33 + cc] + part[3 * (32 * 33) + rr * 33 + cc]);
+            double sum = (part[rr * 33 + cc] + part[(32 * 33) + rr * 33 + cc]) +
+                         (part[2 * (32 * 33) + rr * 33 + cc] + part[3 * (32 * 33) + rr * 33 + cc]);
+            if (NW == 8)
+                sum += (part[4 * (32 * 33) + rr * 33 + cc] + part[5 * (32 * 33) + rr * 33 + cc]) +
+                       (part[6 * (32 * 33) + rr * 33 + cc] + part[7 * (32 * 33) + rr * 33 + cc]);
             if (r < d && c < d) {
                 const double v = alpha * sum + (r == c ? beta_eye : 0.0);
                 C[(int64_t)r * d + c] = v;
@@ -217,7 +226,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int d, GemmArgs g) {
         __syncthreads();
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        if (tid == 0) partials[zb * g.pstride + slot] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) {
+            double t = (red[0] + red[1]) + (red[2] + red[3]);
+            if (NW == 8) t += (red[4] + red[5]) + (red[6] + red[7]);
+            partials[zb * g.pstride + slot] = t;
+        }
     }
 }
 
@@ -268,7 +281,10 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
             if (full) hipLaunchKernelGGL((gemm_f64_kernel<64, 2, false, true>), grid, dim3(256), 0, stream, d, g);
             else hipLaunchKernelGGL((gemm_f64_kernel<64, 2, false, false>), grid, dim3(256), 0, stream, d, g);
         } else {
-            if (full && env_depth == 1) hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true>), grid, dim3(256), 0, stream, d, g);
+            static const int env_w8 = [] { const char* e = getenv("FAD_GEMM_WAVES8"); return e ? atoi(e) : 1; }();
+            const bool w8 = env_w8 && full && (int64_t)grid.x * grid.y * (unsigned)(m * ntypes) <= (int64_t)num_cus(device);
+            if (w8) hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true, 8>), grid, dim3(512), 0, stream, d, g);
+            else if (full && env_depth == 1) hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true>), grid, dim3(256), 0, stream, d, g);
             else if (full && env_depth == 2) hipLaunchKernelGGL((gemm_f64_kernel<32, 2, true, true>), grid, dim3(256), 0, stream, d, g);
             else if (full) hipLaunchKernelGGL((gemm_f64_kernel<32, 3, true, true>), grid, dim3(256), 0, stream, d, g);
             else hipLaunchKernelGGL((gemm_f64_kernel<32, 3, true, false>), grid, dim3(256), 0, stream, d, g);

@@ -20,6 +20,7 @@
 //   partials     [split][tile][BT][BT]   (BT = 128 fp32 | 64 fp64)
 //   colpart      [split][nt*BT] fp64
 #include "fad_common.h"
+#include <dlfcn.h>
 #include <type_traits>
 
 // Build-time ablation switches for scripts/probe_ablate.py (never set in the product build): bit 0 drops the
@@ -1805,6 +1806,28 @@ int fad_moments_import(fad_moments_t* h, const double* packed, int on_device, vo
     h->fresh = false;                              // the whole accumulator is overwritten
     FAD_HIP_TRY(hipMemcpyAsync(h->acc, packed, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
+    return FAD_OK;
+}
+
+int fad_moments_allreduce(fad_moments_t* h, void* rccl_comm, void* stream) {
+    if (!h || !rccl_comm) return set_error(FAD_ERR_INVALID, "NULL argument");
+    // ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_fn fn = [] {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");          // the RCCL the host process uses (e.g. torch's)
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            if (sym) break;
+            if (void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) sym = dlsym(lib, "ncclAllReduce");
+        }
+        return reinterpret_cast<allreduce_fn>(sym);
+    }();
+    if (!fn) return set_error(FAD_ERR_INVALID, "no RCCL in this process (ncclAllReduce not found)");
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    FAD_TRY(settle(h, st));
+    constexpr int kNcclFloat64 = 8, kNcclSum = 0;                   // rccl.h: ncclDataType_t / ncclRedOp_t
+    const int rc = fn(h->acc, h->acc, (size_t)packed_len(h->d), kNcclFloat64, kNcclSum, rccl_comm, st);
+    if (rc != 0) return set_error(FAD_ERR_HIP, "ncclAllReduce failed with ncclResult_t %d", rc);
     return FAD_OK;
 }
 

@@ -92,6 +92,12 @@ class Moments:
         K.check(self._lib.fad_moments_merge(self._h, other._h, self._stream()), "fad_moments_merge")
         return self
 
+    def allreduce_rccl(self, comm_ptr: int) -> "Moments":
+        """Sum the statistics of all ranks in place through the caller's ``ncclComm_t`` (its address as an int).
+        Python hosts normally go through ``fadtk_amd.dist.allreduce_moments`` (torch.distributed) instead."""
+        K.check(self._lib.fad_moments_allreduce(self._h, C.c_void_p(comm_ptr), self._stream()), "fad_moments_allreduce")
+        return self
+
     # -- packed statistics (what an RCCL all-reduce runs over)
     @property
     def packed_len(self) -> int:

@@ -323,14 +323,133 @@ class WhisperModel(ModelLoader):
         return out.squeeze(0)                                                                    # [2, D]
 
 
+class _HFLayerModel(ModelLoader):
+    """Shared body of the wav2vec2-family loaders (reference model_loader.py:254-288, 526-633): the waveform is
+    truncated to ``limit_minutes``, normalised to zero mean / unit variance (what the checkpoints' Wav2Vec2
+    feature extractors do, ``do_normalize=True``), pushed through the encoder with ``output_hidden_states`` and the
+    hidden state of ``layer`` (0 = the projected CNN features) is the embedding, ``[frames, D]``.
+    Weights: a local Hugging Face cache entry, else (opt-in) seeded random weights of the right shape."""
+
+    _family = ""            # prefix of the model name
+    _sizes: dict = {}       # size -> (hidden, layers, heads, hub id)
+    _default_sr = 16000
+
+    def __init__(self, size: str, layer: int, limit_minutes: float = 6, random_init: Optional[bool] = None):
+        hidden, layers, _, hub = self._sizes[size]
+        last = layer == layers
+        super().__init__(f"{self._family}-{size}" + ("" if last else f"-{layer}"), hidden, self._default_sr)
+        self.size, self.layer = size, int(layer)
+        self.huggingface_id = hub
+        self.limit = int(limit_minutes * 60 * self.sr)
+        self.random_init = random_init
+
+    def _hf_classes(self):
+        raise NotImplementedError
+
+    def load_model(self):
+        cfg_cls, model_cls = self._hf_classes()
+        try:
+            self.model = model_cls.from_pretrained(self.huggingface_id, local_files_only=True)
+        except Exception:       # noqa: BLE001
+            if not _allow_random(self.random_init):
+                raise
+            log.warning(f"{self.name}: no local weights, using seeded random weights (synthetic runs only)")
+            hidden, layers, heads, _ = self._sizes[self.size]
+            torch.manual_seed(self._seed())
+            self.model = model_cls(cfg_cls(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                                           intermediate_size=4 * hidden))
+        self.model.eval().to(self.device)
+
+    def _get_embedding(self, audio: np.ndarray):
+        audio = np.asarray(audio, dtype=np.float32).reshape(-1)
+        if audio.shape[0] > self.limit:
+            log.warning(f"Audio is too long ({audio.shape[0] / self.sr / 60:.2f} minutes > "
+                        f"{self.limit / self.sr / 60:.2f} minutes). Truncating.")
+            audio = audio[:self.limit]
+        x = torch.from_numpy(audio).to(self.device)
+        x = (x - x.mean()) / torch.sqrt(x.var(unbiased=False) + 1e-7)
+        with torch.no_grad():
+            out = self.model(x[None, :], output_hidden_states=True)
+        return out.hidden_states[self.layer].squeeze(0)          # [frames, D]
+
+
+class W2V2Model(_HFLayerModel):
+    """wav2vec 2.0 (facebook/wav2vec2-{base,large}-960h), reference model_loader.py:526-560."""
+    _family = "w2v2"
+    _sizes = {"base": (768, 12, 12, "facebook/wav2vec2-base-960h"), "large": (1024, 24, 16, "facebook/wav2vec2-large-960h")}
+
+    def _hf_classes(self):
+        from transformers import Wav2Vec2Config, Wav2Vec2Model
+        return Wav2Vec2Config, Wav2Vec2Model
+
+
+class HuBERTModel(_HFLayerModel):
+    """HuBERT (facebook/hubert-{base,large}-ls960), reference model_loader.py:563-597."""
+    _family = "hubert"
+    _sizes = {"base": (768, 12, 12, "facebook/hubert-base-ls960"), "large": (1024, 24, 16, "facebook/hubert-large-ls960")}
+
+    def _hf_classes(self):
+        from transformers import HubertConfig, HubertModel
+        return HubertConfig, HubertModel
+
+
+class WavLMModel(_HFLayerModel):
+    """WavLM (patrickvonplaten/wavlm-libri-clean-100h-{base,base-plus,large}), reference model_loader.py:600-633."""
+    _family = "wavlm"
+    _sizes = {"base": (768, 12, 12, "patrickvonplaten/wavlm-libri-clean-100h-base"),
+              "base-plus": (768, 12, 12, "patrickvonplaten/wavlm-libri-clean-100h-base-plus"),
+              "large": (1024, 24, 16, "patrickvonplaten/wavlm-libri-clean-100h-large")}
+
+    def _hf_classes(self):
+        from transformers import WavLMConfig
+        from transformers import WavLMModel as HFWavLM
+        return WavLMConfig, HFWavLM
+
+
+class MERTModel(_HFLayerModel):
+    """MERT-v1-95M (m-a-p/MERT-v1-95M; a HuBERT-shaped encoder on 24 kHz audio), reference model_loader.py:254-288.
+    The checkpoint ships its own model class (``trust_remote_code``); only a locally cached copy can be loaded
+    here.  The random-weight stand-in is a HuBERT encoder of the same width, depth and frame rate (75 Hz)."""
+    _family = "MERT"
+    _sizes = {"v1-95M": (768, 12, 12, "m-a-p/MERT-v1-95M")}
+    _default_sr = 24000
+
+    def __init__(self, size: str = "v1-95M", layer: int = 12, limit_minutes: float = 6, random_init: Optional[bool] = None):
+        super().__init__(size, layer, limit_minutes, random_init)
+
+    def load_model(self):
+        try:
+            from transformers import AutoConfig, AutoModel
+            cfg = AutoConfig.from_pretrained(self.huggingface_id, trust_remote_code=True, local_files_only=True)
+            cfg.conv_pos_batch_norm = False
+            self.model = AutoModel.from_pretrained(self.huggingface_id, trust_remote_code=True, config=cfg, local_files_only=True)
+            self.model.eval().to(self.device)
+        except Exception:       # noqa: BLE001
+            if not _allow_random(self.random_init):
+                raise
+            super().load_model()
+
+    def _hf_classes(self):
+        from transformers import HubertConfig, HubertModel
+        return HubertConfig, HubertModel
+
+
 # ---------------------------------------------------------------------------------------------
 def get_all_models() -> List[ModelLoader]:
-    """The loaders on this engine's path, under fadtk's names (model_loader.py:676-701).  Construction
-    is cheap and offline.  MERT / wav2vec2 / HuBERT / WavLM / MS-CLAP / DAC / CDPAM are plain third-party
-    forwards with no FAD-specific compute and are out of scope."""
+    """The loaders under fadtk's names, in the reference's order (model_loader.py:676-701).  Construction is
+    cheap and offline.  Not offered: MS-CLAP 2023, DAC and CDPAM (their packages are optional in the reference too
+    and absent here)."""
     return [
         CLAPLaionModel("audio"), CLAPLaionModel("music"),
         VGGishModel(),
+        *(MERTModel(layer=v) for v in range(1, 13)),
         EncodecEmbModel("24k"), EncodecEmbModel("48k"),
+        *(W2V2Model("base", layer=v) for v in range(1, 13)),
+        *(W2V2Model("large", layer=v) for v in range(1, 25)),
+        *(HuBERTModel("base", layer=v) for v in range(1, 13)),
+        *(HuBERTModel("large", layer=v) for v in range(1, 25)),
+        *(WavLMModel("base", layer=v) for v in range(1, 13)),
+        *(WavLMModel("base-plus", layer=v) for v in range(1, 13)),
+        *(WavLMModel("large", layer=v) for v in range(1, 25)),
         WhisperModel("tiny"), WhisperModel("small"), WhisperModel("base"), WhisperModel("medium"), WhisperModel("large"),
     ]

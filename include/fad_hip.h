@@ -85,6 +85,16 @@ int fad_moments_export(const fad_moments_t* h, double* packed, int on_device, vo
 int fad_moments_import(fad_moments_t* h, const double* packed, int on_device, void* stream);
 int fad_moments_count(const fad_moments_t* h, int64_t* n, void* stream);
 
+/* Sum the packed statistics of all ranks IN PLACE with one collective (the only
+ * exchange of the data-parallel path; replaces the pickled per-file (mean, scatter, n) tuples of
+ * utils.py:19-46 / the process pool of fad_batch.py:43-48).  `rccl_comm` is the caller's ncclComm_t;
+ * ncclAllReduce(count = 1 + D + D*D, ncclFloat64, ncclSum) is looked up in the RCCL library the host
+ * process already has loaded (else librccl.so.1), so the library adds no second RCCL to the process.
+ * FAD_ERR_INVALID when no RCCL can be found, FAD_ERR_HIP when the collective reports an error.
+ * (torch.distributed does not hand out its communicator: the Python host reduces the same buffer through
+ * torch.distributed.all_reduce instead, fadtk_amd/dist.py.) */
+int fad_moments_allreduce(fad_moments_t* h, void* rccl_comm, void* stream);
+
 /* mu = sum_x / n ; cov = (sum_xxT - n mu mu^T) / (n - ddof)   (np.mean / np.cov, fad.py:48).
  * mu [D], cov [D*D] float64.  n < 2 -> FAD_ERR_TOO_FEW_ROWS (fad.py:46-47). */
 int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* cov, int64_t* n,

@@ -536,3 +536,31 @@ def test_score_inf_golden_g6(F, golden, tmp_path):
     np.testing.assert_allclose([p[1] for p in res.points], [p[1] for p in g["points"]], rtol=FAD_BAR / 10)
     assert res.score == pytest.approx(g["score"], rel=FAD_BAR)
     assert res.r2 == pytest.approx(g["r2"], rel=1e-3)
+
+
+def test_moments_allreduce_through_rccl_single_rank(F):
+    """fad_moments_allreduce runs ncclAllReduce over the packed statistics with the caller's communicator.  One GPU
+    here, so the communicator has one rank and the sum must leave the statistics unchanged -- this checks the
+    symbol lookup, the datatype/op constants and the in-place call, not the scaling."""
+    import ctypes as C
+    import torch
+    from pathlib import Path
+    from fadtk_amd.hip import Moments
+    rccl = C.CDLL(str(Path(torch.__file__).parent / "lib" / "librccl.so"))      # the RCCL torch itself uses
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    rccl.ncclCommInitAll.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        x = structured_rows(5, 3000, 256, np.float16)
+        with Moments(256) as m:
+            m.update(x)
+            before = m.export()
+            m.allreduce_rccl(comm.value)
+            torch.cuda.synchronize()
+            after = m.export()
+        np.testing.assert_array_equal(before, after)
+        assert before[0] == 3000
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

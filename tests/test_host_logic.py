@@ -23,9 +23,18 @@ def test_registry_names_and_plugin_contract():
     import pickle
     models = get_all_models()
     names = [m.name for m in models]
-    assert names == ["clap-laion-audio", "clap-laion-music", "vggish", "encodec-emb", "encodec-emb-48k",
-                     "whisper-tiny", "whisper-small", "whisper-base", "whisper-medium", "whisper-large"]
+    # the reference's registry (model_loader.py:676-701) minus MS-CLAP 2023 and the optional DAC / CDPAM
+    expect = ["clap-laion-audio", "clap-laion-music", "vggish"]
+    expect += [f"MERT-v1-95M-{v}" for v in range(1, 12)] + ["MERT-v1-95M"]
+    expect += ["encodec-emb", "encodec-emb-48k"]
+    for fam, sizes in (("w2v2", ("base", "large")), ("hubert", ("base", "large")), ("wavlm", ("base", "base-plus", "large"))):
+        for size in sizes:
+            last = 24 if size == "large" else 12
+            expect += [f"{fam}-{size}-{v}" for v in range(1, last)] + [f"{fam}-{size}"]
+    expect += ["whisper-tiny", "whisper-small", "whisper-base", "whisper-medium", "whisper-large"]
+    assert names == expect
     dims = {m.name: (m.num_features, m.sr) for m in models}
+    assert dims["MERT-v1-95M-4"] == (768, 24000) and dims["w2v2-large-7"] == (1024, 16000) and dims["wavlm-base-plus"] == (768, 16000)
     assert dims["vggish"] == (128, 16000) and dims["encodec-emb"] == (128, 24000)
     assert dims["clap-laion-audio"] == (512, 48000) and dims["whisper-small"] == (768, 16000)
     for m in models:                                   # loaders cross process boundaries before load_model()
@@ -93,3 +102,17 @@ def test_shard_matches_array_split():
         got = [dist.shard(items, r, w) for r in range(w)]
         want = [list(a) for a in np.array_split(items, w)]
         assert got == want
+
+
+def test_wav2vec2_family_loader_layer_and_truncation(monkeypatch):
+    """HuBERT-style loaders return hidden state `layer` as [frames, D] fp16 (50 frames/s at 16 kHz) and cut the
+    audio at `limit_minutes` (reference model_loader.py:580-595).  Seeded random weights: shapes only."""
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    from fadtk_amd.model_loader import HuBERTModel
+    m = HuBERTModel("base", layer=2, limit_minutes=1.0 / 60.0)          # one second
+    assert m.name == "hubert-base-2" and m.limit == 16000
+    m.load_model()
+    x = R.audio_clip(5, 3 * 16000, 16000)
+    e_long, e_cut = m.get_embedding(x), m.get_embedding(x[:16000])
+    assert e_long.dtype == np.float16 and e_long.shape == (49, 768)
+    assert np.array_equal(e_long, e_cut)                                # 3 s were truncated to the same 1 s
