@@ -227,7 +227,7 @@ def main():
         "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,
         "breakdown_ms": {"moments_x2": float(np.median(bm)), "frechet": float(np.median(bf)),
                          "moments_reduce_kernels": reduce_ms},
-        "roofline": {"kernel": "moments_tile_h16<f16>" if variant == 0 else "moments_tile_f64",
+        "roofline": {"kernel": "moments_tile_h16_tr<f16>" if variant == 0 else "moments_tile_f64",
                      "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
                      "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
