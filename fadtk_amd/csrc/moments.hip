@@ -1388,6 +1388,7 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(
 struct fad_moments {
     int d = 0, device = 0;
     double* acc = nullptr;                 // packed [1 + d + d*d]
+    bool owns_acc = true;                  // false after fad_moments_bind: the caller's buffer
     fad::DevBuf partials, colpart, stage, seg_off, seg_out, scratch;
     fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
@@ -1679,7 +1680,7 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
 int fad_moments_destroy(fad_moments_t* h) {
     if (!h) return FAD_OK;
     DeviceGuard g(h->device);
-    if (h->acc) (void)hipFree(h->acc);
+    if (h->acc && h->owns_acc) (void)hipFree(h->acc);
     if (h->shift_flag) (void)hipFree(h->shift_flag);
     h->partials64.release(); h->colpart64.release(); h->presum.release(); h->presum_col.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
@@ -1703,6 +1704,17 @@ int fad_moments_reset(fad_moments_t* h, void* stream) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
     (void)stream;
     h->fresh = true;
+    return FAD_OK;
+}
+
+int fad_moments_bind(fad_moments_t* h, double* device_packed) {
+    if (!h || !device_packed) return set_error(FAD_ERR_INVALID, "NULL argument");
+    if (reinterpret_cast<uintptr_t>(device_packed) & 15u) return set_error(FAD_ERR_INVALID, "buffer must be 16-byte aligned");
+    DeviceGuard g(h->device);
+    if (h->acc && h->owns_acc) FAD_HIP_TRY(hipFree(h->acc));
+    h->acc = device_packed;
+    h->owns_acc = false;
+    h->fresh = true;                               // bind = adopt the buffer and reset
     return FAD_OK;
 }
 

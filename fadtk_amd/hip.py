@@ -51,6 +51,15 @@ class Moments:
         return K.current_stream_ptr(self.device)
 
     # -- accumulation
+    def bind(self, tensor) -> "Moments":
+        """Keep the packed statistics in ``tensor`` (float64 CUDA, ``packed_len`` elements, contiguous) and reset.
+        Collectives can then run over the tensor in place; the handle holds a reference to keep it alive."""
+        assert tensor.is_cuda and tensor.dtype.is_floating_point and tensor.element_size() == 8
+        assert tensor.numel() == self.packed_len and tensor.is_contiguous() and tensor.device.index == self.device
+        K.check(self._lib.fad_moments_bind(self._h, C.c_void_p(tensor.data_ptr())), "fad_moments_bind")
+        self._bound = tensor
+        return self
+
     def reset(self):
         K.check(self._lib.fad_moments_reset(self._h, self._stream()), "fad_moments_reset")
 

@@ -63,6 +63,11 @@ typedef struct fad_moments fad_moments_t;
 int fad_moments_create(int d, int device, fad_moments_t** out);
 int fad_moments_destroy(fad_moments_t* h);
 int fad_moments_reset(fad_moments_t* h, void* stream);
+/* Keep the packed statistics in the CALLER's device buffer (packed_len doubles, 16-byte aligned, same device) from
+ * now on, and reset them.  The buffer then is what a collective runs over in place -- e.g. two handles bound to the
+ * halves of one allocation are summed across ranks by a single all-reduce with no export/import copies (bench.py).
+ * The caller keeps ownership and must outlive the handle or re-bind. */
+int fad_moments_bind(fad_moments_t* h, double* device_packed);
 int fad_moments_dim(const fad_moments_t* h);                 /* D, or <0 on error                */
 int64_t fad_moments_packed_len(const fad_moments_t* h);      /* 1 + D + D*D                      */
 

@@ -564,3 +564,34 @@ def test_moments_allreduce_through_rccl_single_rank(F):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_moments_bind_keeps_statistics_in_callers_buffer(F):
+    """fad_moments_bind: the packed statistics live in the caller's tensor (what a collective then reduces in place);
+    binding resets, updates land in the tensor, reset + update overwrites, and unrelated memory stays untouched."""
+    import torch
+    from fadtk_amd.hip import Moments
+    d = 128
+    x = structured_rows(3, 2500, d, np.float16)
+    with Moments(d) as ref, Moments(d) as m:
+        ref.update(x)
+        want = ref.export()
+        plen = m.packed_len
+        buf = torch.full((plen + 8,), 7.0, dtype=torch.float64, device="cuda")
+        m.update(x[:100])                                   # statistics from before the bind are dropped
+        m.bind(buf[:plen])
+        assert m.count == 0 and float(buf[0]) == 0.0        # (reading settles the pending reset into the buffer)
+        m.update(x)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(buf[:plen].cpu().numpy(), want)
+        np.testing.assert_array_equal(m.export(), want)
+        assert bool((buf[plen:] == 7.0).all())
+        buf[:plen] *= 2.0                                    # e.g. an all-reduce over two identical ranks
+        mu, cov, n = m.finalize()
+        mu_r, cov_r, n_r = ref.finalize()
+        assert n == 2 * n_r
+        np.testing.assert_allclose(mu, mu_r, rtol=1e-14)
+        m.reset(); m.update(x[:1000]); m.update(x[1000:])
+        torch.cuda.synchronize()
+        # (two blocks group the fp32 partial sums differently: fp32-level agreement, as in the streaming test)
+        np.testing.assert_allclose(buf[:plen].cpu().numpy(), want, rtol=0, atol=1e-6 * np.abs(want).max())
