@@ -8,10 +8,13 @@
 // C1 C2, fad.py:91-92) and also runs scipy.linalg.sqrtm for a diagnostic (fad.py:88).  Here
 // tr sqrt(A), A = C1 C2, comes from the coupled Newton-Schulz iteration
 //     Y0 = A / c, Z0 = I;   T = (3 I - Z Y) / 2;   Y <- Y T;   Z <- T Z;     Y -> sqrt(A / c)
-// entirely in fp64 on MFMA tiles (gemm_f64.hip).  c >= rho(A) is the smallest of ||A||_F,
-// ||A||_1, ||A||_inf.  Stopping is decided ON DEVICE per problem, so the host enqueues iterations
-// blindly and syncs once per chunk:
-//   1  ||I - Z Y||_F <= tol                       (full-rank product)
+// entirely in fp64 on MFMA tiles (gemm_f64.hip).  Scale c = max(tr(A^2)/tr(A), U/2.5) with
+// U = min(||A||_F, ||A||_1, ||A||_inf) >= rho(A): every eigenvalue of A/c stays below 3 and the bulk of a
+// flat spectrum starts near 1 (ns_prepare).  Iteration 0 needs no T/Z GEMM (Z0 = I, ns_first).  Stopping is
+// decided ON DEVICE per problem by a checker workgroup that rides on the update-GEMM launch (ns_check.h), so
+// the host enqueues iterations blindly and syncs once per chunk:
+//   1  ||I - Z Y||_F <= tol, or the bound 3/4 r^2 + 1/4 r^3 on the NEXT residual is (one more Y update,
+//      no further T GEMM)                          (full-rank product)
 //   2  trace(Y) AND the residual stand still       (rank-deficient product: null directions never
 //                                                   converge but add nothing to the trace; stopping
 //                                                   here also keeps Z from blowing up)
