@@ -51,6 +51,8 @@ constexpr int PA = KB + 2;             // A pitch (doubles): rows i..i+15 land o
 // 4th k-step; the four partial tiles are summed through LDS at the end.  A wave then carries four
 // independent accumulators instead of one 128-long dependent chain: measured, the dependent
 // v_mfma_f64_16x16x4_f64 chain (not the loads) was what held the first versions at ~20 % of peak.
+// (Tried and dropped: splitting k over TWO workgroups per tile that meet through a ticket in global memory.  The
+// device-scope release/acquire it needs writes back / invalidates the XCD's whole L2 per workgroup: 0.18 -> 0.53 ms.)
 // NW = waves per workgroup (4; 8 only with KSPLIT): a single D = 512 GEMM is 256 workgroups = one per CU, and four
 // waves per CU run the fp64 MFMA at 34 TFLOP/s where eight reach 45 (scripts/probes/mfma_rate.hip).
 template <int BT, int DEPTH, bool KSPLIT, bool FULL, int NW = 4>

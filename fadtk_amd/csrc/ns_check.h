@@ -22,8 +22,8 @@ struct NsState {
     int too_few[2];    // set by finalize_for_frechet: set i has fewer than two rows
     int finished;      // tr_last is final (also the host's "all done" test)
     // Update GEMMs of iteration k skip when upd_skip[k & 1] != 0.  Two words because the check of iteration k
-    // runs concurrently with the update GEMMs of iteration k: it only ever switches OFF the updates of
-    // iteration k+1 (the other word), never the launch it shares the grid with.
+    // runs concurrently with the update GEMMs of iteration k: it only ever WRITES the word of iteration k+1, never
+    // the one the launch it shares the grid with is reading (the two workgroups of a split-K tile must agree).
     int upd_skip[2];
     double res[kMaxIter];
     double tr[kMaxIter];
@@ -61,8 +61,11 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 // One workgroup (256 threads) per problem b; `red` = 4 doubles of LDS.
 __device__ __forceinline__ void ns_check_block(const NsCheckArgs& a, int64_t b, double* red) {
     NsState* st = a.st_all + b;
-    if (st->finished) return;
     const int k = a.k, d = a.d;
+    if (st->finished) {                            // closed earlier: keep the following update launches off
+        if (threadIdx.x == 0) st->upd_skip[(k + 1) & 1] = 1;
+        return;
+    }
     const double* Y = a.Yall + b * a.stride;
     const int tid = threadIdx.x;
     double t = 0.0;
@@ -75,7 +78,7 @@ __device__ __forceinline__ void ns_check_block(const NsCheckArgs& a, int64_t b, 
             const bool finite = (tr == tr) && !isinf(tr);
             if (!finite) st->nonfinite = 1;
             st->tr_last = tr; st->final_iter = k; st->finished = 1;
-            st->upd_skip[0] = 1; st->upd_skip[1] = 1;
+            st->upd_skip[(k + 1) & 1] = 1;         // (the word of iteration k was set by the predicting check)
         }
         return;
     }
@@ -100,9 +103,9 @@ __device__ __forceinline__ void ns_check_block(const NsCheckArgs& a, int64_t b, 
     else if (stalled) { st->conv = 2; finish = 1; }
     else if (k + 1 >= a.max_iter) { st->conv = 0; finish = 1; }
     if (finish) {
-        // Y_k is the answer.  (The update GEMMs of iteration k may be running right now; switching their word
-        // off half way only garbles Y_{k+1}, Z_{k+1}, which nobody reads any more.)
-        st->done = 1; st->finished = 1; st->upd_skip[0] = 1; st->upd_skip[1] = 1;
+        // Y_k is the answer.  The update GEMMs of iteration k are running right now and finish undisturbed (their
+        // result is simply not used); the next launches are switched off, this word by the next check.
+        st->done = 1; st->finished = 1; st->upd_skip[(k + 1) & 1] = 1;
         return;
     }
     // E_{k+1} = (3 E_k^2 + E_k^3) / 4 for E = I - ZY, hence ||E_{k+1}||_F <= 3/4 res^2 + 1/4 res^3: when that
