@@ -1,0 +1,87 @@
+"""Randomised sweeps of the HIP path against float64 numpy / the oracle: shapes, dtypes, pitches, chunking, kernel
+generations for the moments; dimensions, conditioning, rank and scale for the Frechet distance.  Fixed seeds -- these
+are regression nets around the curated cases of test_gpu_parity.py, not new semantics."""
+import logging
+
+import numpy as np
+import pytest
+
+from oracle import fad_oracle as O
+
+pytestmark = pytest.mark.gpu
+logging.getLogger("fad_oracle").setLevel(logging.CRITICAL)
+
+
+@pytest.mark.parametrize("seed", [1, 7])
+def test_fuzz_moments_against_numpy(seed, monkeypatch):
+    import torch
+    from fadtk_amd.hip import Moments
+    rng = np.random.default_rng(seed)
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32, "f64": torch.float64}
+    for case in range(60):
+        d = int(rng.choice([1, 3, 8, 24, 64, 100, 128, 136, 200, 256, 384, 512, 640, 768]))
+        n = int(rng.choice([0, 1, 2, 5, 31, 32, 33, 63, 64, 65, 100, 255, 257, 1000, 4097, 20000, 70001]))
+        dt = str(rng.choice(list(tdt)))
+        pitch = d + int(rng.choice([0, 0, 8, 3]))
+        variant = str(rng.choice(["", "1", "2", "3", "4", "8"]))
+        shift = float(rng.choice([0.0, 0.0, 0.5, 5.0]))
+        x64 = rng.standard_normal((n, pitch)) * (0.3 + rng.random()) + shift
+        view = torch.from_numpy(x64).to(tdt[dt]).cuda()[:, :d]
+        ref = view.double().cpu().numpy()
+        if variant:
+            monkeypatch.setenv("FAD_MOMENTS_VARIANT", variant)
+        else:
+            monkeypatch.delenv("FAD_MOMENTS_VARIANT", raising=False)
+        with Moments(d) as m:
+            chunks = int(rng.choice([1, 1, 2, 3]))
+            cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=chunks - 1)]))
+            if rng.random() < 0.3:
+                m.reset()
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                m.update(view[lo:hi])
+            p = m.export()
+        what = f"case {case}: n={n} d={d} pitch={pitch} dtype={dt} variant={variant!r} shift={shift} cuts={cuts}"
+        S, s1 = ref.T @ ref, ref.sum(0)
+        half = dt in ("f16", "bf16")                 # fp32-accumulating MFMA kernel vs the exact fp64 kernel
+        M = p[1 + d:].reshape(d, d)
+        assert p[0] == n, what
+        assert np.array_equal(M, M.T), what
+        assert np.abs(M - S).max() <= (1e-6 if half else 1e-11) * max(np.abs(S).max(), 1e-30), what
+        np.testing.assert_allclose(p[1:1 + d], s1, rtol=2e-7 if half else 1e-12, atol=1e-6 * max(np.abs(s1).max(), 1e-30),
+                                   err_msg=what)
+
+
+def _random_cov(rng, d, n, decay, scale):
+    """Sample covariance of n rows with spectrum ~ k^-decay (n <= d gives a rank-deficient matrix)."""
+    lam = np.arange(1, d + 1, dtype=np.float64) ** (-decay)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    x = (rng.standard_normal((n, d)) * np.sqrt(lam)) @ q.T * scale
+    return x.mean(0), np.cov(x, rowvar=False)
+
+
+def test_fuzz_frechet_against_oracle(F=None):
+    import fadtk_amd
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for case in range(28):
+        d = int(rng.choice([2, 7, 32, 64, 96, 128, 200, 256, 384]))
+        decay = float(rng.choice([0.0, 0.5, 1.0, 1.5]))
+        n1 = int(rng.choice([4 * d + 3, 2 * d, d + 5]))
+        n2 = int(rng.choice([4 * d + 3, d + 5, max(2, d // 2), 3]))          # the last two: rank-deficient evaluation sets
+        s1, s2 = float(rng.choice([1.0, 1e-3, 30.0])), float(rng.choice([1.0, 1.0, 0.7, 1.3]))
+        mu1, c1 = _random_cov(rng, d, n1, decay, s1)
+        mu2, c2 = _random_cov(rng, d, n2, decay, s1 * s2)
+        want = O.frechet_distance(mu1, c1, mu2, c2, run_sqrtm=False)
+        got = fadtk_amd.calc_frechet_distance(mu1, c1, mu2, c2)
+        what = f"case {case}: d={d} decay={decay} n1={n1} n2={n2} scale={s1}x{s2} want={want:.6e} got={got:.6e}"
+        # FAD is a cancellation: compare relative to the terms that are summed.  With a rank-deficient set the
+        # reference itself is only good to ~sqrt(machine eps): eig returns the zero eigenvalues of C1 C2 as +-1e-16
+        # and takes their square roots (fad.py:91-92).
+        terms = np.trace(c1) + np.trace(c2)
+        full_rank = min(n1, n2) > d
+        err = abs(got - want) / terms
+        print(f"{what} err/terms={err:.2e}")
+        assert err <= (1e-10 if full_rank else 1e-6), what
+        assert abs(got - want) <= 1e-4 * abs(want) + 1e-10 * terms, what
+        worst = max(worst, err if full_rank else 0.0)
+    assert worst < 1e-10
