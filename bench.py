@@ -211,6 +211,8 @@ def main():
     n_gpus = world
     flops = 2.0 * N_ROWS * DIM * DIM                       # algorithmic, per launch
     achieved = flops / (kernel_ms * 1e-3) / 1e12
+    nt = -(-DIM // 128)
+    issued = 2.0 * N_ROWS * 128 * 128 * (nt * (nt + 1) // 2)
     traffic = None
     tpath = ROOT / "profiles" / "moments_traffic.json"     # measured in a separate rocprofv3 --pmc pass
     if tpath.exists():
@@ -240,6 +242,8 @@ def main():
                      "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
                      "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                     # only the upper-triangular 128 x 128 tiles of the symmetric result are issued
+                     "issued_flops_per_launch": issued, "frac_issued": issued / (kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                      "algorithmic_bytes_per_launch": N_ROWS * DIM * 2,
                      "hbm_GBps_algorithmic": N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
                      "hbm_frac_of_8TBps": N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
