@@ -75,6 +75,8 @@ SIGNATURES = {
                                            C.POINTER(C.c_double), C.POINTER(FadDiag)]),
     "fad_frechet_batched_vs_baseline": (C.c_int, [C.c_int, _P, _P, _P, _I64, _I64, C.c_int, C.POINTER(_I64), _I64,
                                                   C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "fad_resample_num_samples": (_I64, [_I64, C.c_int, C.c_int]),
+    "fad_resample_kaiser": (C.c_int, [_P, _I64, C.c_int, C.c_int, C.c_int, _P, _I64, C.c_int, C.c_int, _P]),
     "fad_logmel_vggish_num_examples": (_I64, [_I64]),
     "fad_logmel_vggish": (C.c_int, [_P, C.POINTER(_I64), _I64, _P, _I64, C.POINTER(_I64), C.c_int, C.c_int, _P]),
     "fad_logmel_whisper": (C.c_int, [_P, C.POINTER(_I64), _I64, C.c_int, _P, C.c_int, C.c_int, _P]),

@@ -4,21 +4,17 @@ fadtk normalises every input file to mono 16-bit PCM WAV at the model's sample r
 (`Resample(lowpass_filter_width=64, rolloff=0.9476, resampling_method="sinc_interp_kaiser",
 beta=14.77)`) and caches it under <dir>/convert/<sr>/.  torchaudio / soundfile are optional here:
 WAV files are read with the stdlib, anything else needs soundfile or torchaudio to be installed.
-The Kaiser-windowed sinc resampler below is the same published algorithm, written against plain
-torch ops (conv1d); it is host-side plumbing, not one of the measured kernels.
+The Kaiser-windowed sinc resampler is the same published algorithm as a HIP kernel (csrc/resample.hip,
+`fad_resample_kaiser`); this module is the file I/O around it.
 """
 from __future__ import annotations
 
-import math
 import wave
 from pathlib import Path
 from typing import Tuple
 
 import numpy as np
 
-LOWPASS_FILTER_WIDTH = 64            # fad.py:154-157
-ROLLOFF = 0.9475937167399596
-BETA = 14.769656459379492
 
 
 def read_audio(path) -> Tuple[np.ndarray, int]:
@@ -85,29 +81,11 @@ def write_pcm16(path, mono: np.ndarray, sr: int):
         w.writeframes(q.tobytes())
 
 
-def resample_kaiser(x: np.ndarray, orig_sr: int, new_sr: int, device=None) -> np.ndarray:
-    """Kaiser-windowed sinc interpolation of a mono signal, parameters of fad.py:151-158."""
-    if orig_sr == new_sr:
-        return np.asarray(x, dtype=np.float32)
-    import torch
-    g = math.gcd(int(orig_sr), int(new_sr))
-    orig, new = int(orig_sr) // g, int(new_sr) // g
-    base = min(orig, new) * ROLLOFF
-    width = math.ceil(LOWPASS_FILTER_WIDTH * orig / base)
-    dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
-    idx = torch.arange(-width, width + orig, dtype=torch.float64, device=dev)[None, None] / orig
-    t = torch.arange(0, -new, -1, dtype=torch.float64, device=dev)[:, None, None] / new + idx
-    t = (t * base).clamp(-LOWPASS_FILTER_WIDTH, LOWPASS_FILTER_WIDTH)
-    beta = torch.tensor(BETA, dtype=torch.float64, device=dev)
-    window = torch.i0(beta * torch.sqrt(1 - (t / LOWPASS_FILTER_WIDTH) ** 2)) / torch.i0(beta)
-    t = t * math.pi
-    kernel = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)
-    wav = torch.as_tensor(np.asarray(x, dtype=np.float32), device=dev)[None, None]
-    length = wav.shape[-1]
-    wav = torch.nn.functional.pad(wav, (width, width + orig))
-    out = torch.nn.functional.conv1d(wav, kernel.to(torch.float32), stride=orig)      # [1, new, frames]
-    out = out.transpose(1, 2).reshape(-1)
-    return out[: math.ceil(new * length / orig)].cpu().numpy()
+def resample_kaiser(x: np.ndarray, orig_sr: int, new_sr: int, quantize_pcm16: bool = False, device: int = 0) -> np.ndarray:
+    """Kaiser-windowed sinc interpolation of a mono signal with the parameters of fad.py:151-158, on the GPU
+    (`fad_resample_kaiser`, csrc/resample.hip).  ``quantize_pcm16`` adds the 16-bit round trip of the cache file."""
+    from . import hip
+    return hip.resample_kaiser(np.asarray(x, dtype=np.float32), orig_sr, new_sr, quantize_pcm16=quantize_pcm16, device=device)
 
 
 def convert_to_model_rate(src, dst, sr: int):

@@ -291,3 +291,20 @@ def logmel_htsat(clips, device: int = 0):
     K.check(lib.fad_logmel_htsat(ptr, off.ctypes.data_as(C.POINTER(C.c_int64)), n, frames, optr, on_dev, device,
                                  K.current_stream_ptr(device)), "fad_logmel_htsat")
     return out
+
+
+def resample_kaiser(wav, orig_sr: int, new_sr: int, quantize_pcm16: bool = False, device: int = 0):
+    """Mono float32 audio (numpy, or a torch CUDA tensor that stays on the device) resampled from ``orig_sr`` to
+    ``new_sr`` with fadtk's Kaiser-windowed sinc filter (fad.py:151-159); ``quantize_pcm16`` adds the reference's
+    16-bit cache-file round trip."""
+    lib = K.load_library()
+    K.require_gpu(device)
+    ptr, off, on_dev, keep = _clips_view([wav], device)
+    n = int(off[1])
+    n_out = int(lib.fad_resample_num_samples(n, int(orig_sr), int(new_sr)))
+    if n_out < 0:
+        K.check(n_out, "fad_resample_num_samples")
+    out, optr = _out_buffer((n_out,), on_dev, keep)
+    K.check(lib.fad_resample_kaiser(ptr, n, int(orig_sr), int(new_sr), int(bool(quantize_pcm16)), optr, n_out, on_dev, device,
+                                    K.current_stream_ptr(device)), "fad_resample_kaiser")
+    return out

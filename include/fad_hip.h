@@ -182,6 +182,19 @@ int fad_logmel_whisper(const float* wav, const int64_t* offsets, int64_t n_clips
 int fad_logmel_htsat(const float* wav, const int64_t* offsets, int64_t n_clips, int64_t n_frames_out,
                      float* out, int on_device, int device, void* stream);
 
+/* ------------------------------------------------------------------ audio normalisation
+ * Replaces the resampler of FrechetAudioDistance.load_audio (fadtk/fad.py:151-159):
+ *   torchaudio.transforms.Resample(fs, model_sr, lowpass_filter_width=64, rolloff=0.9475937167399596,
+ *                                  resampling_method="sinc_interp_kaiser", beta=14.769656459379492)
+ * on a mono float32 signal (the mono mix of fad.py:150 is the caller's), output length
+ * ceil(new_sr * n / orig_sr) = fad_resample_num_samples().  quantize_pcm16 != 0 also applies the 16-bit round
+ * trip the reference makes through its cache file (fad.py:160 saves PCM_S 16, model_loader.py:64 reads int16 /
+ * 32768): out = clamp(rint(y * 32768), -32768, 32767) / 32768.
+ * Rates whose ratio needs a filter table above 256 MiB (nearly coprime rates) are refused with FAD_ERR_INVALID. */
+int64_t fad_resample_num_samples(int64_t n, int orig_sr, int new_sr);
+int fad_resample_kaiser(const float* wav, int64_t n, int orig_sr, int new_sr, int quantize_pcm16, float* out,
+                        int64_t out_capacity, int on_device, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

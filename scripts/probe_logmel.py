@@ -15,3 +15,6 @@ g = torch.Generator(device="cuda").manual_seed(0)
 bench("vggish", lambda c: hip.logmel_vggish(c), [torch.randn(160000, generator=g, device="cuda") * 0.1 for _ in range(256)], 10)
 bench("whisper", lambda c: hip.logmel_whisper(c), [torch.randn(480000, generator=g, device="cuda") * 0.1 for _ in range(128)], 30)
 bench("htsat", lambda c: hip.logmel_htsat(c), [torch.randn(480000, generator=g, device="cuda") * 0.1 for _ in range(128)], 10)
+for a, b in ((44100, 16000), (48000, 16000), (44100, 48000)):
+    clip = torch.randn(10 * a, generator=g, device="cuda") * 0.1
+    bench(f"rs{a // 1000}>{b // 1000}", lambda c: [hip.resample_kaiser(x, a, b, quantize_pcm16=True) for x in c], [clip] * 64, 10)

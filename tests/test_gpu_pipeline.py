@@ -130,3 +130,48 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
     assert len(rows) == 4 and all(str(evl) in ln for ln in rows)
     vals = [abs(float(ln.rsplit(",", 1)[1])) for ln in rows]
     assert vals == sorted(vals)
+
+
+@pytest.mark.parametrize("orig_sr,new_sr", [(48000, 16000), (44100, 16000), (8000, 16000), (22050, 24000), (44100, 48000), (32000, 48000)])
+def test_resampler_kernel_matches_oracle(orig_sr, new_sr):
+    """fad_resample_kaiser (fadtk's torchaudio Kaiser-sinc parameters, fad.py:151-159) against the float64 restatement:
+    fp32 accumulation over <= 815 taps, so 2e-6 absolute on a signal of amplitude ~0.5; after the 16-bit round trip
+    the samples are identical except where the unquantised value sits within that error of a rounding boundary."""
+    import torch
+    from oracle import audio_oracle as AO
+    from fadtk_amd import hip
+    x = R.audio_clip(31, orig_sr // 2 + 123, orig_sr)
+    want = AO.resample_kaiser(x, orig_sr, new_sr)
+    got = hip.resample_kaiser(x, orig_sr, new_sr)
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6
+    got_dev = hip.resample_kaiser(torch.from_numpy(x).cuda(), orig_sr, new_sr)          # device in, device out
+    assert got_dev.is_cuda and np.array_equal(got_dev.cpu().numpy(), got)
+    q = hip.resample_kaiser(x, orig_sr, new_sr, quantize_pcm16=True)
+    qw = AO.pcm16_roundtrip(want)
+    lsb = np.abs(q - qw) * 32768
+    assert lsb.max() <= 1.0 and (lsb > 0).mean() < 1e-2       # 2e-6 * 32768 = 0.07 LSB around every .5 boundary
+    near_half = np.abs((want * 32768) % 1.0 - 0.5) < 1e-1
+    assert not np.any((lsb > 0) & ~near_half)
+
+
+def test_resampler_edges_and_audio_normalisation(tmp_path):
+    from oracle import audio_oracle as AO
+    from fadtk_amd import audio, hip
+    assert hip.resample_kaiser(np.zeros(0, np.float32), 44100, 16000).shape == (0,)
+    short = R.audio_clip(5, 37, 44100)                                   # shorter than the filter half-width
+    np.testing.assert_allclose(hip.resample_kaiser(short, 44100, 16000), AO.resample_kaiser(short, 44100, 16000), atol=2e-6)
+    same = R.audio_clip(6, 1000, 16000)
+    np.testing.assert_array_equal(hip.resample_kaiser(same, 16000, 16000), same)        # torchaudio returns the input as is
+    np.testing.assert_array_equal(hip.resample_kaiser(same, 16000, 16000, quantize_pcm16=True), AO.pcm16_roundtrip(same).astype(np.float32))
+    with pytest.raises(Exception):
+        hip.resample_kaiser(same, 44101, 16000)                          # coprime rates: filter table far too large
+    # load_audio's normalisation step (fad.py:148-160): decode, mono mix, resample, PCM16 cache file
+    x = R.audio_clip(400, 24000, 48000)
+    audio.write_pcm16(tmp_path / "a.wav", x, 48000)
+    audio.convert_to_model_rate(tmp_path / "a.wav", tmp_path / "convert" / "16000" / "a.wav", 16000)
+    pcm, fs = audio.read_pcm16(tmp_path / "convert" / "16000" / "a.wav")
+    assert fs == 16000 and pcm.shape == (8000,)
+    src = audio.read_pcm16(tmp_path / "a.wav")[0] / 32768.0
+    want = np.rint(AO.resample_kaiser(src.astype(np.float32), 48000, 16000) * 32768)
+    assert np.abs(pcm - want).max() <= 1

@@ -57,7 +57,7 @@ def test_registry_names_and_plugin_contract():
     assert e.dtype == np.float16 and e.shape == (3, 7) and (e == 5).all()
 
 
-def test_wav_roundtrip_load_wav_and_resampler(tmp_path):
+def test_wav_roundtrip_and_load_wav(tmp_path):
     from fadtk_amd import audio
     from fadtk_amd.model_loader import VGGishModel
     sr = 16000
@@ -72,16 +72,25 @@ def test_wav_roundtrip_load_wav_and_resampler(tmp_path):
     assert wav.dtype == np.float64 and wav.shape == (sr,) and np.all(wav[sr // 2:] == 0)
     np.testing.assert_array_equal(wav[: sr // 2], pcm / 32768.0)
 
-    # resampler: a 1 kHz tone survives 48k -> 16k with its amplitude, an above-Nyquist tone is removed
+
+
+def test_resampler_oracle_properties():
+    """The CPU restatement of fadtk's Kaiser-sinc resampler (oracle/audio_oracle.py; the GPU kernel is checked against
+    it in test_gpu_pipeline.py): a 1 kHz tone survives 48k -> 16k with its amplitude, an above-Nyquist tone is removed,
+    lengths follow ceil(new * n / orig), equal rates pass through, the table has torchaudio's shape."""
+    from oracle import audio_oracle as AO
     t = np.arange(48000) / 48000.0
     low, high = np.sin(2 * np.pi * 1000 * t), np.sin(2 * np.pi * 15000 * t)
-    y = audio.resample_kaiser((low + high).astype(np.float32), 48000, 16000, device="cpu")
+    y = AO.resample_kaiser((low + high).astype(np.float32), 48000, 16000)
     assert y.shape == (16000,)
     ref = np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)
     assert np.abs(y[500:-500] - ref[500:-500]).max() < 2e-3
-    assert audio.resample_kaiser(low.astype(np.float32), 16000, 16000) is not None
-    audio.convert_to_model_rate(tmp_path / "a.wav", tmp_path / "convert" / "8000" / "a.wav", 8000)
-    assert audio.read_pcm16(tmp_path / "convert" / "8000" / "a.wav")[1] == 8000
+    assert AO.resample_kaiser(low[:1001].astype(np.float32), 44100, 16000).shape == (364,)        # ceil(160 * 1001 / 441) = ceil(363.2)
+    np.testing.assert_array_equal(AO.resample_kaiser(low.astype(np.float32), 16000, 16000), low.astype(np.float32).astype(np.float64))
+    k, width, orig, new = AO.sinc_kernel(44100, 16000)
+    assert (orig, new, width) == (441, 160, 187) and k.shape == (160, 2 * 187 + 441) and k.dtype == np.float32
+    q = AO.pcm16_roundtrip(np.array([0.5, -1.5, 1.0, 1e-6]))
+    np.testing.assert_array_equal(q, [0.5, -1.0, 32767 / 32768, 0.0])
 
 
 def test_cli_surface():
