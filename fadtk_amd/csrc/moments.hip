@@ -449,24 +449,27 @@ __device__ __forceinline__ void tile_h16_tr_body(
     const int tr_row = 8 * (grp >> 1) + (t16 >> 2);                 // + ks*16 (+4 for the second read)
     const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);              // + 32*frag + 64*wave-half, in columns
 
-    auto issue = [&](int kb) {
+    // part g of the loads of stage kb: off the diagonal (h, side) = (g >> 1, g & 1), on it h = g (A side only)
+    auto issue_part = [&](int kb, int g) {
         if (FAD_MOM_ABLATE & 4) return;
         uint4* st = smem + (kb % NST) * STAGE;
-        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int64_t r = r0 + 16 * h;
-            const bool ok = r < k_end;
-            if (FAD_MOM_ABLATE & 32) r &= 255;     // probe: every split reads the same 256 rows (L2-resident)
-            // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
-            uint4* dstA = st + 256 * h + 64 * wave;
+        const int h = DIAG ? g : (g >> 1);
+        int64_t r = k_begin + (int64_t)kb * H_KB + sr + 16 * h;
+        const bool ok = r < k_end;
+        if (FAD_MOM_ABLATE & 32) r &= 255;         // probe: every split reads the same 256 rows (L2-resident)
+        // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
+        uint4* dstA = st + 256 * h + 64 * wave;
+        if (DIAG || !(g & 1)) {
             const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
             __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)dstA, 16, 0, 0);
-            if (!DIAG) {
-                const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
-                __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
-            }
+        } else {
+            const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
         }
+    };
+    auto issue = [&](int kb) {
+#pragma unroll
+        for (int g = 0; g < LPS; ++g) issue_part(kb, g);
     };
 
     f32x16 acc[2][2];
@@ -529,14 +532,37 @@ __device__ __forceinline__ void tile_h16_tr_body(
         else if (ahead == 1) wait_vmcnt<LPS>();
         else wait_vmcnt<0>();
         if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // stage kb is in LDS; stage kb-1 is free
-        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+        const bool refill = kb + NST - 1 < nkb;
+        if (!FAD_MOM_SPREAD && refill) issue(kb + NST - 1);
         // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
         // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
         uint4 F0[4], F1[4];
         load_frags(kb, 0, F0);
         load_frags(kb, 1, F1);
-        mma_first(F0); mma_rest(F0);
-        mma_first(F1); mma_rest(F1);
+        if (FAD_MOM_SPREAD) {                      // probe: one load between MFMAs instead of a burst behind the barrier
+            mma_first(F0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) issue_part(kb + NST - 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rest(F0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) issue_part(kb + NST - 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_first(F1);
+            if (!DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (refill) issue_part(kb + NST - 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_rest(F1);
+            if (!DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (refill) issue_part(kb + NST - 1, 3);
+            }
+        } else {
+            mma_first(F0); mma_rest(F0);
+            mma_first(F1); mma_rest(F1);
+        }
     }
 
     float* out = partials + ((int64_t)split * T + tile) * H_TS;
