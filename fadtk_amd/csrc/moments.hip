@@ -1505,10 +1505,13 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
 #ifndef FAD_MOM_NST
 #define FAD_MOM_NST 4
 #endif
+#ifndef FAD_MOM_WGPCU
+#define FAD_MOM_WGPCU 2        // workgroups per CU the split plan of v4 aims for (probe knob; 3 needs NST = 3)
+#endif
         constexpr int NST = FAD_MOM_NST;         // LDS ring depth (stages); a build-time knob for scripts/probe_ablate.py
         // v8: one workgroup per CU, each wave sums at most 8192 rows in fp32 (4 waves per split)
         SplitPlan p = (variant == 8) ? plan_splits(n, d, H_BT, 64, h->n_cu, 1, 256, 4 * 8192)
-                                     : plan_splits(n, d, H_BT, H_KB, h->n_cu, 2, 256, 8192);
+                                     : plan_splits(n, d, H_BT, H_KB, h->n_cu, FAD_MOM_WGPCU, 256, 8192);
         const int layout = (variant == 8) ? 1 : 0;
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
         FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));

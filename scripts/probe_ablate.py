@@ -3,7 +3,8 @@
 bounds it?  `python scripts/probe_ablate.py build` (CPU box, hipcc) makes one library per mask under
 scripts/probes/ablate/; `python scripts/probe_ablate.py` (GPU box) times the tile kernel of each at config 3.
 Mask bits 8..10 select the LDS ring depth of v4 (256 * NST; 0 = default 4), bit 11 (2048) spreads v8's loads
-between its MFMAs, bits 12.. (4096 * aux) set the cache-policy bits of v8's LDS-DMA loads.
+between its MFMAs, bits 12..16 (4096 * aux) set the cache-policy bits of v8's LDS-DMA loads, bit 17 (131072) plans three
+workgroups per CU for v4 (combine with NST = 3: 131072 + 768).
 Masks: 1 = no MFMA, 2 = no LDS reads, 4 = no global loads, 8 = no barrier (results are garbage by design)."""
 import ctypes as C, os, subprocess, sys
 from pathlib import Path
@@ -21,7 +22,7 @@ def build():
     tl = B._torch_lib_dir()
     for m in MASKS:
         o = OUT / f"moments_{m}.o"
-        subprocess.run([B._hipcc(), *B.FLAGS, f"-DFAD_MOM_ABLATE={m & 63}", f"-DFAD_MOM_NST={((m >> 8) & 7) or 4}", f"-DFAD_MOM_SPREAD={(m >> 11) & 1}", f"-DFAD_MOM_AUX={(m >> 12) & 31}", "-c", str(B.CSRC / "moments.hip"), "-o", str(o)], check=True)
+        subprocess.run([B._hipcc(), *B.FLAGS, f"-DFAD_MOM_ABLATE={m & 63}", f"-DFAD_MOM_NST={((m >> 8) & 7) or 4}", f"-DFAD_MOM_SPREAD={(m >> 11) & 1}", f"-DFAD_MOM_WGPCU={3 if (m >> 17) & 1 else 2}", f"-DFAD_MOM_AUX={(m >> 12) & 31}", "-c", str(B.CSRC / "moments.hip"), "-o", str(o)], check=True)
         subprocess.run(["g++", "-shared", "-fPIC", "-o", str(OUT / f"libfad_ablate_{m}.so"), str(o), *objs, f"-L{tl}", "-lamdhip64",
                         f"-Wl,-rpath,{tl}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--enable-new-dtags"], check=True)
         o.unlink()
