@@ -70,9 +70,121 @@ void run(const char* buf, float* out, long long* cyc, int wgs = 512) {
            NL, NM, ms, (double)c / iters, (double)c / (ms * 1e6));
 }
 
+// Specialised waves: a 512-thread workgroup whose waves 0-3 only run MFMAs and whose waves 4-7 only issue LDS-DMA
+// loads (one of each kind per SIMD).  If a CU can move data into LDS while its matrix pipes run, this takes
+// max(loads, MFMA); if not, their sum.
+template <int NG, int NM, int WHO, int MODE, int CK = 0>      // CK 1: the compute waves run VALU FMAs instead of MFMAs; WHO: 1 = MFMA waves only active, 2 = loader waves only, 3 = both
+__global__ __launch_bounds__(512) void spec(const char* __restrict__ buf, int iters, int stride, float* out) {  // MODE 1: register-staged loaders
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];      // 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float s = 0.f;
+    if (wave < 4) {
+        if (WHO & 1) {
+            f32x16 acc[4];
+            for (int i = 0; i < 4; ++i) for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+            f16x8 a, b; for (int q = 0; q < 8; ++q) { a[q] = (_Float16)(lane * 1e-3f); b[q] = (_Float16)1.0f; }
+            if (CK == 0) {
+                for (int it = 0; it < iters; ++it)
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m & 3], 0, 0, 0);
+            } else {
+                float x0 = lane, x1 = lane + 1, x2 = lane + 2, x3 = lane + 3;
+                for (int it = 0; it < iters; ++it)
+#pragma unroll
+                    for (int m = 0; m < NM * 8; ++m) {       // ~ the same wall time as NM MFMAs: 4 dependent chains of v_fma_f32
+                        x0 = fmaf(x0, 1.0001f, 0.5f); x1 = fmaf(x1, 1.0001f, 0.5f);
+                        x2 = fmaf(x2, 1.0001f, 0.5f); x3 = fmaf(x3, 1.0001f, 0.5f);
+                    }
+                s += x0 + x1 + x2 + x3;
+            }
+            for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+        }
+    } else if (WHO & 2) {
+        const int lw = wave - 4;
+        const char* base = buf + (size_t)(blockIdx.x % 32) * 65536 + lw * 1024 + lane * 16;
+        if (MODE == 0) {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    uint4* dst = smem + (((it * NG + g) & 15) * 4 + lw) * 64;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(base + ((it * NG + g) & 15) * 4096), (lptr_t)dst, 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NG) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (MODE == 3) {
+            // LDS-DMA again, but the address is a wave-uniform 64-bit base (SGPR pair) + a loop-invariant 32-bit lane
+            // offset: global_load_lds_dwordx4 v_off, s[base:base+1] -- 4 instead of 8 address bytes per lane
+            const uint32_t voff = (uint32_t)(lane * 16);
+            const char* wbase = buf + (size_t)(blockIdx.x % 32) * 65536 + lw * 1024;
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    uint4* dst = smem + (((it * NG + g) & 15) * 4 + lw) * 64;
+                    const uint64_t sb = (uint64_t)(wbase + ((it * NG + g) & 15) * 4096);
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+                    const uint64_t ub = ((uint64_t)hi << 32) | lo;
+                    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)dst);
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
+                }
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NG) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (MODE == 2) {
+            uint32_t x = 0;
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int g = 0; g < NG * 2; ++g) {
+                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)((char*)smem + ((it + g) & 63) * 1024 + lane * 8));
+                    x ^= (uint32_t)v[0] + (uint32_t)v[3];
+                }
+            s += (float)x;
+        } else {
+            // plain loads into registers; the PREVIOUS iteration's registers go to LDS (ds_write_b128)
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            u4 cur[NG], nxt[NG];
+            for (int g = 0; g < NG; ++g) cur[g] = (u4){(uint32_t)lane, 0u, 0u, 0u};
+            int off = 0;
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    nxt[g] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(base + off));   // bypass L1 reuse
+                    off = (off + stride) & 0xf000;
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    *reinterpret_cast<u4*>(smem + (((it * NG + g) & 15) * 4 + lw) * 64 + lane) = cur[g];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
+            }
+            for (int g = 0; g < NG; ++g) s += (float)cur[g].x;
+        }
+    }
+    __syncthreads();
+    s += reinterpret_cast<float*>(smem)[tid * 37 & 16383];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int NG, int NM, int WHO, int MODE = 0, int CK = 0>
+void run_spec(const char* buf, float* out) {
+    const int iters = 2000, wgs = 256;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&spec<NG, NM, WHO, MODE, CK>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    spec<NG, NM, WHO, MODE, CK><<<wgs, 512, 65536>>>(buf, iters, 4096, out);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    spec<NG, NM, WHO, MODE, CK><<<wgs, 512, 65536>>>(buf, iters, 4096, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("specialised waves (4 %s + 4 %s loader per CU): %s loads=%d mfma=%d : %8.3f ms\n", CK ? "VALU" : "MFMA", MODE == 3 ? "LDS-DMA(saddr)" : MODE == 2 ? "LDS-read" : MODE ? "register-staged" : "LDS-DMA",
+           WHO == 1 ? "MFMA waves only  " : WHO == 2 ? "loader waves only" : "both             ", NG, NM, ms);
+}
+
 int main() {
     char* buf; float* out; long long* cyc;
-    hipMalloc(&buf, 4 << 20); hipMemset(buf, 1, 4 << 20); hipMalloc(&out, 512 * 256 * 4); hipMalloc(&cyc, 8);
+    hipMalloc(&buf, 4 << 20); hipMemset(buf, 1, 4 << 20); hipMalloc(&out, 512 * 512 * 4); hipMalloc(&cyc, 8);
     run<4, 0, 0, 0>(buf, out, cyc);
     run<0, 16, 0, 0>(buf, out, cyc);
     run<0, 0, 8, 0>(buf, out, cyc);
@@ -91,5 +203,12 @@ int main() {
         run<8, 0, 0, 0>(buf, out, cyc, wgs);
         run<8, 16, 16, 0>(buf, out, cyc, wgs);
     }
+    run_spec<8, 16, 1>(buf, out); run_spec<8, 16, 2>(buf, out); run_spec<8, 16, 3>(buf, out);
+    run_spec<4, 16, 2>(buf, out); run_spec<4, 16, 3>(buf, out);
+    run_spec<8, 16, 2, 1>(buf, out); run_spec<8, 16, 3, 1>(buf, out);
+    run_spec<4, 16, 2, 1>(buf, out); run_spec<4, 16, 3, 1>(buf, out);
+    run_spec<8, 16, 1, 0, 1>(buf, out); run_spec<8, 16, 3, 0, 1>(buf, out);      // VALU compute + LDS-DMA
+    run_spec<8, 16, 2, 2>(buf, out); run_spec<8, 16, 3, 2>(buf, out);            // MFMA + LDS transpose reads
+    run_spec<8, 16, 2, 3>(buf, out); run_spec<8, 16, 3, 3>(buf, out);            // MFMA + LDS-DMA with saddr addressing
     return 0;
 }
