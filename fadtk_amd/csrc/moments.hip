@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void moments_tile_h16_glds(
 // ------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int KIND, int NST, bool DIAG>
+template <int KIND, int NST, bool DIAG, bool MULTI>
 __device__ __forceinline__ void tile_h16_tr_body(
     const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
@@ -458,19 +458,51 @@ __device__ __forceinline__ void tile_h16_tr_body(
         const bool ok = r < k_end;
         if (FAD_MOM_ABLATE & 32) r &= 255;         // probe: every split reads the same 256 rows (L2-resident)
         // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
-        uint4* dstA = st + 256 * h + 64 * wave;
-        if (DIAG || !(g & 1)) {
-            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)dstA, 16, 0, 0);
+        const bool side_b = !DIAG && (g & 1);
+        const uint16_t* src = side_b ? ((ok && col_ok_b) ? gb + r * ld : zsrc) : ((ok && col_ok_a) ? ga + r * ld : zsrc);
+        uint4* dstp = st + 256 * h + 64 * wave + (side_b ? H_KB * 16 : 0);
+        if (MULTI) {
+            // inline asm like the fast form below: ONE LDS-DMA builtin anywhere in the kernel and hipcc's hazard
+            // bookkeeping costs the hot loop its gain.  Per-lane 64-bit addresses (lanes may go to the zero block).
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)dstp);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
         } else {
-            const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dstp, 16, 0, 0);
         }
     };
     auto issue = [&](int kb) {
 #pragma unroll
         for (int g = 0; g < LPS; ++g) issue_part(kb, g);
     };
+    // The same loads with a wave-uniform 64-bit base in SGPRs + a loop-invariant 32-bit lane offset
+    // (global_load_lds_dwordx4 v_off, s[base:base+1]; inline asm -- the builtin always produces 64-bit VGPR addresses).
+    // With per-lane 64-bit addresses a CU does not overlap LDS-DMA with MFMAs: independent loader and MFMA waves take
+    // the SUM of their times; with an SGPR base they overlap (scripts/probes/dma_mfma_mix.hip: 0.95 -> 0.56 ms where
+    // either alone takes 0.47; scripts/probes/stream_pipeline.hip: this kernel's skeleton 50.7 -> 34.6 us).  Only for
+    // stages whose 32 rows and 128 + 128 columns are all in range (no zero-source redirection), and kept in a loop of
+    // its own: with the builtin form in the same loop body the gain disappears.
+    const bool cols_full = (ca + H_BT <= d) && (cb + H_BT <= d) && ld < ((int64_t)1 << 26);
+    const uint32_t voff = (uint32_t)(((int64_t)sr * ld + sc * 8) * 2);
+    const uint32_t smem_lds = (uint32_t)(size_t)(lptr_t)smem;
+    auto issue_fast = [&](int kb) {
+        if (FAD_MOM_ABLATE & 4) return;
+#pragma unroll
+        for (int g = 0; g < LPS; ++g) {
+            const int h = DIAG ? g : (g >> 1);
+            const bool side_b = !DIAG && (g & 1);
+            const uint64_t sb = (uint64_t)(E + (k_begin + (int64_t)kb * H_KB + 16 * h) * ld + (side_b ? cb : ca));
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+            const uint64_t ub = ((uint64_t)hi << 32) | lo;
+            const uint32_t dst = smem_lds + (uint32_t)(((kb % NST) * STAGE + 256 * h + 64 * wave + (side_b ? H_KB * 16 : 0)) * 16);
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
+        }
+    };
+    // stages [0, nfast) may be loaded the fast way
+    // (MULTI = more than one tile.  A single-tile problem, D <= 128, is HBM-bound and measured slower with either asm
+    // form -- 63 / 59 vs 53 us for 1M x 128 -- so it keeps the builtin loads throughout.)
+    const int nfast = (MULTI && cols_full && !(FAD_MOM_ABLATE & 32)) ? (int)((k_end - k_begin) / H_KB) : 0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -482,7 +514,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     double csum[2] = {0.0, 0.0};
     const bool do_colsum = DIAG && (wr == wc);     // the diagonal waves also hold sum x^2 (diagonal of acc)
 
-    for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
+    for (int s = 0; s < NST - 1 && s < nkb; ++s) { if (s < nfast) issue_fast(s); else issue(s); }
 
     // fragment of one k-step (16 rows) of a slab: two transpose reads (rows r0..r0+3 and r0+4..r0+7 of the lane's
     // 8-row half) give the 8 consecutive k that the 32x32x16 MFMA wants per lane
@@ -525,45 +557,29 @@ __device__ __forceinline__ void tile_h16_tr_body(
         }
     };
 
-    for (int kb = 0; kb < nkb; ++kb) {
+    // one stage: wait for it, workgroup barrier, refill the freed slot, 16 transpose reads, 8 MFMAs
+    auto stage = [&](int kb, auto refill_tag) {
         // stage kb must have landed; up to NST-2 younger stages may stay in flight
         const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
         if (ahead >= 2) wait_vmcnt<2 * LPS>();
         else if (ahead == 1) wait_vmcnt<LPS>();
         else wait_vmcnt<0>();
         if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // stage kb is in LDS; stage kb-1 is free
-        const bool refill = kb + NST - 1 < nkb;
-        if (!FAD_MOM_SPREAD && refill) issue(kb + NST - 1);
+        if (decltype(refill_tag)::value) issue_fast(kb + NST - 1);
+        else if (kb + NST - 1 < nkb) issue(kb + NST - 1);
         // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
         // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
         uint4 F0[4], F1[4];
         load_frags(kb, 0, F0);
         load_frags(kb, 1, F1);
-        if (FAD_MOM_SPREAD) {                      // probe: one load between MFMAs instead of a burst behind the barrier
-            mma_first(F0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (refill) issue_part(kb + NST - 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_rest(F0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (refill) issue_part(kb + NST - 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_first(F1);
-            if (!DIAG) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (refill) issue_part(kb + NST - 1, 2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mma_rest(F1);
-            if (!DIAG) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (refill) issue_part(kb + NST - 1, 3);
-            }
-        } else {
-            mma_first(F0); mma_rest(F0);
-            mma_first(F1); mma_rest(F1);
-        }
-    }
+        mma_first(F0); mma_rest(F0);
+        mma_first(F1); mma_rest(F1);
+    };
+    // hot loop: the stage to refill is a full one -> SGPR-base loads only; then the tail with the general loads
+    const int hot = (nfast - (NST - 1) > 0) ? nfast - (NST - 1) : 0;
+    int kb = 0;
+    for (; kb < hot; ++kb) stage(kb, std::true_type{});
+    for (; kb < nkb; ++kb) stage(kb, std::false_type{});
 
     float* out = partials + ((int64_t)split * T + tile) * H_TS;
 #pragma unroll
@@ -609,7 +625,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     }
 }
 
-template <int KIND, int NST>
+template <int KIND, int NST, bool MULTI>
 __global__ __launch_bounds__(256) void moments_tile_h16_tr(
     const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
     int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
@@ -623,10 +639,10 @@ __global__ __launch_bounds__(256) void moments_tile_h16_tr(
     const int64_t k_begin = (int64_t)split * rows_per_split;
     const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
     if (ta == tb)
-        tile_h16_tr_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, true, MULTI>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
                                             partials, colpart, smem_dyn, shift_flag);
     else
-        tile_h16_tr_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, false, MULTI>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
                                              partials, colpart, smem_dyn, nullptr);
     if ((FAD_MOM_ABLATE & 16) && threadIdx.x == 0 && blockIdx.x % 97 == 0) {
         const long long c = clock64() - dbg_c0, wt = wall_clock64() - dbg_w0;
@@ -1558,20 +1574,20 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
                                    p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
         } else if (variant == 4) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
+            typedef void (*tr_kernel_t)(const uint16_t*, int64_t, int64_t, int, int, int, int, int64_t, float*, double*, int*);
+            static const tr_kernel_t kern[2][2] = {
+                {&moments_tile_h16_tr<FAD_F16, NST, false>, &moments_tile_h16_tr<FAD_F16, NST, true>},
+                {&moments_tile_h16_tr<FAD_BF16, NST, false>, &moments_tile_h16_tr<FAD_BF16, NST, true>}};
             static bool attr4 = false;
             if (!attr4) {
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_F16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_tr<FAD_BF16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern[a][b]),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr4 = true;
             }
-            if (dtype == FAD_F16)
-                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_F16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
-                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-            else
-                hipLaunchKernelGGL((moments_tile_h16_tr<FAD_BF16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld, d,
-                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
+            hipLaunchKernelGGL(kern[dtype == FAD_F16 ? 0 : 1][p.T > 1 ? 1 : 0], dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld,
+                               d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
         } else if (variant == 2) {
             const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
             static bool attr_set = false;
