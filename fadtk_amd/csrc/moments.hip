@@ -581,18 +581,19 @@ __device__ __forceinline__ void tile_h16_tr_body(
     for (; kb < hot; ++kb) stage(kb, std::true_type{});
     for (; kb < nkb; ++kb) stage(kb, std::false_type{});
 
-    float* out = partials + ((int64_t)split * T + tile) * H_TS;
+    // partial tile, fragment major (the layout moments_reduce calls 1): float4 index ((fa*4 + fb)*4 + q)*64 + lane holds
+    // registers 4q..4q+3 of the 32 x 32 block (fa, fb) = rows 32fa + 8q + 4(lane>>5) + 0..3 of column 32fb + (lane&31);
+    // a wave stores 1 KiB per instruction, 16 instructions instead of 64 scattered dword stores
+    float4* out = reinterpret_cast<float4*>(partials + ((int64_t)split * T + tile) * H_TS);
 #pragma unroll
-    for (int fa = 0; fa < 2; ++fa) {
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-            const int a_local = 64 * wr + 32 * fa + row32;
-            const int b_local = 64 * wc + li;
-            out[a_local * H_BT + b_local] = acc[fa][0][reg];
-            out[a_local * H_BT + b_local + 32] = acc[fa][1][reg];
-        }
-    }
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x16& a = acc[x][y];
+                out[(((2 * wr + x) * 4 + (2 * wc + y)) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+            }
     if (do_colsum) {
         csum[0] += __shfl_xor(csum[0], 32);
         csum[1] += __shfl_xor(csum[1], 32);
@@ -1528,7 +1529,7 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
         // v8: one workgroup per CU, each wave sums at most 8192 rows in fp32 (4 waves per split)
         SplitPlan p = (variant == 8) ? plan_splits(n, d, H_BT, 64, h->n_cu, 1, 256, 4 * 8192)
                                      : plan_splits(n, d, H_BT, H_KB, h->n_cu, FAD_MOM_WGPCU, 256, 8192);
-        const int layout = (variant == 8) ? 1 : 0;
+        const int layout = (variant == 8 || variant == 4) ? 1 : 0;      // fragment-major partial tiles
         FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
         FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
         float* part = static_cast<float*>(h->partials.p);
