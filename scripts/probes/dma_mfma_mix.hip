@@ -88,6 +88,15 @@ __global__ __launch_bounds__(512) void spec(const char* __restrict__ buf, int it
                 for (int it = 0; it < iters; ++it)
 #pragma unroll
                     for (int m = 0; m < NM; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m & 3], 0, 0, 0);
+            } else if (CK == 2) {
+                typedef double f64x4 __attribute__((ext_vector_type(4)));
+                f64x4 dacc[4];
+                for (int i = 0; i < 4; ++i) dacc[i] = (f64x4){0, 0, 0, 0};
+                const double da = lane * 1e-3, db = 1.0 + lane * 1e-4;
+                for (int it = 0; it < iters; ++it)
+#pragma unroll
+                    for (int m = 0; m < NM / 4; ++m) dacc[m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, dacc[m & 3], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) s += (float)(dacc[i][0] + dacc[i][3]);
             } else {
                 float x0 = lane, x1 = lane + 1, x2 = lane + 2, x3 = lane + 3;
                 for (int it = 0; it < iters; ++it)
@@ -131,6 +140,31 @@ __global__ __launch_bounds__(512) void spec(const char* __restrict__ buf, int it
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NG) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (MODE == 4 || MODE == 5) {
+            // plain 16-byte loads into registers, no LDS: MODE 4 = 64-bit VGPR addresses, MODE 5 = SGPR base + 32-bit offset
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            u4 r[NG];
+            uint32_t x = 0;
+            const uint32_t voff = (uint32_t)(lane * 16);
+            const char* wbase = buf + (size_t)(blockIdx.x % 32) * 65536 + lw * 1024;
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const uint64_t sb = (uint64_t)(wbase + ((it * NG + g) & 15) * 4096);
+                    if (MODE == 5) {
+                        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+                        const uint64_t ub = ((uint64_t)hi << 32) | lo;
+                        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r[g]) : "v"(voff), "s"(ub) : "memory");
+                    } else {
+                        const uint64_t va = sb + voff;
+                        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r[g]) : "v"(va) : "memory");
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int g = 0; g < NG; ++g) x ^= r[g].x + r[g].w;
+            }
+            s += (float)x;
         } else if (MODE == 2) {
             uint32_t x = 0;
             for (int it = 0; it < iters; ++it)
@@ -178,7 +212,7 @@ void run_spec(const char* buf, float* out) {
     spec<NG, NM, WHO, MODE, CK><<<wgs, 512, 65536>>>(buf, iters, 4096, out);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("specialised waves (4 %s + 4 %s loader per CU): %s loads=%d mfma=%d : %8.3f ms\n", CK ? "VALU" : "MFMA", MODE == 3 ? "LDS-DMA(saddr)" : MODE == 2 ? "LDS-read" : MODE ? "register-staged" : "LDS-DMA",
+    printf("specialised waves (4 %s + 4 %s loader per CU): %s loads=%d mfma=%d : %8.3f ms\n", CK == 2 ? "MFMA-f64" : CK ? "VALU" : "MFMA", MODE == 5 ? "load(saddr)" : MODE == 4 ? "load(vaddr)" : MODE == 3 ? "LDS-DMA(saddr)" : MODE == 2 ? "LDS-read" : MODE ? "register-staged" : "LDS-DMA",
            WHO == 1 ? "MFMA waves only  " : WHO == 2 ? "loader waves only" : "both             ", NG, NM, ms);
 }
 
@@ -210,5 +244,8 @@ int main() {
     run_spec<8, 16, 1, 0, 1>(buf, out); run_spec<8, 16, 3, 0, 1>(buf, out);      // VALU compute + LDS-DMA
     run_spec<8, 16, 2, 2>(buf, out); run_spec<8, 16, 3, 2>(buf, out);            // MFMA + LDS transpose reads
     run_spec<8, 16, 2, 3>(buf, out); run_spec<8, 16, 3, 3>(buf, out);            // MFMA + LDS-DMA with saddr addressing
+    run_spec<8, 16, 1, 4, 2>(buf, out);                                          // fp64 MFMA alone
+    run_spec<8, 16, 2, 4, 2>(buf, out); run_spec<8, 16, 3, 4, 2>(buf, out);      // fp64 MFMA + plain loads, 64-bit VGPR addresses
+    run_spec<8, 16, 2, 5, 2>(buf, out); run_spec<8, 16, 3, 5, 2>(buf, out);      // fp64 MFMA + plain loads, SGPR base
     return 0;
 }
