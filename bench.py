@@ -111,6 +111,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
