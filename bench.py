@@ -95,6 +95,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts: dmabuf IPC only
     import torch
     import torch.distributed as dist
     from fadtk_amd import hip
@@ -111,7 +112,6 @@ def main():
     device = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
