@@ -59,6 +59,8 @@ SIGNATURES = {
     "fad_moments_dim": (C.c_int, [_P]),
     "fad_moments_packed_len": (_I64, [_P]),
     "fad_moments_update": (C.c_int, [_P, _P, _I64, _I64, C.c_int, C.c_int, _P]),
+    "fad_moments_update_multi": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I64), C.c_int, _P]),
+    "fad_moments_update_file_means": (C.c_int, [_P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "fad_moments_update_segmented": (C.c_int, [_P, _P, _I64, _I64, C.c_int, C.POINTER(_I64), _I64, _P, C.c_int, _P]),
     "fad_moments_merge": (C.c_int, [_P, _P, _P]),
     "fad_moments_export": (C.c_int, [_P, _P, C.c_int, _P]),
@@ -71,7 +73,7 @@ SIGNATURES = {
     "fad_moments_last_timing": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "fad_frechet": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, _P,
                               C.POINTER(C.c_double), C.POINTER(FadDiag)]),
-    "fad_frechet_from_moments": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, C.c_double, _P,
+    "fad_frechet_from_moments": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, _P,
                                            C.POINTER(C.c_double), C.POINTER(FadDiag)]),
     "fad_frechet_batched_vs_baseline": (C.c_int, [C.c_int, _P, _P, _P, _I64, _I64, C.c_int, C.POINTER(_I64), _I64,
                                                   C.c_int, C.c_int, C.c_int, _P, _P, _P]),

@@ -25,6 +25,7 @@
 // Sigma_s = d d^T / 2 is rank one and tr sqrt(Sigma_b Sigma_s) = sqrt(d^T Sigma_b d / 2).
 #include "fad_common.h"
 #include "ns_check.h"
+#include "ns32.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -39,65 +40,160 @@ int moments_dim(const fad_moments* h);
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kStatRows = 5;
-// ---- per row r of A[b]: |row| sum, |col| sum, sum of squares, (row r).(col r), A[r][r]; grid (d, B) ---
-__global__ __launch_bounds__(256) void ns_rowstats(const double* __restrict__ Aall, int d,
-                                                   double* __restrict__ stats_all, const NsState* __restrict__ st) {
-    __shared__ double red[4][4];
-    const int b = blockIdx.y;
+// ---- statistics of A = C1 C2 for the scale of the iteration, by 32 x 32 tile pairs -----------------------------
+// Workgroup (bi, bj, problem) loads tile (bi, bj) of A and its mirror (bj, bi) -- both as coalesced 256-byte row
+// segments -- and writes: sum |a| of the tile's 32 rows / 32 columns (partial infinity / one norms), and the scalars
+// sum a^2 (Frobenius), sum a_ij a_ji (adds up to tr A^2), the tile's share of tr A, tr C1, tr C2.  ns_prepare adds the
+// partials in a fixed order (deterministic).  (The first version gave every ROW its own workgroup, which read the
+// matching column with a 4 KiB stride: 5.5 us at D = 512 for 2 MB of data.)
+constexpr int kStatScal = 8;                         // doubles per tile: sumsq, cross, trA, tr1, tr2, (3 spare)
+static int64_t stat_blocks(int d) { return cdiv(d, 32); }
+static size_t stat_doubles(int d) { const int64_t nb = stat_blocks(d); return (size_t)(2 * nb * d + kStatScal * nb * nb); }
+
+__global__ __launch_bounds__(256) void ns_tilestats(const double* __restrict__ Aall, int d,
+                                                    const double* __restrict__ cov1, int64_t s1,
+                                                    const double* __restrict__ cov2, int64_t s2,
+                                                    double* __restrict__ stats_all, const NsState* __restrict__ st) {
+    __shared__ double P[32][33], Q[32][33];
+    __shared__ double red[20];
+    const int b = blockIdx.z;
     if (st[b].done) return;
+    const int nb = gridDim.x, bi = blockIdx.y, bj = blockIdx.x;
     const double* A = Aall + (int64_t)b * d * d;
-    double* stats = stats_all + (int64_t)b * kStatRows * d;
-    const int r = blockIdx.x, tid = threadIdx.x;
-    double ra = 0.0, ca = 0.0, rs = 0.0, rc = 0.0;
-    for (int j = tid; j < d; j += 256) {
-        const double v = A[(int64_t)r * d + j], w = A[(int64_t)j * d + r];
-        ra += fabs(v); rs += v * v;
-        ca += fabs(w);
-        rc += v * w;                                  // row r of A times column r of A: sums to tr(A^2)
-    }
+    double* stats = stats_all + (int64_t)b * (2 * (int64_t)nb * d + (int64_t)kStatScal * nb * nb);
+    double* rowabs = stats;                            // [bj][d]
+    double* colabs = stats + (int64_t)nb * d;          // [bi][d]
+    double* scal = stats + 2 * (int64_t)nb * d + (int64_t)kStatScal * (bi * nb + bj);
+    const int tid = threadIdx.x, r = tid >> 3, c0 = (tid & 7) * 4;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ra += __shfl_xor(ra, off); ca += __shfl_xor(ca, off); rs += __shfl_xor(rs, off); rc += __shfl_xor(rc, off);
+    for (int q = 0; q < 4; ++q) {
+        const int gi = bi * 32 + r, gj = bj * 32 + c0 + q;          // element (r, c0+q) of tile (bi, bj)
+        P[r][c0 + q] = (gi < d && gj < d) ? A[(int64_t)gi * d + gj] : 0.0;
+        const int hi = bj * 32 + r, hj = bi * 32 + c0 + q;          // element (r, c0+q) of tile (bj, bi)
+        Q[r][c0 + q] = (hi < d && hj < d) ? A[(int64_t)hi * d + hj] : 0.0;
     }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = ra; red[1][tid >> 6] = ca; red[2][tid >> 6] = rs; red[3][tid >> 6] = rc; }
     __syncthreads();
-    if (tid == 0) {
-        stats[r] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        stats[d + r] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        stats[2 * d + r] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-        stats[3 * d + r] = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
-        stats[4 * d + r] = A[(int64_t)r * d + r];
+    if (tid < 32) {
+        double t = 0.0;
+        for (int c = 0; c < 32; ++c) t += fabs(P[tid][c]);
+        if (bi * 32 + tid < d) rowabs[(int64_t)bj * d + bi * 32 + tid] = t;
+    } else if (tid < 64) {
+        const int c = tid - 32;
+        double t = 0.0;
+        for (int rr = 0; rr < 32; ++rr) t += fabs(P[rr][c]);
+        if (bj * 32 + c < d) colabs[(int64_t)bi * d + bj * 32 + c] = t;
     }
+    double sq = 0.0, cr = 0.0, tr = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double v = P[r][c0 + q];
+        sq += v * v;
+        cr += v * Q[c0 + q][r];
+        if (bi == bj && r == c0 + q) {
+            tr += v;
+            const int64_t i = bi * 32 + r;
+            if (i < d) { t1 += cov1[b * s1 + i * d + i]; t2 += cov2[b * s2 + i * d + i]; }
+        }
+    }
+    double v[5] = {sq, cr, tr, t1, t2};
+    block_sum_n<5>(v, red);
+    if (tid == 0) { scal[0] = v[0]; scal[1] = v[1]; scal[2] = v[2]; scal[3] = v[3]; scal[4] = v[4]; }
 }
 
-// one block per problem: scale c, traces, mean term; arms the iteration state
-__global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ stats_all, int d,
-                                                  const double* __restrict__ cov1, int64_t s1,
-                                                  const double* __restrict__ cov2, int64_t s2,
+// rs = sum_k rowabs[k][i], cs = sum_k colabs[k][i] in a fixed order, with the loads of eight partials in flight at once
+// (a plain loop issued them one dependent round trip after the other: 17 us for D = 512)
+__device__ __forceinline__ void sum_partials(const double* __restrict__ rowabs, const double* __restrict__ colabs, int nb,
+                                             int d, int i, double& rs, double& cs) {
+    rs = 0.0; cs = 0.0;
+    int k = 0;
+    for (; k + 8 <= nb; k += 8) {
+        double r[8], c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { r[q] = rowabs[(int64_t)(k + q) * d + i]; c[q] = colabs[(int64_t)(k + q) * d + i]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { rs += r[q]; cs += c[q]; }
+    }
+    for (; k < nb; ++k) { rs += rowabs[(int64_t)k * d + i]; cs += colabs[(int64_t)k * d + i]; }
+}
+
+// np.mean of a float16 / bfloat16 / float32 matrix is rounded to that dtype; fadtk then forms
+// diff = mu1 - mu2 and diff.dot(diff) IN that dtype (fad.py:83, 119): for float16 numpy accumulates the dot product
+// sequentially in float32 and rounds the result to float16 -- reproduced bit for bit by one lane.
+__device__ __forceinline__ double round_f16(double v) { return (double)(float)(_Float16)(float)v; }
+__device__ __forceinline__ double round_bf16(double v) {
+    uint32_t u = __float_as_uint((float)v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (double)__uint_as_float(u & 0xffff0000u);
+}
+
+// one block per problem: scale c, traces, mean term; arms the iteration state.
+// mean_dtype: FAD_F16 / FAD_BF16 / FAD_F32 = the reference's mean term for embeddings of that dtype, else float64.
+__global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ stats_all, int d, int nb,
                                                   const double* __restrict__ mu1, int64_t m1,
-                                                  const double* __restrict__ mu2, int64_t m2,
+                                                  const double* __restrict__ mu2, int64_t m2, int mean_dtype,
                                                   NsState* __restrict__ st_all) {
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     NsState* st = st_all + b;
     if (st->done) return;
-    const double* stats = stats_all + (int64_t)b * kStatRows * d;
-    cov1 += b * s1; cov2 += b * s2; mu1 += b * m1; mu2 += b * m2;
-    double mr = 0.0, mc = 0.0, sq = 0.0, t1 = 0.0, t2 = 0.0, mt = 0.0, ta2 = 0.0, ta = 0.0;
+    const double* stats = stats_all + (int64_t)b * (2 * (int64_t)nb * d + (int64_t)kStatScal * nb * nb);
+    const double* rowabs = stats;
+    const double* colabs = stats + (int64_t)nb * d;
+    const double* scal = stats + 2 * (int64_t)nb * d;
+    mu1 += b * m1; mu2 += b * m2;
+    double mr = 0.0, mc = 0.0, mt = 0.0;
     for (int i = tid; i < d; i += 256) {
-        mr = fmax(mr, stats[i]); mc = fmax(mc, stats[d + i]); sq += stats[2 * d + i];
-        ta2 += stats[3 * d + i]; ta += stats[4 * d + i];
-        t1 += cov1[(int64_t)i * d + i]; t2 += cov2[(int64_t)i * d + i];
+        double rs, cs;
+        sum_partials(rowabs, colabs, nb, d, i, rs, cs);
+        mr = fmax(mr, rs); mc = fmax(mc, cs);
         const double df = mu1[i] - mu2[i];
         mt += df * df;
     }
+    double sq = 0.0, ta2 = 0.0, ta = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int k = tid; k < nb * nb; k += 256) {
+        const double* sc = scal + (int64_t)kStatScal * k;
+        sq += sc[0]; ta2 += sc[1]; ta += sc[2]; t1 += sc[3]; t2 += sc[4];
+    }
+    __shared__ double red6[24];
+    __shared__ float gaps[1024];
     const double inf_norm = block_max(mr, red);
     const double one_norm = block_max(mc, red);
-    const double fro2 = block_sum(sq, red);          // NaNs/Infs propagate through the sums
-    const double tr1 = block_sum(t1, red), tr2 = block_sum(t2, red), mean_term = block_sum(mt, red);
-    const double trA2 = block_sum(ta2, red), trA = block_sum(ta, red);
+    double v6[6] = {sq, t1, t2, mt, ta2, ta};          // NaNs/Infs propagate through the sums
+    block_sum_n<6>(v6, red6);
+    const double fro2 = v6[0], tr1 = v6[1], tr2 = v6[2], trA2 = v6[4], trA = v6[5];
+    double mean_term = v6[3];
+    if (mean_dtype == FAD_F16 || mean_dtype == FAD_BF16) {
+        // the gaps are formed by all threads (through LDS, 1024 at a time); lane 0 only runs the ordered float32 sum
+        float acc = 0.f;
+        for (int i0 = 0; i0 < d; i0 += 1024) {
+            __syncthreads();
+            for (int i = i0 + tid; i < d && i < i0 + 1024; i += 256) {
+                const double a1 = (mean_dtype == FAD_F16) ? round_f16(mu1[i]) : round_bf16(mu1[i]);
+                const double a2 = (mean_dtype == FAD_F16) ? round_f16(mu2[i]) : round_bf16(mu2[i]);
+                gaps[i - i0] = (float)((mean_dtype == FAD_F16) ? round_f16(a1 - a2) : round_bf16(a1 - a2));
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const int m = (d - i0 < 1024) ? d - i0 : 1024;
+                int i = 0;
+                for (; i + 16 <= m; i += 16) {       // 16 LDS reads in flight, then the ordered chain of 16 fmas
+                    float gq[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) gq[q] = gaps[i + q];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = __fmaf_rn(gq[q], gq[q], acc);   // product of two halfs is exact in float
+                }
+                for (; i < m; ++i) acc = __fmaf_rn(gaps[i], gaps[i], acc);
+            }
+        }
+        mean_term = (mean_dtype == FAD_F16) ? round_f16((double)acc) : round_bf16((double)acc);
+    }
     if (tid == 0) {
+        if (mean_dtype == FAD_F32) {
+            double acc = 0.0;
+            for (int i = 0; i < d; ++i) { const double g = (double)(float)((double)(float)mu1[i] - (double)(float)mu2[i]); acc += g * g; }
+            mean_term = (double)(float)acc;
+        }
         // Scale: the iteration needs every eigenvalue of A/c below 3 (above, Y converges to a NEGATIVE root).
         // U = min(||A||_F, ||A||_1, ||A||_inf) >= rho(A) makes c = U/2.5 always safe; the lambda-weighted mean
         // tr(A^2)/tr(A) <= lambda_max is where the bulk of the spectrum sits, and starting the bulk near 1 saves
@@ -112,6 +208,7 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
                          isinf(tr2) || !(mean_term == mean_term) || isinf(mean_term);
         st->c = c; st->tr1 = tr1; st->tr2 = tr2; st->mean_term = mean_term;
         st->res_last = 0.0; st->tr_last = 0.0;
+        st->res_min = 1e300; st->tr_safe = 0.0; st->has_safe = 0;
         st->final_iter = -1; st->conv = 0;
         st->nonfinite = bad ? 1 : 0;
         st->done = bad ? 1 : 0;
@@ -188,17 +285,40 @@ __global__ void clear_states(NsState* st, int64_t B) {
     }
 }
 
+// after a rejected low-precision attempt: the fp64 iteration starts from a clean slate, too_few is kept
+__global__ void rearm_state(NsState* st) {
+    if (threadIdx.x == 0) {
+        st->done = 0; st->finished = 0; st->nonfinite = 0; st->conv = 0; st->final_iter = -1;
+        st->upd_skip[0] = 0; st->upd_skip[1] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 struct Workspace : NsWorkspace {
     int device = -1;
     DevBuf rows, offs, songbuf, songmat, rows2;     // per-song path
+    DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats) + G (doubles)
+    int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
+    int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
+    void release_all() {
+        release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release();
+    }
 };
 
+// One workspace per (host thread, device): calls from a thread pool (fad.py:229, 387 use tmap) never share scratch
+// memory.  The buffers are returned to the device when the thread ends.
+struct WorkspaceSet {
+    Workspace ws[16];
+    ~WorkspaceSet() {
+        for (Workspace& w : ws)
+            if (w.device >= 0) { DeviceGuard g(w.device); if (g.ok) w.release_all(); }
+    }
+};
 static Workspace& thread_ws(int device) {
-    static thread_local Workspace ws[8];
-    Workspace& w = ws[device & 7];
+    static thread_local WorkspaceSet set;
+    Workspace& w = set.ws[device & 15];
     if (w.device != device) {
-        if (w.device >= 0) { w.release(); w.rows.release(); w.offs.release(); w.songbuf.release(); w.songmat.release(); w.rows2.release(); }
+        if (w.device >= 0) { DeviceGuard g(w.device); if (g.ok) w.release_all(); }
         w.device = device;
     }
     return w;
@@ -210,6 +330,7 @@ struct NsProblem {                  // B problems of dimension d; strides in ele
     const double* cov2; int64_t s_cov2;
     const double* mu1; int64_t s_mu1;
     const double* mu2; int64_t s_mu2;
+    int mean_dtype;                 // ns_prepare: dtype whose rounding the mean term reproduces, or -1 (float64)
 };
 
 static int ns_pstride(int d) {                       // partial slots per problem: GEMM tiles or ns_first blocks
@@ -217,7 +338,7 @@ static int ns_pstride(int d) {                       // partial slots per proble
     return (int)(a > b ? a : b);
 }
 static size_t ns_small_bytes(int d, int64_t B) {
-    return (size_t)B * (sizeof(NsState) + ((size_t)ns_pstride(d) + kStatRows * (size_t)d) * sizeof(double)) + 256;
+    return (size_t)B * (sizeof(NsState) + sizeof(Ns32State) + ((size_t)ns_pstride(d) + stat_doubles(d)) * sizeof(double)) + 256;
 }
 
 // Enqueue + run the batched iteration.  On return host_states (pinned, B entries) holds the final
@@ -240,7 +361,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     NsState* dstates = static_cast<NsState*>(ws.small.p);
     double* partials = reinterpret_cast<double*>(dstates + B);
     const int pstride = ns_pstride(d);
-    double* rowstats = partials + (size_t)B * pstride;
+    double* tilestats = partials + (size_t)B * pstride;
     const int* skip_t = &dstates[0].done;            // T GEMMs stop once convergence is known or predicted
 
     const size_t hbytes = (size_t)B * sizeof(NsState);
@@ -257,9 +378,11 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     g[0] = {pb.cov1, pb.s_cov1, pb.cov2, pb.s_cov2, A, dd, 1.0, 0.0, 0.0, nullptr};
     int rc = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device);
     if (rc < 0) return rc;
-    hipLaunchKernelGGL(ns_rowstats, dim3(d, (unsigned)B), dim3(256), 0, stream, A, d, rowstats, dstates);
-    hipLaunchKernelGGL(ns_prepare, dim3((unsigned)B), dim3(256), 0, stream, rowstats, d, pb.cov1, pb.s_cov1, pb.cov2,
-                       pb.s_cov2, pb.mu1, pb.s_mu1, pb.mu2, pb.s_mu2, dstates);
+    const unsigned nb = (unsigned)stat_blocks(d);
+    hipLaunchKernelGGL(ns_tilestats, dim3(nb, nb, (unsigned)B), dim3(256), 0, stream, A, d, pb.cov1, pb.s_cov1, pb.cov2,
+                       pb.s_cov2, tilestats, dstates);
+    hipLaunchKernelGGL(ns_prepare, dim3((unsigned)B), dim3(256), 0, stream, tilestats, d, (int)nb, pb.mu1, pb.s_mu1, pb.mu2,
+                       pb.s_mu2, pb.mean_dtype, dstates);
     // iteration 0 without GEMMs for T and Z (Z0 = I): Y0, T0, Z1 = T0, residual partials
     const int nslots0 = (int)cdiv(dd, 256);
     hipLaunchKernelGGL(ns_first, dim3((unsigned)nslots0, (unsigned)B), dim3(256), 0, stream, A, d, dstates, Y[0], T, Z[1],
@@ -301,13 +424,259 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     return FAD_OK;
 }
 
+// ==========================================================================================
+// Mixed-precision leg (single pair, d % 64 == 0): Newton-Schulz in fp32 on the f32-input MFMA down to the fp32
+// floor, then ONE fp64 correction
+//     tr sqrt(A) = tr Y + 1/2 tr(Z (A - Y Y)) + O(err^2),      A, Y Y and the traces in fp64,
+// (first-order Newton step of X -> X^2 = A around Y with Z ~ Y^-1; SURVEY.md section 7 H1 measured 2e-9).  With
+// S = sqrt(A), D = S - Y and Z = S^-1 + G the neglected terms are 1/2 tr(S^-1 D^2) and 1/2 tr(G R), bounded by
+//     est = ||Z||^3 ||R||_F^2 / 8 + ||Z|| r ||R||_F / 2,    ||Z|| <= sqrt(||Z||_1 ||Z||_inf),  r = last residual;
+// the result is accepted when est <= 1e-9 |tr| (measured: est overestimates the true error 10-1000x; config 3:
+// est 2e-12, error 2e-13), otherwise -- ill-conditioned or rank-deficient products, fp32 not converging -- the
+// all-fp64 iteration above runs from scratch.  Per call: A (fp64 GEMM), statistics, 4-5 fp32 iterations at
+// ~11 us instead of ~25, Y Y (fp64 GEMM on fp32 operands), two small reduction kernels, ONE host sync; the result
+// is written straight into pinned host memory.  The number of blind iterations is the count the previous call on
+// this thread needed (scores of one run need the same count; a short batch is topped up two at a time).
+// ==========================================================================================
+struct MixedResult {
+    int status;            // 0: low-precision iteration not finished yet, 1: accepted, 2: rejected -> fp64 iteration
+    int iters, decided_at, nonfinite, too_few0, too_few1;
+    double tr_scaled, c, tr1, tr2, mean_term, res, est;
+};
+
+// Y0 = A/c in fp32, T0 = (3I - Y0)/2 (also Z1), residual partials of iteration 0; resets the low-precision state.
+__global__ __launch_bounds__(256) void ns32_first(const double* __restrict__ A, int d, const NsState* __restrict__ st,
+                                                  Ns32State* __restrict__ s32, float* __restrict__ Y0,
+                                                  float* __restrict__ T, float* __restrict__ Z1,
+                                                  double* __restrict__ partials) {
+    __shared__ double red[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s32->done = 0; s32->finished = 0; s32->ok = 0; s32->final_iter = -1; s32->failed = 0;
+        s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1;
+    }
+    if (st->done) return;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double e2 = 0.0;
+    if (g < (int64_t)d * d) {
+        const double inv = 1.0 / st->c;
+        const int r = (int)(g / d), c = (int)(g - (int64_t)r * d);
+        const float y = (float)(A[g] * inv);
+        const float t = (float)((r == c ? 1.5 : 0.0) - 0.5 * (double)y);
+        Y0[g] = y; T[g] = t; Z1[g] = t;
+        const double e = (double)t - (r == c ? 1.0 : 0.0);
+        e2 = e * e;
+    }
+    const double sum = block_sum(e2, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = sum;
+}
+
+// Tile pair (bi, bj): sum_{i in bi, j in bj} Z[i][j] R[j][i] with R = A/c - G (G = Y Y in fp64), sum R^2 over tile
+// (bj, bi), sum |Z| of the tile's rows / columns, and the tile's share of tr Y.  Y, Z = final fp32 iterate.
+__global__ __launch_bounds__(256) void ns32_corr_partials(const double* __restrict__ A, const double* __restrict__ G, int d,
+                                                          const float* __restrict__ Y0, const float* __restrict__ Y1,
+                                                          const float* __restrict__ Z0, const float* __restrict__ Z1,
+                                                          const NsState* __restrict__ st, const Ns32State* __restrict__ s32,
+                                                          double* __restrict__ stats) {
+    __shared__ double P[32][33], Q[32][33];
+    __shared__ double red[12];
+    if (!s32->ok) return;
+    const int f = s32->final_iter;
+    const float* Y = (f & 1) ? Y1 : Y0;
+    const float* Z = (f & 1) ? Z1 : Z0;
+    const int nb = gridDim.x, bi = blockIdx.y, bj = blockIdx.x;
+    double* rowabs = stats;
+    double* colabs = stats + (int64_t)nb * d;
+    double* scal = stats + 2 * (int64_t)nb * d + (int64_t)kStatScal * (bi * nb + bj);
+    const double inv = 1.0 / st->c;
+    const int tid = threadIdx.x, r = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t gz = (int64_t)(bi * 32 + r) * d + bj * 32 + c0 + q;       // Z tile (bi, bj)
+        const int64_t gr = (int64_t)(bj * 32 + r) * d + bi * 32 + c0 + q;       // R tile (bj, bi)
+        P[r][c0 + q] = (double)Z[gz];
+        Q[r][c0 + q] = A[gr] * inv - G[gr];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0.0;
+        for (int c = 0; c < 32; ++c) t += fabs(P[tid][c]);
+        rowabs[(int64_t)bj * d + bi * 32 + tid] = t;
+    } else if (tid < 64) {
+        const int c = tid - 32;
+        double t = 0.0;
+        for (int rr = 0; rr < 32; ++rr) t += fabs(P[rr][c]);
+        colabs[(int64_t)bi * d + bj * 32 + c] = t;
+    }
+    double corr = 0.0, r2 = 0.0, tr = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        corr += P[r][c0 + q] * Q[c0 + q][r];
+        const double v = Q[r][c0 + q];
+        r2 += v * v;
+        if (bi == bj && r == c0 + q) tr += (double)Y[(int64_t)(bi * 32 + r) * d + bi * 32 + r];
+    }
+    double v[3] = {corr, r2, tr};
+    block_sum_n<3>(v, red);
+    if (tid == 0) { scal[0] = v[0]; scal[1] = v[1]; scal[2] = v[2]; }
+}
+
+// One block: reduce the partials, decide, write the result where the host reads it (pinned host memory).
+__global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ stats, int d, int nb,
+                                                   const NsState* __restrict__ st, Ns32State* __restrict__ s32,
+                                                   MixedResult* __restrict__ out) {
+    __shared__ double red[4];
+    __shared__ double red3[12];
+    const int tid = threadIdx.x;
+    const bool live = s32->ok != 0;
+    double mr = 0.0, mc = 0.0, corr = 0.0, r2 = 0.0, tr = 0.0;
+    if (live) {
+        const double* rowabs = stats;
+        const double* colabs = stats + (int64_t)nb * d;
+        const double* scal = stats + 2 * (int64_t)nb * d;
+        for (int i = tid; i < d; i += 256) {
+            double rs, cs;
+            sum_partials(rowabs, colabs, nb, d, i, rs, cs);
+            mr = fmax(mr, rs); mc = fmax(mc, cs);
+        }
+        for (int k = tid; k < nb * nb; k += 256) {
+            const double* sc = scal + (int64_t)kStatScal * k;
+            corr += sc[0]; r2 += sc[1]; tr += sc[2];
+        }
+    }
+    const double zinf = block_max(mr, red), zone = block_max(mc, red);
+    double v3[3] = {corr, r2, tr};
+    block_sum_n<3>(v3, red3);
+    corr = v3[0]; r2 = v3[1]; tr = v3[2];
+    if (tid != 0) return;
+    MixedResult o;
+    o.status = 0; o.iters = s32->final_iter; o.decided_at = s32->decided_at; o.nonfinite = st->nonfinite;
+    o.too_few0 = st->too_few[0]; o.too_few1 = st->too_few[1];
+    o.c = st->c; o.tr1 = st->tr1; o.tr2 = st->tr2; o.mean_term = st->mean_term;
+    o.tr_scaled = 0.0; o.res = 0.0; o.est = 0.0;
+    if (st->done || s32->failed) {
+        o.status = 2;                                 // bad / zero product or fp32 gave up: the fp64 path decides
+    } else if (live) {
+        const int f = s32->final_iter;
+        const int fm = f < 16 ? f : 15;
+        // residual of the final iterate: measured when the check stopped AT it, else the bound from the one before
+        double res = s32->res[fm];
+        if (s32->decided_at == f - 1) { const double rp = s32->res[f - 1 < 16 ? f - 1 : 15]; res = 0.75 * rp * rp + 0.25 * rp * rp * rp; if (res < 2e-6) res = 2e-6; }
+        const double zn = sqrt(zinf * zone), rn = sqrt(r2);
+        const double trs = tr + 0.5 * corr;
+        const double est = zn * zn * zn * rn * rn / 8.0 + zn * res * rn / 2.0;
+        const bool finite = (trs == trs) && !isinf(trs) && (est == est) && !isinf(est);
+        o.tr_scaled = trs; o.res = res; o.est = est;
+        o.status = (finite && est <= 1e-9 * fabs(trs)) ? 1 : 2;
+    }
+    *out = o;            // pinned host memory: visible to the host once the stream has been synchronised
+}
+
+// -> FAD_OK with res->status 1 (accepted: res holds the pieces) or 2 (run the fp64 iteration).
+static int run_ns_mixed(const NsProblem& pb, int device, hipStream_t stream, Workspace& ws, MixedResult* res) {
+    const int d = pb.d;
+    const int64_t dd = (int64_t)d * d;
+    constexpr int kMaxLow = 14;
+    FAD_TRY(ws.mats.reserve((size_t)(6 * dd) * sizeof(double)));
+    FAD_TRY(ws.mats32.reserve((size_t)(5 * dd) * sizeof(float) + (size_t)dd * sizeof(double)));
+    double* A = static_cast<double*>(ws.mats.p);
+    double* G = static_cast<double*>(ws.mats32.p);
+    float* Y[2] = {reinterpret_cast<float*>(G + dd), reinterpret_cast<float*>(G + dd) + dd};
+    float* Z[2] = {Y[1] + dd, Y[1] + 2 * dd};
+    float* T = Y[1] + 3 * dd;
+    NsState* dstate = static_cast<NsState*>(ws.small.p);
+    double* partials = reinterpret_cast<double*>(dstate + 1);
+    const int pstride = ns_pstride(d);
+    double* tilestats = partials + pstride;
+    Ns32State* s32 = reinterpret_cast<Ns32State*>(tilestats + stat_doubles(d));
+    const size_t hbytes = sizeof(NsState) + sizeof(MixedResult);
+    if (!ws.pinned || ws.pinned_cap < hbytes) {
+        if (ws.pinned) (void)hipHostFree(ws.pinned);
+        ws.pinned = nullptr; ws.pinned_cap = 0;
+        FAD_HIP_TRY(hipHostMalloc(&ws.pinned, hbytes + 4096, hipHostMallocDefault));
+        ws.pinned_cap = hbytes + 4096;
+    }
+    MixedResult* hres = reinterpret_cast<MixedResult*>(static_cast<char*>(ws.pinned) + sizeof(NsState));
+    hres->status = -1;
+
+    GemmType g64{pb.cov1, 0, pb.cov2, 0, A, dd, 1.0, 0.0, 0.0, nullptr};
+    int rc = gemm_f64_launch(d, &g64, 1, 1, &dstate->done, kStateInts, stream, device);
+    if (rc < 0) return rc;
+    const unsigned nb = (unsigned)stat_blocks(d);
+    hipLaunchKernelGGL(ns_tilestats, dim3(nb, nb, 1), dim3(256), 0, stream, A, d, pb.cov1, (int64_t)0, pb.cov2, (int64_t)0,
+                       tilestats, dstate);
+    hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(256), 0, stream, tilestats, d, (int)nb, pb.mu1, (int64_t)0, pb.mu2,
+                       (int64_t)0, pb.mean_dtype, dstate);
+    const int nslots0 = (int)cdiv(dd, 256);
+    hipLaunchKernelGGL(ns32_first, dim3((unsigned)nslots0), dim3(256), 0, stream, A, d, dstate, s32, Y[0], T, Z[1], partials);
+
+    int k = 0, want = ws.lp_iters;
+    if (want < 2) want = 2;
+    if (want > kMaxLow) want = kMaxLow;
+    for (;;) {
+        for (; k < want; ++k) {
+            const int cur = k & 1;
+            Gemm32Args g;
+            memset(&g, 0, sizeof(g));
+            int nslots = nslots0;
+            if (k > 0) {                               // T = (3I - Z Y)/2 and the residual partials of iteration k
+                g.A[0] = Z[cur]; g.B[0] = Y[cur]; g.C[0] = T; g.alpha[0] = -0.5f; g.beta_eye[0] = 1.5f; g.gamma[0] = 1.0f;
+                g.partials[0] = partials; g.skip = &s32->done; g.ntypes = 1;
+                nslots = gemm_f32_launch(d, g, stream);
+                if (nslots < 0) return nslots;
+                memset(&g, 0, sizeof(g));
+            }
+            // Y <- Y T (and Z <- T Z; Z1 = T0 is in place at k = 0) + the check of iteration k as an extra workgroup
+            g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.alpha[0] = 1.0f;
+            g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1]; g.alpha[1] = 1.0f;
+            g.ntypes = (k == 0) ? 1 : 2;
+            g.skip = &s32->upd_skip[k & 1];
+            g.check = 1; g.k = k; g.max_low = kMaxLow; g.nslots = nslots; g.chk_partials = partials; g.st = s32; g.st64 = dstate;
+            rc = gemm_f32_launch(d, g, stream);
+            if (rc < 0) return rc;
+        }
+        // fp64 correction on the final iterate (which of the ping-pong buffers: known on the device only)
+        FAD_TRY(gemm_f64_from_f32_launch(d, Y[0], Y[0], Y[1], Y[1], &s32->final_iter, G, 1.0, &s32->skip_corr, stream));
+        hipLaunchKernelGGL(ns32_corr_partials, dim3(nb, nb), dim3(256), 0, stream, A, G, d, Y[0], Y[1], Z[0], Z[1], dstate, s32,
+                           tilestats);
+        hipLaunchKernelGGL(ns32_finish, dim3(1), dim3(256), 0, stream, tilestats, d, (int)nb, dstate, s32, hres);
+        FAD_HIP_TRY(hipGetLastError());
+        FAD_HIP_TRY(hipStreamSynchronize(stream));
+        if (hres->status != 0 || k >= kMaxLow) break;
+        want = (k + 2 < kMaxLow) ? k + 2 : kMaxLow;    // not there yet: two more iterations, then the closing kernels again
+    }
+    *res = *hres;
+    if (res->status == 0) res->status = 2;
+    if (res->status == 1 && res->decided_at >= 0) ws.lp_iters = res->decided_at + 1;
+    return FAD_OK;
+}
+
 // single pair, with the reference's eps fallback; cov/mu are DEVICE pointers
 static int frechet_single(int d, const double* cov1, const double* cov2, const double* mu1, const double* mu2,
-                          double eps, int max_iter, double tol, int device, hipStream_t stream, Workspace& ws,
-                          double* out_fad, fad_diag_t* diag, bool check_few) {
+                          double eps, int max_iter, double tol, int mean_dtype, int device, hipStream_t stream,
+                          Workspace& ws, double* out_fad, fad_diag_t* diag, bool check_few) {
     const int64_t dd = (int64_t)d * d;
     NsState* hs = nullptr;
-    NsProblem pb{d, 1, cov1, 0, cov2, 0, mu1, 0, mu2, 0};
+    NsProblem pb{d, 1, cov1, 0, cov2, 0, mu1, 0, mu2, 0, mean_dtype};
+    if (ws.mixed < 0) { const char* e = getenv("FAD_FRECHET_MIXED"); ws.mixed = (e && e[0] == '0') ? 0 : 1; }
+    if (ws.mixed && d % 64 == 0 && max_iter <= 0 && tol <= 0.0) {
+        MixedResult r;
+        FAD_TRY(run_ns_mixed(pb, device, stream, ws, &r));
+        if (check_few && (r.too_few0 || r.too_few1))
+            return set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
+        if (r.status == 1) {
+            const double tr_sqrt = sqrt(r.c) * r.tr_scaled;
+            if (out_fad) *out_fad = r.mean_term + r.tr1 + r.tr2 - 2.0 * tr_sqrt;
+            if (diag) {
+                diag->iters = r.iters + 1; diag->converged = 3; diag->used_eps = 0; diag->reserved = 0;
+                diag->residual = r.res; diag->scale = r.c; diag->mean_term = r.mean_term; diag->tr1 = r.tr1; diag->tr2 = r.tr2;
+                diag->tr_sqrt = tr_sqrt;
+            }
+            return FAD_OK;
+        }
+        // rejected: the state words the fp64 iteration relies on are re-armed by ns_prepare; only the skip words and
+        // `done` need clearing (too_few stays as finalize_for_frechet set it)
+        hipLaunchKernelGGL(rearm_state, dim3(1), dim3(64), 0, stream, static_cast<NsState*>(ws.small.p));
+    }
     FAD_TRY(run_ns(pb, max_iter, tol, device, stream, ws, &hs));
     if (check_few && (hs->too_few[0] || hs->too_few[1]))
         return set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
@@ -322,7 +691,7 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
         hipLaunchKernelGGL(add_diag, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, stream, E1, d, eps);
         hipLaunchKernelGGL(add_diag, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, stream, E2, d, eps);
         hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, stream, static_cast<NsState*>(ws.small.p), (int64_t)1);
-        NsProblem pe{d, 1, E1, 0, E2, 0, mu1, 0, mu2, 0};
+        NsProblem pe{d, 1, E1, 0, E2, 0, mu1, 0, mu2, 0, mean_dtype};
         FAD_TRY(run_ns(pe, max_iter, tol, device, stream, ws, &hs));
         used_eps = true;
     }
@@ -657,11 +1026,11 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
         FAD_HIP_TRY(hipMemcpyAsync(s + 2 * dd + d, mu2, d * sizeof(double), hipMemcpyHostToDevice, st));
         dc1 = s; dc2 = s + dd; dm1 = s + 2 * dd; dm2 = s + 2 * dd + d;
     }
-    return frechet_single(d, dc1, dc2, dm1, dm2, eps, max_iter, tol, device, st, ws, out_fad, diag, false);
+    return frechet_single(d, dc1, dc2, dm1, dm2, eps, max_iter, tol, -1, device, st, ws, out_fad, diag, false);
 }
 
 int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
-                             int max_iter, double tol, void* stream, double* out_fad, fad_diag_t* diag) {
+                             int max_iter, double tol, int mean_dtype, void* stream, double* out_fad, fad_diag_t* diag) {
     if (!h1 || !h2 || !out_fad) return set_error(FAD_ERR_INVALID, "NULL argument");
     const int d = moments_dim(h1), device = moments_device(h1);
     if (moments_dim(h2) != d)
@@ -680,7 +1049,7 @@ int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, i
     const unsigned eg = (unsigned)cdiv(dd, 256);
     hipLaunchKernelGGL(finalize_for_frechet, dim3(eg, 2), dim3(256), 0, st, moments_packed(h1), moments_packed(h2), d, ddof,
                        s + 2 * dd, s, dstate);
-    return frechet_single(d, s, s + dd, s + 2 * dd, s + 2 * dd + d, eps, max_iter, tol, device, st, ws, out_fad, diag, true);
+    return frechet_single(d, s, s + dd, s + 2 * dd, s + 2 * dd + d, eps, max_iter, tol, mean_dtype, device, st, ws, out_fad, diag, true);
 }
 
 }  // extern "C"
@@ -835,7 +1204,7 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             NsState* dstates = static_cast<NsState*>(ws.small.p);
             hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, dstates, B);
             NsState* hs = nullptr;
-            NsProblem pb{d, B, dcov_b, 0, covs, dd, dmu_b, 0, dmu_b, 0};
+            NsProblem pb{d, B, dcov_b, 0, covs, dd, dmu_b, 0, dmu_b, 0, -1};
             FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));
             for (int64_t b = 0; b < B; ++b) {
                 const int64_t s = general[g0 + b];

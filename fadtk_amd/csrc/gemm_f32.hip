@@ -1,0 +1,196 @@
+// fp32 GEMM  C = alpha * A * B + beta_eye * I  on v_mfma_f32_32x32x2_f32 (gfx950), for the LOW-PRECISION leg of the
+// Newton-Schulz square root of the Frechet distance (frechet.hip, run_ns_mixed; replaces scipy.linalg.sqrtm / eig of
+// fadtk/fad.py:88-92 together with the fp64 correction there).
+//
+// Why fp32 at all: the iteration is self-correcting, so its bulk only has to bring (Y, Z) close to (sqrt(A), A^-1/2);
+// one fp64 correction  tr sqrt(A) = tr Y + 1/2 tr(Z (A - Y Y)) + O(err^2)  then restores fp64 accuracy
+// (SURVEY.md section 7, H1).  The f32-input MFMA runs at 64 flop/clk/SIMD -- 3.4x the measured fp64 MFMA rate -- and
+// the operands are half the bytes, so a D = 512 product takes ~5 us instead of 11-14.
+//
+// 512 threads = 8 waves, workgroup tile 32 x 32, 64-deep k stages.  Every wave owns the WHOLE tile (one
+// v_mfma_f32_32x32x2_f32 accumulator, 16 registers) for every 8th pair of k; the eight partial tiles are summed
+// through LDS at the end (a D = 512 product is 256 workgroups = one per CU, so k is split inside the workgroup).
+// Fragment maps: A: lane l holds A[i = l&31][k = l>>5], B: B[k = l>>5][j = l&31],
+//                D: col = l&31, row = (reg&3) + 8 (reg>>2) + 4 (l>>5).
+// LDS: A stored [row][k] with pitch 65 (odd: 32 rows -> 32 banks), B stored [k][col] with pitch 32.
+// Only d % 64 == 0 (no edge handling): other dimensions stay on the fp64 path.
+#include "fad_common.h"
+#include "ns_check.h"
+#include "ns32.h"
+
+namespace fad {
+
+constexpr int KB32 = 64;
+constexpr int PA32 = 65;
+
+// Decision of iteration k from r_k = ||I - Z_k Y_k||_F (= 2 ||T_k - I||_F), one lane.
+//   * finish at Y_k when the residual has reached the fp32 floor: r_k <= 1e-3 and it no longer shrinks fast;
+//   * E_{k+1} = (3 E_k^2 + E_k^3)/4: when that bound is already below ~the floor, Y_{k+1} (being computed by the
+//     update GEMMs this check rides on) is final and no further T GEMM is needed;
+//   * fail (-> fp64 path) on NaN/Inf, after max_low iterations, or when the residual is still > 1 after eight
+//     iterations (eigenvalues of A/c below ~1e-3: the error estimate of the fp64 correction would reject the result
+//     anyway).  An fp32 iteration costs less than half an fp64 one, so moderately conditioned products (a dozen
+//     iterations) still come out ahead.
+__device__ __forceinline__ void ns32_check(const Gemm32Args& g) {
+    Ns32State* st = g.st;
+    const int k = g.k;
+    if (st->finished || g.st64->done) {
+        if (threadIdx.x == 0) { st->upd_skip[(k + 1) & 1] = 1; if (g.st64->done && !st->finished) { st->finished = 1; st->failed = 1; st->done = 1; } }
+        return;
+    }
+    __shared__ double red[8];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < g.nslots; i += 512) s += g.chk_partials[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double sumsq = 0.0;
+    for (int w = 0; w < 8; ++w) sumsq += red[w];
+    const double res = 2.0 * sqrt(sumsq);
+    if (k < 16) st->res[k] = res;
+    const double prev = (k > 0 && k <= 16) ? st->res[k - 1] : 1e300;
+    const bool finite = (res == res) && !isinf(res);
+    if (!finite || k + 1 >= g.max_low || (k >= 8 && res > 1.0)) {
+        st->failed = 1; st->finished = 1; st->done = 1; st->final_iter = k; st->decided_at = k; st->upd_skip[(k + 1) & 1] = 1;
+        return;
+    }
+    if (k >= 1 && res <= 1e-3 && (res > 0.3 * prev || res <= 1e-6)) {       // at the floor: Y_k is final (Z_0 = I is implicit)
+        st->ok = 1; st->skip_corr = 0; st->finished = 1; st->done = 1; st->final_iter = k; st->decided_at = k; st->upd_skip[(k + 1) & 1] = 1;
+        return;
+    }
+    const double bound = 0.75 * res * res + 0.25 * res * res * res;
+    if (bound <= 2e-6) {                                          // Y_{k+1} (this launch's update) is final
+        st->ok = 1; st->skip_corr = 0; st->finished = 1; st->done = 1; st->final_iter = k + 1; st->decided_at = k; st->upd_skip[(k + 1) & 1] = 1;
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_f32_kernel(int d, Gemm32Args g) {
+    constexpr int NT = 512;
+    constexpr int STAGE_F = 32 * PA32 + KB32 * 32;                // floats of one LDS stage
+    constexpr int PART_F = 8 * 32 * 33;                           // k-split partial tiles
+    __shared__ __attribute__((aligned(16))) float smem[(PART_F > 2 * STAGE_F ? PART_F : 2 * STAGE_F) + 16];
+    __shared__ double red[8];
+    if ((int)blockIdx.z >= g.ntypes) {
+        if (g.check && blockIdx.x == 0 && blockIdx.y == 0) ns32_check(g);
+        return;
+    }
+    const int zi = blockIdx.z;
+    const float* __restrict__ A = g.A[zi];
+    const float* __restrict__ B = g.B[zi];
+    float* __restrict__ C = g.C[zi];
+    const float alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
+
+    // XCD-aware tile map (as gemm_f64.hip): XCD (ex, ey) of a 2 x 4 grid owns a contiguous block of output tiles
+    int ty = blockIdx.y, tx = blockIdx.x;
+    const int t = gridDim.x;
+    if ((t & 3) == 0) {
+        const int b = blockIdx.y * t + blockIdx.x;
+        const int xcd = b & 7, idx = b >> 3;
+        const int R = t >> 1, Cc = t >> 2;
+        ty = (xcd >> 2) * R + idx / Cc;
+        tx = (xcd & 3) * Cc + idx % Cc;
+    }
+    const int slot = ty * t + tx;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int row0 = ty * 32, col0 = tx * 32;
+    const int nkb = d / KB32;
+
+    // thread -> one float4 of the A tile [32][64] (row ar, k ak..ak+3) and one of the B tile [64][32] (k bk, col bc..bc+3)
+    const int ar = tid >> 4, ak = (tid & 15) * 4;
+    const int bk = tid >> 3, bc = (tid & 7) * 4;
+    const float* pa = A + (int64_t)(row0 + ar) * d + ak;
+    const float* pb = B + (int64_t)bk * d + col0 + bc;
+    // The operands were written by the PREVIOUS kernel from all eight XCDs, so every first touch of a panel is an L2
+    // miss served by the Infinity Cache (~1-2 us) and all workgroups march through k in lockstep: with a short
+    // prefetch distance every stage pays that latency again.  Hence ALL loads of up to PF = 8 stages (the whole k
+    // range at D = 512) are issued before anything else -- even before the skip word is looked at (a skipped launch
+    // wastes them, a live one has one exposed latency per PF stages instead of two).
+    constexpr int PF = 8;
+    float4 ra[PF], rb[PF];
+    auto fetch_all = [&](int kb0) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            if (kb0 + j < nkb) {
+                ra[j] = *reinterpret_cast<const float4*>(pa + (kb0 + j) * KB32);
+                rb[j] = *reinterpret_cast<const float4*>(pb + (int64_t)(kb0 + j) * KB32 * d);
+            }
+        }
+    };
+    fetch_all(0);
+    if (g.skip && *g.skip != 0) return;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // Two LDS stages: stage j is written to buffer j & 1, ONE barrier, then read; the write of stage j + 1 goes to the
+    // buffer stage j - 1 was read from, which every wave has left by the time it reaches the barrier of stage j.
+    for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
+        if (kb0) fetch_all(kb0);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            if (kb0 + j < nkb) {
+                float* sA = smem + ((kb0 + j) & 1) * STAGE_F;
+                float* sB = sA + 32 * PA32;
+                const float4 a = ra[j], b = rb[j];
+                sA[ar * PA32 + ak] = a.x; sA[ar * PA32 + ak + 1] = a.y; sA[ar * PA32 + ak + 2] = a.z; sA[ar * PA32 + ak + 3] = a.w;
+                *reinterpret_cast<float4*>(sB + bk * 32 + bc) = b;
+                __syncthreads();
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {           // this wave's k pairs of the stage: 2 (wave + 8 s4) + lk
+                    const int k = 2 * (wave + 8 * s4) + lk;
+                    const float av = sA[li * PA32 + k];
+                    const float bv = sB[k * 32 + li];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // sum the eight waves' partial tiles through LDS, then a row-major (coalesced) store of C
+    __syncthreads();
+    float* part = smem;                                           // [8][32][33]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+        part[wave * (32 * 33) + r * 33 + li] = acc[reg];
+    }
+    __syncthreads();
+    double ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < 1024 / NT; ++q) {
+        const int e = tid + q * NT, rr = e >> 5, cc = e & 31;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += part[w * (32 * 33) + rr * 33 + cc];
+        const int r = row0 + rr, c = col0 + cc;
+        const float v = alpha * sum + (r == c ? beta_eye : 0.f);
+        C[(int64_t)r * d + c] = v;
+        const double e2 = (double)v - (r == c ? (double)gamma : 0.0);
+        ss += e2 * e2;
+    }
+    double* partials = g.partials[zi];
+    if (partials) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        __syncthreads();
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (tid == 0) {
+            double tsum = 0.0;
+            for (int w = 0; w < 8; ++w) tsum += red[w];
+            partials[slot] = tsum;
+        }
+    }
+}
+
+int gemm_f32_launch(int d, const Gemm32Args& g, hipStream_t stream) {
+    if (d % KB32 != 0 || d < KB32) return set_error(FAD_ERR_INVALID, "gemm_f32: d=%d is not a multiple of %d", d, KB32);
+    const unsigned t = (unsigned)(d / 32);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(t, t, (unsigned)(g.ntypes + (g.check ? 1 : 0))), dim3(512), 0, stream, d, g);
+    FAD_HIP_TRY(hipGetLastError());
+    return (int)(t * t);
+}
+
+}  // namespace fad

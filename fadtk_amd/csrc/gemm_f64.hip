@@ -34,6 +34,11 @@ struct GemmArgs {
     int remap;                           // XCD-aware tile map on/off
     int pstride;                         // partial slots reserved per problem
     int gemm_z;                          // blockIdx.z >= gemm_z: checker blocks (problem = blockIdx.z - gemm_z)
+    // fp32 operands (TIn = float instantiation: the fp64 correction product of the mixed-precision Newton-Schulz):
+    // A32/B32 replace A/B; when `sel` is given and *sel is odd the *_alt pointers are used (the final iterate of
+    // the low-precision iteration lives in one of two ping-pong buffers, known only on the device)
+    const float* A32; const float* B32; const float* A32_alt; const float* B32_alt;
+    const int* sel;
     NsCheckArgs chk;
 };
 
@@ -55,7 +60,7 @@ constexpr int PA = KB + 2;             // A pitch (doubles): rows i..i+15 land o
 // device-scope release/acquire it needs writes back / invalidates the XCD's whole L2 per workgroup: 0.18 -> 0.53 ms.)
 // NW = waves per workgroup (4; 8 only with KSPLIT): a single D = 512 GEMM is 256 workgroups = one per CU, and four
 // waves per CU run the fp64 MFMA at 34 TFLOP/s where eight reach 45 (scripts/probes/mfma_rate.hip).
-template <int BT, int DEPTH, bool KSPLIT, bool FULL, int NW = 4>
+template <int BT, int DEPTH, bool KSPLIT, bool FULL, int NW = 4, typename TIn = double>
 __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     constexpr int NT = NW * 64;              // threads
     constexpr int MT = KSPLIT ? 2 : BT / 32; // MFMA tiles per wave per side
@@ -79,6 +84,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     if (g.skip && g.skip[zb * g.skip_stride] != 0) return;
     const double* A = g.A[zi] + zb * g.sa[zi];
     const double* B = g.B[zi] + zb * g.sb[zi];
+    const float* A32 = g.A32; const float* B32 = g.B32;
+    if constexpr (sizeof(TIn) == 4) {
+        if (g.sel && (*g.sel & 1)) { A32 = g.A32_alt; B32 = g.B32_alt; }
+    }
     double* C = g.C[zi] + zb * g.sc[zi];
     const double alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
 
@@ -115,7 +124,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
             const int r = row0 + ai, k = k0 + ak;
             const int bk = e / BV, bj = (e % BV) * 2;                    // B tile [64][BT], pairs along j
             const int kk = k0 + bk, c = col0 + bj;
-            if constexpr (FULL) {      // d % 64 == 0: no bounds, no branches -- hipcc otherwise wraps EVERY guarded load in an exec
+            if constexpr (FULL && sizeof(TIn) == 4) {       // fp32 operands, converted on the way in
+                const float2 fa = *reinterpret_cast<const float2*>(A32 + (int64_t)r * d + k);
+                const float2 fb = *reinterpret_cast<const float2*>(B32 + (int64_t)kk * d + c);
+                pa[q] = (d2){(double)fa.x, (double)fa.y};
+                pb[q] = (d2){(double)fb.x, (double)fb.y};
+            } else if constexpr (FULL) {      // d % 64 == 0: no bounds, no branches -- hipcc otherwise wraps EVERY guarded load in an exec
                              // branch with its own s_waitcnt vmcnt(0), which serialises the whole prefetch
                 pa[q] = *reinterpret_cast<const d2*>(A + (int64_t)r * d + k);
                 pb[q] = *reinterpret_cast<const d2*>(B + (int64_t)kk * d + c);
@@ -294,6 +308,22 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
     }
     FAD_HIP_TRY(hipGetLastError());
     return (int)slots;
+}
+
+// C = alpha * A32 * B32 in fp64 (operands fp32, d % 64 == 0, one problem): the correction product Y Y of the
+// mixed-precision Newton-Schulz.  `sel` (device, may be NULL) picks the *_alt operands when odd; `skip` as above.
+int gemm_f64_from_f32_launch(int d, const float* A, const float* B, const float* A_alt, const float* B_alt, const int* sel,
+                             double* C, double alpha, const int* skip, hipStream_t stream) {
+    if (d % KB != 0) return set_error(FAD_ERR_INVALID, "gemm_f64_from_f32: d=%d is not a multiple of %d", d, KB);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.C[0] = C; g.alpha[0] = alpha; g.ntypes = 1; g.remap = 1; g.gemm_z = 1;
+    g.skip = skip; g.skip_stride = 0;
+    g.A32 = A; g.B32 = B; g.A32_alt = A_alt; g.B32_alt = B_alt; g.sel = sel;
+    const unsigned t = (unsigned)(d / 32);
+    hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true, 8, float>), dim3(t, t, 1), dim3(512), 0, stream, d, g);
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
 }
 
 }  // namespace fad

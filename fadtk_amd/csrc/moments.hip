@@ -4,37 +4,33 @@
 // fadtk/utils.py:13-45 by ONE pass over E that accumulates raw moments (sum-reducible).
 //
 // Kernels
-//   moments_tile_h16   fp16/bf16 rows -> fp32 partial tiles of E^T E with
-//                      v_mfma_f32_32x32x16_{f16,bf16}.  fp16 x fp16 products are exact in fp32;
-//                      each workgroup sums a bounded run of rows in fp32 and the partials are
-//                      combined in fp64.  Only upper-triangular 128x128 tiles are computed
-//                      (E^T E is symmetric).  Column sums ride along on the diagonal tiles.
-//   moments_tile_f64   any dtype / any alignment -> fp64 partial tiles with
-//                      v_mfma_f64_16x16x4_f64 (products and sums in fp64, like np.cov).
-//   moments_reduce     partials (fp32|fp64) -> += packed fp64 accumulator, mirrored.
-//   moments_finalize   (n, sum, sumsq) -> mu, cov with ddof.
+//   moments_tile_h16_tr    fp16/bf16 rows -> fp32 partial tiles of E^T E with v_mfma_f32_32x32x16_{f16,bf16}
+//                          (fp16 x fp16 products are exact in fp32; each workgroup sums a bounded run of rows in
+//                          fp32, the partials are combined in fp64).  Only upper-triangular 128x128 tiles are
+//                          computed (E^T E is symmetric); column sums ride along on the diagonal tiles.
+//                          ONE launch serves up to kMaxSets frame matrices ("sets": the two datasets of a FAD
+//                          score, the resamples of score_inf ...): the workgroup slots of the chip are shared
+//                          out over all sets, so every workgroup sums a longer run of rows and the per-workgroup
+//                          costs (a 64 KiB partial tile written and re-read, pipeline fill, launch) are paid once
+//                          for all of them.
+//   moments_tile_h16_wave  the same contract, one 128x128 tile per WAVE; wins on single-tile, HBM-bound shapes.
+//   moments_tile_f64       any dtype / any alignment -> fp64 partial tiles with v_mfma_f64_16x16x4_f64
+//                          (products and sums in fp64, like np.cov); also the exact redo of the shift guard.
+//   moments_reduce         partials (fp32|fp64) -> += packed fp64 accumulator, mirrored; all sets in one launch.
+//   moments_finalize       (n, sum, sumsq) -> mu, cov with ddof.
+// (Earlier generations of the tile kernel: scripts/probes/moments_generations.hip.)
 //
 // Data layout in HBM
 //   E            row-major [N x ld], one frame per row (the layout of fadtk's .npy files)
 //   accumulator  packed fp64 [ n | sum_x[D] | sum_xxT[D*D] ]
-//   partials     [split][tile][BT][BT]   (BT = 128 fp32 | 64 fp64)
+//   partials     [split][tile][BT][BT]   (BT = 128 fp32 | 64 fp64), fragment-major inside a 128x128 tile
 //   colpart      [split][nt*BT] fp64
 #include "fad_common.h"
 #include <dlfcn.h>
+#include <memory>
+#include <mutex>
+#include <new>
 #include <type_traits>
-
-// Build-time ablation switches for scripts/probe_ablate.py (never set in the product build): bit 0 drops the
-// MFMAs, bit 1 the LDS transpose reads, bit 2 the global->LDS loads, bit 3 the per-stage barrier; bit 4 prints
-// per-workgroup clocks, bit 5 makes every split of v4 read the same 256 rows (an L2-resident input).
-#ifndef FAD_MOM_ABLATE
-#define FAD_MOM_ABLATE 0
-#endif
-#ifndef FAD_MOM_AUX
-#define FAD_MOM_AUX 0          // cache-policy bits of the v8 LDS-DMA loads (probe knob)
-#endif
-#ifndef FAD_MOM_SPREAD
-#define FAD_MOM_SPREAD 0       // v8: issue the LDS-DMA loads between the MFMAs instead of in one burst (probe knob)
-#endif
 
 namespace fad {
 
@@ -42,8 +38,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kXcd = 8;
+constexpr int kMaxSets = 8;       // frame matrices per launch
 
 // Workgroup id -> work item such that consecutive items land on the SAME XCD (block b runs on
 // XCD b % 8): the tiles of one row-split then share that XCD's L2 for their slabs of E.
@@ -57,6 +55,37 @@ __device__ __forceinline__ void tile_coords(int tile, int nt, int& ta, int& tb) 
     int a = 0, t = tile;
     while (t >= nt - a) { t -= nt - a; ++a; }
     ta = a; tb = a + t;
+}
+
+// One frame matrix of a launch and where its partial sums go.
+struct TileSet {
+    const void* E;             // rows (device)
+    int64_t n, ld;             // frames, row pitch in elements
+    int64_t rows_per_split;    // split s sums rows [s * rows_per_split, ...)
+    int S;                     // row-splits
+    int item0;                 // first work item of this set; item = item0 + split * T + tile
+    void* partials;            // [S][T][tile stride]
+    double* colpart;           // [S][nt * BT]
+    int* flag;                 // shift guard: raised by the fp16 kernels, gate of the fp64 redo (or nullptr)
+};
+struct TileLaunch {
+    TileSet set[kMaxSets];
+    int nsets, d, nt, T, total;
+};
+
+// work item -> (set, split, tile, row range).  `w` is wave-uniform, so the table is read with scalar loads.
+__device__ __forceinline__ const TileSet& locate(const TileLaunch& L, int w, int& split, int& tile, int64_t& k_begin,
+                                                 int64_t& k_end) {
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxSets; ++i)
+        if (i < L.nsets && w >= L.set[i].item0) si = i;
+    const TileSet& s = L.set[si];
+    const int local = w - s.item0;
+    split = local / L.T; tile = local - split * L.T;
+    k_begin = (int64_t)split * s.rows_per_split;
+    k_end = (k_begin + s.rows_per_split < s.n) ? k_begin + s.rows_per_split : s.n;
+    return s;
 }
 
 template <int KIND> __device__ __forceinline__ float h16_to_f32(uint32_t bits16) {
@@ -89,17 +118,6 @@ template <int KIND> __device__ __forceinline__ float sum8(const uint4& v) {
     return s;
 }
 
-template <int KIND> __device__ __forceinline__ float sumsq8(const uint4& v) {
-    float s = 0.f;
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float lo = h16_to_f32<KIND>(w[q] & 0xffffu), hi = h16_to_f32<KIND>(w[q] >> 16);
-        s = fmaf(lo, lo, s); s = fmaf(hi, hi, s);
-    }
-    return s;
-}
-
 template <int KIND> __device__ __forceinline__ f32x16 mfma_h16(const uint4& a, const uint4& b, const f32x16& c) {
     if constexpr (KIND == FAD_F16) {
         f16x8 va, vb; __builtin_memcpy(&va, &a, 16); __builtin_memcpy(&vb, &b, 16);
@@ -110,148 +128,13 @@ template <int KIND> __device__ __forceinline__ f32x16 mfma_h16(const uint4& a, c
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// fp16 / bf16 tile kernel.  256 threads = 4 waves as 2x2; workgroup tile 128 x 128 of E^T E,
-// wave tile 64 x 64 = 2x2 MFMA 32x32 tiles; 32 rows of E per LDS stage (double buffered).
-//
-// Fragment trick: an MFMA operand wants 8 consecutive k (rows of E) of ONE column per lane, but E
-// is row-major.  The sum over k is order-free and the column<->lane assignment is ours to pick,
-// so lane i reads the 32-bit word holding columns (2i, 2i+1) of 8 rows and two v_perm_b32 per row
-// pair split them into the fragment of the "even" 32x32 tile (columns 2i) and of the "odd" one
-// (columns 2i+1).  Output element (fa, reg, fb) of lane l is then
-//   a = 64*wr + 2*row(reg, l>>5) + fa,  b = 64*wc + 2*(l&31) + fb,
-// i.e. the two fb values are adjacent columns: one 8-byte store.
-// ------------------------------------------------------------------------------------------
 constexpr int H_BT = 128;     // tile edge
 constexpr int H_TS = H_BT * H_BT + 64;   // partial-tile stride (floats): +256 B so that the same element of
                                          // consecutive tiles/splits does not alias onto one memory channel
 constexpr int H_KB = 32;      // rows per stage
+constexpr int H_NST = 4;      // LDS ring depth (stages): 4 x 16 KiB per workgroup, two workgroups per CU
 
-template <int KIND>
-__global__ __launch_bounds__(256) void moments_tile_h16(
-    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart) {
-    __shared__ uint4 smem[2][2][H_KB * 16];     // [buffer][A|B][row*16 + 16B-chunk]  = 32 KiB
-
-    const int w = xcd_contiguous(blockIdx.x, S * T);
-    const int split = w / T, tile = w - split * T;
-    int ta, tb; tile_coords(tile, nt, ta, tb);
-    const bool diag = (ta == tb);
-    const int ca = ta * H_BT, cb = tb * H_BT;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, kg = lane >> 5;
-
-    const int64_t k_begin = (int64_t)split * rows_per_split;
-    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
-    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
-
-    // staging: thread -> (row r, r+16 ; 16-byte chunk c) of each slab
-    const int sr = tid >> 4, sc = tid & 15;
-    const bool col_ok_a = (ca + sc * 8) < d;        // d % 8 == 0 on this path: chunk all-in or all-out
-    const bool col_ok_b = (cb + sc * 8) < d;
-    const uint16_t* ga = E + ca + sc * 8;
-    const uint16_t* gb = E + cb + sc * 8;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    uint4 ra[2], rb[2];
-    auto fetch = [&](int kb) {
-        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t r = r0 + 16 * h;
-            const bool ok = r < k_end;
-            ra[h] = (ok && col_ok_a) ? *reinterpret_cast<const uint4*>(ga + r * ld) : zero4;
-            if (!diag) rb[h] = (ok && col_ok_b) ? *reinterpret_cast<const uint4*>(gb + r * ld) : zero4;
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
-    double csum[2] = {0.0, 0.0};
-    const bool do_colsum = diag && (wr == 0);
-
-    if (nkb > 0) fetch(0);
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        smem[buf][0][sr * 16 + sc] = ra[0];
-        smem[buf][0][(sr + 16) * 16 + sc] = ra[1];
-        if (!diag) { smem[buf][1][sr * 16 + sc] = rb[0]; smem[buf][1][(sr + 16) * 16 + sc] = rb[1]; }
-        __syncthreads();
-        if (kb + 1 < nkb) fetch(kb + 1);
-
-        const uint32_t* sA = reinterpret_cast<const uint32_t*>(smem[buf][0]);
-        const uint32_t* sB = reinterpret_cast<const uint32_t*>(smem[buf][diag ? 0 : 1]);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int rbase = ks * 16 + kg * 8;
-            uint32_t wa[8], wb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                wa[e] = sA[(rbase + e) * 64 + 32 * wr + li];
-                wb[e] = sB[(rbase + e) * 64 + 32 * wc + li];
-            }
-            uint4 a0, a1, b0, b1;
-            // even columns: low halves of consecutive rows; odd columns: high halves
-            a0.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x05040100u); a1.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x07060302u);
-            a0.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x05040100u); a1.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x07060302u);
-            a0.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x05040100u); a1.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x07060302u);
-            a0.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x05040100u); a1.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x07060302u);
-            b0.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x05040100u); b1.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u);
-            b0.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x05040100u); b1.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u);
-            b0.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x05040100u); b1.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x07060302u);
-            b0.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x05040100u); b1.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x07060302u);
-
-            acc[0][0] = mfma_h16<KIND>(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_h16<KIND>(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_h16<KIND>(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_h16<KIND>(a1, b1, acc[1][1]);
-            if (do_colsum) {     // wave-uniform; 8-term fp32 sums of 16-bit values, then fp64
-                csum[0] += (double)sum8<KIND>(b0);
-                csum[1] += (double)sum8<KIND>(b1);
-            }
-        }
-    }
-
-    // ---- epilogue: fp32 partial tile, two adjacent columns per store
-    float* out = partials + ((int64_t)split * T + tile) * H_TS;
-#pragma unroll
-    for (int fa = 0; fa < 2; ++fa) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;       // C/D row of the 32x32 tile
-            const int a_local = 64 * wr + 2 * row32 + fa;
-            const int b_local = 64 * wc + 2 * li;
-            float2 v = make_float2(acc[fa][0][reg], acc[fa][1][reg]);
-            *reinterpret_cast<float2*>(out + a_local * H_BT + b_local) = v;
-        }
-    }
-    if (do_colsum) {
-        // lanes l and l+32 hold the two k-halves of the same column
-        csum[0] += __shfl_xor(csum[0], 32);
-        csum[1] += __shfl_xor(csum[1], 32);
-        if (kg == 0) {
-            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + 2 * li;
-            cp[0] = csum[0]; cp[1] = csum[1];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// v2 of the fp16/bf16 tile kernel: same tiling and fragment trick, but the slabs of E go
-// HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip)
-// through a ring of NST stages, so each workgroup keeps NST-1 stages (up to 48 KiB) of loads in
-// flight instead of one.  v1 was latency-bound: one 16 KiB stage in flight per workgroup gave
-// 0.9 TB/s.  Waits are counted (s_waitcnt vmcnt(N), never 0 in steady state) and the barrier is a
-// raw s_barrier so that younger stages stay in flight across it.
-// Out-of-range rows / columns are redirected per lane to a 16-byte block of zeros.
-// ------------------------------------------------------------------------------------------
+// Out-of-range rows / columns of an LDS-DMA load are redirected per lane to a 16-byte block of zeros.
 __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -261,174 +144,28 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KIND, int NST, bool DIAG>
-__device__ __forceinline__ void tile_h16_glds_body(
-    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
-    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
-    uint4* smem, int* __restrict__ shift_flag) {
-    constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
-    constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, kg = lane >> 5;
-    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
-
-    const int sr = tid >> 4, sc = tid & 15;
-    const bool col_ok_a = (ca + sc * 8) < d;
-    const bool col_ok_b = (cb + sc * 8) < d;
-    const uint16_t* ga = E + ca + sc * 8;
-    const uint16_t* gb = E + cb + sc * 8;
-    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
-
-    auto issue = [&](int kb) {
-        uint4* st = smem + (kb % NST) * STAGE;
-        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t r = r0 + 16 * h;
-            const bool ok = r < k_end;
-            // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
-            uint4* dstA = st + 256 * h + 64 * wave;
-            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)dstA, 16, 0, 0);
-            if (!DIAG) {
-                const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
-                __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
-            }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
-    double csum[2] = {0.0, 0.0};
-    const bool do_colsum = DIAG && (wr == wc);     // the diagonal waves also hold sum x^2 (diagonal of acc)
-
-    for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
-
-    for (int kb = 0; kb < nkb; ++kb) {
-        // stage kb must have landed; up to NST-2 younger stages may stay in flight
-        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
-        if (ahead >= 2) wait_vmcnt<2 * LPS>();
-        else if (ahead == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();              // every wave's pieces of stage kb are in LDS; stage kb-1 is free
-        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
-
-        const uint32_t* sA = reinterpret_cast<const uint32_t*>(smem + (kb % NST) * STAGE);
-        const uint32_t* sB = DIAG ? sA : sA + H_KB * 64;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int rbase = ks * 16 + kg * 8;
-            uint32_t wa[8], wb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                wa[e] = sA[(rbase + e) * 64 + 32 * wr + li];
-                wb[e] = sB[(rbase + e) * 64 + 32 * wc + li];
-            }
-            uint4 a0, a1, b0, b1;
-            a0.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x05040100u); a1.x = __builtin_amdgcn_perm(wa[1], wa[0], 0x07060302u);
-            a0.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x05040100u); a1.y = __builtin_amdgcn_perm(wa[3], wa[2], 0x07060302u);
-            a0.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x05040100u); a1.z = __builtin_amdgcn_perm(wa[5], wa[4], 0x07060302u);
-            a0.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x05040100u); a1.w = __builtin_amdgcn_perm(wa[7], wa[6], 0x07060302u);
-            b0.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x05040100u); b1.x = __builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u);
-            b0.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x05040100u); b1.y = __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u);
-            b0.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x05040100u); b1.z = __builtin_amdgcn_perm(wb[5], wb[4], 0x07060302u);
-            b0.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x05040100u); b1.w = __builtin_amdgcn_perm(wb[7], wb[6], 0x07060302u);
-            acc[0][0] = mfma_h16<KIND>(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_h16<KIND>(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_h16<KIND>(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_h16<KIND>(a1, b1, acc[1][1]);
-            if (do_colsum) {
-                csum[0] += (double)sum8<KIND>(b0);
-                csum[1] += (double)sum8<KIND>(b1);
-            }
-        }
-    }
-
-    float* out = partials + ((int64_t)split * T + tile) * H_TS;
-#pragma unroll
-    for (int fa = 0; fa < 2; ++fa) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-            const int a_local = 64 * wr + 2 * row32 + fa;
-            const int b_local = 64 * wc + 2 * li;
-            *reinterpret_cast<float2*>(out + a_local * H_BT + b_local) = make_float2(acc[fa][0][reg], acc[fa][1][reg]);
-        }
-    }
-    if (do_colsum) {
-        csum[0] += __shfl_xor(csum[0], 32);
-        csum[1] += __shfl_xor(csum[1], 32);
-        if (shift_flag) {
-            // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?
-            // Then fp32 partial sums of x^2 cannot resolve the variance and the block is redone in fp64.
-            // sum x^2 of column (2 li + f) is the diagonal element acc[f][f][reg] of the lane whose C/D row
-            // (reg&3) + 8 (reg>>2) + 4 kg equals li: kg = (li>>2)&1, reg = (li&3) + 4 (li>>3).
-            const double nr = (double)(k_end - k_begin);
-            const int myreg = (li & 3) + 4 * (li >> 3);
-            const bool own = kg == ((li >> 2) & 1);
-            bool hit = false;
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                float dsel = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dsel = (r == myreg) ? acc[f][f][r] : dsel;
-                double s2 = own ? (double)dsel : 0.0;
-                s2 += __shfl_xor(s2, 32);
-                const double mean = csum[f] / nr, var = s2 / nr - mean * mean;
-                const bool col_in = (cb + 64 * wc + 2 * li + f) < d;
-                if (col_in && !(mean * mean <= 64.0 * var) && !(csum[f] == 0.0 && s2 == 0.0)) hit = true;
-            }
-            if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
-        }
-        if (kg == 0) {
-            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + 2 * li;
-            cp[0] = csum[0]; cp[1] = csum[1];
-        }
-    }
-}
-
-template <int KIND, int NST>
-__global__ __launch_bounds__(256) void moments_tile_h16_glds(
-    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
-    int* __restrict__ shift_flag) {
-    extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
-    const int w = xcd_contiguous(blockIdx.x, S * T);
-    const int split = w / T, tile = w - split * T;
-    int ta, tb; tile_coords(tile, nt, ta, tb);
-    const int64_t k_begin = (int64_t)split * rows_per_split;
-    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
-    if (ta == tb)
-        tile_h16_glds_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                            partials, colpart, smem_dyn, shift_flag);
-    else
-        tile_h16_glds_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                             partials, colpart, smem_dyn, nullptr);
-}
-
 // ------------------------------------------------------------------------------------------
-// v4 = v2 with the operand fragments read by ds_read_b64_tr_b16 (LDS transpose read): in a 16-lane group lane t
-// supplies the address of 4 consecutive columns of row t>>2 and receives 4 consecutive ROWS of column t -- exactly
-// the k-contiguous fragment an MFMA wants from a row-major slab.  Two such reads per fragment replace four
-// ds_read_b32 + four v_perm_b32, at twice the LDS bytes per clock; v2's LDS read port was as busy as its MFMA pipe.
-// (Semantics verified on hardware with scripts/probes/tr_probe.hip.)  Columns map naturally: lane i <-> column i.
+// moments_tile_h16_tr.  256 threads = 4 waves as 2x2; workgroup tile 128 x 128 of E^T E, wave tile 64 x 64 = 2x2
+// MFMA 32x32 tiles; 32 rows of E per LDS stage.
+//   * slabs of E go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip)
+//     through a ring of NST stages; waits are counted (s_waitcnt vmcnt(N), never 0 in steady state) and the barrier
+//     is a raw s_barrier so that younger stages stay in flight across it;
+//   * operand fragments by ds_read_b64_tr_b16 (LDS transpose read): in a 16-lane group lane t supplies the address
+//     of 4 consecutive columns of row t>>2 and receives 4 consecutive ROWS of column t -- exactly the k-contiguous
+//     fragment an MFMA wants from a row-major slab (semantics verified with scripts/probes/tr_probe.hip).
+// FAST = LDS-DMA loads issued as inline asm with a wave-uniform SGPR base (see issue_fast); used when the problem has
+// more than one tile (MFMA-bound shapes).  Single-tile problems (D <= 128, HBM-bound) measured slower with either
+// asm form (63 / 59 vs 53 us for 1M x 128) and keep the builtin loads throughout.
 // ------------------------------------------------------------------------------------------
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-template <int KIND, int NST, bool DIAG, bool MULTI>
+template <int KIND, int NST, bool DIAG, bool FAST>
 __device__ __forceinline__ void tile_h16_tr_body(
     const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
     uint4* smem, int* __restrict__ shift_flag) {
     constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
     constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (scalar branches around MFMAs)
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, kg = lane >> 5;
     const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
@@ -451,17 +188,15 @@ __device__ __forceinline__ void tile_h16_tr_body(
 
     // part g of the loads of stage kb: off the diagonal (h, side) = (g >> 1, g & 1), on it h = g (A side only)
     auto issue_part = [&](int kb, int g) {
-        if (FAD_MOM_ABLATE & 4) return;
         uint4* st = smem + (kb % NST) * STAGE;
         const int h = DIAG ? g : (g >> 1);
-        int64_t r = k_begin + (int64_t)kb * H_KB + sr + 16 * h;
+        const int64_t r = k_begin + (int64_t)kb * H_KB + sr + 16 * h;
         const bool ok = r < k_end;
-        if (FAD_MOM_ABLATE & 32) r &= 255;         // probe: every split reads the same 256 rows (L2-resident)
         // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
         const bool side_b = !DIAG && (g & 1);
         const uint16_t* src = side_b ? ((ok && col_ok_b) ? gb + r * ld : zsrc) : ((ok && col_ok_a) ? ga + r * ld : zsrc);
         uint4* dstp = st + 256 * h + 64 * wave + (side_b ? H_KB * 16 : 0);
-        if (MULTI) {
+        if (FAST) {
             // inline asm like the fast form below: ONE LDS-DMA builtin anywhere in the kernel and hipcc's hazard
             // bookkeeping costs the hot loop its gain.  Per-lane 64-bit addresses (lanes may go to the zero block).
             const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)dstp);
@@ -485,7 +220,6 @@ __device__ __forceinline__ void tile_h16_tr_body(
     const uint32_t voff = (uint32_t)(((int64_t)sr * ld + sc * 8) * 2);
     const uint32_t smem_lds = (uint32_t)(size_t)(lptr_t)smem;
     auto issue_fast = [&](int kb) {
-        if (FAD_MOM_ABLATE & 4) return;
 #pragma unroll
         for (int g = 0; g < LPS; ++g) {
             const int h = DIAG ? g : (g >> 1);
@@ -500,9 +234,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
         }
     };
     // stages [0, nfast) may be loaded the fast way
-    // (MULTI = more than one tile.  A single-tile problem, D <= 128, is HBM-bound and measured slower with either asm
-    // form -- 63 / 59 vs 53 us for 1M x 128 -- so it keeps the builtin loads throughout.)
-    const int nfast = (MULTI && cols_full && !(FAD_MOM_ABLATE & 32)) ? (int)((k_end - k_begin) / H_KB) : 0;
+    const int nfast = (FAST && cols_full) ? (int)((k_end - k_begin) / H_KB) : 0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -518,8 +250,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
 
     // fragment of one k-step (16 rows) of a slab: two transpose reads (rows r0..r0+3 and r0+4..r0+7 of the lane's
     // 8-row half) give the 8 consecutive k that the 32x32x16 MFMA wants per lane
-    auto frag = [&](const char* slab, int ks, int col0, int kb) -> uint4 {
-        if (FAD_MOM_ABLATE & 2) return make_uint4(lane + ks, col0 + kb, lane, 0x3c003c00u);
+    auto frag = [&](const char* slab, int ks, int col0) -> uint4 {
         // byte address of (row, col): row*256 + ((col/8) ^ 4*(row&3))*16 + ((col/4)&1)*8
         const int r0 = ks * 16 + tr_row, r1 = r0 + 4, col = col0 + tr_col;
         const int o0 = r0 * 256 + (((col >> 3) ^ ((r0 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
@@ -535,25 +266,41 @@ __device__ __forceinline__ void tile_h16_tr_body(
     auto load_frags = [&](int kb, int ks, uint4 (&F)[4]) {
         const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
         const char* sB = DIAG ? sA : sA + H_KB * 256;
-        F[0] = frag(sA, ks, 64 * wr, kb); F[1] = frag(sA, ks, 64 * wr + 32, kb);
-        F[2] = frag(sB, ks, 64 * wc, kb); F[3] = frag(sB, ks, 64 * wc + 32, kb);
+        F[0] = frag(sA, ks, 64 * wr); F[1] = frag(sA, ks, 64 * wr + 32);
+        F[2] = frag(sB, ks, 64 * wc); F[3] = frag(sB, ks, 64 * wc + 32);
     };
-    auto mma_first = [&](const uint4 (&F)[4]) {
-        if (FAD_MOM_ABLATE & 1) {
-            acc[0][0][0] += (float)((F[0].x ^ F[0].y ^ F[0].z ^ F[0].w) + (F[1].x ^ F[1].y ^ F[1].z ^ F[1].w) +
-                                    (F[2].x ^ F[2].y ^ F[2].z ^ F[2].w) + (F[3].x ^ F[3].y ^ F[3].z ^ F[3].w));
-            return;
-        }
+    auto mma = [&](const uint4 (&F)[4]) {
         acc[0][0] = mfma_h16<KIND>(F[0], F[2], acc[0][0]);
-    };
-    auto mma_rest = [&](const uint4 (&F)[4]) {
-        if (FAD_MOM_ABLATE & 1) return;
         acc[0][1] = mfma_h16<KIND>(F[0], F[3], acc[0][1]);
         acc[1][0] = mfma_h16<KIND>(F[1], F[2], acc[1][0]);
         acc[1][1] = mfma_h16<KIND>(F[1], F[3], acc[1][1]);
-        if (do_colsum) {
-            csum[0] += (double)sum8<KIND>(F[2]);
-            csum[1] += (double)sum8<KIND>(F[3]);
+    };
+    // A DIAGONAL tile is symmetric, so only 20 of the 32 MFMAs of a stage are issued:
+    //   * the waves on the tile's diagonal (wr == wc) own a symmetric 64 x 64 block: A and B fragments coincide
+    //     (8 transpose reads instead of 16) and the lower 32 x 32 block is skipped -- 3 MFMAs per k-step;
+    //   * the block (rows 0..63, columns 64..127) is shared by the two remaining waves: wave (0,1) takes k-step 0 of
+    //     every stage, wave (1,0) k-step 1 (4 MFMAs, 8 reads each); wave (1,0) stores its half-sum in the unused
+    //     lower-left slots of the partial tile and moments_reduce adds the two (reduce_body, "mirror").
+    const bool diag_wave = wr == wc;
+    auto stage_diag = [&](int kb) {
+        const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
+        if (diag_wave) {
+            uint4 A0[2], A1[2];
+            A0[0] = frag(sA, 0, 64 * wr); A0[1] = frag(sA, 0, 64 * wr + 32);
+            A1[0] = frag(sA, 1, 64 * wr); A1[1] = frag(sA, 1, 64 * wr + 32);
+            acc[0][0] = mfma_h16<KIND>(A0[0], A0[0], acc[0][0]);
+            acc[0][1] = mfma_h16<KIND>(A0[0], A0[1], acc[0][1]);
+            acc[1][1] = mfma_h16<KIND>(A0[1], A0[1], acc[1][1]);
+            acc[0][0] = mfma_h16<KIND>(A1[0], A1[0], acc[0][0]);
+            acc[0][1] = mfma_h16<KIND>(A1[0], A1[1], acc[0][1]);
+            acc[1][1] = mfma_h16<KIND>(A1[1], A1[1], acc[1][1]);
+            csum[0] += (double)sum8<KIND>(A0[0]) + (double)sum8<KIND>(A1[0]);
+            csum[1] += (double)sum8<KIND>(A0[1]) + (double)sum8<KIND>(A1[1]);
+        } else {
+            uint4 F[4];
+            F[0] = frag(sA, wr, 0); F[1] = frag(sA, wr, 32);       // wave (0,1): k-step 0, wave (1,0): k-step 1
+            F[2] = frag(sA, wr, 64); F[3] = frag(sA, wr, 96);
+            mma(F);
         }
     };
 
@@ -564,16 +311,20 @@ __device__ __forceinline__ void tile_h16_tr_body(
         if (ahead >= 2) wait_vmcnt<2 * LPS>();
         else if (ahead == 1) wait_vmcnt<LPS>();
         else wait_vmcnt<0>();
-        if (!(FAD_MOM_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // stage kb is in LDS; stage kb-1 is free
+        __builtin_amdgcn_s_barrier();              // stage kb is in LDS; stage kb-1 is free
         if (decltype(refill_tag)::value) issue_fast(kb + NST - 1);
         else if (kb + NST - 1 < nkb) issue(kb + NST - 1);
-        // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
-        // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
-        uint4 F0[4], F1[4];
-        load_frags(kb, 0, F0);
-        load_frags(kb, 1, F1);
-        mma_first(F0); mma_rest(F0);
-        mma_first(F1); mma_rest(F1);
+        if constexpr (DIAG) {
+            stage_diag(kb);
+        } else {
+            // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
+            // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
+            uint4 F0[4], F1[4];
+            load_frags(kb, 0, F0);
+            load_frags(kb, 1, F1);
+            mma(F0);
+            mma(F1);
+        }
     };
     // hot loop: the stage to refill is a full one -> SGPR-base loads only; then the tail with the general loads
     const int hot = (nfast - (NST - 1) > 0) ? nfast - (NST - 1) : 0;
@@ -581,8 +332,8 @@ __device__ __forceinline__ void tile_h16_tr_body(
     for (; kb < hot; ++kb) stage(kb, std::true_type{});
     for (; kb < nkb; ++kb) stage(kb, std::false_type{});
 
-    // partial tile, fragment major (the layout moments_reduce calls 1): float4 index ((fa*4 + fb)*4 + q)*64 + lane holds
-    // registers 4q..4q+3 of the 32 x 32 block (fa, fb) = rows 32fa + 8q + 4(lane>>5) + 0..3 of column 32fb + (lane&31);
+    // partial tile, fragment major: float4 index ((fa*4 + fb)*4 + q)*64 + lane holds registers 4q..4q+3 of the
+    // 32 x 32 block (fa, fb) = rows 32fa + 8q + 4(lane>>5) + 0..3 of column 32fb + (lane&31);
     // a wave stores 1 KiB per instruction, 16 instructions instead of 64 scattered dword stores
     float4* out = reinterpret_cast<float4*>(partials + ((int64_t)split * T + tile) * H_TS);
 #pragma unroll
@@ -626,48 +377,38 @@ __device__ __forceinline__ void tile_h16_tr_body(
     }
 }
 
-template <int KIND, int NST, bool MULTI>
-__global__ __launch_bounds__(256) void moments_tile_h16_tr(
-    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
-    int* __restrict__ shift_flag) {
+template <int KIND, int NST, bool FAST>
+__global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
-    long long dbg_c0 = 0, dbg_w0 = 0;
-    if (FAD_MOM_ABLATE & 16) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
-    const int w = xcd_contiguous(blockIdx.x, S * T);
-    const int split = w / T, tile = w - split * T;
-    int ta, tb; tile_coords(tile, nt, ta, tb);
-    const int64_t k_begin = (int64_t)split * rows_per_split;
-    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    const int w = xcd_contiguous(blockIdx.x, L.total);
+    int split, tile; int64_t k_begin, k_end;
+    const TileSet& s = locate(L, w, split, tile, k_begin, k_end);
+    int ta, tb; tile_coords(tile, L.nt, ta, tb);
+    const uint16_t* E = static_cast<const uint16_t*>(s.E);
+    float* partials = static_cast<float*>(s.partials);
     if (ta == tb)
-        tile_h16_tr_body<KIND, NST, true, MULTI>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                            partials, colpart, smem_dyn, shift_flag);
+        tile_h16_tr_body<KIND, NST, true, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                partials, s.colpart, smem_dyn, s.flag);
     else
-        tile_h16_tr_body<KIND, NST, false, MULTI>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                             partials, colpart, smem_dyn, nullptr);
-    if ((FAD_MOM_ABLATE & 16) && threadIdx.x == 0 && blockIdx.x % 97 == 0) {
-        const long long c = clock64() - dbg_c0, wt = wall_clock64() - dbg_w0;
-        printf("ablate %d pipe 4 block %4d tile %d diag %d: %lld shader cycles, %lld wall ticks (100 MHz) -> %.2f GHz, %.1f us\n",
-               FAD_MOM_ABLATE, (int)blockIdx.x, tile, (int)(ta == tb), c, wt, (double)c / (10.0 * (double)wt), (double)wt / 100.0);
-    }
+        tile_h16_tr_body<KIND, NST, false, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                 partials, s.colpart, smem_dyn, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
-// v8 ("wave tile"): every wave owns a WHOLE 128 x 128 tile in 256 accumulator registers and streams its own
+// moments_tile_h16_wave: every wave owns a WHOLE 128 x 128 tile in 256 accumulator registers and streams its own
 // rows; the four waves of a workgroup take the 16-row k-steps round robin and their tiles are summed once, at
-// the end, through LDS.  Why (all measured, scripts/probes + scripts/probe_ablate.py):
+// the end, through LDS.  Why (measured in round 1):
 //   * LDS transpose reads run at ~120 B/clk per CU.  With 64 x 64 wave tiles an MFMA needs 1 KiB of LDS reads,
-//     which makes the LDS port as busy as the matrix pipe (v4: ~590 vs 544 cycles per 32 rows), and the eight
-//     waves of a CU queue on it in lockstep.  A 128 x 128 wave tile needs 0.5 KiB per MFMA.
-//   * The partial tiles (one per workgroup) are the kernel's other big cost: 510 workgroups x 64 KiB written,
-//     then read by the reduce kernel.  One workgroup per CU halves that.
+//     which makes the LDS port as busy as the matrix pipe, and the eight waves of a CU queue on it in lockstep.
+//     A 128 x 128 wave tile needs 0.5 KiB per MFMA.
+//   * One workgroup per CU halves the partial tiles (written, then read by the reduce kernel).
 //   * No workgroup barrier and no LDS sharing in the main loop: a wave waits only on its own LDS-DMA counter.
 // Per wave: ring of NSL slots of one k-step (16 rows x 128 columns of the A side, + the B side off the diagonal),
-// filled by global_load_lds with the same source-side XOR swizzle as v4; per k-step 16 (8) transpose reads feed
+// filled by global_load_lds with the same source-side XOR swizzle as above; per k-step 16 (8) transpose reads feed
 // 16 (10 on a diagonal tile: upper blocks only) MFMAs; the reads of step i+1 are issued right behind the first
 // MFMA of step i (the compiler only emits lgkmcnt(0) around ds_read_b64_tr_b16, so that is where a full wait is
-// harmless).  Partial tile layout is fragment major: float4 index ((fa*4+fb)*4+q)*64+lane holds registers
-// 4q..4q+3 of the 32 x 32 block (fa, fb), i.e. rows 32fa + 8q + 4(lane>>5) + 0..3 of column 32fb + (lane&31).
+// harmless).  It loses to the kernel above at D = 512 (62 vs 51 us: with one wave per SIMD nothing fills the gaps the
+// loads leave) and wins on the HBM-bound single-tile stream (16.8M x 128: 0.80 vs 0.91 ms).
 // ------------------------------------------------------------------------------------------
 constexpr int W_RING = 32768;                                  // LDS ring bytes per wave
 constexpr int W_LDS = 4 * W_RING + 4 * H_BT * 8 + H_BT * 8;    // + per-wave column sums + their total
@@ -710,17 +451,16 @@ __device__ __forceinline__ void tile_h16_wave_body(
     const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
     // part g of the loads of own k-step i: rows 4g..4g+3 of the A slab (g < 4) or of the B slab (g >= 4)
     auto issue_part = [&](int i, int g) {
-        if (FAD_MOM_ABLATE & 4) return;
         char* slot = ring + (i % NSL) * SLOTB;
         const int h = g & 3;
         const int64_t r = k_begin + (int64_t)(wave + 4 * i) * 16 + srow + 4 * h;
         const bool ok = r < k_end;
         if (g < 4) {
             const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)(slot + h * 1024), 16, 0, FAD_MOM_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)(slot + h * 1024), 16, 0, 0);
         } else {
             const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(slot + 4096 + h * 1024), 16, 0, FAD_MOM_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(slot + 4096 + h * 1024), 16, 0, 0);
         }
     };
     auto issue = [&](int i) {
@@ -728,7 +468,7 @@ __device__ __forceinline__ void tile_h16_wave_body(
         for (int g = 0; g < LPS; ++g) issue_part(i, g);
     };
 
-    // transpose-read addressing (see v4): byte offset of the lane's first read of 32-column fragment f
+    // transpose-read addressing (see above): byte offset of the lane's first read of 32-column fragment f
     const int t16 = lane & 15, grp = lane >> 4;
     const int tr_row = 8 * (grp >> 1) + (t16 >> 2);
     const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);
@@ -739,7 +479,6 @@ __device__ __forceinline__ void tile_h16_wave_body(
         fo[f] = tr_row * 256 + (((col >> 3) ^ ((tr_row & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
     }
     auto frag = [&](const char* slab, int f) -> uint4 {
-        if (FAD_MOM_ABLATE & 2) return make_uint4(lane + f, (uint32_t)(size_t)slab, lane, 0x3c003c00u);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f]));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f] + 1024));
         uint4 v;
@@ -767,26 +506,16 @@ __device__ __forceinline__ void tile_h16_wave_body(
             for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
     double csum[4] = {0.0, 0.0, 0.0, 0.0};
 
-    auto mma_first = [&](const uint4 (&F)[NFR]) {
-        if (FAD_MOM_ABLATE & 1) { acc[0][0][0] += (float)(F[0].x ^ F[1].y ^ F[2].z ^ F[3].w ^ F[NFR - 1].x); return; }
-        acc[0][0] = mfma_h16<KIND>(F[0], F[DIAG ? 0 : 4], acc[0][0]);
-    };
-    auto mma_rest = [&](const uint4 (&F)[NFR], int refill) {      // refill: own k-step whose loads ride along, or -1
-        int m = 0;
+    auto mma_first = [&](const uint4 (&F)[NFR]) { acc[0][0] = mfma_h16<KIND>(F[0], F[DIAG ? 0 : 4], acc[0][0]); };
+    auto mma_rest = [&](const uint4 (&F)[NFR]) {
 #pragma unroll
         for (int fa = 0; fa < 4; ++fa)
 #pragma unroll
             for (int fb = (DIAG ? fa : 0); fb < 4; ++fb) {
                 if (fa == 0 && fb == 0) continue;
-                if (!(FAD_MOM_ABLATE & 1)) acc[fa][fb] = mfma_h16<KIND>(F[fa], F[DIAG ? fb : 4 + fb], acc[fa][fb]);
-                if (FAD_MOM_SPREAD && m < LPS) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (refill >= 0) issue_part(refill, m);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                ++m;
+                acc[fa][fb] = mfma_h16<KIND>(F[fa], F[DIAG ? fb : 4 + fb], acc[fa][fb]);
             }
-        if (DIAG && !(FAD_MOM_ABLATE & 1)) {
+        if (DIAG) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) csum[f] += (double)sum8<KIND>(F[f]);
         }
@@ -796,22 +525,22 @@ __device__ __forceinline__ void tile_h16_wave_body(
     for (int s = 0; s < n0; ++s) issue(s);
     uint4 C[NFR], N[NFR];                          // fragments of the current / the next k-step
     if (nw > 0) {
-        if (!(FAD_MOM_ABLATE & 4)) wait_vmcnt_upto<LPS>(n0 - 1);
+        wait_vmcnt_upto<LPS>(n0 - 1);
         load_frags(0, C);
     }
     for (int i = 0; i < nw; ++i) {
         __builtin_amdgcn_sched_barrier(0);
         mma_first(C);                              // (lgkmcnt(0) before it: every read of step i has landed)
         __builtin_amdgcn_sched_barrier(0);
-        if (!FAD_MOM_SPREAD && i + NSL < nw) issue(i + NSL);          // ... so its slot can be refilled
+        if (i + NSL < nw) issue(i + NSL);          // ... so its slot can be refilled
         if (i + 1 < nw) {
-            const int newest = FAD_MOM_SPREAD ? i + NSL - 1 : i + NSL;
+            const int newest = i + NSL;
             const int youngest = (nw - 1 < newest) ? nw - 1 : newest;
-            if (!(FAD_MOM_ABLATE & 4)) wait_vmcnt_upto<LPS>(youngest - (i + 1));      // step i+1 is in LDS
+            wait_vmcnt_upto<LPS>(youngest - (i + 1));      // step i+1 is in LDS
             load_frags(i + 1, N);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mma_rest(C, (FAD_MOM_SPREAD && i + NSL < nw) ? i + NSL : -1);
+        mma_rest(C);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < NFR; ++f) C[f] = N[f];
@@ -880,192 +609,20 @@ __device__ __forceinline__ void tile_h16_wave_body(
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void moments_tile_h16_wave(
-    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
-    int* __restrict__ shift_flag) {
+__global__ __launch_bounds__(256) void moments_tile_h16_wave(TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) char smem_wave[];   // the ONLY LDS object: W_LDS bytes
-    long long dbg_c0 = 0, dbg_w0 = 0;
-    if (FAD_MOM_ABLATE & 16) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
-    const int w = xcd_contiguous(blockIdx.x, S * T);
-    const int split = w / T, tile = w - split * T;
-    int ta, tb; tile_coords(tile, nt, ta, tb);
-    const int64_t k_begin = (int64_t)split * rows_per_split;
-    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    const int w = xcd_contiguous(blockIdx.x, L.total);
+    int split, tile; int64_t k_begin, k_end;
+    const TileSet& s = locate(L, w, split, tile, k_begin, k_end);
+    int ta, tb; tile_coords(tile, L.nt, ta, tb);
+    const uint16_t* E = static_cast<const uint16_t*>(s.E);
+    float* partials = static_cast<float*>(s.partials);
     if (ta == tb)
-        tile_h16_wave_body<KIND, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT, partials,
-                                       colpart, smem_wave, shift_flag);
+        tile_h16_wave_body<KIND, true>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT, partials,
+                                       s.colpart, smem_wave, s.flag);
     else
-        tile_h16_wave_body<KIND, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT, partials,
-                                        colpart, smem_wave, nullptr);
-    if ((FAD_MOM_ABLATE & 16) && threadIdx.x == 0 && blockIdx.x % 47 == 0) {
-        const long long c = clock64() - dbg_c0, wt = wall_clock64() - dbg_w0;
-        printf("ablate %d pipe 8 block %4d tile %d diag %d: %lld shader cycles, %lld wall ticks (100 MHz) -> %.2f GHz, %.1f us\n",
-               FAD_MOM_ABLATE, (int)blockIdx.x, tile, (int)(ta == tb), c, wt, (double)c / (10.0 * (double)wt), (double)wt / 100.0);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// v3: same 128 x 128 tile, same LDS ring, but TWO waves per workgroup, each owning 128 (A side) x 64
-// (B side) = 4 x 2 MFMA tiles.  The A fragments come from ds_read_b64 (lane i reads columns 4i..4i+3
-// of 8 rows -> four fragments), the B fragments from ds_read_b32 as before: 16 LDS reads + 24 v_perm
-// feed 8 MFMAs instead of 16 + 16 feeding 4.  v2 saturated the LDS read port (8 waves x 16 reads per
-// 128 MFMA cycles); here a CU runs 4 such waves (2 workgroups), one per SIMD.
-// ------------------------------------------------------------------------------------------
-template <int KIND, int NST, bool DIAG>
-__device__ __forceinline__ void tile_h16_w2_body(
-    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
-    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
-    uint4* smem, int* __restrict__ shift_flag) {
-    constexpr int LPS = DIAG ? 4 : 8;              // glds instructions per wave per stage
-    constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = B-side half
-    const int li = lane & 31, kg = lane >> 5;
-    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
-
-    const int sr = tid >> 4, sc = tid & 15;        // staging: rows sr + 8h, 16-byte chunk sc
-    const bool col_ok_a = (ca + sc * 8) < d;
-    const bool col_ok_b = (cb + sc * 8) < d;
-    const uint16_t* ga = E + ca + sc * 8;
-    const uint16_t* gb = E + cb + sc * 8;
-    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
-
-    auto issue = [&](int kb) {
-        uint4* st = smem + (kb % NST) * STAGE;
-        const int64_t r0 = k_begin + (int64_t)kb * H_KB + sr;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int64_t r = r0 + 8 * h;
-            const bool ok = r < k_end;
-            uint4* dstA = st + (8 * h + 4 * wc) * 16;            // wave-uniform base; + lane*16 B by the hardware
-            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)dstA, 16, 0, 0);
-            if (!DIAG) {
-                const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
-                __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstA + H_KB * 16), 16, 0, 0);
-            }
-        }
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
-    double csum[2] = {0.0, 0.0};
-
-    for (int s = 0; s < NST - 1 && s < nkb; ++s) issue(s);
-
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
-        if (ahead >= 2) wait_vmcnt<2 * LPS>();
-        else if (ahead == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kb + NST - 1 < nkb) issue(kb + NST - 1);
-
-        const uint2* sA = reinterpret_cast<const uint2*>(smem + (kb % NST) * STAGE);
-        const uint32_t* sB = reinterpret_cast<const uint32_t*>(smem + (kb % NST) * STAGE + (DIAG ? 0 : H_KB * 16));
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int rbase = ks * 16 + kg * 8;
-            uint2 wa[8];
-            uint32_t wb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                wa[e] = sA[(rbase + e) * 32 + li];               // columns 4 li .. 4 li + 3 of row rbase + e
-                wb[e] = sB[(rbase + e) * 64 + 32 * wc + li];     // columns 64 wc + 2 li, + 1
-            }
-            uint4 a[4], b[2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t x0 = wa[2 * q].x, x1 = wa[2 * q + 1].x, y0 = wa[2 * q].y, y1 = wa[2 * q + 1].y;
-                const uint32_t f0 = __builtin_amdgcn_perm(x1, x0, 0x05040100u), f1 = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-                const uint32_t f2 = __builtin_amdgcn_perm(y1, y0, 0x05040100u), f3 = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
-                const uint32_t g0 = __builtin_amdgcn_perm(wb[2 * q + 1], wb[2 * q], 0x05040100u);
-                const uint32_t g1 = __builtin_amdgcn_perm(wb[2 * q + 1], wb[2 * q], 0x07060302u);
-                if (q == 0) { a[0].x = f0; a[1].x = f1; a[2].x = f2; a[3].x = f3; b[0].x = g0; b[1].x = g1; }
-                if (q == 1) { a[0].y = f0; a[1].y = f1; a[2].y = f2; a[3].y = f3; b[0].y = g0; b[1].y = g1; }
-                if (q == 2) { a[0].z = f0; a[1].z = f1; a[2].z = f2; a[3].z = f3; b[0].z = g0; b[1].z = g1; }
-                if (q == 3) { a[0].w = f0; a[1].w = f1; a[2].w = f2; a[3].w = f3; b[0].w = g0; b[1].w = g1; }
-            }
-#pragma unroll
-            for (int fa = 0; fa < 4; ++fa) {
-                acc[fa][0] = mfma_h16<KIND>(a[fa], b[0], acc[fa][0]);
-                acc[fa][1] = mfma_h16<KIND>(a[fa], b[1], acc[fa][1]);
-            }
-            if (DIAG) {
-                csum[0] += (double)sum8<KIND>(b[0]);
-                csum[1] += (double)sum8<KIND>(b[1]);
-            }
-        }
-    }
-
-    float* out = partials + ((int64_t)split * T + tile) * H_TS;
-#pragma unroll
-    for (int fa = 0; fa < 4; ++fa) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row32 = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-            const int a_local = 4 * row32 + fa;
-            const int b_local = 64 * wc + 2 * li;
-            *reinterpret_cast<float2*>(out + a_local * H_BT + b_local) = make_float2(acc[fa][0][reg], acc[fa][1][reg]);
-        }
-    }
-    if (DIAG) {
-        csum[0] += __shfl_xor(csum[0], 32);
-        csum[1] += __shfl_xor(csum[1], 32);
-        if (shift_flag) {
-            // sum x^2 of column b = 64 wc + 2 li + f is the accumulator element with a_local == b:
-            // fa = b & 3, C/D row r = b >> 2 = 16 wc + (li >> 1), held (for C/D column li) by kg = (r>>2)&1, reg = (r&3) + 4 (r>>3)
-            const double nr = (double)(k_end - k_begin);
-            const int r = 16 * wc + (li >> 1);
-            const int myreg = (r & 3) + 4 * (r >> 3);
-            const bool own = kg == ((r >> 2) & 1);
-            bool hit = false;
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const int fa_need = 2 * (li & 1) + f;
-                float dsel = 0.f;
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) dsel = (x == fa_need && q == myreg) ? acc[x][f][q] : dsel;
-                double s2 = own ? (double)dsel : 0.0;
-                s2 += __shfl_xor(s2, 32);
-                const double mean = csum[f] / nr, var = s2 / nr - mean * mean;
-                const bool col_in = (cb + 64 * wc + 2 * li + f) < d;
-                if (col_in && !(mean * mean <= 64.0 * var) && !(csum[f] == 0.0 && s2 == 0.0)) hit = true;
-            }
-            if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
-        }
-        if (kg == 0) {
-            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + 2 * li;
-            cp[0] = csum[0]; cp[1] = csum[1];
-        }
-    }
-}
-
-template <int KIND, int NST>
-__global__ __launch_bounds__(128) void moments_tile_h16_w2(
-    const uint16_t* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ colpart,
-    int* __restrict__ shift_flag) {
-    extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];
-    const int w = xcd_contiguous(blockIdx.x, S * T);
-    const int split = w / T, tile = w - split * T;
-    int ta, tb; tile_coords(tile, nt, ta, tb);
-    const int64_t k_begin = (int64_t)split * rows_per_split;
-    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
-    if (ta == tb)
-        tile_h16_w2_body<KIND, NST, true>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                          partials, colpart, smem_dyn, shift_flag);
-    else
-        tile_h16_w2_body<KIND, NST, false>(E, k_begin, k_end, ld, d, nt, T, split, tile, ta * H_BT, tb * H_BT,
-                                           partials, colpart, smem_dyn, nullptr);
+        tile_h16_wave_body<KIND, false>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT, partials,
+                                        s.colpart, smem_wave, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1077,10 +634,7 @@ __global__ __launch_bounds__(128) void moments_tile_h16_w2(
 // is launched unconditionally and exits at once when the flag is clear; one reduce launch serves both
 // sources.  Two flags alternate between updates so that the reduce of update k can clear the flag of
 // update k+1 without a memset.
-// ------------------------------------------------------------------------------------------
-// (the test itself lives in the epilogue of the diagonal-tile workgroups of moments_tile_h16_glds)
-
-// ------------------------------------------------------------------------------------------
+//
 // Generic tile kernel: any input dtype, any pitch/alignment.  Everything in fp64 on
 // v_mfma_f64_16x16x4_f64 (A: lane l holds A[i=l&15][k=l>>4]; B[k=l>>4][j=l&15];
 // D: col = l&15, row = (l>>4) + 4*reg).  Workgroup tile 64x64, wave tile 32x32, 16 rows/stage.
@@ -1099,14 +653,17 @@ template <> __device__ __forceinline__ double to_f64<raw_f16>(raw_f16 v) { retur
 template <> __device__ __forceinline__ double to_f64<raw_bf16>(raw_bf16 v) { return (double)h16_to_f32<FAD_BF16>(v.b); }
 
 template <typename TIn>
-__global__ __launch_bounds__(256) void moments_tile_f64(
-    const TIn* __restrict__ E, int64_t n, int64_t ld, int d, int nt, int T, int S,
-    int64_t rows_per_split, double* __restrict__ partials, double* __restrict__ colpart,
-    const int* __restrict__ gate) {
+__global__ __launch_bounds__(256) void moments_tile_f64(TileLaunch L) {
     __shared__ double smem[2][2][G_KB * G_LDS];      // 40 KiB
-    if (gate && *gate == 0) return;                  // shift guard: only runs when the fp16 pass flagged the block
+    // one grid for all sets (sized for the longest); a set whose gate is clear has nothing to redo
+    const TileSet& s = L.set[blockIdx.y];
+    if ((int)blockIdx.x >= s.S * L.T) return;
+    if (s.flag && *s.flag == 0) return;              // shift guard: only runs when the fp16 pass flagged the block
+    const TIn* __restrict__ E = static_cast<const TIn*>(s.E);
+    const int64_t ld = s.ld;
+    const int d = L.d, nt = L.nt, T = L.T;
 
-    const int w = xcd_contiguous(blockIdx.x, S * T);
+    const int w = xcd_contiguous(blockIdx.x, s.S * T);
     const int split = w / T, tile = w - split * T;
     int ta, tb; tile_coords(tile, nt, ta, tb);
     const bool diag = (ta == tb);
@@ -1116,8 +673,8 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
 
-    const int64_t k_begin = (int64_t)split * rows_per_split;
-    const int64_t k_end = (k_begin + rows_per_split < n) ? k_begin + rows_per_split : n;
+    const int64_t k_begin = (int64_t)split * s.rows_per_split;
+    const int64_t k_end = (k_begin + s.rows_per_split < s.n) ? k_begin + s.rows_per_split : s.n;
     const int nkb = (int)((k_end - k_begin + G_KB - 1) / G_KB);
 
     const int sr = tid >> 4, sc4 = (tid & 15) * 4;
@@ -1171,7 +728,7 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
         }
     }
 
-    double* out = partials + ((int64_t)split * T + tile) * G_TS;
+    double* out = static_cast<double*>(s.partials) + ((int64_t)split * T + tile) * G_TS;
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
@@ -1189,7 +746,7 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
             csum[f] += __shfl_xor(csum[f], 32);
         }
         if (lk == 0) {
-            double* cp = colpart + (int64_t)split * (nt * G_BT) + cb + 32 * wc + li;
+            double* cp = s.colpart + (int64_t)split * (nt * G_BT) + cb + 32 * wc + li;
             cp[0] = csum[0]; cp[16] = csum[1];
         }
     }
@@ -1197,7 +754,7 @@ __global__ __launch_bounds__(256) void moments_tile_f64(
 
 // ------------------------------------------------------------------------------------------
 // partials -> packed fp64 accumulator (sum over splits in fp64, fixed order => deterministic).
-// One thread per 4 adjacent columns of one tile row.
+// One thread per 4 adjacent elements of one tile.
 // ------------------------------------------------------------------------------------------
 struct SplitPlan { int nt, T, S; int64_t rows_per_split; };
 
@@ -1206,14 +763,23 @@ struct ReduceSrc {
     const void* partials; const double* colpart;
     int S, T, nt;
     int tile_blocks;      // workgroups that sum tiles; the following ceil(d/256) sum the columns and the row count
-    int layout;           // 0 row major, 1 fragment major (moments_tile_h16_wave)
+    int layout;           // 0 row major, 1 fragment major (the fp16 kernels)
     int sl;               // "split lanes" (1, 4 or 16), see below
 };
+
+// One set of a reduce launch: accumulator += (or =) the sum over splits of ONE of two sources: `prim` when *gate == 0
+// or there is no gate, else `alt` -- the fp64 redo of the block by moments_tile_f64 (shift guard).
+struct ReduceJob {
+    ReduceSrc prim, alt;
+    double* acc; double n_add;
+    const int* gate; int* clear_flag;
+    int overwrite;        // the accumulator was reset since its last update: store instead of add (saves the memset)
+};
+struct ReduceLaunch { ReduceJob job[kMaxSets]; int d; };
 
 // sl "split lanes" share one output group: thread (l, g) sums splits l, l+sl, ... and the sl partial
 // sums are combined through LDS in a fixed order.  With hundreds of row-splits (D = 128 uses every
 // workgroup slot for one tile) a single thread per output would walk all of them serially.
-// overwrite: the accumulator was reset since its last update -- store instead of add (saves the memset).
 template <typename PT, int BT>
 __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* __restrict__ acc_packed, double n_add,
                                             bool overwrite, int block, double* red) {
@@ -1244,7 +810,7 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
         const int e = (int)(g - (int64_t)tile * per_tile);
         if (r.layout == 0) {               // row major: 4 adjacent columns of one row
             a_local = e / (BT / 4); b_local = (e % (BT / 4)) * 4;
-        } else {                           // fragment major (moments_tile_h16_wave): 4 adjacent ROWS of one column
+        } else {                           // fragment major: 4 adjacent ROWS of one column
             const int el = e & 63;
             a_local = 32 * (e >> 10) + 8 * ((e >> 6) & 3) + 4 * (el >> 5);
             b_local = 32 * ((e >> 8) & 3) + (el & 31);
@@ -1252,27 +818,38 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
         constexpr int TS = (sizeof(PT) == 4) ? BT * BT + 64 : BT * BT + 32;      // H_TS / G_TS
         const PT* p = partials + (int64_t)tile * TS + e * 4;
         const int64_t stride = (int64_t)T * TS;
-        int sp = sl;
-        if constexpr (sizeof(PT) == 4) {           // four independent loads in flight per thread
-            for (; sp + 3 * SL < S; sp += 4 * SL) {
-                const float4 v0 = *reinterpret_cast<const float4*>(p + sp * stride);
-                const float4 v1 = *reinterpret_cast<const float4*>(p + (sp + SL) * stride);
-                const float4 v2 = *reinterpret_cast<const float4*>(p + (sp + 2 * SL) * stride);
-                const float4 v3 = *reinterpret_cast<const float4*>(p + (sp + 3 * SL) * stride);
-                s[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-                s[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-                s[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
-                s[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
-            }
+        // "mirror": on a DIAGONAL tile moments_tile_h16_tr splits the k-steps of the block (rows 0..63, columns 64..127)
+        // between two waves; the second half-sum sits in the lower-left slots, 32 x 32 block (fa + 2, fb - 2) =
+        // 6 * 256 float4 further on (zeros when the wave kernel or a presum wrote the tile)
+        int nsrc = 1;
+        if (r.layout == 1) {
+            int ta0, tb0; tile_coords(tile, nt, ta0, tb0);
+            if (ta0 == tb0 && (e >> 10) < 2 && ((e >> 8) & 3) >= 2) nsrc = 2;
         }
-        for (; sp < S; sp += SL) {
-            if constexpr (sizeof(PT) == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
-                s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
-            } else {
-                const double2 v0 = *reinterpret_cast<const double2*>(p + sp * stride);
-                const double2 v1 = *reinterpret_cast<const double2*>(p + sp * stride + 2);
-                s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+        for (int h = 0; h < nsrc; ++h) {
+            const PT* ph = p + h * (6 * 256 * 4);
+            int sp = sl;
+            if constexpr (sizeof(PT) == 4) {           // four independent loads in flight per thread
+                for (; sp + 3 * SL < S; sp += 4 * SL) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(ph + sp * stride);
+                    const float4 v1 = *reinterpret_cast<const float4*>(ph + (sp + SL) * stride);
+                    const float4 v2 = *reinterpret_cast<const float4*>(ph + (sp + 2 * SL) * stride);
+                    const float4 v3 = *reinterpret_cast<const float4*>(ph + (sp + 3 * SL) * stride);
+                    s[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+                    s[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+                    s[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+                    s[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+                }
+            }
+            for (; sp < S; sp += SL) {
+                if constexpr (sizeof(PT) == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(ph + sp * stride);
+                    s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+                } else {
+                    const double2 v0 = *reinterpret_cast<const double2*>(ph + sp * stride);
+                    const double2 v1 = *reinterpret_cast<const double2*>(ph + sp * stride + 2);
+                    s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+                }
             }
         }
     }
@@ -1306,17 +883,19 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
     }
 }
 
-// accumulator += (or =) the sum over splits of ONE of two sources: `prim` (PTA, BTA) when *gate == 0 or there is no
-// gate, else `alt` -- the fp64 redo of the block by moments_tile_f64 (shift guard).  One launch for both cases; the
-// grid is sized for the larger.
+// blockIdx.y = set; the grid's x extent is sized for the largest job.
 template <typename PTA, int BTA>
-__global__ __launch_bounds__(256) void moments_reduce(ReduceSrc prim, ReduceSrc alt, int d, double* __restrict__ acc_packed,
-                                                      double n_add, const int* __restrict__ gate,
-                                                      int* __restrict__ clear_flag, int overwrite) {
+__global__ __launch_bounds__(256) void moments_reduce(ReduceLaunch R) {
     __shared__ double red[256 * 4];
-    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;     // next update's flag
-    if (gate && *gate != 0) reduce_body<double, 64>(alt, d, acc_packed, n_add, overwrite != 0, (int)blockIdx.x, red);
-    else reduce_body<PTA, BTA>(prim, d, acc_packed, n_add, overwrite != 0, (int)blockIdx.x, red);
+    const ReduceJob& j = R.job[blockIdx.y];
+    if (j.clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *j.clear_flag = 0;     // next update's flag
+    const int col_blocks = (R.d + 255) / 256;
+    if (j.gate && *j.gate != 0) {
+        if ((int)blockIdx.x < j.alt.tile_blocks + col_blocks)
+            reduce_body<double, 64>(j.alt, R.d, j.acc, j.n_add, j.overwrite != 0, (int)blockIdx.x, red);
+    } else if ((int)blockIdx.x < j.prim.tile_blocks + col_blocks) {
+        reduce_body<PTA, BTA>(j.prim, R.d, j.acc, j.n_add, j.overwrite != 0, (int)blockIdx.x, red);
+    }
 }
 
 // Stage 1 of the two-level reduce used when an update produced hundreds or thousands of partial tiles (long inputs
@@ -1376,31 +955,87 @@ static ReduceSrc reduce_src(const void* part, const double* colp, const SplitPla
     return r;
 }
 
-// prim: the update's own partials; alt (optional, with `gate`): the fp64 redo made by the shift guard
-template <typename PT, int BT>
-static void launch_reduce(const ReduceSrc& prim, const ReduceSrc* alt, int d, double* acc, double n_add, const int* gate,
-                          int* clear_flag, bool overwrite, hipStream_t st) {
-    const int col_blocks = (int)cdiv(d, 256);
-    int blocks = prim.tile_blocks + col_blocks;
-    if (alt && alt->tile_blocks + col_blocks > blocks) blocks = alt->tile_blocks + col_blocks;
-    hipLaunchKernelGGL((moments_reduce<PT, BT>), dim3((unsigned)blocks), dim3(256), 0, st, prim, alt ? *alt : prim, d, acc,
-                       n_add, alt ? gate : nullptr, clear_flag, overwrite ? 1 : 0);
+// ------------------------------------------------------------------------------------------
+// Per-segment column sums (files / songs stored back to back): seg_sums[s][a] = sum over the rows of segment s of
+// E[r][a], fp64.  Two stages, deterministic: every "piece" (<= SEG_PIECE rows of ONE segment) is summed by one
+// workgroup whose threads each own 8 adjacent columns (16-byte loads of fp16 rows) of every (256 / lanes-per-row)-th
+// row; then one thread per (segment, column) adds that segment's pieces in order.  Short segments are single
+// pieces; a 2250-row file (config 4) is 9 pieces, so a batch of 64 files already fills the chip.
+// ------------------------------------------------------------------------------------------
+constexpr int SEG_PIECE = 256;
+struct SegPiece { int64_t r0; int rows; int seg; };
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void segment_piece_sums(
+    const TIn* __restrict__ E, int64_t ld, int d, const SegPiece* __restrict__ pieces, double* __restrict__ piece_sums) {
+    __shared__ double red[256 * 8];
+    const SegPiece pc = pieces[blockIdx.x];
+    const int cg = (d + 7) / 8;                    // column groups of 8
+    const int tid = threadIdx.x;
+    for (int g0 = 0; g0 < cg; g0 += 256) {         // d <= 2048: one pass
+        const int lanes = (cg - g0 < 256) ? cg - g0 : 256;          // threads that own a column group
+        const int rpi = 256 / lanes;                                // rows handled per iteration
+        const int g = g0 + tid % lanes, rl = tid / lanes;
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (rl < rpi) {
+            for (int r = rl; r < pc.rows; r += rpi) {
+                const TIn* p = E + (pc.r0 + r) * ld + g * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (g * 8 + q < d) s[q] += to_f64<TIn>(p[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[tid * 8 + q] = s[q];
+        __syncthreads();
+        if (tid < lanes) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double t = 0.0;
+                for (int l = 0; l < rpi; ++l) t += red[(l * lanes + tid) * 8 + q];
+                if (g * 8 + q < d) piece_sums[(int64_t)blockIdx.x * d + g * 8 + q] = t;
+            }
+        }
+        __syncthreads();
+    }
 }
 
-// per-segment column sums: seg_sums[s][a] = sum over rows of segment s of E[r][a]   (fp64)
-template <typename TIn>
-__global__ __launch_bounds__(128) void segment_colsums(
-    const TIn* __restrict__ E, int64_t ld, int d, const int64_t* __restrict__ offsets,
-    double* __restrict__ seg_sums) {
+__global__ __launch_bounds__(128) void segment_gather_sums(const double* __restrict__ piece_sums,
+                                                           const int64_t* __restrict__ seg_first_piece, int d,
+                                                           double* __restrict__ seg_sums) {
     const int64_t seg = blockIdx.x;
     const int a = blockIdx.y * 128 + threadIdx.x;
     if (a >= d) return;
-    const int64_t r0 = offsets[seg], r1 = offsets[seg + 1];
-    double s0 = 0.0, s1 = 0.0;
-    int64_t r = r0;
-    for (; r + 1 < r1; r += 2) { s0 += to_f64<TIn>(E[r * ld + a]); s1 += to_f64<TIn>(E[(r + 1) * ld + a]); }
-    if (r < r1) s0 += to_f64<TIn>(E[r * ld + a]);
-    seg_sums[seg * d + a] = s0 + s1;
+    double t = 0.0;
+    for (int64_t p = seg_first_piece[seg]; p < seg_first_piece[seg + 1]; ++p) t += piece_sums[p * d + a];
+    seg_sums[seg * d + a] = t;
+}
+
+// Per-file mean rows of the online statistics (fadtk/utils.py:16, 36-40), see fad_moments_update_file_means:
+// exact[f] = sqrt(n_f) m_f, rounded[f] = sqrt(n_f) m~_f (m~ = the mean as np.mean returns it for `dtype`),
+// weighted[f] = n_f m~_f; empty files give zero rows.
+template <int DT>
+__device__ __forceinline__ double round_mean_like(double v) {
+    if constexpr (DT == FAD_F16) return (double)(float)(_Float16)(float)v;
+    else if constexpr (DT == FAD_BF16) {
+        uint32_t u = __float_as_uint((float)v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (double)__uint_as_float(u & 0xffff0000u);
+    } else if constexpr (DT == FAD_F32) return (double)(float)v;
+    else return v;
+}
+template <int DT>
+__global__ __launch_bounds__(256) void file_mean_rows(const double* __restrict__ seg_sums, const int64_t* __restrict__ sizes,
+                                                      int64_t n_files, int d, double* __restrict__ exact,
+                                                      double* __restrict__ rounded, double* __restrict__ weighted) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_files * d) return;
+    const int64_t f = g / d;
+    const double n = (double)sizes[f];
+    double m = 0.0, mr = 0.0;
+    if (n > 0.0) { m = seg_sums[g] / n; mr = round_mean_like<DT>(m); }
+    const double rt = sqrt(n);
+    exact[g] = rt * m; rounded[g] = rt * mr; weighted[g] = n * mr;
 }
 
 __global__ __launch_bounds__(256) void packed_axpy(double* __restrict__ dst, const double* __restrict__ src,
@@ -1432,12 +1067,14 @@ struct fad_moments {
     int d = 0, device = 0;
     double* acc = nullptr;                 // packed [1 + d + d*d]
     bool owns_acc = true;                  // false after fad_moments_bind: the caller's buffer
-    fad::DevBuf partials, colpart, stage, seg_off, seg_out, scratch;
+    fad::DevBuf partials, colpart, stage, seg_tab, seg_piece, seg_out, scratch;
     fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
     int* shift_flag = nullptr;             // device int[2], ping-pong between updates
     unsigned update_seq = 0;
-    int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0)
+    int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0, read at creation)
+    int force_variant = 0;                 // FAD_MOMENTS_VARIANT=4|8 (read at creation): pin the fp16 tile kernel
+    bool force_generic = false;            // FAD_MOMENTS_FORCE_GENERIC=1 (read at creation): always the fp64 kernel
     bool fresh = false;                    // reset since the last update: the next reduce stores instead of adding
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
     // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
@@ -1446,6 +1083,7 @@ struct fad_moments {
     hipEvent_t* ev = nullptr;              // [kRing][3]
     int ev_count = 0;                      // entries recorded since the last query
     int last_variant = -1;                 // 0: h16 MFMA tile kernel, 1: generic fp64 kernel
+    int last_sets = 1;                     // frame matrices the last timed launch covered
     int n_cu = 256;
 };
 
@@ -1466,207 +1104,250 @@ void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 static int64_t packed_len(int d) { return 1 + (int64_t)d + (int64_t)d * d; }
 
+// The dynamic-LDS limit of the fp16 tile kernels is a per-device function attribute: set it once per device,
+// under a lock (two host threads may make their first update on different GPUs at the same time).
+typedef void (*tile_kernel_t)(TileLaunch);
+static tile_kernel_t tr_kernel(int dtype, bool fast) {
+    if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, H_NST, false>;
+    return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, H_NST, false>;
+}
+static tile_kernel_t wave_kernel(int dtype) {
+    return dtype == FAD_F16 ? &moments_tile_h16_wave<FAD_F16> : &moments_tile_h16_wave<FAD_BF16>;
+}
+constexpr size_t kTrLds = (size_t)H_NST * 2 * H_KB * 16 * sizeof(uint4);
+static int ensure_kernel_attrs(int device) {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return set_error(FAD_ERR_INVALID, "device %d out of range", device);
+    if (done[device]) return FAD_OK;
+    for (int dt : {FAD_F16, FAD_BF16}) {
+        for (bool fast : {false, true})
+            FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
+        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wave_kernel(dt)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    }
+    done[device] = true;
+    return FAD_OK;
+}
 
-// max_rows bounds the run of rows one workgroup sums in fp32 (0 = unbounded).  The MFMA accumulate error is
-// systematic (it behaves like truncation): measured -3.5e-7 relative at 32768 rows per run, ~1e-8 per 1000 rows,
-// so runs are capped at 8192 rows and long inputs simply use more splits than resident slots.
-static SplitPlan plan_splits(int64_t n, int d, int bt, int kb, int n_cu, int wg_per_cu, int64_t min_rows,
-                             int64_t max_rows = 0) {
-    SplitPlan p;
-    p.nt = (int)cdiv(d, bt);
-    p.T = p.nt * (p.nt + 1) / 2;
-    int64_t want = ((int64_t)n_cu * wg_per_cu) / p.T;      // floor: never more workgroups than resident slots
-    int64_t max_by_rows = cdiv(n, min_rows);
-    int64_t s = want < max_by_rows ? want : max_by_rows;
-    if (s < 1) s = 1;
-    if (max_rows > 0 && cdiv(n, s) > max_rows) s = cdiv(n, max_rows);
-    int64_t rps = cdiv(cdiv(n, s), kb) * kb;
-    p.rows_per_split = rps;
-    p.S = (int)cdiv(n, rps);
-    return p;
+// Split plan of one launch over `count` frame matrices of n[i] rows: every workgroup sums a run of `r` rows of one
+// tile of one set, the same r for all sets.  r is the SMALLEST run (multiple of kb, >= min_rows) for which the work
+// items fit into R "rounds" of the resident workgroup slots (n_cu * wg_per_cu), R being the number of rounds the
+// longest allowed run needs -- one, unless max_rows forces more items than slots: then the items are sized to fill R
+// whole rounds instead of leaving a nearly empty last one (4 x [100k x 512]: 520 items at r = 8192 took two rounds of
+// 8192 rows; 1000 items of 4000 rows take two rounds of 4000).
+// max_rows bounds the run of rows one workgroup sums in fp32 (0 = unbounded): the MFMA accumulate error is systematic
+// (it behaves like truncation): measured -3.5e-7 relative at 32768 rows per run, ~1e-8 per 1000 rows, so runs are
+// capped at 8192 rows and long inputs simply use more splits than resident slots.
+static void plan_splits(int count, const int64_t* n, int d, int bt, int kb, int n_cu, int wg_per_cu, int64_t min_rows,
+                        int64_t max_rows, SplitPlan* out) {
+    const int nt = (int)cdiv(d, bt), T = nt * (nt + 1) / 2;
+    const int64_t slots = (int64_t)n_cu * wg_per_cu;
+    int64_t total = 0, longest = 1;
+    for (int i = 0; i < count; ++i) { total += n[i]; if (n[i] > longest) longest = n[i]; }
+    auto items = [&](int64_t r) { int64_t w = 0; for (int i = 0; i < count; ++i) w += cdiv(n[i], r); return w * T; };
+    int64_t r_cap = cdiv((max_rows > 0 && max_rows < longest) ? max_rows : longest, kb) * kb;
+    if (max_rows > 0 && r_cap > max_rows) r_cap = (max_rows / kb) * kb;
+    if (r_cap < kb) r_cap = kb;
+    const int64_t rounds = cdiv(items(r_cap), slots);
+    int64_t r = cdiv(cdiv(total * T, rounds * slots), kb) * kb;
+    const int64_t r_min = cdiv(min_rows, kb) * kb;
+    if (r < r_min) r = r_min;
+    while (r < r_cap && items(r) > rounds * slots) r += kb;
+    if (r > r_cap) r = r_cap;
+    for (int i = 0; i < count; ++i) {
+        out[i].nt = nt; out[i].T = T;
+        out[i].rows_per_split = r;
+        out[i].S = (int)cdiv(n[i], r);
+        if (out[i].S < 1) out[i].S = 1;
+    }
+}
+
+static int timing_events(fad_moments* h, hipEvent_t** ev) {
+    *ev = nullptr;
+    if (!h->timing) return FAD_OK;
+    if (!h->ev) {
+        h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3];
+        if (!h->ev) return set_error(FAD_ERR_ALLOC, "out of host memory");
+        for (int i = 0; i < fad_moments::kRing * 3; ++i) FAD_HIP_TRY(hipEventCreate(&h->ev[i]));
+    }
+    *ev = h->ev + 3 * (h->ev_count % fad_moments::kRing);
+    h->ev_count++;
+    return FAD_OK;
 }
 
 template <typename TIn>
-static void launch_generic(const void* rows, int64_t n, int64_t ld, int d, const SplitPlan& p,
-                           double* partials, double* colpart, hipStream_t st, const int* gate = nullptr) {
-    hipLaunchKernelGGL((moments_tile_f64<TIn>), dim3(p.S * p.T), dim3(256), 0, st,
-                       reinterpret_cast<const TIn*>(rows), n, ld, d, p.nt, p.T, p.S, p.rows_per_split,
-                       partials, colpart, gate);
+static void launch_generic(const TileLaunch& L, int max_items, hipStream_t st) {
+    hipLaunchKernelGGL((moments_tile_f64<TIn>), dim3((unsigned)max_items, (unsigned)L.nsets), dim3(256), 0, st, L);
+}
+static int launch_generic_dtype(const TileLaunch& L, int max_items, int dtype, hipStream_t st) {
+    switch (dtype) {
+        case FAD_F16: launch_generic<raw_f16>(L, max_items, st); break;
+        case FAD_BF16: launch_generic<raw_bf16>(L, max_items, st); break;
+        case FAD_F32: launch_generic<float>(L, max_items, st); break;
+        case FAD_F64: launch_generic<double>(L, max_items, st); break;
+        default: return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+    }
+    return FAD_OK;
 }
 
-// rows must be a DEVICE pointer here.
-static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld, int dtype, hipStream_t st) {
-    const int d = h->d;
+// One pass over `count` frame matrices (DEVICE pointers), all of the handles' dimension, dtype and device:
+// tile kernel (one launch for all sets) -> gated fp64 redo (one launch) -> reduce (one launch).
+static int update_device_multi(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n,
+                               const int64_t* ld, int dtype, hipStream_t st) {
+    fad_moments* h0 = hs[0];
+    const int d = h0->d;
     const bool is16 = (dtype == FAD_F16 || dtype == FAD_BF16);
-    const bool aligned = is16 && (d % 8 == 0) && (ld % 8 == 0) &&
-                         ((reinterpret_cast<uintptr_t>(rows) & 15u) == 0);
-    const char* force = getenv("FAD_MOMENTS_FORCE_GENERIC");
-    const bool use_h16 = aligned && !(force && force[0] == '1');
+    bool aligned = is16 && (d % 8 == 0);
+    for (int i = 0; i < count && aligned; ++i)
+        aligned = (ld[i] % 8 == 0) && ((reinterpret_cast<uintptr_t>(rows[i]) & 15u) == 0);
+    const bool use_h16 = aligned && !h0->force_generic;
 
     hipEvent_t* ev = nullptr;
-    if (h->timing) {
-        if (!h->ev) {
-            h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3];
-            if (!h->ev) return set_error(FAD_ERR_ALLOC, "out of host memory");
-            for (int i = 0; i < fad_moments::kRing * 3; ++i) FAD_HIP_TRY(hipEventCreate(&h->ev[i]));
-        }
-        ev = h->ev + 3 * (h->ev_count % fad_moments::kRing);
-        h->ev_count++;
-    }
+    FAD_TRY(timing_events(h0, &ev));
+    h0->last_sets = count;
+    SplitPlan plan[kMaxSets];
+    ReduceLaunch R;
+    memset(&R, 0, sizeof(R));
+    R.d = d;
     if (use_h16) {
-        const char* var = getenv("FAD_MOMENTS_VARIANT");
-        // default: v4; the one-tile-per-wave kernel (v8) wins on the HBM-bound single-tile shape (16.8M x 128: 0.80 vs
-        // 0.91 ms) and loses at D = 512 (62 vs 51 us), see DESIGN.md section 4
-        int variant = (var && var[0] >= '1' && var[0] <= '8') ? (var[0] - '0') : ((d <= H_BT && n >= (1 << 22)) ? 8 : 4);
-        if (variant >= 5 && variant <= 7) variant = 4;        // 5..7 were experiments, gone
-#ifndef FAD_MOM_NST
-#define FAD_MOM_NST 4
-#endif
-#ifndef FAD_MOM_WGPCU
-#define FAD_MOM_WGPCU 2        // workgroups per CU the split plan of v4 aims for (probe knob; 3 needs NST = 3)
-#endif
-        constexpr int NST = FAD_MOM_NST;         // LDS ring depth (stages); a build-time knob for scripts/probe_ablate.py
-        // v8: one workgroup per CU, each wave sums at most 8192 rows in fp32 (4 waves per split)
-        SplitPlan p = (variant == 8) ? plan_splits(n, d, H_BT, 64, h->n_cu, 1, 256, 4 * 8192)
-                                     : plan_splits(n, d, H_BT, H_KB, h->n_cu, FAD_MOM_WGPCU, 256, 8192);
-        const int layout = (variant == 8 || variant == 4) ? 1 : 0;      // fragment-major partial tiles
-        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
-        FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
-        float* part = static_cast<float*>(h->partials.p);
-        double* colp = static_cast<double*>(h->colpart.p);
+        FAD_TRY(ensure_kernel_attrs(h0->device));
+        int64_t total_rows = 0;
+        for (int i = 0; i < count; ++i) total_rows += n[i];
+        // default: the 4-wave kernel; the one-tile-per-wave kernel wins on the HBM-bound single-tile shape (16.8M x 128:
+        // 0.80 vs 0.91 ms) and loses at D = 512 (62 vs 51 us), see DESIGN.md section 4
+        int variant = h0->force_variant ? h0->force_variant : ((d <= H_BT && total_rows >= (1 << 22)) ? 8 : 4);
+        // wave kernel: one workgroup per CU, each wave sums at most 8192 rows in fp32 (4 waves per split)
+        if (variant == 8) plan_splits(count, n, d, H_BT, 64, h0->n_cu, 1, 256, 4 * 8192, plan);
+        else plan_splits(count, n, d, H_BT, H_KB, h0->n_cu, 2, 256, 8192, plan);
+        TileLaunch L;
+        memset(&L, 0, sizeof(L));
+        L.nsets = count; L.d = d; L.nt = plan[0].nt; L.T = plan[0].T;
+        int item = 0, max_s = 0;
+        for (int i = 0; i < count; ++i) {
+            fad_moments* h = hs[i];
+            const SplitPlan& p = plan[i];
+            FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
+            FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
+            TileSet& s = L.set[i];
+            s.E = rows[i]; s.n = n[i]; s.ld = ld[i]; s.rows_per_split = p.rows_per_split; s.S = p.S; s.item0 = item;
+            s.partials = h->partials.p; s.colpart = static_cast<double*>(h->colpart.p);
+            s.flag = nullptr;
+            if (h->guard) {
+                s.flag = h->shift_flag + (h->update_seq & 1u);
+                R.job[i].clear_flag = h->shift_flag + ((h->update_seq + 1u) & 1u);
+                h->update_seq++;
+            }
+            item += p.S * p.T;
+            if (p.S > max_s) max_s = p.S;
+        }
+        L.total = item;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-        const uint16_t* e16 = static_cast<const uint16_t*>(rows);
-        int* flag_now = nullptr; int* flag_next = nullptr;
-        if (h->guard && variant != 1) {
-            flag_now = h->shift_flag + (h->update_seq & 1u);
-            flag_next = h->shift_flag + ((h->update_seq + 1u) & 1u);
-            h->update_seq++;
-        }
-        if (variant == 8) {
-            static bool attr8 = false;
-            if (!attr8) {
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_wave<FAD_F16>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_wave<FAD_BF16>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
-                attr8 = true;
-            }
-            if (dtype == FAD_F16)
-                hipLaunchKernelGGL((moments_tile_h16_wave<FAD_F16>), dim3(p.S * p.T), dim3(256), W_LDS, st, e16, n, ld, d, p.nt,
-                                   p.T, p.S, p.rows_per_split, part, colp, flag_now);
-            else
-                hipLaunchKernelGGL((moments_tile_h16_wave<FAD_BF16>), dim3(p.S * p.T), dim3(256), W_LDS, st, e16, n, ld, d, p.nt,
-                                   p.T, p.S, p.rows_per_split, part, colp, flag_now);
-        } else if (variant == 3) {
-            const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
-            static bool attr3 = false;
-            if (!attr3) {
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_w2<FAD_F16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_w2<FAD_BF16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr3 = true;
-            }
-            if (dtype == FAD_F16)
-                hipLaunchKernelGGL((moments_tile_h16_w2<FAD_F16, NST>), dim3(p.S * p.T), dim3(128), lds, st, e16, n, ld, d,
-                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-            else
-                hipLaunchKernelGGL((moments_tile_h16_w2<FAD_BF16, NST>), dim3(p.S * p.T), dim3(128), lds, st, e16, n, ld, d,
-                                   p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-        } else if (variant == 4) {
-            const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
-            typedef void (*tr_kernel_t)(const uint16_t*, int64_t, int64_t, int, int, int, int, int64_t, float*, double*, int*);
-            static const tr_kernel_t kern[2][2] = {
-                {&moments_tile_h16_tr<FAD_F16, NST, false>, &moments_tile_h16_tr<FAD_F16, NST, true>},
-                {&moments_tile_h16_tr<FAD_BF16, NST, false>, &moments_tile_h16_tr<FAD_BF16, NST, true>}};
-            static bool attr4 = false;
-            if (!attr4) {
-                for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 2; ++b)
-                        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern[a][b]),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr4 = true;
-            }
-            hipLaunchKernelGGL(kern[dtype == FAD_F16 ? 0 : 1][p.T > 1 ? 1 : 0], dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld,
-                               d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-        } else if (variant == 2) {
-            const size_t lds = (size_t)NST * 2 * H_KB * 16 * sizeof(uint4);
-            static bool attr_set = false;
-            if (!attr_set) {
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_glds<FAD_F16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile_h16_glds<FAD_BF16, NST>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
-            }
-            if (dtype == FAD_F16)
-                hipLaunchKernelGGL((moments_tile_h16_glds<FAD_F16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n, ld,
-                                   d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-            else
-                hipLaunchKernelGGL((moments_tile_h16_glds<FAD_BF16, NST>), dim3(p.S * p.T), dim3(256), lds, st, e16, n,
-                                   ld, d, p.nt, p.T, p.S, p.rows_per_split, part, colp, flag_now);
-        } else if (dtype == FAD_F16) {
-            hipLaunchKernelGGL((moments_tile_h16<FAD_F16>), dim3(p.S * p.T), dim3(256), 0, st, e16, n, ld, d, p.nt, p.T,
-                               p.S, p.rows_per_split, part, colp);
-        } else {
-            hipLaunchKernelGGL((moments_tile_h16<FAD_BF16>), dim3(p.S * p.T), dim3(256), 0, st, e16, n, ld, d, p.nt, p.T,
-                               p.S, p.rows_per_split, part, colp);
-        }
+        if (variant == 8)
+            hipLaunchKernelGGL(wave_kernel(dtype), dim3((unsigned)L.total), dim3(256), W_LDS, st, L);
+        else
+            hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
-        ReduceSrc alt; const ReduceSrc* altp = nullptr;
-        if (flag_now) {
-            SplitPlan q = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
-            FAD_TRY(h->partials64.reserve((size_t)q.S * q.T * G_TS * sizeof(double)));
-            FAD_TRY(h->colpart64.reserve((size_t)q.S * q.nt * G_BT * sizeof(double)));
-            double* part64 = static_cast<double*>(h->partials64.p);
-            double* colp64 = static_cast<double*>(h->colpart64.p);
-            if (dtype == FAD_F16) launch_generic<raw_f16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
-            else launch_generic<raw_bf16>(rows, n, ld, d, q, part64, colp64, st, flag_now);
-            alt = reduce_src(part64, colp64, q, G_BT, 0);
-            altp = &alt;
+
+        // shift guard: exact fp64 redo of every flagged set, one gated launch for all of them
+        bool any_guard = false;
+        TileLaunch G;
+        memset(&G, 0, sizeof(G));
+        G.nsets = count; G.d = d;
+        SplitPlan q[kMaxSets];
+        int max_items64 = 0;
+        for (int i = 0; i < count; ++i) any_guard = any_guard || (L.set[i].flag != nullptr);
+        if (any_guard) {
+            plan_splits(count, n, d, G_BT, G_KB, h0->n_cu, 2, 128, 0, q);
+            G.nt = q[0].nt; G.T = q[0].T;
+            for (int i = 0; i < count; ++i) {
+                fad_moments* h = hs[i];
+                FAD_TRY(h->partials64.reserve((size_t)q[i].S * q[i].T * G_TS * sizeof(double)));
+                FAD_TRY(h->colpart64.reserve((size_t)q[i].S * q[i].nt * G_BT * sizeof(double)));
+                TileSet& s = G.set[i];
+                s = L.set[i];
+                s.rows_per_split = q[i].rows_per_split; s.S = L.set[i].flag ? q[i].S : 0; s.item0 = 0;
+                s.partials = h->partials64.p; s.colpart = static_cast<double*>(h->colpart64.p);
+                if (s.S * G.T > max_items64) max_items64 = s.S * G.T;
+                R.job[i].alt = reduce_src(h->partials64.p, s.colpart, q[i], G_BT, 0);
+                R.job[i].gate = L.set[i].flag;
+            }
+            FAD_TRY(launch_generic_dtype(G, max_items64, dtype, st));
         }
-        const bool overwrite = h->fresh;
-        if (p.S > 128) {                   // two-level: S -> ceil(S/32) fp64 partials -> accumulator
-            SplitPlan p2 = p;
-            p2.S = (int)cdiv(p.S, PRESUM_CHUNK);
-            FAD_TRY(h->presum.reserve((size_t)p2.S * p.T * (H_BT * H_BT + 32) * sizeof(double)));
-            FAD_TRY(h->presum_col.reserve((size_t)p2.S * p.nt * H_BT * sizeof(double)));
-            double* ps = static_cast<double*>(h->presum.p);
-            double* pc = static_cast<double*>(h->presum_col.p);
-            const int gb = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
-            hipLaunchKernelGGL((moments_presum<H_BT>), dim3((unsigned)(gb + cdiv(p.nt * H_BT, 256)), (unsigned)p2.S), dim3(256),
-                               0, st, part, colp, p.S, p.T, p.nt, gb, ps, pc, (const int*)flag_now);
-            launch_reduce<double, H_BT>(reduce_src(ps, pc, p2, H_BT, layout), altp, d, h->acc, (double)n, flag_now, flag_next,
-                                        overwrite, st);
-        } else {
-            launch_reduce<float, H_BT>(reduce_src(part, colp, p, H_BT, layout), altp, d, h->acc, (double)n, flag_now, flag_next,
-                                       overwrite, st);
+        // reduce: two-level when any set made more than 128 splits (S -> ceil(S/32) fp64 partials -> accumulator)
+        const bool two_level = max_s > 128;
+        int max_blocks = 0;
+        const int col_blocks = (int)cdiv(d, 256);
+        for (int i = 0; i < count; ++i) {
+            fad_moments* h = hs[i];
+            const SplitPlan& p = plan[i];
+            ReduceJob& j = R.job[i];
+            float* part = static_cast<float*>(h->partials.p);
+            double* colp = static_cast<double*>(h->colpart.p);
+            if (two_level) {
+                SplitPlan p2 = p;
+                p2.S = (int)cdiv(p.S, PRESUM_CHUNK);
+                FAD_TRY(h->presum.reserve((size_t)p2.S * p.T * (H_BT * H_BT + 32) * sizeof(double)));
+                FAD_TRY(h->presum_col.reserve((size_t)p2.S * p.nt * H_BT * sizeof(double)));
+                double* ps = static_cast<double*>(h->presum.p);
+                double* pc = static_cast<double*>(h->presum_col.p);
+                const int gb = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
+                hipLaunchKernelGGL((moments_presum<H_BT>), dim3((unsigned)(gb + cdiv(p.nt * H_BT, 256)), (unsigned)p2.S), dim3(256),
+                                   0, st, part, colp, p.S, p.T, p.nt, gb, ps, pc, (const int*)L.set[i].flag);
+                j.prim = reduce_src(ps, pc, p2, H_BT, 1);
+            } else {
+                j.prim = reduce_src(part, colp, p, H_BT, 1);
+            }
+            if (!j.gate) j.alt = j.prim;
+            j.acc = h->acc; j.n_add = (double)n[i]; j.overwrite = h->fresh ? 1 : 0;
+            h->fresh = false;
+            int blocks = j.prim.tile_blocks + col_blocks;
+            if (j.gate && j.alt.tile_blocks + col_blocks > blocks) blocks = j.alt.tile_blocks + col_blocks;
+            if (blocks > max_blocks) max_blocks = blocks;
+            h->last_variant = 0;
         }
-        h->fresh = false;
+        if (two_level) hipLaunchKernelGGL((moments_reduce<double, H_BT>), dim3((unsigned)max_blocks, (unsigned)count), dim3(256), 0, st, R);
+        else hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)max_blocks, (unsigned)count), dim3(256), 0, st, R);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
-        h->last_variant = (variant == 1) ? 2 : 0;
     } else {
-        SplitPlan p = plan_splits(n, d, G_BT, G_KB, h->n_cu, 2, 128);
-        FAD_TRY(h->partials.reserve((size_t)p.S * p.T * G_TS * sizeof(double)));
-        FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * G_BT * sizeof(double)));
-        double* part = static_cast<double*>(h->partials.p);
-        double* colp = static_cast<double*>(h->colpart.p);
-        if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-        switch (dtype) {
-            case FAD_F16: launch_generic<raw_f16>(rows, n, ld, d, p, part, colp, st); break;
-            case FAD_BF16: launch_generic<raw_bf16>(rows, n, ld, d, p, part, colp, st); break;
-            case FAD_F32: launch_generic<float>(rows, n, ld, d, p, part, colp, st); break;
-            case FAD_F64: launch_generic<double>(rows, n, ld, d, p, part, colp, st); break;
-            default: return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+        plan_splits(count, n, d, G_BT, G_KB, h0->n_cu, 2, 128, 0, plan);
+        TileLaunch L;
+        memset(&L, 0, sizeof(L));
+        L.nsets = count; L.d = d; L.nt = plan[0].nt; L.T = plan[0].T;
+        int max_items = 0, max_blocks = 0;
+        const int col_blocks = (int)cdiv(d, 256);
+        for (int i = 0; i < count; ++i) {
+            fad_moments* h = hs[i];
+            const SplitPlan& p = plan[i];
+            FAD_TRY(h->partials.reserve((size_t)p.S * p.T * G_TS * sizeof(double)));
+            FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * G_BT * sizeof(double)));
+            TileSet& s = L.set[i];
+            s.E = rows[i]; s.n = n[i]; s.ld = ld[i]; s.rows_per_split = p.rows_per_split; s.S = p.S; s.item0 = 0;
+            s.partials = h->partials.p; s.colpart = static_cast<double*>(h->colpart.p); s.flag = nullptr;
+            if (p.S * p.T > max_items) max_items = p.S * p.T;
+            ReduceJob& j = R.job[i];
+            j.prim = reduce_src(s.partials, s.colpart, p, G_BT, 0);
+            j.alt = j.prim;
+            j.acc = h->acc; j.n_add = (double)n[i]; j.overwrite = h->fresh ? 1 : 0;
+            h->fresh = false;
+            if (j.prim.tile_blocks + col_blocks > max_blocks) max_blocks = j.prim.tile_blocks + col_blocks;
+            h->last_variant = 1;
         }
+        L.total = max_items;
+        if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
+        FAD_TRY(launch_generic_dtype(L, max_items, dtype, st));
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
-        launch_reduce<double, G_BT>(reduce_src(part, colp, p, G_BT, 0), nullptr, d, h->acc, (double)n, nullptr, nullptr, h->fresh, st);
-        h->fresh = false;
+        hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)max_blocks, (unsigned)count), dim3(256), 0, st, R);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
-        h->last_variant = 1;
     }
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
+}
+
+static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld, int dtype, hipStream_t st) {
+    return update_device_multi(1, &h, &rows, &n, &ld, dtype, st);
 }
 
 // Host rows -> staged through h->stage in bounded chunks (PCIe), then update_device.
@@ -1688,6 +1369,50 @@ static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, i
         // the staging buffer is reused by the next chunk: wait for the kernels that read it
         if (r0 + m < n) FAD_HIP_TRY(hipStreamSynchronize(st));
     }
+    return FAD_OK;
+}
+
+// Per-segment column sums of DEVICE rows into a DEVICE buffer [n_segments x d] (offsets: host).
+static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int dtype, const int64_t* offsets,
+                               int64_t n_segments, double* dout, hipStream_t st) {
+    const int d = h->d;
+    int64_t n_pieces = 0;
+    for (int64_t s = 0; s < n_segments; ++s) n_pieces += cdiv(offsets[s + 1] - offsets[s], SEG_PIECE);
+    // host table: [n_segments + 1] first piece of each segment, then the pieces
+    const size_t tab_bytes = (size_t)(n_segments + 1) * sizeof(int64_t) + (size_t)n_pieces * sizeof(SegPiece);
+    std::unique_ptr<char[]> tab(new (std::nothrow) char[tab_bytes]);
+    if (!tab) return set_error(FAD_ERR_ALLOC, "out of host memory");
+    int64_t* first = reinterpret_cast<int64_t*>(tab.get());
+    SegPiece* pieces = reinterpret_cast<SegPiece*>(first + n_segments + 1);
+    int64_t np = 0;
+    for (int64_t s = 0; s < n_segments; ++s) {
+        first[s] = np;
+        for (int64_t r = offsets[s]; r < offsets[s + 1]; r += SEG_PIECE) {
+            const int64_t m = offsets[s + 1] - r;
+            pieces[np].r0 = r; pieces[np].rows = (int)(m < SEG_PIECE ? m : SEG_PIECE); pieces[np].seg = (int)s;
+            ++np;
+        }
+    }
+    first[n_segments] = np;
+    FAD_TRY(h->seg_tab.reserve(tab_bytes));
+    FAD_HIP_TRY(hipMemcpyAsync(h->seg_tab.p, tab.get(), tab_bytes, hipMemcpyHostToDevice, st));
+    FAD_HIP_TRY(hipStreamSynchronize(st));         // the host table goes out of scope (pageable copy)
+    const int64_t* dfirst = static_cast<const int64_t*>(h->seg_tab.p);
+    const SegPiece* dpieces = reinterpret_cast<const SegPiece*>(dfirst + n_segments + 1);
+    if (n_pieces > 0) {
+        FAD_TRY(h->seg_piece.reserve((size_t)n_pieces * d * sizeof(double)));
+        double* ps = static_cast<double*>(h->seg_piece.p);
+        const dim3 grid((unsigned)n_pieces);
+        switch (dtype) {
+            case FAD_F16: hipLaunchKernelGGL((segment_piece_sums<raw_f16>), grid, dim3(256), 0, st, static_cast<const raw_f16*>(rows), ld, d, dpieces, ps); break;
+            case FAD_BF16: hipLaunchKernelGGL((segment_piece_sums<raw_bf16>), grid, dim3(256), 0, st, static_cast<const raw_bf16*>(rows), ld, d, dpieces, ps); break;
+            case FAD_F32: hipLaunchKernelGGL((segment_piece_sums<float>), grid, dim3(256), 0, st, static_cast<const float*>(rows), ld, d, dpieces, ps); break;
+            default: hipLaunchKernelGGL((segment_piece_sums<double>), grid, dim3(256), 0, st, static_cast<const double*>(rows), ld, d, dpieces, ps); break;
+        }
+    }
+    hipLaunchKernelGGL(segment_gather_sums, dim3((unsigned)n_segments, (unsigned)cdiv(d, 128)), dim3(128), 0, st,
+                       static_cast<const double*>(h->seg_piece.p), dfirst, d, dout);
+    FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
 }
 
@@ -1717,8 +1442,13 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
         (void)hipFree(h->acc); delete h;
         return set_error(FAD_ERR_HIP, "hipMemset / hipMalloc failed");
     }
+    // the knobs are read once, here: nothing on the update path calls getenv
     const char* gs = getenv("FAD_MOMENTS_SHIFT_GUARD");
     h->guard = !(gs && gs[0] == '0');
+    const char* var = getenv("FAD_MOMENTS_VARIANT");
+    h->force_variant = (var && (var[0] == '4' || var[0] == '8')) ? (var[0] - '0') : 0;
+    const char* fg = getenv("FAD_MOMENTS_FORCE_GENERIC");
+    h->force_generic = fg && fg[0] == '1';
     *out = h;
     return FAD_OK;
 }
@@ -1730,7 +1460,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     if (h->shift_flag) (void)hipFree(h->shift_flag);
     h->partials64.release(); h->colpart64.release(); h->presum.release(); h->presum_col.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
-    h->seg_off.release(); h->seg_out.release(); h->scratch.release();
+    h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release();
     if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
     delete h;
     return FAD_OK;
@@ -1780,6 +1510,31 @@ int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld
     return update_any(h, rows, n, ld, dtype, on_device, static_cast<hipStream_t>(stream));
 }
 
+int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* const* rows, const int64_t* n,
+                             const int64_t* ld, int dtype, void* stream) {
+    if (count < 1 || count > kMaxSets) return set_error(FAD_ERR_INVALID, "count=%d out of range [1, %d]", count, kMaxSets);
+    if (!hs || !rows || !n || !ld) return set_error(FAD_ERR_INVALID, "NULL argument");
+    if (dtype_size(dtype) == 0) return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+    fad_moments* live_h[kMaxSets]; const void* live_rows[kMaxSets]; int64_t live_n[kMaxSets], live_ld[kMaxSets];
+    int m = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!hs[i]) return set_error(FAD_ERR_INVALID, "handle %d is NULL", i);
+        if (hs[i]->d != hs[0]->d || hs[i]->device != hs[0]->device)
+            return set_error(FAD_ERR_SHAPE, "handle %d: d=%d device=%d, handle 0: d=%d device=%d", i, hs[i]->d, hs[i]->device,
+                             hs[0]->d, hs[0]->device);
+        for (int k = 0; k < i; ++k)
+            if (hs[k] == hs[i]) return set_error(FAD_ERR_INVALID, "handle %d appears twice", i);
+        if (n[i] < 0 || ld[i] < hs[i]->d)
+            return set_error(FAD_ERR_SHAPE, "set %d: n=%lld ld=%lld d=%d", i, (long long)n[i], (long long)ld[i], hs[i]->d);
+        if (n[i] == 0) continue;
+        if (!rows[i]) return set_error(FAD_ERR_INVALID, "rows[%d] is NULL", i);
+        live_h[m] = hs[i]; live_rows[m] = rows[i]; live_n[m] = n[i]; live_ld[m] = ld[i]; ++m;
+    }
+    if (m == 0) return FAD_OK;
+    DeviceGuard g(live_h[0]->device);
+    return update_device_multi(m, live_h, live_rows, live_n, live_ld, dtype, static_cast<hipStream_t>(stream));
+}
+
 int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
                                  const int64_t* offsets, int64_t n_segments, double* seg_sums,
                                  int on_device, void* stream) {
@@ -1805,28 +1560,63 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
     }
     FAD_TRY(update_device(h, drows, n, dld, dtype, st));
     if (seg_sums && n_segments > 0) {
-        FAD_TRY(h->seg_off.reserve((size_t)(n_segments + 1) * sizeof(int64_t)));
-        FAD_HIP_TRY(hipMemcpyAsync(h->seg_off.p, offsets, (size_t)(n_segments + 1) * sizeof(int64_t),
-                                   hipMemcpyHostToDevice, st));
         double* dout = seg_sums;
         if (!on_device) {
             FAD_TRY(h->seg_out.reserve((size_t)n_segments * h->d * sizeof(double)));
             dout = static_cast<double*>(h->seg_out.p);
         }
-        const dim3 grid((unsigned)n_segments, (unsigned)cdiv(h->d, 128));
-        const int64_t* doff = static_cast<const int64_t*>(h->seg_off.p);
-        switch (dtype) {
-            case FAD_F16: hipLaunchKernelGGL((segment_colsums<raw_f16>), grid, dim3(128), 0, st, static_cast<const raw_f16*>(drows), dld, h->d, doff, dout); break;
-            case FAD_BF16: hipLaunchKernelGGL((segment_colsums<raw_bf16>), grid, dim3(128), 0, st, static_cast<const raw_bf16*>(drows), dld, h->d, doff, dout); break;
-            case FAD_F32: hipLaunchKernelGGL((segment_colsums<float>), grid, dim3(128), 0, st, static_cast<const float*>(drows), dld, h->d, doff, dout); break;
-            default: hipLaunchKernelGGL((segment_colsums<double>), grid, dim3(128), 0, st, static_cast<const double*>(drows), dld, h->d, doff, dout); break;
-        }
-        FAD_HIP_TRY(hipGetLastError());
+        FAD_TRY(segment_sums_device(h, drows, dld, dtype, offsets, n_segments, dout, st));
         if (!on_device) {
             FAD_HIP_TRY(hipMemcpyAsync(seg_sums, dout, (size_t)n_segments * h->d * sizeof(double),
                                        hipMemcpyDeviceToHost, st));
         }
     }
+    if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
+    return FAD_OK;
+}
+
+int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
+                                  const double* seg_sums, const int64_t* sizes, int64_t n_files, int dtype,
+                                  int on_device, void* stream) {
+    if (!exact || !rounded || !weighted) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    if (exact == rounded || exact == weighted || rounded == weighted) return set_error(FAD_ERR_INVALID, "three distinct handles are needed");
+    const int d = exact->d;
+    if (rounded->d != d || weighted->d != d || rounded->device != exact->device || weighted->device != exact->device)
+        return set_error(FAD_ERR_SHAPE, "the three handles must share dimension and device");
+    if (dtype_size(dtype) == 0) return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+    if (n_files < 0) return set_error(FAD_ERR_INVALID, "n_files=%lld", (long long)n_files);
+    if (n_files == 0) return FAD_OK;
+    if (!seg_sums || !sizes) return set_error(FAD_ERR_INVALID, "NULL argument");
+    DeviceGuard g(exact->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t cells = (size_t)n_files * d;
+    // scratch of `exact`: [sums | sizes] when they arrive from the host, then the three row blocks
+    const size_t in_bytes = on_device ? 0 : cells * sizeof(double) + (size_t)n_files * sizeof(int64_t);
+    FAD_TRY(exact->scratch.reserve(in_bytes + 3 * cells * sizeof(double) + 64));
+    char* base = static_cast<char*>(exact->scratch.p);
+    const double* dsums = seg_sums; const int64_t* dsizes = sizes;
+    if (!on_device) {
+        FAD_HIP_TRY(hipMemcpyAsync(base, seg_sums, cells * sizeof(double), hipMemcpyHostToDevice, st));
+        FAD_HIP_TRY(hipMemcpyAsync(base + cells * sizeof(double), sizes, (size_t)n_files * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        dsums = reinterpret_cast<const double*>(base);
+        dsizes = reinterpret_cast<const int64_t*>(base + cells * sizeof(double));
+    }
+    double* r_exact = reinterpret_cast<double*>(base + ((in_bytes + 15) & ~(size_t)15));
+    double* r_round = r_exact + cells;
+    double* r_weight = r_round + cells;
+    const dim3 grid((unsigned)cdiv((int64_t)cells, 256));
+    switch (dtype) {
+        case FAD_F16: hipLaunchKernelGGL((file_mean_rows<FAD_F16>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
+        case FAD_BF16: hipLaunchKernelGGL((file_mean_rows<FAD_BF16>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
+        case FAD_F32: hipLaunchKernelGGL((file_mean_rows<FAD_F32>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
+        default: hipLaunchKernelGGL((file_mean_rows<FAD_F64>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    fad_moments* hs[3] = {exact, rounded, weighted};
+    const void* rows[3] = {r_exact, r_round, r_weight};
+    const int64_t ns[3] = {n_files, n_files, n_files};
+    const int64_t lds[3] = {d, d, d};
+    FAD_TRY(update_device_multi(3, hs, rows, ns, lds, FAD_F64, st));
     if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
     return FAD_OK;
 }

@@ -17,6 +17,8 @@ constexpr int kMaxIter = 64;
 struct NsState {
     double c, tr1, tr2, mean_term;
     double res_last, tr_last;
+    double res_min, tr_safe;   // divergence guard: smallest residual so far, trace(Y) of the last iterate within 1.5x of it
+    int has_safe, pad_;
     int done;          // no more T GEMMs / residual checks for this problem
     int final_iter, conv, nonfinite;
     int too_few[2];    // set by finalize_for_frechet: set i has fewer than two rows
@@ -48,6 +50,21 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// N sums at once for a 256-thread block (one barrier pair instead of N): red = 4 * N doubles of LDS
+template <int N> __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) red[(threadIdx.x >> 6) * N + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = (red[q] + red[N + q]) + (red[2 * N + q] + red[3 * N + q]);
 }
 __device__ __forceinline__ double block_max(double v, double* red) {
 #pragma unroll
@@ -92,6 +109,27 @@ __device__ __forceinline__ void ns_check_block(const NsCheckArgs& a, int64_t b, 
     const bool finite = (res == res) && !isinf(res) && (tr == tr) && !isinf(tr);
     const double tr_prev = st->tr_last;
     const double res_prev = (k > 0) ? st->res[k - 1] : 0.0;
+    // Divergence guard.  Eigenvalues of the product at roundoff level (slightly negative ones of a near-singular or
+    // rank-deficient C1 C2 with a smoothly decaying spectrum) grow ~2.25x per iteration and blow Y, Z up around
+    // iteration 50, long after trace(Y) has converged -- they add ~0 to the trace until then.  Two exits keep the
+    // converged trace instead of a NaN:
+    //   runaway  trace quiet (two increments <= 1e-9 |tr|) while the residual has GROWN twice in a row;
+    //   explode  the residual quadruples (or leaves the floats) after iteration 3: return the trace of the last
+    //            iterate whose residual was within 1.5x of the smallest seen -- provided the trace of the previous
+    //            iterate still agrees with it to 1e-6 (a product with genuinely negative eigenvalues diverges in
+    //            the trace as well: that stays an error, fad.py:102-106).
+    if (finite && res <= 1.5 * st->res_min) { st->tr_safe = tr; st->has_safe = 1; }
+    if (finite && res < st->res_min) st->res_min = res;
+    const bool explode = k >= 4 && st->has_safe && (!finite || res > 4.0 * res_prev) &&
+                         fabs(tr_prev - st->tr_safe) <= 1e-6 * fabs(st->tr_safe);
+    const bool runaway = finite && k >= 3 && fabs(tr - tr_prev) <= 1e-9 * fabs(tr) &&
+                         fabs(tr_prev - st->tr[k - 2]) <= 1e-9 * fabs(tr) && res > res_prev && res_prev > st->res[k - 2];
+    if (explode || runaway) {
+        st->tr_last = explode ? st->tr_safe : tr_prev;
+        st->conv = 2; st->final_iter = k;
+        st->done = 1; st->finished = 1; st->upd_skip[(k + 1) & 1] = 1;
+        return;
+    }
     if (finite) { st->res_last = res; st->tr_last = tr; st->final_iter = k; }
     // Stagnation = a rank-deficient product: the null directions keep the residual frozen while the trace has
     // converged.  Both must stand still (the trace alone can pause by coincidence: with c = tr(A^2)/tr(A),

@@ -72,8 +72,9 @@ class Moments:
             self._keep = keep          # torch tensor must outlive the enqueued kernels
         return self
 
-    def update_segmented(self, rows, offsets: Sequence[int], want_sums: bool = True):
-        """Feed files/songs stored back to back; returns per-segment column sums [S x D] (float64, host)."""
+    def update_segmented(self, rows, offsets: Sequence[int], want_sums: bool = True, sums_on_device: bool = False):
+        """Feed files/songs stored back to back; returns per-segment column sums [S x D] float64 -- a numpy array, or
+        (``sums_on_device`` with device rows) a torch CUDA tensor that never leaves HBM."""
         ptr, n, d, ld, code, on_dev, keep = K.rows_view(rows)
         if d != self.d:
             raise AssertionError(f"frame matrix has {d} features, accumulator has {self.d}")
@@ -85,17 +86,61 @@ class Moments:
         if want_sums and n_seg > 0:
             if on_dev:
                 import torch
-                sums_dev = torch.empty((n_seg, self.d), dtype=torch.float64, device=keep.device)
+                sums_dev = torch.zeros((n_seg, self.d), dtype=torch.float64, device=keep.device)
                 sums_ptr = sums_dev.data_ptr()
             else:
-                sums = np.empty((n_seg, self.d), dtype=np.float64)
+                sums = np.zeros((n_seg, self.d), dtype=np.float64)
                 sums_ptr = sums.ctypes.data
         K.check(self._lib.fad_moments_update_segmented(
             self._h, ptr, n, ld, code, off.ctypes.data_as(C.POINTER(C.c_int64)), n_seg, sums_ptr, on_dev,
             self._stream()), "fad_moments_update_segmented")
+        if on_dev:
+            self._keep = keep
         if sums_dev is not None:
-            sums = sums_dev.cpu().numpy()
+            sums = sums_dev if sums_on_device else sums_dev.cpu().numpy()
         return sums
+
+    @staticmethod
+    def update_multi(accs: Sequence["Moments"], blocks: Sequence) -> None:
+        """``accs[i].update(blocks[i])`` for up to 8 accumulators of one dimension with ONE launch of each kernel
+        (``fad_moments_update_multi``); every block must be a device tensor of one common dtype."""
+        assert 1 <= len(accs) == len(blocks) <= 8
+        views = [K.rows_view(b) for b in blocks]
+        code = views[0][4]
+        for a, v in zip(accs, views):
+            if v[1] > 0 and v[2] != a.d:
+                raise AssertionError(f"frame matrix has {v[2]} features, accumulator has {a.d}")
+            if not v[5] or v[4] != code:
+                raise AssertionError("update_multi needs device tensors of one common dtype")
+        m = len(accs)
+        hs = (C.c_void_p * m)(*[a._h for a in accs])
+        ptrs = (C.c_void_p * m)(*[v[0] for v in views])
+        ns = (C.c_int64 * m)(*[v[1] for v in views])
+        lds = (C.c_int64 * m)(*[max(v[3], a.d) for a, v in zip(accs, views)])
+        K.check(accs[0]._lib.fad_moments_update_multi(m, hs, ptrs, ns, lds, code, accs[0]._stream()), "fad_moments_update_multi")
+        for a, v in zip(accs, views):
+            a._keep = v[6]
+
+    @staticmethod
+    def update_file_means(exact: "Moments", rounded: "Moments", weighted: "Moments", seg_sums, sizes, dtype_code: int) -> None:
+        """Accumulate the per-file mean rows of the online statistics (``fad_moments_update_file_means``).
+        ``seg_sums`` [F x D] float64 and ``sizes`` [F] int64: both numpy, or both torch CUDA tensors."""
+        if K._is_torch(seg_sums) and seg_sums.is_cuda:
+            import torch
+            sizes_t = sizes if K._is_torch(sizes) else torch.as_tensor(np.asarray(sizes, dtype=np.int64))
+            sizes_t = sizes_t.to(device=seg_sums.device, dtype=torch.int64).contiguous()
+            sums_t = seg_sums.to(torch.float64).contiguous()
+            n_files = int(sums_t.shape[0])
+            K.check(exact._lib.fad_moments_update_file_means(exact._h, rounded._h, weighted._h, sums_t.data_ptr(),
+                                                             sizes_t.data_ptr(), n_files, int(dtype_code), 1, exact._stream()),
+                    "fad_moments_update_file_means")
+            exact._keep = (sums_t, sizes_t)
+        else:
+            sums = K.f64_host(seg_sums)
+            sz = np.ascontiguousarray(np.asarray(sizes, dtype=np.int64))
+            K.check(exact._lib.fad_moments_update_file_means(exact._h, rounded._h, weighted._h, sums.ctypes.data,
+                                                             sz.ctypes.data, int(sums.shape[0]), int(dtype_code), 0, exact._stream()),
+                    "fad_moments_update_file_means")
 
     def merge(self, other: "Moments") -> "Moments":
         K.check(self._lib.fad_moments_merge(self._h, other._h, self._stream()), "fad_moments_merge")
@@ -176,12 +221,13 @@ def frechet(mu1, cov1, mu2, cov2, eps: float = 1e-6, max_iter: int = 0, tol: flo
 
 
 def frechet_from_moments(m1: Moments, m2: Moments, ddof: int = 1, eps: float = 1e-6, max_iter: int = 0,
-                         tol: float = 0.0):
-    """FAD straight from two accumulators, all in HBM (``fad_frechet_from_moments``)."""
+                         tol: float = 0.0, mean_dtype: int = -1):
+    """FAD straight from two accumulators, all in HBM (``fad_frechet_from_moments``).  ``mean_dtype`` = ``K.FAD_F16``
+    gives the reference's value for float16 embeddings (means and mean term rounded the way numpy does)."""
     lib = K.load_library()
     out = C.c_double()
     diag = K.FadDiag()
-    st = lib.fad_frechet_from_moments(m1._h, m2._h, int(ddof), float(eps), int(max_iter), float(tol),
+    st = lib.fad_frechet_from_moments(m1._h, m2._h, int(ddof), float(eps), int(max_iter), float(tol), int(mean_dtype),
                                       K.current_stream_ptr(m1.device), C.byref(out), C.byref(diag))
     K.check(st, "fad_frechet_from_moments")
     return float(out.value), diag.as_dict()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FAD_ABI_VERSION 1
+#define FAD_ABI_VERSION 2
 
 typedef enum fad_status {
     FAD_OK = 0,
@@ -75,6 +75,16 @@ int64_t fad_moments_packed_len(const fad_moments_t* h);      /* 1 + D + D*D     
 int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
                        int on_device, void* stream);
 
+/* Feed `count` (1..8) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE
+ * launch of each kernel: rows[i] (a DEVICE pointer, n[i] frames, pitch ld[i]) goes to hs[i].  The two datasets of a
+ * FAD score (fad.py:292-302 calls calc_embd_statistics / load_stats twice), the 25 resamples of score_inf
+ * (fad.py:333-341) ...: the workgroup slots of the GPU are shared out over all sets in proportion to their rows,
+ * so the fixed costs of a pass (one 64 KiB partial tile per workgroup, pipeline fill, launches) are paid once.
+ * Results are identical to `count` separate fad_moments_update calls up to the fp64 summation order of the
+ * partial tiles.  Sets with n[i] == 0 are skipped. */
+int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* const* rows, const int64_t* n,
+                             const int64_t* ld, int dtype, void* stream);
+
 /* Same, for `n_segments` files/songs stored back to back: segment s owns rows
  * [offsets[s], offsets[s+1]) (offsets is a HOST array of n_segments+1 entries).  If
  * seg_sums != NULL it receives the per-segment column sums, [n_segments x D] float64 (host or
@@ -83,6 +93,18 @@ int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld
 int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
                                  const int64_t* offsets, int64_t n_segments, double* seg_sums,
                                  int on_device, void* stream);
+
+/* The per-file mean terms of the online statistics.  fadtk merges per-file (mean, scatter, n) triplets
+ * (utils.py:13-16, 36-40) and np.mean of a float16 file is float16, so the dataset covariance it returns is
+ *   (sum xx^T - sum_f n_f m_f m_f^T  +  sum_f n_f m~_f m~_f^T - N mu~ mu~^T) / (N - 1),  mu~ = sum_f n_f m~_f / N
+ * with m_f the exact and m~_f the dtype-rounded mean of file f.  Given the per-file column sums (seg_sums
+ * [n_files x D] float64, from fad_moments_update_segmented) and sizes (int64 [n_files]; host or device per
+ * on_device), this accumulates the rows sqrt(n_f) m_f into `exact`, sqrt(n_f) m~_f into `rounded` and n_f m~_f into
+ * `weighted` (three distinct handles of dimension D): afterwards sum_xxT(exact) and sum_xxT(rounded) are the two
+ * D x D terms and sum_x(weighted) = N mu~ -- all sum-reducible across batches and ranks.  Empty files add nothing. */
+int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
+                                  const double* seg_sums, const int64_t* sizes, int64_t n_files, int dtype,
+                                  int on_device, void* stream);
 
 int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream);   /* dst += src */
 /* Copy the packed float64 statistics out / in (the buffer an RCCL all-reduce runs over). */
@@ -108,7 +130,8 @@ int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* c
 /* Opt-in HIP-event timing (bench.py's roofline): while enabled every update records events around
  * its tile kernel on the caller's stream (no synchronisation); last_timing() returns the AVERAGE
  * duration in ms of the tile kernel and of the reduce kernels over the updates recorded since the
- * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA, 1 = generic fp64). */
+ * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA, 1 = generic fp64).
+ * A fad_moments_update_multi call is ONE update recorded on hs[0]: its tile-kernel time covers all sets. */
 int fad_moments_set_timing(fad_moments_t* h, int enabled);
 int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_reduce_kernel,
                             int* kernel_variant);
@@ -117,13 +140,16 @@ int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_r
  * Replaces calc_frechet_distance (fadtk/fad.py:51-120):
  *   ||mu1-mu2||^2 + tr C1 + tr C2 - 2 tr sqrt(C1 C2)
  * tr sqrt(C1 C2) = sum_i sqrt(lambda_i(C1 C2)) -- the value the reference returns through
- * scipy.linalg.eig (fad.py:91-92) -- is computed with a coupled Newton-Schulz iteration in
- * float64 on MFMA tiles.  eps: added to both diagonals for a retry when the first attempt
- * diverges (fad.py:94-99).  max_iter <= 0 -> default (64); tol <= 0 -> default.
+ * scipy.linalg.eig (fad.py:91-92) -- is computed with a coupled Newton-Schulz iteration on MFMA tiles: for
+ * well-conditioned products (and d a multiple of 64) the iterations run in float32 and one float64 correction
+ * restores float64 accuracy; otherwise (or when max_iter / tol are given) everything runs in float64.
+ * eps: added to both diagonals for a retry when the first attempt diverges (fad.py:94-99).
+ * max_iter <= 0 -> default (64); tol <= 0 -> default.
  */
 typedef struct fad_diag {
     int32_t iters;          /* Newton-Schulz iterations executed                                 */
-    int32_t converged;      /* 1: residual < tol, 2: trace stagnated (rank-deficient product), 0: max_iter */
+    int32_t converged;      /* 1: residual < tol, 2: trace stagnated / divergence guard (rank-deficient or near-singular
+                               product), 3: float32 iterations + float64 correction accepted, 0: max_iter */
     int32_t used_eps;       /* 1 if the eps-regularised retry produced the result                */
     int32_t reserved;
     double residual;        /* ||I - Z Y||_F at the last iteration                               */
@@ -137,9 +163,13 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
                 double eps, int max_iter, double tol, int on_device, int device, void* stream,
                 double* out_fad, fad_diag_t* diag);
 
-/* Same, straight from two moment handles (no host round trip of mu/cov). */
+/* Same, straight from two moment handles (no host round trip of mu/cov).
+ * mean_dtype: how ||mu1 - mu2||^2 is formed.  FAD_F16 / FAD_BF16 / FAD_F32 = as the reference does for embeddings
+ * of that dtype: np.mean keeps the dtype (fad.py:48 on the float16 arrays of model_loader.py:47-48), so the means are
+ * rounded to it, subtracted in it, and diff.dot(diff) (fad.py:83, 119) is accumulated in float32 and rounded to it
+ * (float16: bit for bit what numpy returns).  Anything else (FAD_F64, -1): float64 means. */
 int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
-                             int max_iter, double tol, void* stream, double* out_fad, fad_diag_t* diag);
+                             int max_iter, double tol, int mean_dtype, void* stream, double* out_fad, fad_diag_t* diag);
 
 /* ------------------------------------------------------------------ per-song FAD (--indiv)
  * Replaces the loop of score_individual (fadtk/fad.py:373-387): for every song s (rows

@@ -29,6 +29,16 @@ def main():
         for r in rows[:40]:
             print(f"\"{short(r[0])}\",{r[1]},{r[2]:.1f},{r[3]:.2f},{r[4]:.2f},{r[5]:.2f},{100 * r[2] / total:.2f},"
                   f"{r[6]},{r[7]},{r[8]},{r[9]},{r[10]}")
+    elif mode == "seq":
+        # the last N dispatches in launch order: name, duration, gap to the previous kernel's end (us)
+        n = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+        rows = cur.execute("select name, start, end, grid_x*grid_y*grid_z, workgroup_x from kernels order by start desc limit ?", (n,)).fetchall()[::-1]
+        print("kernel,dur_us,gap_us,grid,workgroup")
+        prev_end = None
+        for name, st, en, grid, wg in rows:
+            gap = (st - prev_end) / 1e3 if prev_end is not None else 0.0
+            print(f"\"{short(name)}\",{(en - st) / 1e3:.2f},{gap:.2f},{grid},{wg}")
+            prev_end = en
     else:
         print("kernel,counter,mean_per_dispatch,dispatches")
         for r in cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "

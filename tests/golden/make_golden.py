@@ -18,6 +18,8 @@ Fixture groups:
   G6 score_inf with np.random.seed(0)
   G7 config-3 scalar (N=100000, D=512, seeds 10/11)
   G8 config-5 shape: D=768 baseline, 64 two-row songs
+  G10 hard spectra for the square root: eval sets of N < D frames with power-law spectra (k^-2 .. k^-4), full-rank
+      power-law pairs, covariances that went through float32 (near-singular products with eigenvalues at roundoff level)
 """
 from __future__ import annotations
 
@@ -263,13 +265,34 @@ def g8():
                                 "rows": [10, 3, 50, 200, 2, 129], "n_songs": 12, "scores": scores2}}
 
 
+# ---------------------------------------------------------------- G10
+def g10():
+    out = {}
+    for p in (2.0, 3.0, 4.0):
+        base = R.decaying_rows(50, 4096, 256, 52, power=p)
+        song = R.decaying_rows(51, 150, 256, 53, power=p)
+        mb, cb = ref_fad.calc_embd_statistics(base)
+        ms, cs = ref_fad.calc_embd_statistics(song)
+        out[f"short_eval_d256_n150_p{p:g}"] = {"fad": f(ref_fad.calc_frechet_distance(mb, cb, ms, cs)), "power": p,
+                                               "in_checksum": [R.checksum(base), R.checksum(song)]}
+    for p in (3.0, 4.0):
+        a = R.decaying_rows(30, 4096, 128, 32, power=p)
+        b = R.decaying_rows(31, 4096, 128, 33, power=p, gain=1.05)
+        out[f"fullrank_d128_p{p:g}"] = dict(zip(("fad", "tr1", "tr2"), _fd(a, b)))
+        m1, c1 = ref_fad.calc_embd_statistics(a)
+        m2, c2 = ref_fad.calc_embd_statistics(b)
+        c1f, c2f = c1.astype(np.float32).astype(np.float64), c2.astype(np.float32).astype(np.float64)
+        out[f"f32cov_d128_p{p:g}"] = {"fad": f(ref_fad.calc_frechet_distance(m1, c1f, m2, c2f)), "power": p}
+    OUT_JSON["g10"] = out
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     prev = {}
     jpath = HERE / "golden.json"
     if only and jpath.exists():
         prev = json.loads(jpath.read_text())
-    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g4", g4_g5), ("g6", g6), ("g7", g7), ("g8", g8)):
+    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g4", g4_g5), ("g6", g6), ("g7", g7), ("g8", g8), ("g10", g10)):
         if only and name not in only:
             continue
         t = time.time()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.load_library()
     missing = [n for n in _declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in fad_hip.h but not exported by libfad_hip.so: {missing}"
-    assert lib.fad_version() == 1
+    assert lib.fad_version() == 2
     unbound = [n for n in _declared_functions() if n not in _capi.SIGNATURES]
     assert not unbound, f"no ctypes prototype for {unbound}"
 

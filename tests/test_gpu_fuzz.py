@@ -23,7 +23,7 @@ def test_fuzz_moments_against_numpy(seed, monkeypatch):
         n = int(rng.choice([0, 1, 2, 5, 31, 32, 33, 63, 64, 65, 100, 255, 257, 1000, 4097, 20000, 70001]))
         dt = str(rng.choice(list(tdt)))
         pitch = d + int(rng.choice([0, 0, 8, 3]))
-        variant = str(rng.choice(["", "1", "2", "3", "4", "8"]))
+        variant = str(rng.choice(["", "", "4", "8"]))
         shift = float(rng.choice([0.0, 0.0, 0.5, 5.0]))
         x64 = rng.standard_normal((n, pitch)) * (0.3 + rng.random()) + shift
         view = torch.from_numpy(x64).to(tdt[dt]).cuda()[:, :d]

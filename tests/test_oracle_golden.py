@@ -83,6 +83,32 @@ def test_g2_rank_deficient(golden, d, rows):
     assert fad == pytest.approx(g["fad"], rel=1e-7)     # eig noise of a singular product
 
 
+def _g10_case(key):
+    """(mu1, cov1, mu2, cov2) of a G10 fixture, rebuilt from the seeded recipe."""
+    if key.startswith("short_eval"):
+        p = float(key.rsplit("_p", 1)[1])
+        base = R.decaying_rows(50, 4096, 256, 52, power=p)
+        song = R.decaying_rows(51, 150, 256, 53, power=p)
+        return (*O.embd_statistics(base), *O.embd_statistics(song))
+    p = float(key.rsplit("_p", 1)[1])
+    a = R.decaying_rows(30, 4096, 128, 32, power=p)
+    b = R.decaying_rows(31, 4096, 128, 33, power=p, gain=1.05)
+    m1, c1 = O.embd_statistics(a)
+    m2, c2 = O.embd_statistics(b)
+    if key.startswith("f32cov"):
+        c1, c2 = c1.astype(np.float32).astype(np.float64), c2.astype(np.float32).astype(np.float64)
+    return m1, c1, m2, c2
+
+
+@pytest.mark.parametrize("key", ["short_eval_d256_n150_p2", "short_eval_d256_n150_p3", "short_eval_d256_n150_p4",
+                                 "fullrank_d128_p3", "fullrank_d128_p4", "f32cov_d128_p3", "f32cov_d128_p4"])
+def test_g10_hard_spectra(golden, key):
+    """Near-singular products (eval set of N < D frames, power-law spectra k^-2..k^-4, covariances that went through
+    float32): the oracle must reproduce what the reference's eig route returns for them."""
+    fad = O.frechet_distance(*_g10_case(key), run_sqrtm=False)
+    assert fad == pytest.approx(golden["g10"][key]["fad"], rel=1e-7)
+
+
 def test_g2_shape_asserts_and_both_roots():
     a, b = R.c1_pair()
     m1, c1 = O.embd_statistics(a[:, :16])
