@@ -5,22 +5,28 @@
 
 Workload (BASELINE.json configs[2], "C3"): two synthetic float16 embedding matrices of
 [100000 x 512] per GPU, RESIDENT IN HBM when the timed region starts.  One *step* is one pass of the
-hot path over that batch:
+hot path over that batch -- one FAD score:
 
-    moments(A) ; moments(B)           hand-written HIP, fp16 MFMA E^T E + column sums  -> (n, sum x, sum xxT)
-    [N>1]  one all-reduce (RCCL/xGMI) of the packed float64 statistics of both sets
-    frechet(A, B)                     finalise (mu, Sigma) x2 + Newton-Schulz sqrt(S1 S2) in fp64 MFMA
+    moments(A, B)      hand-written HIP, fp16 MFMA E^T E + column sums -> (n, sum x, sum xxT) of BOTH sets in one launch
+                       of each kernel (fad_moments_update_multi)
+    [N>1]              ONE in-place all-reduce (RCCL/xGMI) over the buffer that holds both sets' packed float64
+                       statistics (fadtk_amd.dist.SharedStats -- the same object the product's --gpus path uses)
+    frechet(A, B)      finalise (mu, Sigma) x2, Newton-Schulz sqrt(S1 S2): fp32 MFMA iterations + one fp64 correction
+                       (fp64 throughout when the product is ill-conditioned), the reference's float16 mean term
 
 i.e. exactly one FAD score over the union of all ranks' rows.  With N GPUs every rank holds its own
 100k-row shard of both sets (weak scaling: rows grow with N), so `value` is reported in
 config-3-sized score workloads per second:  value = N * K / seconds  (at N=1: plain FAD scores/s).
 
 Rank 0 prints ONE JSON line with the driver's fields plus
-  roofline      dominant kernel (moments tile kernel): achieved TFLOP/s from ALGORITHMIC flops
-                2*N*D^2 per launch / mean launch duration (HIP events on the launch stream,
-                recorded inside the timed region by the library), vs the dense fp16 MFMA peak
-  cpu_baseline  the numpy/scipy oracle (a line-by-line restatement of fadtk's CPU path, both
-                sqrtm and eig as in fad.py:88-92) timed on this node's host cores, rank 0, N=1.
+  roofline          dominant kernel (moments tile kernel): achieved TFLOP/s from ALGORITHMIC flops
+                    2 sets x 2*N*D^2 per launch / mean launch duration (HIP events on the launch stream,
+                    recorded inside the timed region by the library), vs the dense fp16 MFMA peak
+  roofline_frechet  the square-root chain: GEMMs x 2 D^3 / its duration (events on the same stream)
+  cpu_baseline      the numpy/scipy oracle (a line-by-line restatement of fadtk's CPU path, both
+                    sqrtm and eig as in fad.py:88-92) timed on this node's host cores, rank 0, N=1
+  extra             config-4 pure-moments pass (files of [2250 x 128] frames, per-file mean terms included) and the
+                    config-5 per-song pass (10k two-frame songs at D=768) with its own CPU baseline and roofline
 """
 from __future__ import annotations
 
@@ -38,8 +44,11 @@ sys.path.insert(0, str(ROOT))
 
 N_ROWS = 100_000
 DIM = 512
-MFMA_F16_PEAK_TFLOPS = 2500.0          # dense, /opt/skills/guides/MI355X_MICROARCH.md
+SETS = 2                                # frame matrices per launch of the tile kernel (the two sets of a score)
+MFMA_F16_PEAK_TFLOPS = 2500.0           # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3            # f32-input MFMA = the fp32 vector rate, same guide
 HBM_PEAK_GBS = 8000.0
+FAD_F16 = 0                             # fad_dtype code: the reference's float16 mean term
 
 
 def make_sets(torch, device, rank):
@@ -52,11 +61,8 @@ def make_sets(torch, device, rank):
     return a, b
 
 
-def cpu_baseline(a_host, b_host):
-    """Reference CPU path (oracle port), best of 3 after one warm-up, same arrays as the GPU run."""
-    from oracle import fad_oracle as O
-    threads = os.cpu_count()
-    blas = "unknown"
+def _blas_threads():
+    threads, blas = os.cpu_count(), "unknown"
     try:
         from threadpoolctl import threadpool_info
         info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
@@ -65,6 +71,13 @@ def cpu_baseline(a_host, b_host):
             blas = f"{info[0].get('internal_api')} {info[0].get('version')}"
     except Exception:       # noqa: BLE001
         pass
+    return int(threads), blas
+
+
+def cpu_baseline(a_host, b_host):
+    """Reference CPU path (oracle port), best of 3 after one warm-up, same arrays as the GPU run."""
+    from oracle import fad_oracle as O
+    threads, blas = _blas_threads()
     times, fad = [], None
     for it in range(4):
         t0 = time.perf_counter()
@@ -73,10 +86,79 @@ def cpu_baseline(a_host, b_host):
         if it > 0:
             times.append(dt)
     import scipy
-    return {"value": 1.0 / min(times), "unit": "FAD scores/s", "cores": int(threads), "kind": "port",
+    return {"value": 1.0 / min(times), "unit": "FAD scores/s", "cores": threads, "kind": "port",
             "sample": f"full config-3 workload (2 x [{N_ROWS}x{DIM}] fp16 -> 1 score), best of 3 after 1 warm-up; "
                       f"{os.cpu_count()} logical CPUs, BLAS {blas}, numpy {np.__version__}, scipy {scipy.__version__}",
             "seconds_best": min(times)}, float(fad)
+
+
+def extra_c4(torch, hip, device, local_rank):
+    """Config 4, pure-moments variant: Encodec-shaped files of [2250 x 128] float16 frames fed the way
+    the product feeds them -- groups of files, ONE update per group (fad_moments_update_segmented: tile kernel + reduce
+    + per-file column sums), plus the per-file mean terms of the reference's online path
+    (fad_moments_update_file_means) -- all on data resident in HBM.  Wall time of the whole pass, not of one kernel."""
+    from fadtk_amd.utils import OnlineStats
+    files_per_group, rows_per_file, d, groups = 1024, 2250, 128, 8
+    x = torch.randn((files_per_group * rows_per_file, d), device=device, dtype=torch.float16)
+    sizes = np.full(files_per_group, rows_per_file, dtype=np.int64)
+    stats = OnlineStats(d, local_rank, compat=True)
+    stats.add_group(x, sizes)                                    # warm-up (allocations)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(groups):
+        stats.add_group(x, sizes)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats.frames.set_timing(True)
+    stats.frames.update(x)
+    k_ms, r_ms, _ = stats.frames.last_timing()
+    stats.frames.set_timing(False)
+    mu, cov = stats.finish()
+    stats.close()
+    nbytes = groups * x.numel() * 2
+    return {"files": groups * files_per_group, "frames_per_file": rows_per_file, "dim": d, "files_per_update": files_per_group,
+            "ms": dt * 1e3, "frames_per_s": groups * x.shape[0] / dt, "GBps_algorithmic": nbytes / dt / 1e9,
+            "frac_of_8TBps": nbytes / dt / 1e9 / HBM_PEAK_GBS, "includes": "tile kernel + reduce + per-file sums + per-file mean terms",
+            "tile_kernel_ms_per_update": k_ms, "tile_kernel_frac_of_8TBps": x.numel() * 2 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "cov_trace": float(np.trace(cov))}
+
+
+def extra_c5(torch, hip, device):
+    """Config 5 shape (Whisper-small): 10k two-frame songs at D=768 against one baseline, one batched
+    call; CPU baseline = 8 of the same songs through the oracle on a pool of 8 threads (fad.py:387), extrapolated;
+    the GPU scores of those songs are checked against the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fad_oracle as O
+    nsongs, d5 = 10_000, 768
+    g5 = torch.Generator(device=device); g5.manual_seed(5)
+    songs = torch.randn((2 * nsongs, d5), generator=g5, device=device).to(torch.float16)
+    base = torch.randn((3 * d5, d5), generator=g5, device=device, dtype=torch.float64)
+    mu5 = base.mean(0).cpu().numpy(); cov5 = torch.cov(base.T).cpu().numpy()
+    offs = np.arange(0, 2 * nsongs + 1, 2)
+    hip.frechet_batched(mu5, cov5, songs, offs)
+    torch.cuda.synchronize(); t5 = time.perf_counter()
+    for _ in range(3):
+        sc5, st5 = hip.frechet_batched(mu5, cov5, songs, offs)
+    torch.cuda.synchronize(); dt5 = (time.perf_counter() - t5) / 3
+    n_cpu = 8                                                     # ~20 s of host work: one song per pool thread
+    sample = songs[:2 * n_cpu].cpu().numpy()
+    blocks = [sample[2 * i:2 * i + 2] for i in range(n_cpu)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        want = list(ex.map(lambda s: O.individual_scores(mu5, cov5, [s], run_sqrtm=True)[0], blocks))
+    dt_cpu = time.perf_counter() - t0
+    want = np.array([np.nan if w is None else float(w) for w in want])
+    rel = float(np.nanmax(np.abs(sc5[:n_cpu] - want) / np.abs(want)))
+    flops = 2.0 * nsongs * d5 * d5                                # the quadratic forms d^T Sigma_b d (Sigma_b is L2-resident)
+    return {"songs": nsongs, "dim": d5, "frames_per_song": 2, "ms": dt5 * 1e3, "songs_per_s": nsongs / dt5, "ok": int((st5 == 0).sum()),
+            "max_rel_err_vs_oracle_sample": rel,
+            "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": 8, "kind": "port",
+                             "sample": f"{n_cpu} of the same songs through the oracle (eig + sqrtm per song, fad.py:373-378) on a "
+                                       "thread pool of 8 (fad.py:387, BLAS threads as numpy finds them), one pass", "seconds": dt_cpu},
+            "roofline": {"kernel": "pair_quadform (whole batched call timed)", "bound": "fp64 mfma", "achieved": flops / dt5 / 1e12,
+                         "peak": 78.6, "unit": "TFLOP/s", "frac": flops / dt5 / 1e12 / 78.6,
+                         "note": "2 n_songs D^2 flops; peak = fp64 matrix datasheet figure (the guide lists none); measured "
+                                 "v_mfma_f64_16x16x4 ceiling on this chip 45-47 TFLOP/s (scripts/probes/mfma_rate.hip)"}}
 
 
 def main():
@@ -98,7 +180,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts: dmabuf IPC only
     import torch
     import torch.distributed as dist
-    from fadtk_amd import hip
+    from fadtk_amd import dist as fdist, hip
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,22 +198,18 @@ def main():
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     a, b = make_sets(torch, device, rank)
-    ma, mb = hip.Moments(DIM, local_rank), hip.Moments(DIM, local_rank)
+    # both handles keep their statistics in ONE device buffer: the exchange of the path -- the sum of the ranks'
+    # sufficient statistics -- is a single in-place all-reduce over it (the product's --gpus path uses the same class)
+    shared = fdist.SharedStats(DIM, SETS, local_rank)
+    ma, mb = shared.moments
     plen = ma.packed_len
-    if distributed:
-        # both handles keep their statistics in one buffer, so the exchange of the path -- the sum of the ranks'
-        # sufficient statistics -- runs over it in place; plen is odd, pad the second half to 16 bytes
-        off = plen + (plen & 1)
-        packed = torch.zeros(off + plen, dtype=torch.float64, device=device)
-        pa, pb = packed[:plen], packed[off:off + plen]
-        ma.bind(pa); mb.bind(pb)
 
     def step():
         ma.reset(); mb.reset()
         hip.Moments.update_multi([ma, mb], [a, b])           # both sets: one launch of each kernel
         if distributed:
-            dist.all_reduce(packed)                          # ONE collective over both sets' packed statistics, in place
-        return hip.frechet_from_moments(ma, mb, mean_dtype=0)    # 0 = FAD_F16: the reference's float16 mean term
+            dist.all_reduce(shared.buffer)                   # (SharedStats.allreduce minus the settle calls: both sets were just fed)
+        return hip.frechet_from_moments(ma, mb, mean_dtype=FAD_F16)
 
     def fence():
         torch.cuda.synchronize()
@@ -141,61 +219,42 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ma.set_timing(True); mb.set_timing(True)
+    ma.set_timing(True)
     fence()
-    t0 = time.perf_counter()
+    marks = [time.perf_counter()]
     for _ in range(args.steps):
-        fad, diag = step()
+        fad, diag = step()                                   # returns the score: every step ends with the stream drained
+        marks.append(time.perf_counter())
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - marks[0]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    step_ms = np.diff(np.array(marks)) * 1e3
 
-    kernel_ms, reduce_ms, variant = ma.last_timing()       # ONE launch covers both sets (recorded on the first handle)
-    ma.set_timing(False); mb.set_timing(False)
+    kernel_ms, reduce_ms, variant = ma.last_timing()         # ONE launch covers both sets (recorded on the first handle)
+    ma.set_timing(False)
 
     # ---- untimed breakdown (torch events on the same stream: stream 0 is torch's current stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     bm, bf = [], []
-    for _ in range(5):
+    for _ in range(7):
         ma.reset(); mb.reset()
         ev[0].record(); hip.Moments.update_multi([ma, mb], [a, b]); ev[1].record()
-        hip.frechet_from_moments(ma, mb, mean_dtype=0); ev[2].record()
+        hip.frechet_from_moments(ma, mb, mean_dtype=FAD_F16); ev[2].record()
         torch.cuda.synchronize()
         bm.append(ev[0].elapsed_time(ev[1])); bf.append(ev[1].elapsed_time(ev[2]))
 
-    # ---- untimed side measurements (rank 0, single GPU): the HBM-bound shape of the same kernel and the per-song path
+    # ---- untimed side measurements (rank 0, single GPU)
     extra = {}
     if rank == 0 and not distributed and not args.no_extras:
-        try:
-            n128, d128 = 4_000_000, 128                                  # config-4-like frames: D=128 is HBM-bound
-            x128 = torch.randn((n128, d128), device=device, dtype=torch.float16)
-            m128 = hip.Moments(d128, local_rank)
-            m128.update(x128); m128.set_timing(True)
-            for _ in range(5):
-                m128.update(x128)
-            k128, r128, _ = m128.last_timing()
-            extra["moments_d128_hbm_bound"] = {"rows": n128, "dim": d128, "kernel_ms": k128, "reduce_ms": r128,
-                                               "GBps_algorithmic": n128 * d128 * 2 / (k128 * 1e-3) / 1e9,
-                                               "frac_of_8TBps": n128 * d128 * 2 / (k128 * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            m128.close(); del x128
-            nsongs, d5 = 10_000, 768                                     # config-5 shape: two-frame songs vs one baseline
-            g5 = torch.Generator(device=device); g5.manual_seed(5)
-            songs = torch.randn((2 * nsongs, d5), generator=g5, device=device).to(torch.float16)
-            base = torch.randn((3 * d5, d5), generator=g5, device=device, dtype=torch.float64)
-            mu5 = base.mean(0).cpu().numpy(); cov5 = torch.cov(base.T).cpu().numpy()
-            offs = np.arange(0, 2 * nsongs + 1, 2)
-            hip.frechet_batched(mu5, cov5, songs, offs)
-            torch.cuda.synchronize(); t5 = time.perf_counter()
-            for _ in range(3):
-                sc5, st5 = hip.frechet_batched(mu5, cov5, songs, offs)
-            torch.cuda.synchronize(); dt5 = (time.perf_counter() - t5) / 3
-            extra["per_song_config5_shape"] = {"songs": nsongs, "dim": d5, "frames_per_song": 2, "ms": dt5 * 1e3,
-                                               "songs_per_s": nsongs / dt5, "ok": int((st5 == 0).sum())}
-        except Exception as e:      # noqa: BLE001  side measurements must never break the bench line
-            extra["error"] = repr(e)
+        for name, fn in (("c4_moments", lambda: extra_c4(torch, hip, device, local_rank)),
+                         ("per_song_config5_shape", lambda: extra_c5(torch, hip, device))):
+            try:
+                extra[name] = fn()
+            except Exception as e:      # noqa: BLE001  side measurements must never break the bench line
+                extra[name] = {"error": repr(e)}
 
     if distributed:
         dist.destroy_process_group()
@@ -203,19 +262,28 @@ def main():
         return
 
     n_gpus = world
-    SETS = 2                                               # one launch of the tile kernel covers both sets of the score
     flops = SETS * 2.0 * N_ROWS * DIM * DIM                # algorithmic, per launch
     achieved = flops / (kernel_ms * 1e-3) / 1e12
     nt = -(-DIM // 128)
     # issued: upper-triangular 128 x 128 tiles, 32 MFMAs per 32-row stage off the diagonal, 20 on it
     issued = SETS * 2.0 * N_ROWS * 128 * 128 * (nt * (nt - 1) // 2 + nt * 20.0 / 32.0)
-    traffic = None
-    tpath = ROOT / "profiles" / "moments_traffic.json"     # measured in a separate rocprofv3 --pmc pass
+    traffic, traffic_src = None, None
+    tpath = ROOT / "profiles" / "moments_traffic.json"     # separate rocprofv3 --pmc passes of this same command
     if tpath.exists():
         try:
-            traffic = json.loads(tpath.read_text()).get("hbm_bytes_per_launch")
+            tj = json.loads(tpath.read_text())
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:       # noqa: BLE001
             traffic = None
+    # Frechet chain: 2 fp64 products (C1 C2, Y Y) + the fp32 iterations (iteration 0 needs one product, every later one
+    # three) when the mixed route ran; 3 fp64 products per iteration (+ C1 C2) on the all-fp64 route
+    it = int(diag["iters"])
+    if diag["converged"] == 3:
+        gemms = {"f32": 1 + 3 * max(it - 2, 0), "f64": 2}
+    else:
+        gemms = {"f32": 0, "f64": 1 + 1 + 3 * max(it - 1, 0)}
+    fr_ms = float(np.median(bf))
+    fr_flops = (gemms["f32"] + gemms["f64"]) * 2.0 * DIM ** 3
     out = {
         "metric": "FAD scores/sec + cov-GEMM TFLOP/s (% MFMA peak), N=100k D=512",
         "value": n_gpus * args.steps / elapsed,
@@ -223,26 +291,35 @@ def main():
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 in, f32 MFMA accumulate (moments); f64 (Frechet)", "data": "synthetic",
+        "dtype": "f16 in, f32 MFMA accumulate (moments); f32 MFMA iterations + f64 correction (Frechet)", "data": "synthetic",
         "config": {"workload": "C3: CLAP-sized embeddings N=100000 D=512 fp16 per set per GPU, "
-                               "moments x2 + Newton-Schulz Frechet, inputs resident in HBM",
+                               "moments of both sets + Newton-Schulz Frechet, inputs resident in HBM",
                    "rows_per_set_per_gpu": N_ROWS, "dim": DIM,
-                   "sharding": "rows sharded over ranks; per set one in-place all-reduce of the packed (n, sum x, sum xxT) "
-                               f"fp64 [{plen} doubles], the first overlapped with the second set's moments"
-                               if distributed else "single GPU, no collective"},
+                   "sharding": "rows sharded over ranks; ONE in-place all-reduce over the buffer holding both sets' packed "
+                               f"(n, sum x, sum xxT) fp64 [2 x {plen} doubles]" if distributed else "single GPU, no collective"},
         "fad": fad, "newton_schulz_iters": diag["iters"], "ns_converged": diag["converged"],
         "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,
-        "breakdown_ms": {"moments_x2": float(np.median(bm)), "frechet": float(np.median(bf)),
+        "step_ms_spread": {"min": float(step_ms.min()), "p10": float(np.percentile(step_ms, 10)), "median": float(np.median(step_ms)),
+                           "p90": float(np.percentile(step_ms, 90)), "max": float(step_ms.max())},
+        "breakdown_ms": {"moments_both_sets": float(np.median(bm)), "frechet": fr_ms,
                          "moments_reduce_kernels": reduce_ms},
         "roofline": {"kernel": "moments_tile_h16_tr<f16>" if variant == 0 else "moments_tile_f64",
                      "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                     "traffic_source": traffic_src or "not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                      "this command, committed under profiles/ (FETCH_SIZE doubled per the gfx950 note)",
+                     "kernel_ms": kernel_ms, "sets_per_launch": SETS, "algorithmic_flops_per_launch": flops,
                      # only the upper-triangular 128 x 128 tiles of the symmetric result are issued
                      "issued_flops_per_launch": issued, "frac_issued": issued / (kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                     "sets_per_launch": SETS, "algorithmic_bytes_per_launch": SETS * N_ROWS * DIM * 2,
+                     "algorithmic_bytes_per_launch": SETS * N_ROWS * DIM * 2,
                      "hbm_GBps_algorithmic": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
                      "hbm_frac_of_8TBps": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "roofline_frechet": {"kernels": "finalize + gemm_f64 (C1 C2, Y Y) + gemm_f32 x%d + 5 small kernels" % gemms["f32"],
+                             "bound": "launch-chain latency (dependent D^3 products of 0.27 GFLOP each)",
+                             "gemms": gemms, "flops": fr_flops, "ms": fr_ms, "achieved": fr_flops / (fr_ms * 1e-3) / 1e12,
+                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fr_flops / (fr_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                             "peak_source": "f32-input MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md); the two fp64 products run on "
+                                            "v_mfma_f64_16x16x4 (measured ceiling 45-47 TFLOP/s, scripts/probes/mfma_rate.hip)"},
     }
     if extra:
         out["extra"] = extra
@@ -250,13 +327,10 @@ def main():
         base, fad_cpu = cpu_baseline(a.cpu().numpy(), b.cpu().numpy())
         out["cpu_baseline"] = base
         out["speedup_vs_cpu"] = out["value"] / base["value"]
-        # parity on the very same inputs; the device route keeps float64 means, the reference rounds
-        # them to float16 first, so compare both the raw value and the root-only part
-        mu1, _, _ = ma.finalize(); mu2, _, _ = mb.finalize()
-        gap = mu1.astype(np.float32).astype(np.float16) - mu2.astype(np.float32).astype(np.float16)
-        fad_compat = float(gap.dot(gap)) + diag["tr1"] + diag["tr2"] - 2.0 * diag["tr_sqrt"]
-        out["parity_rel_err_vs_cpu"] = abs(fad_compat - fad_cpu) / abs(fad_cpu)
-        out["parity_rel_err_vs_cpu_f64_means"] = abs(fad - fad_cpu) / abs(fad_cpu)
+        # parity on the very same inputs: the step asks for the reference's float16 mean term (mean_dtype = FAD_F16)
+        out["parity_rel_err_vs_cpu"] = abs(fad - fad_cpu) / abs(fad_cpu)
+        fad64, _ = hip.frechet_from_moments(ma, mb)
+        out["parity_rel_err_vs_cpu_f64_means"] = abs(fad64 - fad_cpu) / abs(fad_cpu)
         out["fad_cpu"] = fad_cpu
     sys.stdout.flush()
     os.dup2(real_stdout, 1)

@@ -88,8 +88,8 @@ def resample_kaiser(x: np.ndarray, orig_sr: int, new_sr: int, quantize_pcm16: bo
     return hip.resample_kaiser(np.asarray(x, dtype=np.float32), orig_sr, new_sr, quantize_pcm16=quantize_pcm16, device=device)
 
 
-def convert_to_model_rate(src, dst, sr: int):
-    """Decode, mix to mono, resample to ``sr`` and store as PCM16 WAV (fad.py:148-160)."""
+def convert_to_model_rate(src, dst, sr: int, device: int = 0):
+    """Decode, mix to mono, resample to ``sr`` (on GPU ``device``) and store as PCM16 WAV (fad.py:148-160)."""
     x, fs = read_audio(src)
     mono = x.mean(axis=0)
-    write_pcm16(dst, resample_kaiser(mono, fs, sr), sr)
+    write_pcm16(dst, resample_kaiser(mono, fs, sr, device=device), sr)

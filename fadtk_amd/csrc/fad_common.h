@@ -54,6 +54,27 @@ struct DevBuf {
     void release();
 };
 
+// Scratch buffers of the handle-less entry points: one set per (host thread, device), so callers in a thread pool
+// (fad.py:229, 387 use tmap) never share scratch memory, and the memory goes back to the device when the thread ends.
+// T needs a default constructor and release_all().
+template <typename T> struct PerThreadDevice {
+    static constexpr int kSlots = 16;
+    T slot[kSlots]; int dev[kSlots];
+    PerThreadDevice() { for (int& d : dev) d = -1; }
+    ~PerThreadDevice() {
+        for (int i = 0; i < kSlots; ++i)
+            if (dev[i] >= 0) { DeviceGuard g(dev[i]); if (g.ok) slot[i].release_all(); }
+    }
+    T& get(int device) {
+        const int i = device & (kSlots - 1);
+        if (dev[i] != device) {
+            if (dev[i] >= 0) { DeviceGuard g(dev[i]); if (g.ok) slot[i].release_all(); }
+            dev[i] = device;
+        }
+        return slot[i];
+    }
+};
+
 // ---- fp64 GEMM on v_mfma_f64_16x16x4_f64 (gemm_f64.hip) ------------------------------------
 // One launch = `ntypes` (1 or 2) GEMM shapes x `batch` independent problems:
 //   C = alpha * A * B + beta_eye * I,  operands of problem b at base + b * stride (stride 0 = shared),

@@ -295,7 +295,6 @@ __global__ void rearm_state(NsState* st) {
 
 // ------------------------------------------------------------------------------------------
 struct Workspace : NsWorkspace {
-    int device = -1;
     DevBuf rows, offs, songbuf, songmat, rows2;     // per-song path
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats) + G (doubles)
     int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
@@ -305,23 +304,10 @@ struct Workspace : NsWorkspace {
     }
 };
 
-// One workspace per (host thread, device): calls from a thread pool (fad.py:229, 387 use tmap) never share scratch
-// memory.  The buffers are returned to the device when the thread ends.
-struct WorkspaceSet {
-    Workspace ws[16];
-    ~WorkspaceSet() {
-        for (Workspace& w : ws)
-            if (w.device >= 0) { DeviceGuard g(w.device); if (g.ok) w.release_all(); }
-    }
-};
+// One workspace per (host thread, device), returned to the device when the thread ends (PerThreadDevice).
 static Workspace& thread_ws(int device) {
-    static thread_local WorkspaceSet set;
-    Workspace& w = set.ws[device & 15];
-    if (w.device != device) {
-        if (w.device >= 0) { DeviceGuard g(w.device); if (g.ok) w.release_all(); }
-        w.device = device;
-    }
-    return w;
+    static thread_local PerThreadDevice<Workspace> set;
+    return set.get(device);
 }
 
 struct NsProblem {                  // B problems of dimension d; strides in elements (0 = shared)

@@ -264,12 +264,13 @@ static int get_tables(int kind, int nmel, int device, Tables* out) {
     return FAD_OK;
 }
 
-struct FeWorkspace { int device = -1; DevBuf wav, meta, out, cmax; };
+struct FeWorkspace {
+    DevBuf wav, meta, out, cmax;
+    void release_all() { wav.release(); meta.release(); out.release(); cmax.release(); }
+};
 static FeWorkspace& fe_ws(int device) {
-    static thread_local FeWorkspace ws[8];
-    FeWorkspace& w = ws[device & 7];
-    if (w.device != device) { w.wav.release(); w.meta.release(); w.out.release(); w.cmax.release(); w.device = device; }
-    return w;
+    static thread_local PerThreadDevice<FeWorkspace> ws;
+    return ws.get(device);
 }
 
 template <int KIND>

@@ -1483,6 +1483,12 @@ int fad_moments_reset(fad_moments_t* h, void* stream) {
     return FAD_OK;
 }
 
+int fad_moments_settle(fad_moments_t* h, void* stream) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    DeviceGuard g(h->device);
+    return settle(h, static_cast<hipStream_t>(stream));
+}
+
 int fad_moments_bind(fad_moments_t* h, double* device_packed) {
     if (!h || !device_packed) return set_error(FAD_ERR_INVALID, "NULL argument");
     if (reinterpret_cast<uintptr_t>(device_packed) & 15u) return set_error(FAD_ERR_INVALID, "buffer must be 16-byte aligned");

@@ -147,7 +147,10 @@ int fad_resample_kaiser(const float* wav, int64_t n, int orig_sr, int new_sr, in
     ResampleTable tb;
     if (orig_sr != new_sr) FAD_TRY(get_table(orig_sr, new_sr, device, st, &tb));
 
-    thread_local DevBuf stage_in, stage_out;
+    struct Stage { DevBuf in, out; void release_all() { in.release(); out.release(); } };
+    static thread_local PerThreadDevice<Stage> stages;
+    Stage& stg = stages.get(device);
+    DevBuf& stage_in = stg.in; DevBuf& stage_out = stg.out;
     const float* dwav = wav; float* dout = out;
     if (!on_device) {
         FAD_TRY(stage_in.reserve((size_t)n * sizeof(float)));

@@ -57,8 +57,8 @@ def init(backend: str = None) -> bool:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:         # FAD_DIST_BACKEND=gloo: ranks that share one GPU (tests), or a CPU-only rendezvous
+        backend = os.environ.get("FAD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(env_local_rank())
         dist.init_process_group(backend, device_id=torch.device("cuda", env_local_rank()))
@@ -78,21 +78,61 @@ def shard(items: Sequence, r: int = None, w: int = None) -> list:
 
 
 def allreduce_packed(packed, device=None):
-    """Sum a packed float64 statistics vector (numpy or torch) over all ranks; returns the same kind."""
+    """Sum a packed float64 statistics vector (numpy or torch) over all ranks; returns the same kind.
+    RCCL reduces device tensors in place; under gloo (CPU collectives) a device tensor takes the host route."""
     if world_size() <= 1:
         return packed
     import torch
     import torch.distributed as dist
     is_np = isinstance(packed, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float64)) if is_np else packed
-    if dist.get_backend() == "nccl" and not t.is_cuda:
+    backend = dist.get_backend()
+    if backend == "nccl" and not t.is_cuda:
         t = t.to(device if device is not None else torch.device("cuda", env_local_rank()))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    elif backend != "nccl" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy() if is_np else t
 
 
+class SharedStats:
+    """``count`` GPU accumulators of dimension ``d`` (+ ``extra`` loose float64 words) living in ONE device buffer, so
+    that the exchange of the data-parallel path -- the sum of all ranks' sufficient statistics -- is a single in-place
+    all-reduce with no export/import copies (``fad_moments_bind``).  bench.py and ``embed_and_accumulate`` share it."""
+
+    def __init__(self, d: int, count: int, device: int = 0, extra: int = 0):
+        import torch
+        from .hip import Moments
+        self.d, self.device = int(d), int(device)
+        plen = 1 + d + d * d
+        self.stride = plen + (plen & 1)                     # every slice starts 16-byte aligned
+        self.buffer = torch.zeros(self.stride * count + extra, dtype=torch.float64, device=torch.device("cuda", self.device))
+        self.moments = []
+        for i in range(count):
+            m = Moments(d, self.device)
+            m.bind(self.buffer[i * self.stride:i * self.stride + plen])
+            self.moments.append(m)
+        self.extra = self.buffer[self.stride * count:]
+
+    def allreduce(self):
+        """Sum the whole buffer over all ranks, in place (one collective)."""
+        for m in self.moments:
+            m.settle()                                      # a handle that saw no update since bind/reset still holds garbage
+        allreduce_packed(self.buffer)
+
+    def close(self):
+        for m in self.moments:
+            m.close()
+        self.moments = []
+
+
 def allreduce_moments(moments: Sequence) -> None:
-    """In-place all-reduce of GPU accumulators (fadtk_amd.hip.Moments): one collective for all of them."""
+    """In-place all-reduce of GPU accumulators (fadtk_amd.hip.Moments) that were NOT created through SharedStats:
+    packs them into one buffer, one collective, unpacks.  Prefer SharedStats (no copies)."""
     if world_size() <= 1:
         return
     import torch
@@ -105,6 +145,16 @@ def allreduce_moments(moments: Sequence) -> None:
     o = 0
     for m, n in zip(moments, lens):
         m.import_(buf[o:o + n]); o += n
+
+
+def broadcast_object(obj, src: int = 0):
+    """Rank ``src``'s python object on every rank (file lists: every rank must shard the SAME list)."""
+    if world_size() <= 1:
+        return obj
+    import torch.distributed as dist
+    box = [obj if rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
 
 
 def gather_objects(obj) -> List:

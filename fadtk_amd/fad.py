@@ -117,7 +117,7 @@ class FrechetAudioDistance:
         new = (cache_dir / f.name).with_suffix(".wav")
         if not new.exists():
             cache_dir.mkdir(parents=True, exist_ok=True)
-            convert_to_model_rate(f, new, self.ml.sr)
+            convert_to_model_rate(f, new, self.ml.sr, device=self.device_index)
         return self.ml.load_wav(new)
 
     def cache_embedding_file(self, audio_dir: PathLike):
@@ -177,9 +177,18 @@ class FrechetAudioDistance:
                     raise ValueError(f"FAD statistics file {path} doesn't contain data for model {self.ml.name}")
                 return data[k_mu], data[k_cov]
 
+        from . import dist
+        from .utils import write_stats_cache
         cache_dir = path / "stats" / self.ml.name
         emb_dir = path / "embeddings" / self.ml.name
-        if cache_dir.exists():
+
+        def cached():
+            return (cache_dir / "mu.npy").exists() and (cache_dir / "cov.npy").exists()
+
+        # Several ranks (--gpus N --indiv) ask for the same statistics: rank 0 decides whether the cache is there,
+        # computes and writes it if not (atomic renames), everybody else waits at the barrier and then reads it.
+        have = dist.broadcast_object(cached() if dist.rank() == 0 else None)
+        if have:
             log.info(f"Embedding statistics is already cached for {path}, loading...")
             return np.load(cache_dir / "mu.npy"), np.load(cache_dir / "cov.npy")
 
@@ -187,13 +196,15 @@ class FrechetAudioDistance:
             log.error(f"The dataset you want to use ({path}) is not a directory nor a file.")
             exit(1)
 
-        log.info(f"Loading embedding files from {path}...")
-        mu, cov = calculate_embd_statistics_online(list(emb_dir.glob("*.npy")), device=self.device_index,
-                                                   workers=self.audio_load_worker)
-        log.info("> Embeddings statistics calculated.")
-        cache_dir.mkdir(parents=True, exist_ok=True)
-        np.save(cache_dir / "mu.npy", mu)
-        np.save(cache_dir / "cov.npy", cov)
+        if dist.rank() == 0:
+            log.info(f"Loading embedding files from {path}...")
+            mu, cov = calculate_embd_statistics_online(list(emb_dir.glob("*.npy")), device=self.device_index,
+                                                       workers=self.audio_load_worker)
+            log.info("> Embeddings statistics calculated.")
+            write_stats_cache(cache_dir, mu, cov)
+        dist.barrier()
+        if dist.rank() != 0:
+            mu, cov = np.load(cache_dir / "mu.npy"), np.load(cache_dir / "cov.npy")
         return mu, cov
 
     # ------------------------------------------------------------------ scores

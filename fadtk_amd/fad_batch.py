@@ -21,9 +21,41 @@ from .utils import get_cache_embedding_path
 log = logging.getLogger("fadtk_amd")
 
 
-def _cache_embedding_batch(fs, ml, workers: int = 8, moments=None, file_sums=None, **kwargs):
+class _DeviceFeeder:
+    """Collects per-file float16 embeddings while they are still in HBM and folds them into an ``OnlineStats`` a
+    group at a time (>= 64 files or 64 MiB of frames per GPU call: one launch of each kernel per group, per-file
+    column sums never leave the device).  The reference instead writes every file, reads it back and merges per-file
+    (mean, scatter, n) triplets on the host (fad_batch.py:43-48 + utils.py:19-46)."""
+    GROUP_FILES, GROUP_BYTES = 64, 64 << 20
+
+    def __init__(self, stats):
+        self.stats = stats
+        self.pending, self.bytes = [], 0
+
+    def add(self, dev):
+        self.pending.append(dev)
+        self.bytes += dev.numel() * dev.element_size()
+        if len(self.pending) >= self.GROUP_FILES or self.bytes >= self.GROUP_BYTES:
+            self.flush()
+
+    def add_host(self, arr):
+        """A cached .npy: goes in as its own group (its dtype may differ from the device embeddings')."""
+        self.flush()
+        self.stats.add_group(arr, [arr.shape[0]])
+
+    def flush(self):
+        if not self.pending:
+            return
+        import torch
+        sizes = [int(t.shape[0]) for t in self.pending]
+        rows = torch.cat(self.pending, dim=0) if len(self.pending) > 1 else self.pending[0]
+        self.stats.add_group(rows.contiguous(), sizes)
+        self.pending, self.bytes = [], 0
+
+
+def _cache_embedding_batch(fs, ml, workers: int = 8, feeder=None, **kwargs):
     """Embed a list of files on this process's GPU; audio decode runs ``workers`` files ahead.
-    With ``moments`` (a fadtk_amd.hip.Moments) every embedding is also accumulated while it is still in HBM."""
+    With ``feeder`` (a _DeviceFeeder) every embedding is also accumulated while it is still in HBM."""
     import numpy as np
     fad = FrechetAudioDistance(ml, audio_load_worker=workers, **kwargs)
     if not fs:
@@ -45,23 +77,17 @@ def _cache_embedding_batch(fs, ml, workers: int = 8, moments=None, file_sums=Non
             submit()
             cache = get_cache_embedding_path(ml.name, f)
             if cache.exists():
-                if moments is not None:
-                    e = np.load(cache)
-                    moments.update(e)
-                    if file_sums is not None:
-                        file_sums.append((e.shape[0], e.astype(np.float64).sum(axis=0), e.dtype))
+                if feeder is not None:
+                    feeder.add_host(np.load(cache))
                 continue
             log.info(f"Loading {f} using {ml.name}")
             try:
-                if moments is not None:          # keep the frames on the device: fp16 exactly as stored, then moments
+                if feeder is not None:           # keep the frames on the device: fp16 exactly as stored, then moments
                     import torch
                     dev = ml._get_embedding(fut.result()).detach()
                     dev = dev.to(torch.float16) if dev.dtype == torch.float32 else dev
-                    if dev.shape[0] > 0:
-                        moments.update(dev.contiguous())
-                    embd = dev.cpu().numpy()
-                    if file_sums is not None:          # per-file column sums (D numbers) for the reference's mean quirk
-                        file_sums.append((embd.shape[0], dev.to(torch.float64).sum(dim=0).cpu().numpy(), embd.dtype))
+                    feeder.add(dev.contiguous())
+                    embd = dev.cpu().numpy()     # the embedding cache file is part of the contract (fad.py:188-201)
                 else:
                     embd = ml.get_embedding(fut.result())
             except Exception as e:      # noqa: BLE001  a bad file must not take the shard down
@@ -69,25 +95,40 @@ def _cache_embedding_batch(fs, ml, workers: int = 8, moments=None, file_sums=Non
                 continue
             cache.parent.mkdir(parents=True, exist_ok=True)
             np.save(cache, embd)
+    if feeder is not None:
+        feeder.flush()
 
 
-def cache_embedding_files(files: Union[list, str, Path], ml, workers: int = 8, **kwargs):
-    """Get embeddings for all audio files in a directory (or list), skipping cached ones."""
-    if isinstance(files, (str, Path)):
-        files = sorted(Path(files).glob("*.*"))
-    files = [Path(f) for f in files if not get_cache_embedding_path(ml.name, f).exists()]
-    if len(files) == 0:
-        log.info("All files already have embeddings, skipping.")
-        return
-    log.info(f"[Frechet Audio Distance] Loading {len(files)} audio files...")
-    dist.init()
+def _select_device(ml, kwargs):
+    """One process per GPU: under torchrun every rank drives the GPU named by LOCAL_RANK."""
     if dist.world_size() > 1:
         import torch
         if torch.cuda.is_available():
             torch.cuda.set_device(dist.env_local_rank())
             ml.device = torch.device("cuda", dist.env_local_rank())
             kwargs.setdefault("device", dist.env_local_rank())
-    _cache_embedding_batch(dist.shard(files), ml, workers, **kwargs)
+        return dist.env_local_rank()
+    return int(kwargs.get("device", 0))
+
+
+def cache_embedding_files(files: Union[list, str, Path], ml, workers: int = 8, **kwargs):
+    """Get embeddings for all audio files in a directory (or list), skipping cached ones.
+    Multi-rank: rank 0 lists the uncached files and every rank shards THAT list (ranks listing on their own while
+    others already write cache files would shard different lists), and no rank leaves before the closing barrier."""
+    dist.init()
+    todo = None
+    if dist.rank() == 0:
+        if isinstance(files, (str, Path)):
+            files = sorted(Path(files).glob("*.*"))
+        todo = [Path(f) for f in files if not get_cache_embedding_path(ml.name, f).exists()]
+    todo = dist.broadcast_object(todo)
+    if len(todo) == 0:
+        log.info("All files already have embeddings, skipping.")
+        dist.barrier()
+        return
+    log.info(f"[Frechet Audio Distance] Loading {len(todo)} audio files...")
+    _select_device(ml, kwargs)
+    _cache_embedding_batch(dist.shard(todo), ml, workers, **kwargs)
     dist.barrier()
 
 
@@ -97,51 +138,32 @@ def embed_and_accumulate(directory: Union[str, Path], ml, workers: int = 8, comp
     statistics once (RCCL over xGMI) and let rank 0 store ``<dir>/stats/<model>/{mu,cov}.npy`` -- the cache
     ``FrechetAudioDistance.load_stats`` picks up, so a following ``score`` never re-reads the .npy files.
 
-    compat=True adds the sum-reducible per-file mean terms (``utils.per_file_mean_terms``) so that the result is
+    compat=True adds the sum-reducible per-file mean terms (``fad_moments_update_file_means``) so that the result is
     what the reference's online path gives, including its per-file float16 rounding of the means (which is worth up to
-    3e-4 of the FAD for files of a few frames); compat=False is the plain raw-moment estimate.
+    3e-4 of the FAD for files of a few frames); compat=False is the plain raw-moment estimate.  All accumulators of a
+    rank live in one device buffer (``dist.SharedStats``): the exchange of the path is ONE in-place all-reduce.
     Returns (mu, cov) on every rank.
     """
-    import numpy as np
-    from . import hip
-    from .utils import combine_online_statistics, per_file_mean_terms
+    from .utils import OnlineStats, write_stats_cache
     directory = Path(directory)
-    files = sorted(p for p in directory.glob("*.*") if p.is_file())
     dist.init()
-    dev_index = dist.env_local_rank() if dist.world_size() > 1 else 0
-    if dist.world_size() > 1:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.set_device(dev_index)
-            ml.device = torch.device("cuda", dev_index)
-            kwargs.setdefault("device", dev_index)
+    files = dist.broadcast_object(sorted(p for p in directory.glob("*.*") if p.is_file()) if dist.rank() == 0 else None)
+    dev_index = _select_device(ml, kwargs)
     d = ml.num_features
-    acc = hip.Moments(d, dev_index)
-    file_sums = [] if compat else None
-    _cache_embedding_batch(dist.shard(files), ml, workers, moments=acc, file_sums=file_sums, **kwargs)
-    dist.allreduce_moments([acc])                                      # the one collective of the data path
-    packed = acc.export()
-    acc.close()
-    if compat:
-        sizes = np.array([f[0] for f in file_sums], dtype=np.int64)
-        sums = np.stack([f[1] for f in file_sums]) if file_sums else np.zeros((0, d))
-        dtype = file_sums[0][2] if file_sums else np.float16
-        wsum, within, between, n_short, n_empty = per_file_mean_terms(sums, sizes, dtype, dev_index)
-        extra = np.concatenate([wsum, within.reshape(-1), between.reshape(-1), [n_short, n_empty]])
-        extra = dist.allreduce_packed(extra)                           # D + 2 D^2 + 2 doubles, once per dataset
-        wsum, within, between = extra[:d], extra[d:d + d * d].reshape(d, d), extra[d + d * d:d + 2 * d * d].reshape(d, d)
-        mu, cov = combine_online_statistics(packed, wsum, within, between, int(round(extra[-2])), int(round(extra[-1])))
-        n = int(round(packed[0]))
-    else:
-        n = int(round(packed[0]))
+    shared = dist.SharedStats(d, 4 if compat else 1, dev_index, extra=2)
+    stats = OnlineStats(d, dev_index, compat, shared=shared)
+    _cache_embedding_batch(dist.shard(files), ml, workers, feeder=_DeviceFeeder(stats), **kwargs)
+    import torch
+    shared.extra.copy_(torch.tensor([stats.n_short, stats.n_empty], dtype=torch.float64))
+    shared.allreduce()                                                 # the one collective of the data path
+    stats.n_short, stats.n_empty = (int(round(v)) for v in shared.extra.cpu().tolist())
+    mu, cov = stats.finish()
+    n = stats.frames.count
+    shared.close()
+    if not compat:
         assert n >= 2, f"FAD requires at least two embedding window frames, you have {n}."
-        sx, sxx = packed[1:1 + d], packed[1 + d:].reshape(d, d)
-        mu, cov = sx / n, (sxx - np.outer(sx, sx) / n) / (n - 1)
     if dist.rank() == 0:
-        out = directory / "stats" / ml.name
-        out.mkdir(parents=True, exist_ok=True)
-        np.save(out / "mu.npy", mu)
-        np.save(out / "cov.npy", cov)
+        write_stats_cache(directory / "stats" / ml.name, mu, cov)
     dist.barrier()
     log.info(f"[{ml.name}] {n} frames from {len(files)} files accumulated on {dist.world_size()} GPU(s)")
     return mu, cov

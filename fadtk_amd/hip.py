@@ -63,6 +63,10 @@ class Moments:
     def reset(self):
         K.check(self._lib.fad_moments_reset(self._h, self._stream()), "fad_moments_reset")
 
+    def settle(self):
+        """Make a pending reset visible in the packed buffer (the zeroing is deferred until something reads it)."""
+        K.check(self._lib.fad_moments_settle(self._h, self._stream()), "fad_moments_settle")
+
     def update(self, rows) -> "Moments":
         ptr, n, d, ld, code, on_dev, keep = K.rows_view(rows)
         if d != self.d:

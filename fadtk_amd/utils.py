@@ -56,6 +56,20 @@ def find_sox_formats(sox_path: str) -> List[str]:
         return []
 
 
+def write_stats_cache(cache_dir: PathLike, mu: np.ndarray, cov: np.ndarray) -> None:
+    """<dir>/stats/<model>/{mu,cov}.npy (fad.py:286-289), written so that a concurrent reader never sees a
+    half-written file: temporary names first, cov.npy renamed last-but-one, the directory's mu.npy last."""
+    import os
+    cache_dir = Path(cache_dir)
+    cache_dir.mkdir(parents=True, exist_ok=True)
+    tag = f".tmp{os.getpid()}"
+    for name, arr in (("cov.npy", cov), ("mu.npy", mu)):
+        tmp = cache_dir / (name + tag)
+        with open(tmp, "wb") as fh:
+            np.save(fh, arr)
+        os.replace(tmp, cache_dir / name)
+
+
 def get_cache_embedding_path(model: str, audio_dir: PathLike) -> Path:
     """<dir>/embeddings/<model>/<stem>.npy for an audio file <dir>/<stem>.<ext> (fadtk/utils.py:60-68)."""
     audio = Path(audio_dir)
@@ -72,79 +86,146 @@ def _round_like(values: np.ndarray, dtype: np.dtype) -> np.ndarray:
     return values
 
 
-def dataset_statistics(blocks: Sequence[np.ndarray], compat: bool = True, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+_DT_CODES = {np.dtype(np.float16): 0, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
+
+
+class OnlineStats:
+    """Dataset statistics from per-file frame matrices, fed in groups -- the sum-reducible form of what
+    ``calculate_embd_statistics_online`` (fadtk/utils.py:19-46) merges file by file.
+
+    Four GPU accumulators: the raw moments of all frames, and -- for the reference's quirk that every per-file mean is
+    rounded to the file's dtype (float16) before the merge -- the rows sqrt(n_f) m_f, sqrt(n_f) m~_f and n_f m~_f
+    (``fad_moments_update_file_means``).  ``buffers`` is a ``dist.SharedStats`` when several ranks feed shards of one
+    dataset: their sum is then ONE all-reduce.  Nothing but per-group column sums [files x D] is kept besides."""
+
+    def __init__(self, d: int, device: int = 0, compat: bool = True, shared=None):
+        from .hip import Moments
+        self.d, self.device, self.compat = int(d), int(device), compat
+        self.shared = shared
+        if shared is not None:          # 4 accumulators when compat, else 1
+            self.frames = shared.moments[0]
+            self.exact, self.rounded, self.weighted = shared.moments[1:4] if compat else (None, None, None)
+        else:
+            self.frames = Moments(d, device)
+            self.exact, self.rounded, self.weighted = (Moments(d, device) for _ in range(3)) if compat else (None, None, None)
+        self.n_short = 0          # files with fewer than two frames (np.cov -> NaN, SURVEY.md Q5)
+        self.n_empty = 0
+        self.n_files = 0
+
+    def add_group(self, rows, sizes: Sequence[int]) -> None:
+        """``rows`` = the frames of ``len(sizes)`` files stored back to back (numpy on the host, or a torch CUDA tensor that
+        stays in HBM); one dtype per group."""
+        sizes = np.asarray(sizes, dtype=np.int64)
+        self.n_files += len(sizes)
+        self.n_short += int((sizes < 2).sum())
+        self.n_empty += int((sizes < 1).sum())
+        if int(sizes.sum()) == 0:
+            return
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        if not self.compat:
+            self.frames.update(rows)
+            return
+        on_dev = type(rows).__module__.split(".")[0] == "torch" and rows.is_cuda
+        sums = self.frames.update_segmented(rows, offs, want_sums=True, sums_on_device=on_dev)
+        if on_dev:
+            import torch
+            code = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}.get(rows.dtype, 3)
+        else:
+            code = _DT_CODES.get(np.asarray(rows).dtype, 3)
+        type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code)
+
+    def pieces(self):
+        """(packed frames, sum_f n_f m~_f, sum_f n_f m_f m_f^T, sum_f n_f m~_f m~_f^T) as host arrays."""
+        d = self.d
+        packed = self.frames.export()
+        if not self.compat:
+            return packed, None, None, None
+        return (packed, self.weighted.export()[1:1 + d], self.exact.export()[1 + d:].reshape(d, d),
+                self.rounded.export()[1 + d:].reshape(d, d))
+
+    def finish(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(mu, Sigma) as the reference's sequential merge leaves them (compat) or the plain raw-moment estimate."""
+        d = self.d
+        packed, wsum, within, between = self.pieces()
+        total = int(round(packed[0]))
+        if not self.compat:
+            if total < 1:
+                return np.full(d, np.nan), np.zeros((d, d))
+            sum_x, sum_xx = packed[1:1 + d], packed[1 + d:].reshape(d, d)
+            mu = sum_x / total
+            if total < 2:
+                return mu, np.zeros((d, d))                                   # utils.py:42-43
+            return mu, (sum_xx - np.outer(sum_x, sum_x) / total) / (total - 1)
+        return combine_online_statistics(packed, wsum, within, between, self.n_short, self.n_empty)
+
+    def close(self):
+        if self.shared is None:
+            for m in (self.frames, self.exact, self.rounded, self.weighted):
+                if m is not None:
+                    m.close()
+
+
+def _groups(blocks: Iterable[np.ndarray], limit_bytes: int):
+    """Consecutive blocks of ONE dtype whose frames total <= limit_bytes (at least one block per group)."""
+    group, nbytes, dt = [], 0, None
+    for b in blocks:
+        b = np.asarray(b)
+        if group and (b.dtype != dt or nbytes + b.nbytes > limit_bytes):
+            yield group
+            group, nbytes = [], 0
+        group.append(b); nbytes += b.nbytes; dt = b.dtype
+    if group:
+        yield group
+
+
+def dataset_statistics(blocks: Iterable[np.ndarray], compat: bool = True, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
     """Dataset (mu, Sigma) from per-file frame matrices, as calculate_embd_statistics_online
-    (fadtk/utils.py:19-46) computes it -- but in ONE GPU pass over raw moments.
+    (fadtk/utils.py:19-46) computes it -- but in ONE GPU pass over raw moments.  ``blocks`` may be a generator: the
+    frames are consumed in groups of <= STAGE_BYTES, so host memory holds one group, not the dataset.
 
     compat=True reproduces the reference's quirk that every per-file mean is rounded to the file's
     dtype (float16) before the merge:  Sigma = (W + B~) / (N-1) with the within-file scatter W from
     exact means and the between-file scatter B~ from the rounded means (algebraically what the
     sequential merge of utils.py:36-40 yields).  compat=False is the plain (sum, sum xx^T) estimate.
     """
-    from .hip import Moments
-    if len(blocks) == 0:
+    it = iter(blocks)
+    first = next(it, None)
+    if first is None:
         raise AssertionError("No files provided")
-    d = int(blocks[0].shape[-1])
-    dtype = np.asarray(blocks[0]).dtype
-    sizes = np.array([b.shape[0] for b in blocks], dtype=np.int64)
-    total = int(sizes.sum())
+    first = np.asarray(first)
+    d = int(first.shape[-1])
 
-    with Moments(d, device) as acc:
-        seg_sums = []
-        i = 0
-        while i < len(blocks):                       # host blocks of <= STAGE_BYTES, one GPU call each
-            j, nbytes = i, 0
-            while j < len(blocks) and (j == i or nbytes + blocks[j].nbytes <= STAGE_BYTES):
-                nbytes += blocks[j].nbytes
-                j += 1
-            group = [np.asarray(b) for b in blocks[i:j]]
-            same = all(g.dtype == group[0].dtype for g in group)
-            rows = np.concatenate(group if same else [g.astype(np.float64) for g in group], axis=0)
-            offs = np.concatenate([[0], np.cumsum(sizes[i:j])])
-            if rows.shape[0] > 0:
-                seg_sums.append(acc.update_segmented(rows, offs, want_sums=True))
-            else:
-                seg_sums.append(np.zeros((j - i, d)))
-            i = j
-        packed = acc.export()
-    seg_sums = np.concatenate(seg_sums, axis=0)
-    n = packed[0]
-    sum_x, sum_xx = packed[1:1 + d], packed[1 + d:].reshape(d, d)
+    def chain():
+        yield first
+        yield from it
 
-    if total < 1:
-        return np.full(d, np.nan), np.zeros((d, d))
-    if not compat:
-        mu = sum_x / n
-        if total < 2:
-            return mu, np.zeros((d, d))                                   # utils.py:42-43
-        return mu, (sum_xx - np.outer(sum_x, sum_x) / n) / (n - 1)
-
-    return finish_online_statistics(packed, seg_sums, sizes, dtype, device)
+    acc = OnlineStats(d, device, compat)
+    try:
+        for group in _groups(chain(), STAGE_BYTES):
+            sizes = [g.shape[0] for g in group]
+            rows = np.concatenate(group, axis=0) if len(group) > 1 else group[0]
+            acc.add_group(rows, sizes)
+        return acc.finish()
+    finally:
+        acc.close()
 
 
 def per_file_mean_terms(seg_sums: np.ndarray, sizes: np.ndarray, dtype, device: int = 0):
     """What the reference's per-file float16 means (utils.py:16) change, as additive (sum-reducible) pieces:
     -> (sum_f n_f m~_f  [D],  sum_f n_f m_f m_f^T  [D x D] with exact means,  sum_f n_f m~_f m~_f^T with rounded means,
-        number of files with < 2 rows, number of empty files).  The two matrices are raw moments of the rows
-    sqrt(n_f) m_f, computed by the same GPU kernel."""
+        number of files with < 2 rows, number of empty files).  Computed on the GPU (fad_moments_update_file_means)."""
     from .hip import Moments
+    seg_sums = np.asarray(seg_sums, dtype=np.float64)
     d = seg_sums.shape[1]
     sizes = np.asarray(sizes, dtype=np.int64)
-    ok = sizes > 0
-    means = np.zeros_like(seg_sums)
-    means[ok] = seg_sums[ok] / sizes[ok, None]
-    means_ref = _round_like(means, np.dtype(dtype))
-    w = sizes.astype(np.float64)
-    wsum_ref = (means_ref * w[:, None]).sum(axis=0)
-    root_w = np.sqrt(w)[:, None]
     if len(sizes) == 0:
         z = np.zeros((d, d))
-        return wsum_ref, z, z.copy(), 0, 0
-    with Moments(d, device) as a_exact, Moments(d, device) as a_ref:
-        a_exact.update(np.ascontiguousarray(means * root_w))
-        a_ref.update(np.ascontiguousarray(means_ref * root_w))
-        within_corr = a_exact.export()[1 + d:].reshape(d, d)
-        between = a_ref.export()[1 + d:].reshape(d, d)
+        return np.zeros(d), z, z.copy(), 0, 0
+    with Moments(d, device) as e, Moments(d, device) as r, Moments(d, device) as w:
+        Moments.update_file_means(e, r, w, seg_sums, sizes, _DT_CODES.get(np.dtype(dtype), 3))
+        within_corr = e.export()[1 + d:].reshape(d, d)
+        between = r.export()[1 + d:].reshape(d, d)
+        wsum_ref = w.export()[1:1 + d]
     return wsum_ref, within_corr, between, int((sizes < 2).sum()), int((sizes < 1).sum())
 
 
@@ -167,13 +248,20 @@ def combine_online_statistics(packed: np.ndarray, wsum_ref, within_corr, between
     return mu, scatter / (total - 1)
 
 
-def finish_online_statistics(packed, seg_sums, sizes, dtype, device: int = 0):
-    return combine_online_statistics(packed, *per_file_mean_terms(seg_sums, sizes, dtype, device))
-
-
 def calculate_embd_statistics_online(files: List[PathLike], compat: bool = True, device: int = 0,
                                      workers: int = 8) -> Tuple[np.ndarray, np.ndarray]:
     """(mu, Sigma) of all frames stored in ``files`` (.npy, [n_frames x n_features]) -- fadtk/utils.py:19-46."""
     assert len(files) > 0, "No files provided"
-    blocks = tmap(np.load, files, desc="Loading embeddings", max_workers=workers)
-    return dataset_statistics(blocks, compat=compat, device=device)
+
+    def stream():                                    # files are read `workers` ahead of the GPU, never all at once
+        files_l = list(files)
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+            window = 4 * max(1, workers)
+            pending = [ex.submit(np.load, f) for f in files_l[:window]]
+            nxt = len(pending)
+            while pending:
+                blk = pending.pop(0).result()
+                if nxt < len(files_l):
+                    pending.append(ex.submit(np.load, files_l[nxt])); nxt += 1
+                yield blk
+    return dataset_statistics(stream(), compat=compat, device=device)

@@ -63,6 +63,10 @@ typedef struct fad_moments fad_moments_t;
 int fad_moments_create(int d, int device, fad_moments_t** out);
 int fad_moments_destroy(fad_moments_t* h);
 int fad_moments_reset(fad_moments_t* h, void* stream);
+/* The zeroing of a reset (or bind) is deferred: an update right after it overwrites the accumulator instead.  Whoever
+ * reads the packed buffer BEHIND the library's back (a collective over a bound buffer) calls this first so that a
+ * handle that received no rows holds zeros. */
+int fad_moments_settle(fad_moments_t* h, void* stream);
 /* Keep the packed statistics in the CALLER's device buffer (packed_len doubles, 16-byte aligned, same device) from
  * now on, and reset them.  The buffer then is what a collective runs over in place -- e.g. two handles bound to the
  * halves of one allocation are summed across ranks by a single all-reduce with no export/import copies (bench.py).

@@ -37,6 +37,8 @@ def _worker(rank, world, port, tmp):
     local = sum((_packed(files[i]) for i in mine), np.zeros(1 + 24 + 24 * 24))
     total = dist.allreduce_packed(local)                                # the one collective of the path
     scores = dist.gather_objects([(i, float(files[i].sum())) for i in mine])
+    listing = dist.broadcast_object(["a", "b", rank] if rank == 0 else None)      # rank 0's list on every rank
+    assert listing == ["a", "b", 0]
     dist.barrier()
     if rank == 0:
         np.save(Path(tmp) / "total.npy", total)

@@ -1,0 +1,88 @@
+"""Two ranks driving the HIP multi-GPU path on ONE GPU (gloo rendezvous, both ranks on cuda:0): file sharding, the
+HIP accumulators in a shared device buffer, the per-file mean terms, ONE all-reduce, sharded --indiv scoring and the
+rank-ordered gather -- everything `--gpus 2` does except that the collective runs over gloo instead of RCCL
+(a single-GPU box cannot host a 2-rank RCCL communicator).  Results are checked against the oracle on the union."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import recipes as R
+from oracle import fad_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      FAD_DIST_BACKEND="gloo", FADTK_AMD_RANDOM_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import fadtk_amd
+    from fadtk_amd import dist, hip
+    from fadtk_amd.fad_batch import cache_embedding_files, embed_and_accumulate
+    from fadtk_amd.model_loader import EncodecEmbModel
+    tmp = Path(tmp)
+    ml = EncodecEmbModel("24k")
+    # 1. fused embedding + statistics over file shards, one all-reduce of the shared buffer
+    mu, cov = embed_and_accumulate(tmp / "base", ml, workers=2)
+    assert dist.world_size() == world and dist.rank() == rank
+    # 2. plain embedding cache of the eval set (rank 0 lists, everybody shards the same list)
+    cache_embedding_files(tmp / "eval", ml, workers=2)
+    # 3. per-song scores, songs sharded over the ranks, gathered in file order; load_stats served by rank 0's cache
+    fad = fadtk_amd.FrechetAudioDistance(ml, audio_load_worker=2, load_model=False, device=0)
+    fad.score_individual(tmp / "base", tmp / "eval", tmp / "indiv.csv")
+    # 4. the shared-buffer reduce on bare accumulators: rank r feeds rows r::world
+    x = torch.from_numpy(R.normal_rows(7, 4001, 128)).cuda()
+    sh = dist.SharedStats(128, 2, 0)
+    hip.Moments.update_multi(sh.moments, [x[rank::world], (2 * x)[rank::world].contiguous()])
+    sh.allreduce()
+    packed = [m.export() for m in sh.moments]
+    sh.close()
+    dist.barrier()
+    if rank == 0:
+        np.savez(tmp / "rank0.npz", mu=mu, cov=cov, p0=packed[0], p1=packed[1])
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_oracle_on_the_union(tmp_path):
+    import torch.multiprocessing as mp
+    from fadtk_amd import audio
+    for name, n, seed, gain in (("base", 9, 800, 1.0), ("eval", 5, 900, 0.7)):
+        (tmp_path / name).mkdir()
+        for i in range(n):
+            audio.write_pcm16(tmp_path / name / f"clip{i:03d}.wav", gain * R.audio_clip(seed + i, int((1.0 + 0.5 * (i % 3)) * 24000), 24000), 24000)
+    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+    z = np.load(tmp_path / "rank0.npz")
+    blocks = [np.load(p) for p in sorted((tmp_path / "base" / "embeddings" / "encodec-emb").glob("*.npy"))]
+    assert len(blocks) == 9 and all(b.dtype == np.float16 and b.shape[1] == 128 for b in blocks)
+    mu_o, cov_o = O.statistics_online(blocks)                   # the reference's online path on the union of both shards
+    np.testing.assert_allclose(z["mu"], mu_o, rtol=0, atol=1e-9 * np.abs(mu_o).max() + 1e-12)
+    np.testing.assert_allclose(z["cov"], cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+    assert np.array_equal(np.load(tmp_path / "base" / "stats" / "encodec-emb" / "cov.npy"), z["cov"])
+
+    lines = (tmp_path / "indiv.csv").read_text().split("\n")
+    assert len(lines) == 5
+    got = {Path(ln.rsplit(",", 1)[0]).name: float(ln.rsplit(",", 1)[1]) for ln in lines}
+    for p in sorted((tmp_path / "eval").glob("*.wav")):
+        e = np.load(tmp_path / "eval" / "embeddings" / "encodec-emb" / (p.stem + ".npy"))
+        ref = O.frechet_distance(z["mu"], z["cov"], *O.embd_statistics(e), run_sqrtm=False)
+        assert abs(got[p.name] - ref) / abs(ref) < 1e-4, p.name
+
+    x = R.normal_rows(7, 4001, 128).astype(np.float64)
+    for p, rows in ((z["p0"], x), (z["p1"], 2 * x)):
+        assert p[0] == 4001
+        np.testing.assert_allclose(p[1:129], rows.sum(0), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(p[129:].reshape(128, 128), rows.T @ rows, rtol=0, atol=1e-6 * np.abs(rows.T @ rows).max())

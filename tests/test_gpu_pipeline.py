@@ -176,3 +176,150 @@ def test_resampler_edges_and_audio_normalisation(tmp_path):
     src = audio.read_pcm16(tmp_path / "a.wav")[0] / 32768.0
     want = np.rint(AO.resample_kaiser(src.astype(np.float32), 48000, 16000) * 32768)
     assert np.abs(pcm - want).max() <= 1
+
+
+# --------------------------------------------------------------------------------- reference surface not exercised elsewhere
+def _toy_fad(name="toy-model", d=32):
+    import types
+    import fadtk_amd
+    ml = types.SimpleNamespace(name=name, sr=16000, num_features=d, load_model=lambda: None)
+    return fadtk_amd.FrechetAudioDistance(ml, audio_load_worker=2, load_model=False)
+
+
+def test_load_embeddings_max_count_and_concat_false(tmp_path):
+    """fad.py:211-243: load_embeddings reads every cached .npy of a directory; max_count stops once MORE than max_count
+    frames are in; concat=False returns (list of matrices, files)."""
+    fad = _toy_fad()
+    root = tmp_path / "set"
+    (root / "embeddings" / "toy-model").mkdir(parents=True)
+    blocks = R.songs(300, 7, [5, 9, 2, 33, 12, 7, 4], 32)
+    names = [f"s{i}.wav" for i in range(7)]
+    for nm, blk in zip(names, blocks):
+        (root / nm).write_bytes(b"")
+        np.save(root / "embeddings" / "toy-model" / (Path(nm).stem + ".npy"), blk)
+    files = sorted(root.glob("*.wav"))
+    allrows = fad._load_embeddings(files, concat=True)
+    assert allrows.shape == (sum(b.shape[0] for b in blocks), 32) and allrows.dtype == np.float16
+    np.testing.assert_array_equal(allrows, np.concatenate(blocks))
+    got = fad.load_embeddings(root, concat=True)                        # glob order of the directory, same rows overall
+    assert got.shape == allrows.shape and np.isclose(got.astype(np.float64).sum(), allrows.astype(np.float64).sum())
+    part = fad._load_embeddings(files, max_count=15, concat=True)       # 5 + 9 = 14 <= 15, + 2 = 16 > 15 -> stops after 3 files
+    assert part.shape[0] == 16
+    lst, fs = fad._load_embeddings(files, max_count=15, concat=False)
+    assert [b.shape[0] for b in lst] == [5, 9, 2] and fs == files
+    with pytest.raises(ValueError):
+        fad._load_embeddings([], concat=True)
+
+
+from pathlib import Path     # noqa: E402
+
+
+def test_package_stats_round_trip_into_load_stats(tmp_path, monkeypatch):
+    """`python -m fadtk.package <dir> <out.npz>` (package.py:34-42) writes {model}.mu / {model}.cov that load_stats
+    (fad.py:262-268) reads back; the statistics equal the directory's own."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    base = _make_set(tmp_path / "base", 4, 3.0, 16000, 1200)
+    env = dict(os.environ, FADTK_AMD_RANDOM_WEIGHTS="1", PYTHONPATH=str(root))
+    out = tmp_path / "packed.npz"
+    r = subprocess.run([sys.executable, "-m", "fadtk.package", str(base), str(out), "-m", "vggish", "-w", "2"],
+                       capture_output=True, text=True, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with np.load(out) as z:
+        assert sorted(z.files) == ["vggish.cov", "vggish.mu"]
+        mu_p, cov_p = z["vggish.mu"], z["vggish.cov"]
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    import fadtk_amd
+    from fadtk_amd.model_loader import VGGishModel
+    fad = fadtk_amd.FrechetAudioDistance(VGGishModel(), load_model=False)
+    mu_f, cov_f = fad.load_stats(str(out))                              # an .npz file
+    assert np.array_equal(mu_f, mu_p) and np.array_equal(cov_f, cov_p)
+    mu_d, cov_d = fad.load_stats(base)                                  # the directory (its stats cache was written by package)
+    assert np.array_equal(mu_d, mu_p) and np.array_equal(cov_d, cov_p)
+    blocks = [np.load(p) for p in (base / "embeddings" / "vggish").glob("*.npy")]
+    mu_o, cov_o = O.statistics_online(blocks)
+    np.testing.assert_allclose(cov_p, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+    with pytest.raises(ValueError):                                     # missing key (fad.py:265)
+        _toy_fad("other-model").load_stats(str(out))
+
+
+def test_cli_inf_end_to_end(tmp_path):
+    """`python -m fadtk <model> <baseline> <eval> <csv> --inf` (__main__.py:45-49): FAD-inf over the eval directory,
+    score and r2 appended to the CSV; the extrapolation equals the oracle's on the same cached embeddings and seed."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    base = _make_set(tmp_path / "base", 12, 6.0, 16000, 1300)
+    evl = _make_set(tmp_path / "eval", 30, 10.0, 16000, 1400, gain=0.8)       # 30 x 10 examples = 300 eval frames
+    env = dict(os.environ, FADTK_AMD_RANDOM_WEIGHTS="1", PYTHONPATH=str(root))
+    csv = tmp_path / "inf.csv"
+    code = ("import sys, numpy as np; np.random.seed(0); sys.argv = ['fadtk', 'vggish', %r, %r, %r, '--inf', '-w', '2'];"
+            "import fadtk_amd.cli as c; c.score_main()" % (str(base), str(evl), str(csv)))
+    # score_inf's default min_n is 500 > 300 frames: numpy then draws MORE than the set holds (with replacement), like the reference
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "FAD-inf Information:" in r.stdout
+    cols = csv.read_text().strip().split("\n")[1].split(",")
+    assert cols[0] == "vggish" and np.isfinite(float(cols[3])) and cols[4] != "None" and 0.0 <= float(cols[4]) <= 1.0 + 1e-9
+    # oracle on the same embeddings, same RNG stream, same file order as the CLI's glob
+    mu_b, cov_b = O.statistics_online([np.load(p) for p in (base / "embeddings" / "vggish").glob("*.npy")])
+    files = [evl / "embeddings" / "vggish" / (p.stem + ".npy") for p in evl.glob("*.*")]
+    embeds = np.concatenate([np.load(f) for f in files], axis=0)
+    np.random.seed(0)
+    want = O.score_inf(mu_b, cov_b, embeds)
+    assert abs(float(cols[3]) - want.score) / abs(want.score) < 5e-4
+    assert abs(float(cols[4]) - want.r2) < 1e-3
+
+
+def test_encodec_48k_segments_of_one_second(monkeypatch, tmp_path):
+    """model_loader.py:139-152: the 48 kHz Encodec embeds 1-second stereo segments independently and concatenates the
+    frames (150 per full second; the tail segment gives ceil(samples / 320) frames)."""
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    import torch
+    from fadtk_amd import audio
+    from fadtk_amd.model_loader import EncodecEmbModel
+    ml = EncodecEmbModel("48k")
+    ml.load_model()
+    sr = 48000
+    audio.write_pcm16(tmp_path / "x.wav", R.audio_clip(1500, int(2.5 * sr), sr), sr)
+    wav = ml.load_wav(tmp_path / "x.wav")
+    assert tuple(wav.shape) == (1, 2, int(2.5 * sr))                     # mono file -> the model's two channels
+    emb = ml.get_embedding(wav)
+    assert emb.dtype == np.float16 and emb.shape == (150 + 150 + 75, 128) and np.isfinite(emb).all()
+    seg0 = ml._get_frame(wav[:, :, :sr]).cpu().numpy()                   # segments do not see each other
+    np.testing.assert_allclose(emb[:150].astype(np.float32), seg0, rtol=0, atol=4e-3)   # (conv algorithm choice may differ by an fp16 ulp)
+    other = ml.get_embedding(wav[:, :, :2 * sr])                          # the first two segments of a shorter file: same frames
+    np.testing.assert_allclose(emb[:300].astype(np.float32), other.astype(np.float32), rtol=0, atol=4e-3)
+
+
+def test_config4_many_files_device_resident_matches_online_oracle():
+    """Config 4, pure-moments variant: 1000 Encodec-shaped files (~2250 frames x 128, float16) fed from HBM in groups of
+    256 files -- one update per group, per-file sums and the per-file mean terms on the device -- against the
+    reference's file-by-file online merge (utils.py:19-46) of the same files."""
+    import torch
+    from fadtk_amd.utils import OnlineStats
+    rng = np.random.default_rng(44)
+    sizes = rng.integers(1500, 3001, size=1000)
+    sizes[17], sizes[500] = 2, 9000                                       # a 2-frame file and one longer than a split
+    shift = rng.standard_normal(128) * 0.3
+    blocks = [((0.6 + 0.8 * rng.random()) * rng.standard_normal((int(n), 128)) + shift + 0.05 * rng.standard_normal(128)).astype(np.float16)
+              for n in sizes]
+    stats = OnlineStats(128, 0, compat=True)
+    for g0 in range(0, 1000, 256):
+        grp = blocks[g0:g0 + 256]
+        stats.add_group(torch.from_numpy(np.concatenate(grp)).cuda(), [b.shape[0] for b in grp])
+    mu, cov = stats.finish()
+    assert stats.n_files == 1000 and stats.n_short == 0
+    stats.close()
+    mu_o, cov_o = O.statistics_online(blocks)
+    # mu is the weighted mean of the float16-ROUNDED file means; numpy's own float32 running sum puts a handful of the
+    # 128000 file-mean entries one float16 ulp away from the exactly rounded value (SURVEY.md Q1): 1.2e-4 / 1000 files each
+    np.testing.assert_allclose(mu, mu_o, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(cov, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+    # the float16 rounding of the per-file means is visible: the plain raw-moment estimate differs
+    x = np.concatenate(blocks).astype(np.float64)
+    plain = np.cov(x, rowvar=False)
+    assert np.abs(cov - plain).max() > 10 * np.abs(cov - cov_o).max()
