@@ -98,7 +98,7 @@ def extra_c4(torch, hip, device, local_rank):
     + per-file column sums), plus the per-file mean terms of the reference's online path
     (fad_moments_update_file_means) -- all on data resident in HBM.  Wall time of the whole pass, not of one kernel."""
     from fadtk_amd.utils import OnlineStats
-    files_per_group, rows_per_file, d, groups = 1024, 2250, 128, 8
+    files_per_group, rows_per_file, d, groups = 4096, 2250, 128, 4
     x = torch.randn((files_per_group * rows_per_file, d), device=device, dtype=torch.float16)
     sizes = np.full(files_per_group, rows_per_file, dtype=np.int64)
     stats = OnlineStats(d, local_rank, compat=True)

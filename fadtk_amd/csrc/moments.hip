@@ -58,6 +58,7 @@ __device__ __forceinline__ void tile_coords(int tile, int nt, int& ta, int& tb) 
 }
 
 // One frame matrix of a launch and where its partial sums go.
+struct SegRun;
 struct TileSet {
     const void* E;             // rows (device)
     int64_t n, ld;             // frames, row pitch in elements
@@ -65,9 +66,15 @@ struct TileSet {
     int S;                     // row-splits
     int item0;                 // first work item of this set; item = item0 + split * T + tile
     void* partials;            // [S][T][tile stride]
-    double* colpart;           // [S][nt * BT]
+    double* colpart;           // [S][nt * BT] -- [runs][nt * BT] when `runs` is set
     int* flag;                 // shift guard: raised by the fp16 kernels, gate of the fp64 redo (or nullptr)
+    // Segment-aligned splits (fad_moments_update_segmented on long files): split s sums the runs
+    // [split_first_run[s], split_first_run[s+1]), each run = rows of ONE file, and writes every run's column sums to
+    // its own colpart row -- the per-file sums fall out of the one pass over E (moments_tile_h16_tr only).
+    const SegRun* runs;
+    const int* split_first_run;
 };
+struct SegRun { int64_t r0; int32_t rows; int32_t seg; };
 struct TileLaunch {
     TileSet set[kMaxSets];
     int nsets, d, nt, T, total;
@@ -75,7 +82,7 @@ struct TileLaunch {
 
 // work item -> (set, split, tile, row range).  `w` is wave-uniform, so the table is read with scalar loads.
 __device__ __forceinline__ const TileSet& locate(const TileLaunch& L, int w, int& split, int& tile, int64_t& k_begin,
-                                                 int64_t& k_end) {
+                                                 int64_t& k_end, int& run_lo, int& run_hi) {
     int si = 0;
 #pragma unroll
     for (int i = 1; i < kMaxSets; ++i)
@@ -85,6 +92,8 @@ __device__ __forceinline__ const TileSet& locate(const TileLaunch& L, int w, int
     split = local / L.T; tile = local - split * L.T;
     k_begin = (int64_t)split * s.rows_per_split;
     k_end = (k_begin + s.rows_per_split < s.n) ? k_begin + s.rows_per_split : s.n;
+    run_lo = 0; run_hi = 0;
+    if (s.runs) { run_lo = s.split_first_run[split]; run_hi = s.split_first_run[split + 1]; }
     return s;
 }
 
@@ -144,6 +153,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int outstanding_steps) {
+    // s_waitcnt vmcnt(outstanding_steps * N) for outstanding_steps in 0..7 (the count must be an immediate)
+    switch (outstanding_steps) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<N>(); break;
+        case 2: wait_vmcnt<2 * N>(); break;
+        case 3: wait_vmcnt<3 * N>(); break;
+        case 4: wait_vmcnt<4 * N>(); break;
+        case 5: wait_vmcnt<5 * N>(); break;
+        case 6: wait_vmcnt<6 * N>(); break;
+        default: wait_vmcnt<7 * N>(); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // moments_tile_h16_tr.  256 threads = 4 waves as 2x2; workgroup tile 128 x 128 of E^T E, wave tile 64 x 64 = 2x2
 // MFMA 32x32 tiles; 32 rows of E per LDS stage.
@@ -159,16 +182,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // ------------------------------------------------------------------------------------------
 template <int KIND, int NST, bool DIAG, bool FAST>
 __device__ __forceinline__ void tile_h16_tr_body(
-    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
+    const uint16_t* __restrict__ E, int64_t k_begin0, int64_t k_end0, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
-    uint4* smem, int* __restrict__ shift_flag) {
+    uint4* smem, int* __restrict__ shift_flag, const SegRun* __restrict__ runs, int run_lo, int run_hi) {
     constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
-    constexpr int STAGE = 2 * H_KB * 16;           // uint4 per stage (A slab + B slab)
+    // uint4 per stage: A slab + B slab; a launch whose only tile is the diagonal one (FAST = false: D <= 128, the
+    // HBM-bound shape) has no B slab and spends the same 64 KiB on twice as many stages in flight
+    constexpr int STAGE = FAST ? 2 * H_KB * 16 : H_KB * 16;
+    static_assert(FAST || DIAG, "single-tile launches only have the diagonal tile");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (scalar branches around MFMAs)
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, kg = lane >> 5;
-    const int nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
+    // rows of the current run (the whole split unless `runs` is given); the lambdas below see these by reference
+    int64_t k_begin = k_begin0, k_end = k_end0;
+    int nkb = 0;
 
     // LDS position (row, chunk p) holds global chunk p ^ 4*(row & 3): the transpose reads of four consecutive rows
     // then fall into the four different 64-byte quarters of the bank space (conflict-free).  The swizzle is applied
@@ -233,8 +261,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
         }
     };
-    // stages [0, nfast) may be loaded the fast way
-    const int nfast = (FAST && cols_full) ? (int)((k_end - k_begin) / H_KB) : 0;
+    int nfast = 0;                                 // stages [0, nfast) of the current run may be loaded the fast way
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -243,10 +270,9 @@ __device__ __forceinline__ void tile_h16_tr_body(
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
-    double csum[2] = {0.0, 0.0};
+    double csum[2] = {0.0, 0.0};                   // column sums of the current run
+    double ctot[2] = {0.0, 0.0};                   // ... of the whole split (shift guard)
     const bool do_colsum = DIAG && (wr == wc);     // the diagonal waves also hold sum x^2 (diagonal of acc)
-
-    for (int s = 0; s < NST - 1 && s < nkb; ++s) { if (s < nfast) issue_fast(s); else issue(s); }
 
     // fragment of one k-step (16 rows) of a slab: two transpose reads (rows r0..r0+3 and r0+4..r0+7 of the lane's
     // 8-row half) give the 8 consecutive k that the 32x32x16 MFMA wants per lane
@@ -308,9 +334,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     auto stage = [&](int kb, auto refill_tag) {
         // stage kb must have landed; up to NST-2 younger stages may stay in flight
         const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
-        if (ahead >= 2) wait_vmcnt<2 * LPS>();
-        else if (ahead == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
+        wait_vmcnt_upto<LPS>(ahead);
         __builtin_amdgcn_s_barrier();              // stage kb is in LDS; stage kb-1 is free
         if (decltype(refill_tag)::value) issue_fast(kb + NST - 1);
         else if (kb + NST - 1 < nkb) issue(kb + NST - 1);
@@ -326,11 +350,37 @@ __device__ __forceinline__ void tile_h16_tr_body(
             mma(F1);
         }
     };
-    // hot loop: the stage to refill is a full one -> SGPR-base loads only; then the tail with the general loads
-    const int hot = (nfast - (NST - 1) > 0) ? nfast - (NST - 1) : 0;
-    int kb = 0;
-    for (; kb < hot; ++kb) stage(kb, std::true_type{});
-    for (; kb < nkb; ++kb) stage(kb, std::false_type{});
+    // One run = a range of rows streamed through the ring: prologue, hot loop (the stage to refill is a full one ->
+    // SGPR-base loads only), tail with the general loads.  A split is one run, or -- segment-aligned splits -- the
+    // runs of several files back to back: the accumulators carry over, the column sums are flushed per run.
+    double total_rows = 0.0;
+    const int n_runs = runs ? run_hi - run_lo : 1;
+    for (int ri = 0; ri < n_runs; ++ri) {
+        int64_t crow = split;                      // colpart row of this run
+        if (runs) {
+            const SegRun rn = runs[run_lo + ri];
+            k_begin = rn.r0; k_end = rn.r0 + rn.rows; crow = run_lo + ri;
+            if (ri) __builtin_amdgcn_s_barrier();  // every wave has left the previous run's last stage: its slots are free
+        }
+        nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
+        nfast = (FAST && cols_full) ? (int)((k_end - k_begin) / H_KB) : 0;
+        total_rows += (double)(k_end - k_begin);
+        for (int s0 = 0; s0 < NST - 1 && s0 < nkb; ++s0) { if (s0 < nfast) issue_fast(s0); else issue(s0); }
+        const int hot = (nfast - (NST - 1) > 0) ? nfast - (NST - 1) : 0;
+        int kb = 0;
+        for (; kb < hot; ++kb) stage(kb, std::true_type{});
+        for (; kb < nkb; ++kb) stage(kb, std::false_type{});
+        if (do_colsum) {
+            csum[0] += __shfl_xor(csum[0], 32);
+            csum[1] += __shfl_xor(csum[1], 32);
+            if (kg == 0) {
+                double* cp = colpart + crow * (int64_t)(nt * H_BT) + cb + 64 * wc + li;
+                cp[0] = csum[0]; cp[32] = csum[1];
+            }
+            ctot[0] += csum[0]; ctot[1] += csum[1];
+            csum[0] = 0.0; csum[1] = 0.0;
+        }
+    }
 
     // partial tile, fragment major: float4 index ((fa*4 + fb)*4 + q)*64 + lane holds registers 4q..4q+3 of the
     // 32 x 32 block (fa, fb) = rows 32fa + 8q + 4(lane>>5) + 0..3 of column 32fb + (lane&31);
@@ -345,35 +395,27 @@ __device__ __forceinline__ void tile_h16_tr_body(
                 const f32x16& a = acc[x][y];
                 out[(((2 * wr + x) * 4 + (2 * wc + y)) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
             }
-    if (do_colsum) {
-        csum[0] += __shfl_xor(csum[0], 32);
-        csum[1] += __shfl_xor(csum[1], 32);
-        if (shift_flag) {
-            // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?
-            // Then fp32 partial sums of x^2 cannot resolve the variance and the block is redone in fp64.
-            // sum x^2 of column (32 f + li) is the diagonal element acc[f][f][reg] of the lane whose C/D row
-            // (reg&3) + 8 (reg>>2) + 4 kg equals li: kg = (li>>2)&1, reg = (li&3) + 4 (li>>3).
-            const double nr = (double)(k_end - k_begin);
-            const int myreg = (li & 3) + 4 * (li >> 3);
-            const bool own = kg == ((li >> 2) & 1);
-            bool hit = false;
+    if (do_colsum && shift_flag) {
+        // Shift guard (see moments_tile_f64): within this split's rows, is any column's mean^2 > 64 var?
+        // Then fp32 partial sums of x^2 cannot resolve the variance and the block is redone in fp64.
+        // sum x^2 of column (32 f + li) is the diagonal element acc[f][f][reg] of the lane whose C/D row
+        // (reg&3) + 8 (reg>>2) + 4 kg equals li: kg = (li>>2)&1, reg = (li&3) + 4 (li>>3).
+        const double nr = total_rows;
+        const int myreg = (li & 3) + 4 * (li >> 3);
+        const bool own = kg == ((li >> 2) & 1);
+        bool hit = false;
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                float dsel = 0.f;
+        for (int f = 0; f < 2; ++f) {
+            float dsel = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dsel = (r == myreg) ? acc[f][f][r] : dsel;
-                double s2 = own ? (double)dsel : 0.0;
-                s2 += __shfl_xor(s2, 32);
-                const double mean = csum[f] / nr, var = s2 / nr - mean * mean;
-                const bool col_in = (cb + 64 * wc + 32 * f + li) < d;
-                if (col_in && !(mean * mean <= 64.0 * var) && !(csum[f] == 0.0 && s2 == 0.0)) hit = true;
-            }
-            if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
+            for (int r = 0; r < 16; ++r) dsel = (r == myreg) ? acc[f][f][r] : dsel;
+            double s2 = own ? (double)dsel : 0.0;
+            s2 += __shfl_xor(s2, 32);
+            const double mean = ctot[f] / nr, var = s2 / nr - mean * mean;
+            const bool col_in = (cb + 64 * wc + 32 * f + li) < d;
+            if (col_in && !(mean * mean <= 64.0 * var) && !(ctot[f] == 0.0 && s2 == 0.0)) hit = true;
         }
-        if (kg == 0) {
-            double* cp = colpart + (int64_t)split * (nt * H_BT) + cb + 64 * wc + li;
-            cp[0] = csum[0]; cp[32] = csum[1];
-        }
+        if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
     }
 }
 
@@ -381,17 +423,17 @@ template <int KIND, int NST, bool FAST>
 __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
     const int w = xcd_contiguous(blockIdx.x, L.total);
-    int split, tile; int64_t k_begin, k_end;
-    const TileSet& s = locate(L, w, split, tile, k_begin, k_end);
+    int split, tile, run_lo, run_hi; int64_t k_begin, k_end;
+    const TileSet& s = locate(L, w, split, tile, k_begin, k_end, run_lo, run_hi);
     int ta, tb; tile_coords(tile, L.nt, ta, tb);
     const uint16_t* E = static_cast<const uint16_t*>(s.E);
     float* partials = static_cast<float*>(s.partials);
     if (ta == tb)
         tile_h16_tr_body<KIND, NST, true, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
-                                                partials, s.colpart, smem_dyn, s.flag);
-    else
+                                                partials, s.colpart, smem_dyn, s.flag, s.runs, run_lo, run_hi);
+    else if constexpr (FAST)
         tile_h16_tr_body<KIND, NST, false, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
-                                                 partials, s.colpart, smem_dyn, nullptr);
+                                                 partials, s.colpart, smem_dyn, nullptr, s.runs, run_lo, run_hi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -412,20 +454,6 @@ __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
 // ------------------------------------------------------------------------------------------
 constexpr int W_RING = 32768;                                  // LDS ring bytes per wave
 constexpr int W_LDS = 4 * W_RING + 4 * H_BT * 8 + H_BT * 8;    // + per-wave column sums + their total
-
-template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int outstanding_steps) {
-    // s_waitcnt vmcnt(outstanding_steps * N) for outstanding_steps in 0..7 (the count must be an immediate)
-    switch (outstanding_steps) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<N>(); break;
-        case 2: wait_vmcnt<2 * N>(); break;
-        case 3: wait_vmcnt<3 * N>(); break;
-        case 4: wait_vmcnt<4 * N>(); break;
-        case 5: wait_vmcnt<5 * N>(); break;
-        case 6: wait_vmcnt<6 * N>(); break;
-        default: wait_vmcnt<7 * N>(); break;
-    }
-}
 
 template <int KIND, bool DIAG>
 __device__ __forceinline__ void tile_h16_wave_body(
@@ -612,8 +640,8 @@ template <int KIND>
 __global__ __launch_bounds__(256) void moments_tile_h16_wave(TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) char smem_wave[];   // the ONLY LDS object: W_LDS bytes
     const int w = xcd_contiguous(blockIdx.x, L.total);
-    int split, tile; int64_t k_begin, k_end;
-    const TileSet& s = locate(L, w, split, tile, k_begin, k_end);
+    int split, tile, run_lo, run_hi; int64_t k_begin, k_end;
+    const TileSet& s = locate(L, w, split, tile, k_begin, k_end, run_lo, run_hi);      // (runs are a moments_tile_h16_tr feature)
     int ta, tb; tile_coords(tile, L.nt, ta, tb);
     const uint16_t* E = static_cast<const uint16_t*>(s.E);
     float* partials = static_cast<float*>(s.partials);
@@ -762,6 +790,7 @@ struct SplitPlan { int nt, T, S; int64_t rows_per_split; };
 struct ReduceSrc {
     const void* partials; const double* colpart;
     int S, T, nt;
+    int SC;               // rows of colpart (= S, or the number of runs of segment-aligned splits)
     int tile_blocks;      // workgroups that sum tiles; the following ceil(d/256) sum the columns and the row count
     int layout;           // 0 row major, 1 fragment major (the fp16 kernels)
     int sl;               // "split lanes" (1, 4 or 16), see below
@@ -794,9 +823,10 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
         const int dpad = nt * BT;
         const double* __restrict__ colpart = r.colpart;
         double s0 = 0.0, s1 = 0.0;
+        const int SC = r.SC;
         int sp = 0;
-        for (; sp + 1 < S; sp += 2) { s0 += colpart[(int64_t)sp * dpad + a]; s1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
-        if (sp < S) s0 += colpart[(int64_t)sp * dpad + a];
+        for (; sp + 1 < SC; sp += 2) { s0 += colpart[(int64_t)sp * dpad + a]; s1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
+        if (sp < SC) s0 += colpart[(int64_t)sp * dpad + a];
         acc_packed[1 + a] = overwrite ? s0 + s1 : acc_packed[1 + a] + (s0 + s1);
         return;
     }
@@ -905,7 +935,7 @@ __global__ __launch_bounds__(256) void moments_reduce(ReduceLaunch R) {
 constexpr int PRESUM_CHUNK = 32;
 template <int BT>
 __global__ __launch_bounds__(256) void moments_presum(
-    const float* __restrict__ partials, const double* __restrict__ colpart, int S, int T, int nt, int group_blocks,
+    const float* __restrict__ partials, const double* __restrict__ colpart, int S, int SC, int T, int nt, int group_blocks,
     double* __restrict__ partials2, double* __restrict__ colpart2, const int* __restrict__ gate) {
     if (gate && *gate != 0) return;                // the block is being redone in fp64: nothing to pre-sum
     const int c = blockIdx.y;
@@ -914,9 +944,14 @@ __global__ __launch_bounds__(256) void moments_presum(
     if ((int)blockIdx.x >= group_blocks) {
         const int a = ((int)blockIdx.x - group_blocks) * 256 + threadIdx.x;
         if (a >= dpad) return;
-        double t = 0.0;
-        for (int sp = s0; sp < s1; ++sp) t += colpart[(int64_t)sp * dpad + a];
-        colpart2[(int64_t)c * dpad + a] = t;
+        // the colpart rows (SC of them: one per split, or one per run) are shared out evenly over the chunks
+        const int per = (SC + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int c0 = c * per, c1 = (c0 + per < SC) ? c0 + per : SC;
+        double t0 = 0.0, t1 = 0.0;
+        int sp = c0;
+        for (; sp + 1 < c1; sp += 2) { t0 += colpart[(int64_t)sp * dpad + a]; t1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
+        if (sp < c1) t0 += colpart[(int64_t)sp * dpad + a];
+        colpart2[(int64_t)c * dpad + a] = t0 + t1;
         return;
     }
     constexpr int per_tile = BT * BT / 4;
@@ -949,7 +984,7 @@ __global__ __launch_bounds__(256) void moments_presum(
 
 static ReduceSrc reduce_src(const void* part, const double* colp, const SplitPlan& p, int bt, int layout) {
     ReduceSrc r;
-    r.partials = part; r.colpart = colp; r.S = p.S; r.T = p.T; r.nt = p.nt; r.layout = layout;
+    r.partials = part; r.colpart = colp; r.S = p.S; r.SC = p.S; r.T = p.T; r.nt = p.nt; r.layout = layout;
     r.sl = (p.S > 64) ? 16 : (p.S > 8) ? 4 : 1;
     r.tile_blocks = (int)cdiv((int64_t)p.T * (bt * bt / 4), 256 / r.sl);
     return r;
@@ -1000,14 +1035,14 @@ __global__ __launch_bounds__(256) void segment_piece_sums(
     }
 }
 
-__global__ __launch_bounds__(128) void segment_gather_sums(const double* __restrict__ piece_sums,
+__global__ __launch_bounds__(128) void segment_gather_sums(const double* __restrict__ piece_sums, int64_t pitch,
                                                            const int64_t* __restrict__ seg_first_piece, int d,
                                                            double* __restrict__ seg_sums) {
     const int64_t seg = blockIdx.x;
     const int a = blockIdx.y * 128 + threadIdx.x;
     if (a >= d) return;
     double t = 0.0;
-    for (int64_t p = seg_first_piece[seg]; p < seg_first_piece[seg + 1]; ++p) t += piece_sums[p * d + a];
+    for (int64_t p = seg_first_piece[seg]; p < seg_first_piece[seg + 1]; ++p) t += piece_sums[p * pitch + a];
     seg_sums[seg * d + a] = t;
 }
 
@@ -1070,6 +1105,8 @@ struct fad_moments {
     fad::DevBuf partials, colpart, stage, seg_tab, seg_piece, seg_out, scratch;
     fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
+    void* tab_host = nullptr; size_t tab_host_cap = 0;     // pinned staging of the segment tables of update_segmented
+    hipEvent_t tab_ev = nullptr;           // recorded behind the upload of tab_host: the next call waits before rewriting it
     int* shift_flag = nullptr;             // device int[2], ping-pong between updates
     unsigned update_seq = 0;
     int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0, read at creation)
@@ -1107,9 +1144,9 @@ static int64_t packed_len(int d) { return 1 + (int64_t)d + (int64_t)d * d; }
 // The dynamic-LDS limit of the fp16 tile kernels is a per-device function attribute: set it once per device,
 // under a lock (two host threads may make their first update on different GPUs at the same time).
 typedef void (*tile_kernel_t)(TileLaunch);
-static tile_kernel_t tr_kernel(int dtype, bool fast) {
-    if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, H_NST, false>;
-    return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, H_NST, false>;
+static tile_kernel_t tr_kernel(int dtype, bool fast) {       // multi-tile: 4 stages of 16 KiB; single tile: 8 stages of 8 KiB
+    if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false>;
+    return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, 2 * H_NST, false>;
 }
 static tile_kernel_t wave_kernel(int dtype) {
     return dtype == FAD_F16 ? &moments_tile_h16_wave<FAD_F16> : &moments_tile_h16_wave<FAD_BF16>;
@@ -1193,10 +1230,33 @@ static int launch_generic_dtype(const TileLaunch& L, int max_items, int dtype, h
     return FAD_OK;
 }
 
+// Segment-aligned splits of ONE set (fad_moments_update_segmented on long files): device tables + counts.
+struct SegPlan {
+    const SegRun* runs; const int* split_first_run;   // device
+    int n_runs, S;
+    int64_t max_split_rows;
+};
+
+// Pinned host staging for the small tables update_segmented uploads (no pageable copy, no stream sync): the buffer is
+// reused by the next call, which first waits for the event recorded behind this call's upload.
+static int stage_tables(fad_moments* h, size_t bytes, char** host) {
+    if (!h->tab_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&h->tab_ev, hipEventDisableTiming));
+    else FAD_HIP_TRY(hipEventSynchronize(h->tab_ev));
+    if (bytes > h->tab_host_cap) {
+        if (h->tab_host) (void)hipHostFree(h->tab_host);
+        h->tab_host = nullptr; h->tab_host_cap = 0;
+        FAD_HIP_TRY(hipHostMalloc(&h->tab_host, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        h->tab_host_cap = bytes + bytes / 4 + 4096;
+    }
+    *host = static_cast<char*>(h->tab_host);
+    return FAD_OK;
+}
+
 // One pass over `count` frame matrices (DEVICE pointers), all of the handles' dimension, dtype and device:
 // tile kernel (one launch for all sets) -> gated fp64 redo (one launch) -> reduce (one launch).
+// `seg` (count == 1, fp16/bf16 aligned input only): segment-aligned splits; colpart then has one row per run.
 static int update_device_multi(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n,
-                               const int64_t* ld, int dtype, hipStream_t st) {
+                               const int64_t* ld, int dtype, hipStream_t st, const SegPlan* seg = nullptr) {
     fad_moments* h0 = hs[0];
     const int d = h0->d;
     const bool is16 = (dtype == FAD_F16 || dtype == FAD_BF16);
@@ -1219,9 +1279,11 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         // default: the 4-wave kernel; the one-tile-per-wave kernel wins on the HBM-bound single-tile shape (16.8M x 128:
         // 0.80 vs 0.91 ms) and loses at D = 512 (62 vs 51 us), see DESIGN.md section 4
         int variant = h0->force_variant ? h0->force_variant : ((d <= H_BT && total_rows >= (1 << 22)) ? 8 : 4);
+        if (seg) variant = 4;                      // runs are a feature of the four-wave kernel
         // wave kernel: one workgroup per CU, each wave sums at most 8192 rows in fp32 (4 waves per split)
         if (variant == 8) plan_splits(count, n, d, H_BT, 64, h0->n_cu, 1, 256, 4 * 8192, plan);
         else plan_splits(count, n, d, H_BT, H_KB, h0->n_cu, 2, 256, 8192, plan);
+        if (seg) { plan[0].S = seg->S; plan[0].rows_per_split = seg->max_split_rows; }
         TileLaunch L;
         memset(&L, 0, sizeof(L));
         L.nsets = count; L.d = d; L.nt = plan[0].nt; L.T = plan[0].T;
@@ -1230,9 +1292,10 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
             fad_moments* h = hs[i];
             const SplitPlan& p = plan[i];
             FAD_TRY(h->partials.reserve((size_t)p.S * p.T * H_TS * sizeof(float)));
-            FAD_TRY(h->colpart.reserve((size_t)p.S * p.nt * H_BT * sizeof(double)));
+            FAD_TRY(h->colpart.reserve((size_t)(seg ? seg->n_runs : p.S) * p.nt * H_BT * sizeof(double)));
             TileSet& s = L.set[i];
             s.E = rows[i]; s.n = n[i]; s.ld = ld[i]; s.rows_per_split = p.rows_per_split; s.S = p.S; s.item0 = item;
+            if (seg) { s.runs = seg->runs; s.split_first_run = seg->split_first_run; }
             s.partials = h->partials.p; s.colpart = static_cast<double*>(h->colpart.p);
             s.flag = nullptr;
             if (h->guard) {
@@ -1295,10 +1358,11 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
                 double* pc = static_cast<double*>(h->presum_col.p);
                 const int gb = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
                 hipLaunchKernelGGL((moments_presum<H_BT>), dim3((unsigned)(gb + cdiv(p.nt * H_BT, 256)), (unsigned)p2.S), dim3(256),
-                                   0, st, part, colp, p.S, p.T, p.nt, gb, ps, pc, (const int*)L.set[i].flag);
+                                   0, st, part, colp, p.S, seg ? seg->n_runs : p.S, p.T, p.nt, gb, ps, pc, (const int*)L.set[i].flag);
                 j.prim = reduce_src(ps, pc, p2, H_BT, 1);
             } else {
                 j.prim = reduce_src(part, colp, p, H_BT, 1);
+                if (seg) j.prim.SC = seg->n_runs;
             }
             if (!j.gate) j.alt = j.prim;
             j.acc = h->acc; j.n_add = (double)n[i]; j.overwrite = h->fresh ? 1 : 0;
@@ -1378,11 +1442,11 @@ static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int
     const int d = h->d;
     int64_t n_pieces = 0;
     for (int64_t s = 0; s < n_segments; ++s) n_pieces += cdiv(offsets[s + 1] - offsets[s], SEG_PIECE);
-    // host table: [n_segments + 1] first piece of each segment, then the pieces
+    // host table (pinned staging): [n_segments + 1] first piece of each segment, then the pieces
     const size_t tab_bytes = (size_t)(n_segments + 1) * sizeof(int64_t) + (size_t)n_pieces * sizeof(SegPiece);
-    std::unique_ptr<char[]> tab(new (std::nothrow) char[tab_bytes]);
-    if (!tab) return set_error(FAD_ERR_ALLOC, "out of host memory");
-    int64_t* first = reinterpret_cast<int64_t*>(tab.get());
+    char* tab = nullptr;
+    FAD_TRY(stage_tables(h, tab_bytes, &tab));
+    int64_t* first = reinterpret_cast<int64_t*>(tab);
     SegPiece* pieces = reinterpret_cast<SegPiece*>(first + n_segments + 1);
     int64_t np = 0;
     for (int64_t s = 0; s < n_segments; ++s) {
@@ -1395,8 +1459,8 @@ static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int
     }
     first[n_segments] = np;
     FAD_TRY(h->seg_tab.reserve(tab_bytes));
-    FAD_HIP_TRY(hipMemcpyAsync(h->seg_tab.p, tab.get(), tab_bytes, hipMemcpyHostToDevice, st));
-    FAD_HIP_TRY(hipStreamSynchronize(st));         // the host table goes out of scope (pageable copy)
+    FAD_HIP_TRY(hipMemcpyAsync(h->seg_tab.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
+    FAD_HIP_TRY(hipEventRecord(h->tab_ev, st));
     const int64_t* dfirst = static_cast<const int64_t*>(h->seg_tab.p);
     const SegPiece* dpieces = reinterpret_cast<const SegPiece*>(dfirst + n_segments + 1);
     if (n_pieces > 0) {
@@ -1411,7 +1475,7 @@ static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int
         }
     }
     hipLaunchKernelGGL(segment_gather_sums, dim3((unsigned)n_segments, (unsigned)cdiv(d, 128)), dim3(128), 0, st,
-                       static_cast<const double*>(h->seg_piece.p), dfirst, d, dout);
+                       static_cast<const double*>(h->seg_piece.p), (int64_t)d, dfirst, d, dout);
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
 }
@@ -1461,6 +1525,8 @@ int fad_moments_destroy(fad_moments_t* h) {
     h->partials64.release(); h->colpart64.release(); h->presum.release(); h->presum_col.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
     h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release();
+    if (h->tab_host) (void)hipHostFree(h->tab_host);
+    if (h->tab_ev) (void)hipEventDestroy(h->tab_ev);
     if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
     delete h;
     return FAD_OK;
@@ -1564,14 +1630,81 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
         FAD_HIP_TRY(hipMemcpy2DAsync(h->stage.p, row_bytes, rows, ld * es, row_bytes, n, hipMemcpyHostToDevice, st));
         drows = h->stage.p; dld = h->d;
     }
-    FAD_TRY(update_device(h, drows, n, dld, dtype, st));
-    if (seg_sums && n_segments > 0) {
-        double* dout = seg_sums;
-        if (!on_device) {
-            FAD_TRY(h->seg_out.reserve((size_t)n_segments * h->d * sizeof(double)));
-            dout = static_cast<double*>(h->seg_out.p);
+    double* dout = seg_sums;
+    const bool want_sums = seg_sums && n_segments > 0;
+    if (want_sums && !on_device) {
+        FAD_TRY(h->seg_out.reserve((size_t)n_segments * h->d * sizeof(double)));
+        dout = static_cast<double*>(h->seg_out.p);
+    }
+    // Long files of aligned fp16/bf16 frames (config 4: 2250 frames per file): splits aligned to the files, so that the
+    // column sums every diagonal-tile workgroup holds anyway ARE the per-file sums -- no second pass over E.  Short
+    // segments (a few frames per song) would make one pipeline fill per segment: they keep the two-stage kernel.
+    const int d = h->d;
+    const bool is16 = (dtype == FAD_F16 || dtype == FAD_BF16);
+    const bool aligned = is16 && (d % 8 == 0) && (dld % 8 == 0) && ((reinterpret_cast<uintptr_t>(drows) & 15u) == 0) && !h->force_generic;
+    bool fused = false;
+    if (want_sums && aligned && h->force_variant != 8) {
+        constexpr int64_t kCap = 8192;             // rows one workgroup may sum in fp32 (see plan_splits)
+        int64_t n_runs = 0, covered = 0;
+        for (int64_t sg = 0; sg < n_segments; ++sg) { const int64_t len = offsets[sg + 1] - offsets[sg]; n_runs += len > 0 ? cdiv(len, kCap) : 1; covered += len; }
+        fused = covered == n && offsets[0] == 0 && n_runs > 0 && covered / n_runs >= 256 && n_runs < (1 << 30);
+        if (fused) {
+            // target rows per split: what the uniform planner would choose, but never above the fp32 cap
+            SplitPlan up;
+            plan_splits(1, &n, d, H_BT, H_KB, h->n_cu, 2, 256, kCap, &up);
+            const int64_t target = up.rows_per_split;
+            // host tables: runs | seg_first_run (int64) | split_first_run (int32)
+            const size_t bytes_runs = (size_t)n_runs * sizeof(SegRun), bytes_first = (size_t)(n_segments + 1) * sizeof(int64_t);
+            const size_t bytes_split = (size_t)(n_runs + 1) * sizeof(int);
+            char* host = nullptr;
+            FAD_TRY(stage_tables(h, bytes_runs + bytes_first + bytes_split, &host));
+            SegRun* runs = reinterpret_cast<SegRun*>(host);
+            int64_t* seg_first = reinterpret_cast<int64_t*>(host + bytes_runs);
+            int* split_first = reinterpret_cast<int*>(host + bytes_runs + bytes_first);
+            int64_t nr = 0;
+            for (int64_t sg = 0; sg < n_segments; ++sg) {
+                seg_first[sg] = nr;
+                const int64_t len = offsets[sg + 1] - offsets[sg];
+                const int64_t parts = len > 0 ? cdiv(len, kCap) : 1;
+                const int64_t per = len > 0 ? cdiv(cdiv(len, parts), H_KB) * H_KB : 0;
+                for (int64_t q = 0; q < parts; ++q) {
+                    const int64_t r0 = offsets[sg] + q * per;
+                    int64_t m = offsets[sg + 1] - r0; if (m > per) m = per; if (m < 0) m = 0;
+                    runs[nr].r0 = r0; runs[nr].rows = (int32_t)m; runs[nr].seg = (int32_t)sg; ++nr;
+                }
+            }
+            seg_first[n_segments] = nr;
+            int S = 0; int64_t acc_rows = 0, max_rows = 0;
+            split_first[0] = 0;
+            for (int64_t r = 0; r < nr; ++r) {          // greedy: consecutive runs until the target (or the cap) would be passed
+                if (acc_rows > 0 && (acc_rows + runs[r].rows > target || acc_rows + runs[r].rows > kCap)) {
+                    if (acc_rows > max_rows) max_rows = acc_rows;
+                    split_first[++S] = (int)r; acc_rows = 0;
+                }
+                acc_rows += runs[r].rows;
+            }
+            if (acc_rows > max_rows) max_rows = acc_rows;
+            split_first[++S] = (int)nr;
+            FAD_TRY(h->seg_tab.reserve(bytes_runs + bytes_first + bytes_split));
+            FAD_HIP_TRY(hipMemcpyAsync(h->seg_tab.p, host, bytes_runs + bytes_first + (size_t)(S + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipEventRecord(h->tab_ev, st));
+            char* dev = static_cast<char*>(h->seg_tab.p);
+            SegPlan sp;
+            sp.runs = reinterpret_cast<const SegRun*>(dev);
+            sp.split_first_run = reinterpret_cast<const int*>(dev + bytes_runs + bytes_first);
+            sp.n_runs = (int)nr; sp.S = S; sp.max_split_rows = max_rows > 0 ? max_rows : H_KB;
+            fad_moments* hh = h;
+            FAD_TRY(update_device_multi(1, &hh, &drows, &n, &dld, dtype, st, &sp));
+            const int nt = (int)cdiv(d, H_BT);
+            hipLaunchKernelGGL(segment_gather_sums, dim3((unsigned)n_segments, (unsigned)cdiv(d, 128)), dim3(128), 0, st,
+                               static_cast<const double*>(h->colpart.p), (int64_t)nt * H_BT,
+                               reinterpret_cast<const int64_t*>(dev + bytes_runs), d, dout);
+            FAD_HIP_TRY(hipGetLastError());
         }
-        FAD_TRY(segment_sums_device(h, drows, dld, dtype, offsets, n_segments, dout, st));
+    }
+    if (!fused) FAD_TRY(update_device(h, drows, n, dld, dtype, st));
+    if (want_sums) {
+        if (!fused) FAD_TRY(segment_sums_device(h, drows, dld, dtype, offsets, n_segments, dout, st));
         if (!on_device) {
             FAD_HIP_TRY(hipMemcpyAsync(seg_sums, dout, (size_t)n_segments * h->d * sizeof(double),
                                        hipMemcpyDeviceToHost, st));
@@ -1596,16 +1729,25 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
     DeviceGuard g(exact->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t cells = (size_t)n_files * d;
-    // scratch of `exact`: [sums | sizes] when they arrive from the host, then the three row blocks
-    const size_t in_bytes = on_device ? 0 : cells * sizeof(double) + (size_t)n_files * sizeof(int64_t);
+    const bool sums_dev = (on_device & 1) != 0, sizes_dev = (on_device & 2) != 0;
+    // scratch of `exact`: [sums | sizes] as far as they arrive from the host, then the three row blocks
+    const size_t sums_bytes = sums_dev ? 0 : cells * sizeof(double);
+    const size_t sizes_bytes = sizes_dev ? 0 : (size_t)n_files * sizeof(int64_t);
+    const size_t in_bytes = sums_bytes + sizes_bytes;
     FAD_TRY(exact->scratch.reserve(in_bytes + 3 * cells * sizeof(double) + 64));
     char* base = static_cast<char*>(exact->scratch.p);
     const double* dsums = seg_sums; const int64_t* dsizes = sizes;
-    if (!on_device) {
-        FAD_HIP_TRY(hipMemcpyAsync(base, seg_sums, cells * sizeof(double), hipMemcpyHostToDevice, st));
-        FAD_HIP_TRY(hipMemcpyAsync(base + cells * sizeof(double), sizes, (size_t)n_files * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (!sums_dev) {
+        FAD_HIP_TRY(hipMemcpyAsync(base, seg_sums, sums_bytes, hipMemcpyHostToDevice, st));
         dsums = reinterpret_cast<const double*>(base);
-        dsizes = reinterpret_cast<const int64_t*>(base + cells * sizeof(double));
+    }
+    if (!sizes_dev) {                              // through the handle's pinned staging: no pageable copy on the stream
+        char* host = nullptr;
+        FAD_TRY(stage_tables(exact, sizes_bytes, &host));
+        memcpy(host, sizes, sizes_bytes);
+        FAD_HIP_TRY(hipMemcpyAsync(base + sums_bytes, host, sizes_bytes, hipMemcpyHostToDevice, st));
+        FAD_HIP_TRY(hipEventRecord(exact->tab_ev, st));
+        dsizes = reinterpret_cast<const int64_t*>(base + sums_bytes);
     }
     double* r_exact = reinterpret_cast<double*>(base + ((in_bytes + 15) & ~(size_t)15));
     double* r_round = r_exact + cells;
@@ -1623,7 +1765,7 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
     const int64_t ns[3] = {n_files, n_files, n_files};
     const int64_t lds[3] = {d, d, d};
     FAD_TRY(update_device_multi(3, hs, rows, ns, lds, FAD_F64, st));
-    if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
+    if (!sums_dev) FAD_HIP_TRY(hipStreamSynchronize(st));          // the caller's host sums were read asynchronously
     return FAD_OK;
 }
 

@@ -131,14 +131,18 @@ class Moments:
         ``seg_sums`` [F x D] float64 and ``sizes`` [F] int64: both numpy, or both torch CUDA tensors."""
         if K._is_torch(seg_sums) and seg_sums.is_cuda:
             import torch
-            sizes_t = sizes if K._is_torch(sizes) else torch.as_tensor(np.asarray(sizes, dtype=np.int64))
-            sizes_t = sizes_t.to(device=seg_sums.device, dtype=torch.int64).contiguous()
             sums_t = seg_sums.to(torch.float64).contiguous()
             n_files = int(sums_t.shape[0])
+            if K._is_torch(sizes) and sizes.is_cuda:
+                sizes_t = sizes.to(torch.int64).contiguous()
+                flag, sizes_ptr, keep = 3, sizes_t.data_ptr(), sizes_t
+            else:                                       # the usual case: sums in HBM, sizes known on the host
+                sz = np.ascontiguousarray(np.asarray(sizes.cpu() if K._is_torch(sizes) else sizes, dtype=np.int64))
+                flag, sizes_ptr, keep = 1, sz.ctypes.data, sz
             K.check(exact._lib.fad_moments_update_file_means(exact._h, rounded._h, weighted._h, sums_t.data_ptr(),
-                                                             sizes_t.data_ptr(), n_files, int(dtype_code), 1, exact._stream()),
+                                                             sizes_ptr, n_files, int(dtype_code), flag, exact._stream()),
                     "fad_moments_update_file_means")
-            exact._keep = (sums_t, sizes_t)
+            exact._keep = (sums_t, keep)
         else:
             sums = K.f64_host(seg_sums)
             sz = np.ascontiguousarray(np.asarray(sizes, dtype=np.int64))

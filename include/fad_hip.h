@@ -102,8 +102,9 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
  * (utils.py:13-16, 36-40) and np.mean of a float16 file is float16, so the dataset covariance it returns is
  *   (sum xx^T - sum_f n_f m_f m_f^T  +  sum_f n_f m~_f m~_f^T - N mu~ mu~^T) / (N - 1),  mu~ = sum_f n_f m~_f / N
  * with m_f the exact and m~_f the dtype-rounded mean of file f.  Given the per-file column sums (seg_sums
- * [n_files x D] float64, from fad_moments_update_segmented) and sizes (int64 [n_files]; host or device per
- * on_device), this accumulates the rows sqrt(n_f) m_f into `exact`, sqrt(n_f) m~_f into `rounded` and n_f m~_f into
+ * [n_files x D] float64, from fad_moments_update_segmented) and sizes (int64 [n_files]) -- on_device bit 0: seg_sums is
+ * a device pointer, bit 1: sizes is (the usual call has the sums in HBM and the sizes on the host: on_device = 1) --
+ * this accumulates the rows sqrt(n_f) m_f into `exact`, sqrt(n_f) m~_f into `rounded` and n_f m~_f into
  * `weighted` (three distinct handles of dimension D): afterwards sum_xxT(exact) and sum_xxT(rounded) are the two
  * D x D terms and sum_x(weighted) = N mu~ -- all sum-reducible across batches and ranks.  Empty files add nothing. */
 int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
