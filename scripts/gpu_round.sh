@@ -10,7 +10,7 @@ echo "== rocminfo" ; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "gfx|Compute U
 echo "== smoke"
 timeout 600 python __graft_entry__.py --smoke > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $out/smoke.log
 echo "== pytest -m gpu"
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -40 $out/pytest_gpu.log
 echo "== bench"
 timeout 900 python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; cat $out/bench.json; tail -5 $out/bench.err
