@@ -137,7 +137,10 @@ class VGGishModel(ModelLoader):
         ckpt = next((p for p in (_checkpoint_dir() / "vggish-10086976.pth",
                                  Path.home() / ".cache/torch/hub/checkpoints/vggish-10086976.pth") if p.exists()), None)
         if ckpt is not None:
-            self.model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=False)
+            # the published checkpoint also carries the PCA post-processor (pproc.*), which fadtk switches off; every
+            # other key must match: a renamed / missing layer would otherwise keep its random initialisation silently
+            state = {k: v for k, v in torch.load(ckpt, map_location="cpu").items() if not k.startswith("pproc.")}
+            self.model.load_state_dict(state, strict=True)
         elif _allow_random(self.random_init):
             log.warning("vggish: no local checkpoint, using seeded random weights (synthetic runs only)")
             g = torch.Generator().manual_seed(self._seed())
@@ -278,6 +281,67 @@ class CLAPLaionModel(ModelLoader):
 
 
 # ---------------------------------------------------------------------------------------------
+# MS-CLAP 2023 (model_loader.py:463-522)
+# ---------------------------------------------------------------------------------------------
+class _StandInAudioEncoder(nn.Module):
+    """Seeded stand-in for msclap's audio encoder (synthetic runs only -- the real one lives in the `msclap` package):
+    strided 1-D convolutions over the 7 s window, mean over time, projection to 1024.  Same call shape as
+    `CLAP.clap.audio_encoder`: waveform [B, samples] -> (embedding [B, 1024], None)."""
+
+    def __init__(self, out_dim: int = 1024):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv1d(1, 32, 1024, stride=441), nn.GELU(), nn.Conv1d(32, 128, 8, stride=4), nn.GELU(),
+                                 nn.Conv1d(128, 256, 4, stride=2), nn.GELU())
+        self.proj = nn.Linear(256, out_dim)
+
+    def forward(self, wav):
+        return self.proj(self.net(wav.unsqueeze(1)).mean(dim=-1)), None
+
+
+class CLAPModel(ModelLoader):
+    """Microsoft CLAP (https://github.com/microsoft/CLAP), version 2023: 1024-d embedding per 7 s window, 1 s hop, 44.1 kHz.
+    The audio encoder comes from the `msclap` package and its `CLAP_weights_2023.pth` (looked up locally under
+    FADTK_AMD_CHECKPOINTS / fadtk's `.model-checkpoints`; nothing is downloaded); when either is missing the loader fails
+    loudly unless random weights are allowed, in which case a seeded stand-in encoder keeps the plumbing testable."""
+
+    def __init__(self, type: Literal["2023"] = "2023", random_init: Optional[bool] = None):
+        super().__init__(f"clap-{type}", 1024, 44100)
+        self.type = type
+        self.random_init = random_init
+
+    def load_model(self):
+        ckpt = next((p for p in (_checkpoint_dir() / "CLAP_weights_2023.pth",
+                                 Path(__file__).parent / ".model-checkpoints" / "CLAP_weights_2023.pth") if p.exists()), None)
+        try:
+            if ckpt is None:
+                raise FileNotFoundError("CLAP_weights_2023.pth not found (set FADTK_AMD_CHECKPOINTS)")
+            from msclap import CLAP
+            self.model = CLAP(str(ckpt), version=self.type, use_cuda=self.device.type == "cuda")
+            self.encoder = self.model.clap.audio_encoder
+        except Exception:       # noqa: BLE001
+            if not _allow_random(self.random_init):
+                raise
+            log.warning(f"{self.name}: msclap / its checkpoint not available, using a seeded stand-in encoder (synthetic runs only)")
+            torch.manual_seed(self._seed())
+            self.model = _StandInAudioEncoder(self.num_features)
+            self.encoder = self.model
+        self.encoder.eval().to(self.device)
+
+    def _get_embedding(self, audio: np.ndarray):
+        audio = np.asarray(audio, dtype=np.float32).reshape(-1)
+        size, hop = 7 * self.sr, self.sr                                     # 7 s windows, 1 s hop (:498-500)
+        out = []
+        with torch.no_grad():
+            for i in range(0, audio.shape[0], hop):                          # every window zero-padded to 7 s (:503-512)
+                c = audio[i:i + size]
+                c = c if c.shape[0] == size else np.pad(c, (0, size - c.shape[0]))
+                out.append(self.encoder(torch.from_numpy(c)[None, :].float().to(self.device))[0])
+        if not out:
+            return torch.zeros((0, self.num_features))
+        return torch.cat(out, dim=0)                                         # [windows, 1024]
+
+
+# ---------------------------------------------------------------------------------------------
 # Whisper (model_loader.py:636-672)
 # ---------------------------------------------------------------------------------------------
 _WHISPER_SHAPES = {  # size: (d_model, layers, heads)
@@ -325,8 +389,8 @@ class WhisperModel(ModelLoader):
 
 class _HFLayerModel(ModelLoader):
     """Shared body of the wav2vec2-family loaders (reference model_loader.py:254-288, 526-633): the waveform is
-    truncated to ``limit_minutes``, normalised to zero mean / unit variance (what the checkpoints' Wav2Vec2
-    feature extractors do, ``do_normalize=True``), pushed through the encoder with ``output_hidden_states`` and the
+    truncated to ``limit_minutes``, normalised to zero mean / unit variance when the checkpoint's feature extractor
+    says so (``do_normalize`` of its preprocessor_config.json; Wav2Vec2's default is True), pushed through the encoder with ``output_hidden_states`` and the
     hidden state of ``layer`` (0 = the projected CNN features) is the embedding, ``[frames, D]``.
     Weights: a local Hugging Face cache entry, else (opt-in) seeded random weights of the right shape."""
 
@@ -358,7 +422,23 @@ class _HFLayerModel(ModelLoader):
             torch.manual_seed(self._seed())
             self.model = model_cls(cfg_cls(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
                                            intermediate_size=4 * hidden))
+        self.do_normalize = self._checkpoint_do_normalize()
         self.model.eval().to(self.device)
+
+    def _checkpoint_do_normalize(self) -> bool:
+        """``do_normalize`` of the checkpoint's own feature extractor (the reference builds it with
+        ``AutoFeatureExtractor.from_pretrained``): read from the locally cached preprocessor_config.json, True (the
+        Wav2Vec2FeatureExtractor default) when there is none."""
+        try:
+            import json
+            from transformers.utils import cached_file
+            path = cached_file(self.huggingface_id, "preprocessor_config.json", local_files_only=True,
+                               _raise_exceptions_for_missing_entries=False)
+            if path:
+                return bool(json.loads(Path(path).read_text()).get("do_normalize", True))
+        except Exception:       # noqa: BLE001
+            pass
+        return True
 
     def _get_embedding(self, audio: np.ndarray):
         audio = np.asarray(audio, dtype=np.float32).reshape(-1)
@@ -367,7 +447,8 @@ class _HFLayerModel(ModelLoader):
                         f"{self.limit / self.sr / 60:.2f} minutes). Truncating.")
             audio = audio[:self.limit]
         x = torch.from_numpy(audio).to(self.device)
-        x = (x - x.mean()) / torch.sqrt(x.var(unbiased=False) + 1e-7)
+        if getattr(self, "do_normalize", True):
+            x = (x - x.mean()) / torch.sqrt(x.var(unbiased=False) + 1e-7)
         with torch.no_grad():
             out = self.model(x[None, :], output_hidden_states=True)
         return out.hidden_states[self.layer].squeeze(0)          # [frames, D]
@@ -437,10 +518,10 @@ class MERTModel(_HFLayerModel):
 # ---------------------------------------------------------------------------------------------
 def get_all_models() -> List[ModelLoader]:
     """The loaders under fadtk's names, in the reference's order (model_loader.py:676-701).  Construction is
-    cheap and offline.  Not offered: MS-CLAP 2023, DAC and CDPAM (their packages are optional in the reference too
-    and absent here)."""
+    cheap and offline (the reference's CLAP constructors download checkpoints; these never do).  Not offered: DAC and CDPAM
+    (optional in the reference too: its registry skips them when their packages are missing, as they are here)."""
     return [
-        CLAPLaionModel("audio"), CLAPLaionModel("music"),
+        CLAPModel("2023"), CLAPLaionModel("audio"), CLAPLaionModel("music"),
         VGGishModel(),
         *(MERTModel(layer=v) for v in range(1, 13)),
         EncodecEmbModel("24k"), EncodecEmbModel("48k"),

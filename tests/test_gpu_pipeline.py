@@ -83,7 +83,7 @@ def test_fused_embed_and_accumulate_matches_cache_route(tmp_path, monkeypatch):
     assert np.array_equal(mu_c, mu) and np.array_equal(cov_c, cov)
 
 
-@pytest.mark.parametrize("which", ["whisper-tiny", "encodec-emb", "clap-laion-audio", "hubert-base", "MERT-v1-95M-6"])
+@pytest.mark.parametrize("which", ["whisper-tiny", "encodec-emb", "clap-laion-audio", "hubert-base", "MERT-v1-95M-6", "clap-2023"])
 def test_loader_shapes_on_gpu(which, monkeypatch, tmp_path):
     monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
     from fadtk_amd import audio
@@ -95,7 +95,7 @@ def test_loader_shapes_on_gpu(which, monkeypatch, tmp_path):
     emb = ml.get_embedding(ml.load_wav(tmp_path / "x.wav"))
     assert emb.dtype == np.float16 and emb.ndim == 2 and emb.shape[1] == ml.num_features and np.isfinite(emb).all()
     expect = {"whisper-tiny": 2, "encodec-emb": 75 * secs, "clap-laion-audio": secs, "hubert-base": 50 * secs - 1,
-              "MERT-v1-95M-6": 75 * secs - 1}[which]
+              "MERT-v1-95M-6": 75 * secs - 1, "clap-2023": secs}[which]            # clap-2023: one 7 s window per second of audio
     assert emb.shape[0] == expect
 
 

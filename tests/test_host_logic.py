@@ -23,8 +23,8 @@ def test_registry_names_and_plugin_contract():
     import pickle
     models = get_all_models()
     names = [m.name for m in models]
-    # the reference's registry (model_loader.py:676-701) minus MS-CLAP 2023 and the optional DAC / CDPAM
-    expect = ["clap-laion-audio", "clap-laion-music", "vggish"]
+    # the reference's registry (model_loader.py:676-701) minus the optional DAC / CDPAM
+    expect = ["clap-2023", "clap-laion-audio", "clap-laion-music", "vggish"]
     expect += [f"MERT-v1-95M-{v}" for v in range(1, 12)] + ["MERT-v1-95M"]
     expect += ["encodec-emb", "encodec-emb-48k"]
     for fam, sizes in (("w2v2", ("base", "large")), ("hubert", ("base", "large")), ("wavlm", ("base", "base-plus", "large"))):
@@ -36,7 +36,7 @@ def test_registry_names_and_plugin_contract():
     dims = {m.name: (m.num_features, m.sr) for m in models}
     assert dims["MERT-v1-95M-4"] == (768, 24000) and dims["w2v2-large-7"] == (1024, 16000) and dims["wavlm-base-plus"] == (768, 16000)
     assert dims["vggish"] == (128, 16000) and dims["encodec-emb"] == (128, 24000)
-    assert dims["clap-laion-audio"] == (512, 48000) and dims["whisper-small"] == (768, 16000)
+    assert dims["clap-laion-audio"] == (512, 48000) and dims["whisper-small"] == (768, 16000) and dims["clap-2023"] == (1024, 44100)
     for m in models:                                   # loaders cross process boundaries before load_model()
         assert pickle.loads(pickle.dumps(m)).name == m.name and m.model is None
 
