@@ -49,6 +49,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0           # dense, /opt/skills/guides/MI355X_MICRO
 MFMA_F32_PEAK_TFLOPS = 157.3            # f32-input MFMA = the fp32 vector rate, same guide
 HBM_PEAK_GBS = 8000.0
 FAD_F16 = 0                             # fad_dtype code: the reference's float16 mean term
+DEFAULT_INFLIGHT = 2
 
 
 def make_sets(torch, device, rank):
@@ -166,6 +167,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--inflight", type=int, default=DEFAULT_INFLIGHT,
+                    help="scores in flight: consecutive steps alternate over this many pairs of accumulators (each with its own "
+                         "Frechet job), and step k+1 is enqueued before the score of step k is collected; 1 = every step waits "
+                         "for its score before the next one starts")
+    ap.add_argument("--lane-streams", action="store_true",
+                    help="one HIP stream per score in flight instead of one stream for all of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (used under rocprofv3 "
                                                              "so that the kernel statistics hold the config-3 launches only)")
@@ -198,18 +205,57 @@ def main():
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     a, b = make_sets(torch, device, rank)
-    # both handles keep their statistics in ONE device buffer: the exchange of the path -- the sum of the ranks'
-    # sufficient statistics -- is a single in-place all-reduce over it (the product's --gpus path uses the same class)
-    shared = fdist.SharedStats(DIM, SETS, local_rank)
-    ma, mb = shared.moments
-    plen = ma.packed_len
+    # both handles of a score keep their statistics in ONE device buffer: the exchange of the path -- the sum of the ranks'
+    # sufficient statistics -- is a single in-place all-reduce over it (the product's --gpus path uses the same class).
+    # One such buffer per score in flight ("lane").  By default the lanes share ONE stream: the host enqueues step k+1
+    # before it collects step k, so the device never waits for the host between steps, and the kernels of different steps
+    # never overlap (the HIP-event duration of the tile kernel stays a clean single-kernel measurement).  --lane-streams
+    # gives every lane its own stream: more scores/s (the latency-bound Frechet chain of one step overlaps the tile kernel
+    # of the next), at the price of per-kernel durations that include the contention.
+    n_lanes = max(1, min(int(args.inflight), 8))
 
-    def step():
-        ma.reset(); mb.reset()
-        hip.Moments.update_multi([ma, mb], [a, b])           # both sets: one launch of each kernel
-        if distributed:
-            dist.all_reduce(shared.buffer)                   # (SharedStats.allreduce minus the settle calls: both sets were just fed)
-        return hip.frechet_from_moments(ma, mb, mean_dtype=FAD_F16)
+    class Lane:
+        def __init__(self, k):
+            own = args.lane_streams and n_lanes > 1
+            self.stream = torch.cuda.Stream(device=device) if own else torch.cuda.current_stream(device)
+            self.shared = fdist.SharedStats(DIM, SETS, local_rank)
+            self.ma, self.mb = self.shared.moments
+            self.job = None
+
+        def launch(self):
+            """Enqueue one whole step on this lane's stream; nothing is waited for."""
+            with torch.cuda.stream(self.stream):
+                self.ma.reset(); self.mb.reset()
+                hip.Moments.update_multi([self.ma, self.mb], [a, b])     # both sets: one launch of each kernel
+                if distributed:
+                    dist.all_reduce(self.shared.buffer)                  # (SharedStats.allreduce minus the settle calls: both sets were just fed)
+                self.job = hip.FrechetJob(self.ma, self.mb, mean_dtype=FAD_F16)
+
+        def collect(self):
+            job, self.job = self.job, None
+            return job.result()
+
+    lanes = [Lane(k) for k in range(n_lanes)]
+    plen = lanes[0].ma.packed_len
+    ma, mb = lanes[0].ma, lanes[0].mb
+
+    def run_steps(count, marks=None):
+        """`count` steps, at most n_lanes of them in flight; every one of them is collected before this returns."""
+        out = None
+        for i in range(count):
+            lane = lanes[i % n_lanes]
+            if lane.job is not None:
+                out = lane.collect()
+                if marks is not None:
+                    marks.append(time.perf_counter())
+            lane.launch()
+        for k in range(n_lanes):                                         # drain, oldest first
+            lane = lanes[(count + k) % n_lanes]
+            if lane.job is not None:
+                out = lane.collect()
+                if marks is not None:
+                    marks.append(time.perf_counter())
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -217,14 +263,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ma.set_timing(True)
+    run_steps(max(args.warmup, 0))
+    for ln in lanes:
+        ln.ma.set_timing(True)
     fence()
     marks = [time.perf_counter()]
-    for _ in range(args.steps):
-        fad, diag = step()                                   # returns the score: every step ends with the stream drained
-        marks.append(time.perf_counter())
+    fad, diag = run_steps(args.steps, marks)                             # every score is delivered inside the timed region
     fence()
     elapsed = time.perf_counter() - marks[0]
     if distributed:
@@ -233,8 +277,11 @@ def main():
         elapsed = float(t.item())
     step_ms = np.diff(np.array(marks)) * 1e3
 
-    kernel_ms, reduce_ms, variant = ma.last_timing()         # ONE launch covers both sets (recorded on the first handle)
-    ma.set_timing(False)
+    # ONE launch of the tile kernel covers both sets (recorded on the first handle of each lane)
+    timings = [ln.ma.last_timing() for ln in lanes[:min(n_lanes, args.steps)]]
+    kernel_ms = float(np.mean([t[0] for t in timings])); reduce_ms = float(np.mean([t[1] for t in timings])); variant = timings[0][2]
+    for ln in lanes:
+        ln.ma.set_timing(False)
 
     # ---- untimed breakdown (torch events on the same stream: stream 0 is torch's current stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -299,6 +346,7 @@ def main():
                                f"(n, sum x, sum xxT) fp64 [2 x {plen} doubles]" if distributed else "single GPU, no collective"},
         "fad": fad, "newton_schulz_iters": diag["iters"], "ns_converged": diag["converged"],
         "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,
+        "scores_in_flight": n_lanes, "lane_streams": bool(args.lane_streams and n_lanes > 1),
         "step_ms_spread": {"min": float(step_ms.min()), "p10": float(np.percentile(step_ms, 10)), "median": float(np.median(step_ms)),
                            "p90": float(np.percentile(step_ms, 90)), "max": float(step_ms.max())},
         "breakdown_ms": {"moments_both_sets": float(np.median(bm)), "frechet": fr_ms,
@@ -335,6 +383,7 @@ def main():
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                       # whatever libraries say while the process winds down stays off stdout as well
 
 
 if __name__ == "__main__":

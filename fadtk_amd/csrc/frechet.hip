@@ -294,20 +294,50 @@ __global__ void rearm_state(NsState* st) {
 }
 
 // ------------------------------------------------------------------------------------------
+struct MixedResult;
 struct Workspace : NsWorkspace {
     DevBuf rows, offs, songbuf, songmat, rows2;     // per-song path
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats) + G (doubles)
-    int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
-    int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
+    // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
+    bool busy = false;
+    struct Job {
+        int d = 0, device = 0, k = 0, mean_dtype = -1, ddof = 1;
+        bool mixed = false;                         // the low-precision chain was enqueued (else: end() runs the synchronous path)
+        double eps = 0.0;
+        hipStream_t stream = nullptr;
+        const double *cov1 = nullptr, *cov2 = nullptr, *mu1 = nullptr, *mu2 = nullptr;
+    } job;
+    hipEvent_t done_ev = nullptr;
+    struct Pool* pool = nullptr;
     void release_all() {
         release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release();
+        if (done_ev) { (void)hipEventDestroy(done_ev); done_ev = nullptr; }
     }
 };
 
-// One workspace per (host thread, device), returned to the device when the thread ends (PerThreadDevice).
-static Workspace& thread_ws(int device) {
-    static thread_local PerThreadDevice<Workspace> set;
+// One pool of workspaces per (host thread, device), returned to the device when the thread ends (PerThreadDevice):
+// calls from a thread pool (fad.py:229, 387 use tmap) never share scratch memory, and one thread can keep up to
+// kSlots scores in flight (fad_frechet_from_moments_begin) -- each owns a slot until fad_frechet_end collects it.
+struct Pool {
+    static constexpr int kSlots = 8;
+    Workspace slot[kSlots];
+    int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
+    int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
+    void release_all() { for (Workspace& w : slot) w.release_all(); }
+};
+static Pool& thread_pool(int device) {
+    static thread_local PerThreadDevice<Pool> set;
     return set.get(device);
+}
+static Workspace* free_slot(int device) {
+    Pool& p = thread_pool(device);
+    for (Workspace& w : p.slot)
+        if (!w.busy) { w.pool = &p; return &w; }
+    return nullptr;
+}
+static Workspace& thread_ws(int device) {           // synchronous entry points: any slot that is not in flight
+    Workspace* w = free_slot(device);
+    return w ? *w : thread_pool(device).slot[0];
 }
 
 struct NsProblem {                  // B problems of dimension d; strides in elements (0 = shared)
@@ -557,23 +587,75 @@ __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ st
     *out = o;            // pinned host memory: visible to the host once the stream has been synchronised
 }
 
-// -> FAD_OK with res->status 1 (accepted: res holds the pieces) or 2 (run the fp64 iteration).
-static int run_ns_mixed(const NsProblem& pb, int device, hipStream_t stream, Workspace& ws, MixedResult* res) {
+constexpr int kMaxLow = 14;
+struct MixedBufs {
+    double *A, *G; float *Y[2], *Z[2], *T;
+    NsState* dstate; double* partials; double* tilestats; Ns32State* s32; MixedResult* hres;
+    int nslots0; unsigned nb;
+};
+static MixedBufs mixed_bufs(Workspace& ws, int d) {
+    const int64_t dd = (int64_t)d * d;
+    MixedBufs m;
+    m.A = static_cast<double*>(ws.mats.p);
+    m.G = static_cast<double*>(ws.mats32.p);
+    m.Y[0] = reinterpret_cast<float*>(m.G + dd); m.Y[1] = m.Y[0] + dd;
+    m.Z[0] = m.Y[1] + dd; m.Z[1] = m.Y[1] + 2 * dd;
+    m.T = m.Y[1] + 3 * dd;
+    m.dstate = static_cast<NsState*>(ws.small.p);
+    m.partials = reinterpret_cast<double*>(m.dstate + 1);
+    m.tilestats = m.partials + ns_pstride(d);
+    m.s32 = reinterpret_cast<Ns32State*>(m.tilestats + stat_doubles(d));
+    m.hres = reinterpret_cast<MixedResult*>(static_cast<char*>(ws.pinned) + sizeof(NsState));
+    m.nslots0 = (int)cdiv(dd, 256);
+    m.nb = (unsigned)stat_blocks(d);
+    return m;
+}
+
+// iterations [ws.job.k, upto) of the low-precision leg, then the closing kernels (fp64 correction, result -> pinned host)
+static int mixed_enqueue(Workspace& ws, int upto) {
+    const int d = ws.job.d;
+    hipStream_t stream = ws.job.stream;
+    MixedBufs m = mixed_bufs(ws, d);
+    int rc;
+    for (int& k = ws.job.k; k < upto; ++k) {
+        const int cur = k & 1;
+        Gemm32Args g;
+        memset(&g, 0, sizeof(g));
+        int nslots = m.nslots0;
+        if (k > 0) {                               // T = (3I - Z Y)/2 and the residual partials of iteration k
+            g.A[0] = m.Z[cur]; g.B[0] = m.Y[cur]; g.C[0] = m.T; g.alpha[0] = -0.5f; g.beta_eye[0] = 1.5f; g.gamma[0] = 1.0f;
+            g.partials[0] = m.partials; g.skip = &m.s32->done; g.ntypes = 1;
+            nslots = gemm_f32_launch(d, g, stream);
+            if (nslots < 0) return nslots;
+            memset(&g, 0, sizeof(g));
+        }
+        // Y <- Y T (and Z <- T Z; Z1 = T0 is in place at k = 0) + the check of iteration k as an extra workgroup
+        g.A[0] = m.Y[cur]; g.B[0] = m.T; g.C[0] = m.Y[cur ^ 1]; g.alpha[0] = 1.0f;
+        g.A[1] = m.T; g.B[1] = m.Z[cur]; g.C[1] = m.Z[cur ^ 1]; g.alpha[1] = 1.0f;
+        g.ntypes = (k == 0) ? 1 : 2;
+        g.skip = &m.s32->upd_skip[k & 1];
+        g.check = 1; g.k = k; g.max_low = kMaxLow; g.nslots = nslots; g.chk_partials = m.partials; g.st = m.s32; g.st64 = m.dstate;
+        rc = gemm_f32_launch(d, g, stream);
+        if (rc < 0) return rc;
+    }
+    // fp64 correction on the final iterate (which of the ping-pong buffers: known on the device only)
+    FAD_TRY(gemm_f64_from_f32_launch(d, m.Y[0], m.Y[0], m.Y[1], m.Y[1], &m.s32->final_iter, m.G, 1.0, &m.s32->skip_corr, stream));
+    hipLaunchKernelGGL(ns32_corr_partials, dim3(m.nb, m.nb), dim3(256), 0, stream, m.A, m.G, d, m.Y[0], m.Y[1], m.Z[0], m.Z[1],
+                       m.dstate, m.s32, m.tilestats);
+    hipLaunchKernelGGL(ns32_finish, dim3(1), dim3(256), 0, stream, m.tilestats, d, (int)m.nb, m.dstate, m.s32, m.hres);
+    FAD_HIP_TRY(hipGetLastError());
+    if (!ws.done_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&ws.done_ev, hipEventDisableTiming));
+    FAD_HIP_TRY(hipEventRecord(ws.done_ev, stream));
+    return FAD_OK;
+}
+
+// Enqueue the whole low-precision chain of ONE problem on `stream` (nothing is waited for): C1 C2, statistics, scale,
+// iteration 0, the blind batch of iterations, the closing kernels.  The state words must have been cleared.
+static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Workspace& ws) {
     const int d = pb.d;
     const int64_t dd = (int64_t)d * d;
-    constexpr int kMaxLow = 14;
     FAD_TRY(ws.mats.reserve((size_t)(6 * dd) * sizeof(double)));
     FAD_TRY(ws.mats32.reserve((size_t)(5 * dd) * sizeof(float) + (size_t)dd * sizeof(double)));
-    double* A = static_cast<double*>(ws.mats.p);
-    double* G = static_cast<double*>(ws.mats32.p);
-    float* Y[2] = {reinterpret_cast<float*>(G + dd), reinterpret_cast<float*>(G + dd) + dd};
-    float* Z[2] = {Y[1] + dd, Y[1] + 2 * dd};
-    float* T = Y[1] + 3 * dd;
-    NsState* dstate = static_cast<NsState*>(ws.small.p);
-    double* partials = reinterpret_cast<double*>(dstate + 1);
-    const int pstride = ns_pstride(d);
-    double* tilestats = partials + pstride;
-    Ns32State* s32 = reinterpret_cast<Ns32State*>(tilestats + stat_doubles(d));
     const size_t hbytes = sizeof(NsState) + sizeof(MixedResult);
     if (!ws.pinned || ws.pinned_cap < hbytes) {
         if (ws.pinned) (void)hipHostFree(ws.pinned);
@@ -581,59 +663,43 @@ static int run_ns_mixed(const NsProblem& pb, int device, hipStream_t stream, Wor
         FAD_HIP_TRY(hipHostMalloc(&ws.pinned, hbytes + 4096, hipHostMallocDefault));
         ws.pinned_cap = hbytes + 4096;
     }
-    MixedResult* hres = reinterpret_cast<MixedResult*>(static_cast<char*>(ws.pinned) + sizeof(NsState));
-    hres->status = -1;
-
-    GemmType g64{pb.cov1, 0, pb.cov2, 0, A, dd, 1.0, 0.0, 0.0, nullptr};
-    int rc = gemm_f64_launch(d, &g64, 1, 1, &dstate->done, kStateInts, stream, device);
+    MixedBufs m = mixed_bufs(ws, d);
+    m.hres->status = -1;
+    ws.job.d = d; ws.job.device = device; ws.job.stream = stream; ws.job.k = 0;
+    GemmType g64{pb.cov1, 0, pb.cov2, 0, m.A, dd, 1.0, 0.0, 0.0, nullptr};
+    int rc = gemm_f64_launch(d, &g64, 1, 1, &m.dstate->done, kStateInts, stream, device);
     if (rc < 0) return rc;
-    const unsigned nb = (unsigned)stat_blocks(d);
-    hipLaunchKernelGGL(ns_tilestats, dim3(nb, nb, 1), dim3(256), 0, stream, A, d, pb.cov1, (int64_t)0, pb.cov2, (int64_t)0,
-                       tilestats, dstate);
-    hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(256), 0, stream, tilestats, d, (int)nb, pb.mu1, (int64_t)0, pb.mu2,
-                       (int64_t)0, pb.mean_dtype, dstate);
-    const int nslots0 = (int)cdiv(dd, 256);
-    hipLaunchKernelGGL(ns32_first, dim3((unsigned)nslots0), dim3(256), 0, stream, A, d, dstate, s32, Y[0], T, Z[1], partials);
-
-    int k = 0, want = ws.lp_iters;
+    hipLaunchKernelGGL(ns_tilestats, dim3(m.nb, m.nb, 1), dim3(256), 0, stream, m.A, d, pb.cov1, (int64_t)0, pb.cov2, (int64_t)0,
+                       m.tilestats, m.dstate);
+    hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(256), 0, stream, m.tilestats, d, (int)m.nb, pb.mu1, (int64_t)0, pb.mu2,
+                       (int64_t)0, pb.mean_dtype, m.dstate);
+    hipLaunchKernelGGL(ns32_first, dim3((unsigned)m.nslots0), dim3(256), 0, stream, m.A, d, m.dstate, m.s32, m.Y[0], m.T, m.Z[1],
+                       m.partials);
+    int want = ws.pool ? ws.pool->lp_iters : 5;
     if (want < 2) want = 2;
     if (want > kMaxLow) want = kMaxLow;
+    return mixed_enqueue(ws, want);
+}
+
+// Wait for the chain, top it up two iterations at a time while the device says "not finished yet".
+// -> FAD_OK with res->status 1 (accepted: res holds the pieces) or 2 (run the fp64 iteration).
+static int mixed_finish(Workspace& ws, MixedResult* res) {
+    MixedBufs m = mixed_bufs(ws, ws.job.d);
     for (;;) {
-        for (; k < want; ++k) {
-            const int cur = k & 1;
-            Gemm32Args g;
-            memset(&g, 0, sizeof(g));
-            int nslots = nslots0;
-            if (k > 0) {                               // T = (3I - Z Y)/2 and the residual partials of iteration k
-                g.A[0] = Z[cur]; g.B[0] = Y[cur]; g.C[0] = T; g.alpha[0] = -0.5f; g.beta_eye[0] = 1.5f; g.gamma[0] = 1.0f;
-                g.partials[0] = partials; g.skip = &s32->done; g.ntypes = 1;
-                nslots = gemm_f32_launch(d, g, stream);
-                if (nslots < 0) return nslots;
-                memset(&g, 0, sizeof(g));
-            }
-            // Y <- Y T (and Z <- T Z; Z1 = T0 is in place at k = 0) + the check of iteration k as an extra workgroup
-            g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.alpha[0] = 1.0f;
-            g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1]; g.alpha[1] = 1.0f;
-            g.ntypes = (k == 0) ? 1 : 2;
-            g.skip = &s32->upd_skip[k & 1];
-            g.check = 1; g.k = k; g.max_low = kMaxLow; g.nslots = nslots; g.chk_partials = partials; g.st = s32; g.st64 = dstate;
-            rc = gemm_f32_launch(d, g, stream);
-            if (rc < 0) return rc;
-        }
-        // fp64 correction on the final iterate (which of the ping-pong buffers: known on the device only)
-        FAD_TRY(gemm_f64_from_f32_launch(d, Y[0], Y[0], Y[1], Y[1], &s32->final_iter, G, 1.0, &s32->skip_corr, stream));
-        hipLaunchKernelGGL(ns32_corr_partials, dim3(nb, nb), dim3(256), 0, stream, A, G, d, Y[0], Y[1], Z[0], Z[1], dstate, s32,
-                           tilestats);
-        hipLaunchKernelGGL(ns32_finish, dim3(1), dim3(256), 0, stream, tilestats, d, (int)nb, dstate, s32, hres);
-        FAD_HIP_TRY(hipGetLastError());
-        FAD_HIP_TRY(hipStreamSynchronize(stream));
-        if (hres->status != 0 || k >= kMaxLow) break;
-        want = (k + 2 < kMaxLow) ? k + 2 : kMaxLow;    // not there yet: two more iterations, then the closing kernels again
+        FAD_HIP_TRY(hipEventSynchronize(ws.done_ev));
+        if (m.hres->status != 0 || ws.job.k >= kMaxLow) break;
+        FAD_TRY(mixed_enqueue(ws, (ws.job.k + 2 < kMaxLow) ? ws.job.k + 2 : kMaxLow));
     }
-    *res = *hres;
+    *res = *m.hres;
     if (res->status == 0) res->status = 2;
-    if (res->status == 1 && res->decided_at >= 0) ws.lp_iters = res->decided_at + 1;
+    if (res->status == 1 && res->decided_at >= 0 && ws.pool) ws.pool->lp_iters = res->decided_at + 1;
     return FAD_OK;
+}
+
+static bool mixed_eligible(Workspace& ws, int d, int max_iter, double tol) {
+    Pool* p = ws.pool;
+    if (p && p->mixed < 0) { const char* e = getenv("FAD_FRECHET_MIXED"); p->mixed = (e && e[0] == '0') ? 0 : 1; }
+    return (!p || p->mixed) && d % 64 == 0 && max_iter <= 0 && tol <= 0.0;
 }
 
 // single pair, with the reference's eps fallback; cov/mu are DEVICE pointers
@@ -643,10 +709,11 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
     const int64_t dd = (int64_t)d * d;
     NsState* hs = nullptr;
     NsProblem pb{d, 1, cov1, 0, cov2, 0, mu1, 0, mu2, 0, mean_dtype};
-    if (ws.mixed < 0) { const char* e = getenv("FAD_FRECHET_MIXED"); ws.mixed = (e && e[0] == '0') ? 0 : 1; }
-    if (ws.mixed && d % 64 == 0 && max_iter <= 0 && tol <= 0.0) {
+    if (mixed_eligible(ws, d, max_iter, tol)) {
         MixedResult r;
-        FAD_TRY(run_ns_mixed(pb, device, stream, ws, &r));
+        if (!ws.job.mixed) FAD_TRY(mixed_begin(pb, device, stream, ws));       // (an async job enqueued it already)
+        ws.job.mixed = false;
+        FAD_TRY(mixed_finish(ws, &r));
         if (check_few && (r.too_few0 || r.too_few1))
             return set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
         if (r.status == 1) {
@@ -998,7 +1065,10 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
     DeviceGuard g(device);
     if (!g.ok) return set_error(FAD_ERR_HIP, "cannot select device %d", device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    Workspace& ws = thread_ws(device);
+    Workspace* wsp = free_slot(device);
+    if (!wsp) return set_error(FAD_ERR_INVALID, "all %d Frechet slots of this thread are in flight: collect one with fad_frechet_end", Pool::kSlots);
+    Workspace& ws = *wsp;
+    ws.job = Workspace::Job();
     FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
     hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, st, static_cast<NsState*>(ws.small.p), (int64_t)1);
     const int64_t dd = (int64_t)d * d;
@@ -1015,18 +1085,16 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
     return frechet_single(d, dc1, dc2, dm1, dm2, eps, max_iter, tol, -1, device, st, ws, out_fad, diag, false);
 }
 
-int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
-                             int max_iter, double tol, int mean_dtype, void* stream, double* out_fad, fad_diag_t* diag) {
-    if (!h1 || !h2 || !out_fad) return set_error(FAD_ERR_INVALID, "NULL argument");
+// finalize (mu, Sigma) of both handles into the slot's staging area and clear the iteration state
+static int stage_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, hipStream_t st, Workspace& ws,
+                              int* d_out, int* device_out) {
+    if (!h1 || !h2) return set_error(FAD_ERR_INVALID, "NULL argument");
     const int d = moments_dim(h1), device = moments_device(h1);
     if (moments_dim(h2) != d)
         return set_error(FAD_ERR_SHAPE, "Training and test covariances have different dimensions (%d vs %d)", d, moments_dim(h2));
     if (moments_device(h2) != device) return set_error(FAD_ERR_INVALID, "handles live on different devices");
-    DeviceGuard g(device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     FAD_TRY(moments_settle(h1, st));
     FAD_TRY(moments_settle(h2, st));
-    Workspace& ws = thread_ws(device);
     FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
     NsState* dstate = static_cast<NsState*>(ws.small.p);
     const int64_t dd = (int64_t)d * d;
@@ -1035,7 +1103,63 @@ int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, i
     const unsigned eg = (unsigned)cdiv(dd, 256);
     hipLaunchKernelGGL(finalize_for_frechet, dim3(eg, 2), dim3(256), 0, st, moments_packed(h1), moments_packed(h2), d, ddof,
                        s + 2 * dd, s, dstate);
+    *d_out = d; *device_out = device;
+    return FAD_OK;
+}
+
+int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
+                             int max_iter, double tol, int mean_dtype, void* stream, double* out_fad, fad_diag_t* diag) {
+    if (!h1 || !h2 || !out_fad) return set_error(FAD_ERR_INVALID, "NULL argument");
+    const int device = moments_device(h1);
+    DeviceGuard g(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace* wsp = free_slot(device);
+    if (!wsp) return set_error(FAD_ERR_INVALID, "all %d Frechet slots of this thread are in flight: collect one with fad_frechet_end", Pool::kSlots);
+    Workspace& ws = *wsp;
+    int d = 0, dev = 0;
+    FAD_TRY(stage_from_moments(h1, h2, ddof, st, ws, &d, &dev));
+    const int64_t dd = (int64_t)d * d;
+    double* s = static_cast<double*>(ws.stage.p);
     return frechet_single(d, s, s + dd, s + 2 * dd, s + 2 * dd + d, eps, max_iter, tol, mean_dtype, device, st, ws, out_fad, diag, true);
+}
+
+int fad_frechet_from_moments_begin(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps, int mean_dtype,
+                                   void* stream, fad_frechet_job_t** job) {
+    if (!h1 || !h2 || !job) return set_error(FAD_ERR_INVALID, "NULL argument");
+    *job = nullptr;
+    const int device = moments_device(h1);
+    DeviceGuard g(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace* wsp = free_slot(device);
+    if (!wsp) return set_error(FAD_ERR_INVALID, "all %d Frechet slots of this thread are in flight: collect one with fad_frechet_end", Pool::kSlots);
+    Workspace& ws = *wsp;
+    int d = 0, dev = 0;
+    FAD_TRY(stage_from_moments(h1, h2, ddof, st, ws, &d, &dev));
+    const int64_t dd = (int64_t)d * d;
+    double* s = static_cast<double*>(ws.stage.p);
+    ws.job = Workspace::Job();
+    ws.job.d = d; ws.job.device = device; ws.job.stream = st; ws.job.eps = eps; ws.job.mean_dtype = mean_dtype; ws.job.ddof = ddof;
+    ws.job.cov1 = s; ws.job.cov2 = s + dd; ws.job.mu1 = s + 2 * dd; ws.job.mu2 = s + 2 * dd + d;
+    if (mixed_eligible(ws, d, 0, 0.0)) {
+        NsProblem pb{d, 1, ws.job.cov1, 0, ws.job.cov2, 0, ws.job.mu1, 0, ws.job.mu2, 0, mean_dtype};
+        FAD_TRY(mixed_begin(pb, device, st, ws));
+        ws.job.mixed = true;
+    }
+    ws.busy = true;
+    *job = reinterpret_cast<fad_frechet_job_t*>(wsp);
+    return FAD_OK;
+}
+
+int fad_frechet_end(fad_frechet_job_t* job, double* out_fad, fad_diag_t* diag) {
+    if (!job || !out_fad) return set_error(FAD_ERR_INVALID, "NULL argument");
+    Workspace& ws = *reinterpret_cast<Workspace*>(job);
+    if (!ws.busy) return set_error(FAD_ERR_INVALID, "this job was collected already");
+    DeviceGuard g(ws.job.device);
+    ws.busy = false;                               // the slot is free again whatever happens below
+    const Workspace::Job j = ws.job;
+    // the low-precision chain is in flight (or nothing is: the synchronous path runs now); frechet_single collects /
+    // tops up / falls back to the fp64 iteration exactly as the blocking entry point does
+    return frechet_single(j.d, j.cov1, j.cov2, j.mu1, j.mu2, j.eps, 0, 0.0, j.mean_dtype, j.device, j.stream, ws, out_fad, diag, true);
 }
 
 }  // extern "C"

@@ -241,6 +241,27 @@ def frechet_from_moments(m1: Moments, m2: Moments, ddof: int = 1, eps: float = 1
     return float(out.value), diag.as_dict()
 
 
+class FrechetJob:
+    """A score in flight (``fad_frechet_from_moments_begin``): the whole square-root chain is enqueued on the stream that
+    was current when it was created; ``result()`` waits for it -> (fad, diag dict).  Collect it on the creating thread."""
+
+    def __init__(self, m1: Moments, m2: Moments, ddof: int = 1, eps: float = 1e-6, mean_dtype: int = -1):
+        self._lib = K.load_library()
+        job = C.c_void_p()
+        K.check(self._lib.fad_frechet_from_moments_begin(m1._h, m2._h, int(ddof), float(eps), int(mean_dtype),
+                                                         K.current_stream_ptr(m1.device), C.byref(job)),
+                "fad_frechet_from_moments_begin")
+        self._job = job
+
+    def result(self):
+        if self._job is None:
+            raise RuntimeError("this job was collected already")
+        out, diag = C.c_double(), K.FadDiag()
+        job, self._job = self._job, None
+        K.check(self._lib.fad_frechet_end(job, C.byref(out), C.byref(diag)), "fad_frechet_end")
+        return float(out.value), diag.as_dict()
+
+
 def frechet_batched(mu_b, cov_b, rows, offsets: Sequence[int], mean_mode: int = 1, device: int = 0):
     """Per-song FAD against one baseline (``fad_frechet_batched_vs_baseline``).
 

@@ -513,6 +513,54 @@ def test_frechet_from_moments_mean_dtype_reproduces_float16_mean_term(F, golden)
     assert abs(fad_f64 - g["fad"]) / abs(g["fad"]) > 1e-5         # float64 means are a different (better) estimate
 
 
+def test_frechet_jobs_in_flight_match_the_blocking_call(F):
+    """fad_frechet_from_moments_begin / fad_frechet_end: several scores enqueued on different streams before any is collected
+    give bit for bit what the blocking call gives -- well-conditioned pairs (float32 leg accepted), an ill-conditioned one (the
+    float64 iteration runs inside end()), a dimension off the float32 route, and the errors of the blocking call."""
+    import torch
+    from fadtk_amd import hip, _capi as K
+    rng = np.random.default_rng(3)
+    cases = []
+    for d, n, decay in ((128, 1500, 0.0), (256, 3000, 0.0), (512, 2048, 1.5), (96, 700, 0.0), (128, 900, 0.0)):
+        lam = np.arange(1, d + 1) ** (-decay / 2.0)
+        a = (rng.standard_normal((n, d)) * lam).astype(np.float16)
+        b = (1.05 * rng.standard_normal((n, d)) * lam + 0.02).astype(np.float16)
+        cases.append((torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), d))
+    want = []
+    for a, b, d in cases:
+        with hip.Moments(d) as ma, hip.Moments(d) as mb:
+            hip.Moments.update_multi([ma, mb], [a, b])
+            want.append(hip.frechet_from_moments(ma, mb, mean_dtype=K.FAD_F16))
+    streams = [torch.cuda.Stream() for _ in cases]
+    handles, jobs = [], []
+    for (a, b, d), st in zip(cases, streams):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            ma, mb = hip.Moments(d), hip.Moments(d)
+            hip.Moments.update_multi([ma, mb], [a, b])
+            jobs.append(hip.FrechetJob(ma, mb, mean_dtype=K.FAD_F16))
+            handles.append((ma, mb))
+    got = [j.result() for j in reversed(jobs)][::-1]                      # collected in another order than begun
+    for (f0, d0), (f1, d1) in zip(want, got):
+        assert f1 == f0 and d1["converged"] == d0["converged"] and d1["tr_sqrt"] == d0["tr_sqrt"]
+    assert [d["converged"] for _, d in got][:2] == [3, 3] and got[2][1]["converged"] in (1, 2) and got[3][1]["converged"] in (1, 2)
+    with pytest.raises(RuntimeError):
+        jobs[0].result()                                                  # collected already
+    ma, mb = handles[0]
+    mb.reset(); mb.update(cases[0][1][:1])
+    with pytest.raises(AssertionError):                                   # fewer than two frames: the error arrives at end()
+        hip.FrechetJob(ma, mb).result()
+    ma.reset(); ma.update(cases[0][0])
+    mb.reset(); mb.update(cases[0][1])
+    pending = [hip.FrechetJob(ma, mb) for _ in range(8)]                  # eight slots per thread and device
+    with pytest.raises(RuntimeError):
+        hip.FrechetJob(ma, mb)
+    vals = [j.result()[0] for j in pending]
+    assert len(set(vals)) == 1
+    for ma, mb in handles:
+        ma.close(); mb.close()
+
+
 def test_frechet_properties(F):
     """Size-independent properties: symmetry in its arguments and quadratic scaling."""
     a = structured_rows(21, 3000, 96, np.float32)
