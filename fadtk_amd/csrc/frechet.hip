@@ -323,6 +323,7 @@ struct Pool {
     Workspace slot[kSlots];
     int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
     int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
+    double pred_thr = 0.0;                          // FAD_FRECHET_PRED_THR (read once; -1 = the built-in rule), see pred_threshold
     void release_all() { for (Workspace& w : slot) w.release_all(); }
 };
 static Pool& thread_pool(int device) {
@@ -455,7 +456,8 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
 // this thread needed (scores of one run need the same count; a short batch is topped up two at a time).
 // ==========================================================================================
 struct MixedResult {
-    int status;            // 0: low-precision iteration not finished yet, 1: accepted, 2: rejected -> fp64 iteration
+    int status;            // 0: low-precision iteration not finished yet, 1: accepted, 2: rejected -> fp64 iteration,
+                           // 4: a PREDICTED final iterate was rejected -> iterate on from `iters` with the strict threshold
     int iters, decided_at, nonfinite, too_few0, too_few1;
     double tr_scaled, c, tr1, tr2, mean_term, res, est;
 };
@@ -464,11 +466,11 @@ struct MixedResult {
 __global__ __launch_bounds__(256) void ns32_first(const double* __restrict__ A, int d, const NsState* __restrict__ st,
                                                   Ns32State* __restrict__ s32, float* __restrict__ Y0,
                                                   float* __restrict__ T, float* __restrict__ Z1,
-                                                  double* __restrict__ partials) {
+                                                  double* __restrict__ partials, int strict) {
     __shared__ double red[4];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         s32->done = 0; s32->finished = 0; s32->ok = 0; s32->final_iter = -1; s32->failed = 0;
-        s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1;
+        s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = strict;
     }
     if (st->done) return;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(256) void ns32_corr_partials(const double* __restri
 // One block: reduce the partials, decide, write the result where the host reads it (pinned host memory).
 __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ stats, int d, int nb,
                                                    const NsState* __restrict__ st, Ns32State* __restrict__ s32,
-                                                   MixedResult* __restrict__ out) {
+                                                   MixedResult* __restrict__ out, int max_low) {
     __shared__ double red[4];
     __shared__ double red3[12];
     const int tid = threadIdx.x;
@@ -583,11 +585,34 @@ __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ st
         const bool finite = (trs == trs) && !isinf(trs) && (est == est) && !isinf(est);
         o.tr_scaled = trs; o.res = res; o.est = est;
         o.status = (finite && est <= 1e-9 * fabs(trs)) ? 1 : 2;
+        if (o.status == 2 && finite && !s32->strict && s32->decided_at == f - 1 && f + 1 < max_low) {
+            // the iterate was taken as final on a PREDICTED residual and the correction cannot absorb it: nothing is
+            // lost -- (Y_f, Z_f) are intact, the iteration goes on from there and only the fp32 floor ends it now
+            o.status = 4;
+            s32->done = 0; s32->finished = 0; s32->ok = 0; s32->skip_corr = 1; s32->upd_skip[0] = 0; s32->upd_skip[1] = 0;
+            s32->strict = 1;
+        }
     }
     *out = o;            // pinned host memory: visible to the host once the stream has been synchronised
 }
 
 constexpr int kMaxLow = 14;
+
+// When may the check of iteration k declare Y_{k+1} final from the bound b = 3/4 r_k^2 + 1/4 r_k^3 on its residual?
+// The fp64 correction leaves an error of about (||Z||^3/8 + ||Z||/2) b^2 (ns32_finish: est, with ||R|| <~ b), which has
+// to stay below 1e-9 |tr sqrt| ~ 1e-9 d for a flat spectrum: b <~ 2.5e-3 sqrt-ish of d/512 for ||Z|| ~ 2-3.  The
+// Frobenius bound b itself overestimates the residual it predicts ~10x (measured, config 3: b = 1.4e-3, next residual
+// 1.4e-4, est 3e-10 |tr|), so 2.5e-3 d/512 is taken as is.  Waiting for the fp32 floor instead (b <= 2e-6, round 1)
+// costs one more iteration -- two launches of ~10 us -- on every well-conditioned score.  A rejected prediction costs
+// one correction and one more trip to the host; the rest of THAT score then runs strict (Ns32State::strict), so the
+// result is a function of the inputs alone, never of what the thread scored before.  FAD_FRECHET_PRED_THR (read once
+// per thread) overrides the rule (tests use it to force a rejection).
+static double pred_threshold(Pool* p, int d) {
+    if (p && p->pred_thr == 0.0) { const char* e = getenv("FAD_FRECHET_PRED_THR"); p->pred_thr = (e && atof(e) > 0.0) ? atof(e) : -1.0; }
+    if (p && p->pred_thr > 0.0) return p->pred_thr;
+    return 2.5e-3 * (double)d / 512.0;
+}
+
 struct MixedBufs {
     double *A, *G; float *Y[2], *Z[2], *T;
     NsState* dstate; double* partials; double* tilestats; Ns32State* s32; MixedResult* hres;
@@ -635,6 +660,7 @@ static int mixed_enqueue(Workspace& ws, int upto) {
         g.ntypes = (k == 0) ? 1 : 2;
         g.skip = &m.s32->upd_skip[k & 1];
         g.check = 1; g.k = k; g.max_low = kMaxLow; g.nslots = nslots; g.chk_partials = m.partials; g.st = m.s32; g.st64 = m.dstate;
+        g.thr_pred = pred_threshold(ws.pool, d);
         rc = gemm_f32_launch(d, g, stream);
         if (rc < 0) return rc;
     }
@@ -642,7 +668,7 @@ static int mixed_enqueue(Workspace& ws, int upto) {
     FAD_TRY(gemm_f64_from_f32_launch(d, m.Y[0], m.Y[0], m.Y[1], m.Y[1], &m.s32->final_iter, m.G, 1.0, &m.s32->skip_corr, stream));
     hipLaunchKernelGGL(ns32_corr_partials, dim3(m.nb, m.nb), dim3(256), 0, stream, m.A, m.G, d, m.Y[0], m.Y[1], m.Z[0], m.Z[1],
                        m.dstate, m.s32, m.tilestats);
-    hipLaunchKernelGGL(ns32_finish, dim3(1), dim3(256), 0, stream, m.tilestats, d, (int)m.nb, m.dstate, m.s32, m.hres);
+    hipLaunchKernelGGL(ns32_finish, dim3(1), dim3(256), 0, stream, m.tilestats, d, (int)m.nb, m.dstate, m.s32, m.hres, kMaxLow);
     FAD_HIP_TRY(hipGetLastError());
     if (!ws.done_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&ws.done_ev, hipEventDisableTiming));
     FAD_HIP_TRY(hipEventRecord(ws.done_ev, stream));
@@ -674,7 +700,7 @@ static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Work
     hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(256), 0, stream, m.tilestats, d, (int)m.nb, pb.mu1, (int64_t)0, pb.mu2,
                        (int64_t)0, pb.mean_dtype, m.dstate);
     hipLaunchKernelGGL(ns32_first, dim3((unsigned)m.nslots0), dim3(256), 0, stream, m.A, d, m.dstate, m.s32, m.Y[0], m.T, m.Z[1],
-                       m.partials);
+                       m.partials, 0);
     int want = ws.pool ? ws.pool->lp_iters : 5;
     if (want < 2) want = 2;
     if (want > kMaxLow) want = kMaxLow;
@@ -687,7 +713,13 @@ static int mixed_finish(Workspace& ws, MixedResult* res) {
     MixedBufs m = mixed_bufs(ws, ws.job.d);
     for (;;) {
         FAD_HIP_TRY(hipEventSynchronize(ws.done_ev));
-        if (m.hres->status != 0 || ws.job.k >= kMaxLow) break;
+        if (m.hres->status == 4) {                 // predicted final iterate rejected: go on from it (state re-armed on the device)
+            ws.job.k = m.hres->iters;
+            m.hres->status = 0;
+        } else if (m.hres->status != 0 || ws.job.k >= kMaxLow) {
+            break;
+        }
+        if (ws.job.k >= kMaxLow) break;
         FAD_TRY(mixed_enqueue(ws, (ws.job.k + 2 < kMaxLow) ? ws.job.k + 2 : kMaxLow));
     }
     *res = *m.hres;

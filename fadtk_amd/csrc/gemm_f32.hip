@@ -25,8 +25,11 @@ constexpr int PA32 = 65;
 
 // Decision of iteration k from r_k = ||I - Z_k Y_k||_F (= 2 ||T_k - I||_F), one lane.
 //   * finish at Y_k when the residual has reached the fp32 floor: r_k <= 1e-3 and it no longer shrinks fast;
-//   * E_{k+1} = (3 E_k^2 + E_k^3)/4: when that bound is already below ~the floor, Y_{k+1} (being computed by the
-//     update GEMMs this check rides on) is final and no further T GEMM is needed;
+//   * E_{k+1} = (3 E_k^2 + E_k^3)/4: when that bound is below thr_pred, Y_{k+1} (being computed by the update GEMMs
+//     this check rides on) is final and no further T GEMM is needed.  thr_pred comes from what the fp64 correction
+//     can absorb (its error estimate is quadratic in the residual: frechet.hip, mixed_enqueue), NOT from the fp32
+//     floor; should the estimate reject such an iterate, ns32_finish re-arms the iteration with `strict` set and
+//     the floor (2e-6) is the threshold from then on;
 //   * fail (-> fp64 path) on NaN/Inf, after max_low iterations, or when the residual is still > 1 after eight
 //     iterations (eigenvalues of A/c below ~1e-3: the error estimate of the fp64 correction would reject the result
 //     anyway).  An fp32 iteration costs less than half an fp64 one, so moderately conditioned products (a dozen
@@ -61,7 +64,7 @@ __device__ __forceinline__ void ns32_check(const Gemm32Args& g) {
         return;
     }
     const double bound = 0.75 * res * res + 0.25 * res * res * res;
-    if (bound <= 2e-6) {                                          // Y_{k+1} (this launch's update) is final
+    if (bound <= (st->strict ? 2e-6 : g.thr_pred)) {              // Y_{k+1} (this launch's update) is final
         st->ok = 1; st->skip_corr = 0; st->finished = 1; st->done = 1; st->final_iter = k + 1; st->decided_at = k; st->upd_skip[(k + 1) & 1] = 1;
     }
 }

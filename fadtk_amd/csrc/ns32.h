@@ -17,7 +17,8 @@ struct Ns32State {
     int upd_skip[2];     // as NsState::upd_skip
     int skip_corr;       // 1 until `ok`: keeps the fp64 correction GEMM off
     int decided_at;      // iteration whose check closed the problem (the host sizes the next call's batch by it)
-    int pad[2];
+    int strict;          // 1: predict the final iterate only from the fp32 floor (set for a retry, see ns32_finish)
+    int pad;
     double res[16];
 };
 
@@ -30,6 +31,7 @@ struct Gemm32Args {
     // checker (rides on the update launch, see ns_check.h for the idea)
     int check;                           // 1: blockIdx.z == ntypes runs the convergence check of iteration k
     int k, max_low, nslots;
+    double thr_pred;                     // bound on the NEXT residual below which the next iterate is taken as final
     const double* chk_partials;
     Ns32State* st;
     const NsState* st64;                 // problem-level state (done = A was bad / zero)

@@ -480,6 +480,38 @@ def test_frechet_mixed_precision_matches_float64_iteration(F, monkeypatch, d, n,
     assert abs(fad_mixed - ref) <= 1e-7 * abs(ref)
 
 
+def test_frechet_rejected_prediction_iterates_on(F, monkeypatch):
+    """The float32 leg takes Y_{k+1} as final when the predicted residual is small enough for the float64 correction to
+    absorb.  With an absurdly generous threshold (FAD_FRECHET_PRED_THR, read once per thread) the prediction fires too
+    early, the error estimate rejects the iterate, and the iteration must go on from it -- same answer, still on the
+    float32 route, and the thread predicts from the float32 floor from then on."""
+    import threading
+    from fadtk_amd import hip
+    rng = np.random.default_rng(77)
+    d, n = 256, 4000
+    a = (rng.standard_normal((n, d)) * (0.5 + rng.random(d))).astype(np.float32)
+    b = (1.05 * rng.standard_normal((n, d)) * (0.5 + rng.random(d)) + 0.02).astype(np.float32)
+    m1, c1, m2, c2 = _pair_stats(a, b)
+    args = (m1.astype(np.float64), c1, m2.astype(np.float64), c2)
+    fad0, diag0 = hip.frechet(*args)
+    assert diag0["converged"] == 3
+    out = {}
+
+    def run():
+        out["first"] = hip.frechet(*args)
+        out["second"] = hip.frechet(*args)
+    monkeypatch.setenv("FAD_FRECHET_PRED_THR", "0.9")
+    t = threading.Thread(target=run); t.start(); t.join()
+    for key in ("first", "second"):
+        fad, diag = out[key]
+        assert diag["converged"] == 3, diag
+        assert abs(diag["tr_sqrt"] - diag0["tr_sqrt"]) <= 1e-9 * abs(diag0["tr_sqrt"])
+        assert abs(fad - fad0) <= 1e-7 * abs(fad0)
+    assert out["first"][1]["iters"] >= diag0["iters"] - 1
+    ref = O.frechet_distance(*args, run_sqrtm=False)
+    assert abs(out["first"][0] - ref) <= 1e-7 * abs(ref)
+
+
 def test_frechet_mixed_precision_falls_back_when_ill_conditioned(F):
     """Decaying spectrum (cond ~ 1e7): the float32 leg either does not converge or its error estimate is too large;
     the float64 iteration must take over transparently."""
