@@ -69,19 +69,27 @@ __device__ __forceinline__ void ns32_check(const Gemm32Args& g) {
     }
 }
 
+// FIRST: iteration 0.  The operands do not exist yet as fp32 matrices: A-operand Y0 = (float)(A64 / c), B-operand
+// T0 = (float)(1.5 I - 0.5 Y0), both formed from the fp64 product while it is staged (twice the bytes of an fp32
+// operand, but a launch of its own -- ns32_first, 5 us at D = 512 -- and a round trip of Y0 and T0 through memory are
+// saved); the workgroup also writes its tile of Z1 = T0.  Same values, same MFMA order as the two-launch version.
+template <bool FIRST>
 __global__ __launch_bounds__(512) void gemm_f32_kernel(int d, Gemm32Args g) {
     constexpr int NT = 512;
     constexpr int STAGE_F = 32 * PA32 + KB32 * 32;                // floats of one LDS stage
     constexpr int PART_F = 8 * 32 * 33;                           // k-split partial tiles
     __shared__ __attribute__((aligned(16))) float smem[(PART_F > 2 * STAGE_F ? PART_F : 2 * STAGE_F) + 16];
     __shared__ double red[8];
-    if ((int)blockIdx.z >= g.ntypes) {
-        if (g.check && blockIdx.x == 0 && blockIdx.y == 0) ns32_check(g);
-        return;
+    if constexpr (!FIRST) {
+        if ((int)blockIdx.z >= g.ntypes) {
+            if (g.check && blockIdx.x == 0 && blockIdx.y == 0) ns32_check(g);
+            return;
+        }
     }
-    const int zi = blockIdx.z;
+    const int zi = FIRST ? 0 : blockIdx.z;
     const float* __restrict__ A = g.A[zi];
     const float* __restrict__ B = g.B[zi];
+    const double* __restrict__ A64 = g.A64;
     float* __restrict__ C = g.C[zi];
     const float alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
 
@@ -107,24 +115,47 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(int d, Gemm32Args g) {
     const int bk = tid >> 3, bc = (tid & 7) * 4;
     const float* pa = A + (int64_t)(row0 + ar) * d + ak;
     const float* pb = B + (int64_t)bk * d + col0 + bc;
+    const double* qa = A64 + (int64_t)(row0 + ar) * d + ak;
+    const double* qb = A64 + (int64_t)bk * d + col0 + bc;
     // The operands were written by the PREVIOUS kernel from all eight XCDs, so every first touch of a panel is an L2
     // miss served by the Infinity Cache (~1-2 us) and all workgroups march through k in lockstep: with a short
     // prefetch distance every stage pays that latency again.  Hence ALL loads of up to PF = 8 stages (the whole k
     // range at D = 512) are issued before anything else -- even before the skip word is looked at (a skipped launch
     // wastes them, a live one has one exposed latency per PF stages instead of two).
-    constexpr int PF = 8;
+    constexpr int PF = FIRST ? 4 : 8;                            // (FIRST: fp64 operands, twice the registers per stage)
+    typedef double d2v __attribute__((ext_vector_type(2)));
     float4 ra[PF], rb[PF];
+    d2v da[FIRST ? PF : 1][2], db[FIRST ? PF : 1][2];
     auto fetch_all = [&](int kb0) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             if (kb0 + j < nkb) {
-                ra[j] = *reinterpret_cast<const float4*>(pa + (kb0 + j) * KB32);
-                rb[j] = *reinterpret_cast<const float4*>(pb + (int64_t)(kb0 + j) * KB32 * d);
+                if constexpr (FIRST) {
+                    const double* xa = qa + (kb0 + j) * KB32;
+                    const double* xb = qb + (int64_t)(kb0 + j) * KB32 * d;
+                    da[j][0] = *reinterpret_cast<const d2v*>(xa); da[j][1] = *reinterpret_cast<const d2v*>(xa + 2);
+                    db[j][0] = *reinterpret_cast<const d2v*>(xb); db[j][1] = *reinterpret_cast<const d2v*>(xb + 2);
+                } else {
+                    ra[j] = *reinterpret_cast<const float4*>(pa + (kb0 + j) * KB32);
+                    rb[j] = *reinterpret_cast<const float4*>(pb + (int64_t)(kb0 + j) * KB32 * d);
+                }
             }
         }
     };
     fetch_all(0);
     if (g.skip && *g.skip != 0) return;
+    double inv = 0.0;
+    double z_in[2] = {0.0, 0.0};
+    if constexpr (FIRST) {
+        inv = 1.0 / g.st64->c;
+#pragma unroll
+        for (int q = 0; q < 1024 / NT; ++q) {                     // this thread's two elements of the tile of Z1 = T0
+            const int e = tid + q * NT, rr = e >> 5, cc = e & 31;
+            z_in[q] = A64[(int64_t)(row0 + rr) * d + col0 + cc];
+        }
+    }
+    auto y0 = [&](double a) { return (float)(a * inv); };
+    auto t0 = [&](double a, bool diag) { return (float)((diag ? 1.5 : 0.0) - 0.5 * (double)(float)(a * inv)); };
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -137,7 +168,15 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(int d, Gemm32Args g) {
             if (kb0 + j < nkb) {
                 float* sA = smem + ((kb0 + j) & 1) * STAGE_F;
                 float* sB = sA + 32 * PA32;
-                const float4 a = ra[j], b = rb[j];
+                float4 a, b;
+                if constexpr (FIRST) {
+                    const int kg = (kb0 + j) * KB32 + bk;           // global k of this thread's B elements
+                    a = make_float4(y0(da[j][0].x), y0(da[j][0].y), y0(da[j][1].x), y0(da[j][1].y));
+                    b = make_float4(t0(db[j][0].x, kg == col0 + bc), t0(db[j][0].y, kg == col0 + bc + 1),
+                                    t0(db[j][1].x, kg == col0 + bc + 2), t0(db[j][1].y, kg == col0 + bc + 3));
+                } else {
+                    a = ra[j]; b = rb[j];
+                }
                 sA[ar * PA32 + ak] = a.x; sA[ar * PA32 + ak + 1] = a.y; sA[ar * PA32 + ak + 2] = a.z; sA[ar * PA32 + ak + 3] = a.w;
                 *reinterpret_cast<float4*>(sB + bk * 32 + bc) = b;
                 __syncthreads();
@@ -170,6 +209,7 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(int d, Gemm32Args g) {
         const int r = row0 + rr, c = col0 + cc;
         const float v = alpha * sum + (r == c ? beta_eye : 0.f);
         C[(int64_t)r * d + c] = v;
+        if constexpr (FIRST) g.C[1][(int64_t)r * d + c] = t0(z_in[q], r == c);
         const double e2 = (double)v - (r == c ? (double)gamma : 0.0);
         ss += e2 * e2;
     }
@@ -191,9 +231,17 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(int d, Gemm32Args g) {
 int gemm_f32_launch(int d, const Gemm32Args& g, hipStream_t stream) {
     if (d % KB32 != 0 || d < KB32) return set_error(FAD_ERR_INVALID, "gemm_f32: d=%d is not a multiple of %d", d, KB32);
     const unsigned t = (unsigned)(d / 32);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(t, t, (unsigned)(g.ntypes + (g.check ? 1 : 0))), dim3(512), 0, stream, d, g);
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(t, t, (unsigned)(g.ntypes + (g.check ? 1 : 0))), dim3(512), 0, stream, d, g);
     FAD_HIP_TRY(hipGetLastError());
     return (int)(t * t);
+}
+
+int gemm_f32_first_launch(int d, const Gemm32Args& g, hipStream_t stream) {
+    if (d % KB32 != 0 || d < KB32) return set_error(FAD_ERR_INVALID, "gemm_f32: d=%d is not a multiple of %d", d, KB32);
+    const unsigned t = (unsigned)(d / 32);
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(t, t, 1), dim3(512), 0, stream, d, g);
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
 }
 
 }  // namespace fad

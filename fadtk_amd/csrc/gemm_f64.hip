@@ -13,6 +13,8 @@
 // (deterministic two-level reduction; no atomics).
 #include "fad_common.h"
 #include "ns_check.h"
+#include "ns32.h"
+#include "ns_mean.h"
 
 #include <cstdlib>
 
@@ -40,6 +42,7 @@ struct GemmArgs {
     const float* A32; const float* B32; const float* A32_alt; const float* B32_alt;
     const int* sel;
     NsCheckArgs chk;
+    NsProductExt ext;                    // MODE 1 / 2 epilogues (ns32.h)
 };
 
 constexpr int KB = 64;                 // k depth of one LDS stage
@@ -60,7 +63,14 @@ constexpr int PA = KB + 2;             // A pitch (doubles): rows i..i+15 land o
 // device-scope release/acquire it needs writes back / invalidates the XCD's whole L2 per workgroup: 0.18 -> 0.53 ms.)
 // NW = waves per workgroup (4; 8 only with KSPLIT): a single D = 512 GEMM is 256 workgroups = one per CU, and four
 // waves per CU run the fp64 MFMA at 34 TFLOP/s where eight reach 45 (scripts/probes/mfma_rate.hip).
-template <int BT, int DEPTH, bool KSPLIT, bool FULL, int NW = 4, typename TIn = double>
+// MODE (KSPLIT + FULL, one problem): what the workgroup does with its finished 32 x 32 tile besides / instead of storing it
+//   1  C = C1 C2 of the Frechet distance: also the tile's statistics for the scale of the iteration (what ns_tilestats
+//      computes in a launch of its own: row / column sums of |a|, sum a^2, shares of tr A, tr C1, tr C2); one spare
+//      workgroup (blockIdx.z == 1) forms the mean term ||mu1 - mu2||^2 meanwhile
+//   2  G = Y Y of the fp64 correction: the tile is NOT stored; R = A/c - G stays in the workgroup, which writes the
+//      tile's share of tr(Z R), ||R||_F^2, tr Y and the row / column sums of |Z| (what ns32_corr_partials did in a
+//      launch of its own, re-reading A and G)
+template <int BT, int DEPTH, bool KSPLIT, bool FULL, int NW = 4, typename TIn = double, int MODE = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     constexpr int NT = NW * 64;              // threads
     constexpr int MT = KSPLIT ? 2 : BT / 32; // MFMA tiles per wave per side
@@ -74,6 +84,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     double* sB = smem + BT * PA;
     double* red = smem + SMEM_D;
 
+    if constexpr (MODE == 1) {
+        if (blockIdx.z == 1) {                 // the spare workgroup: mean term -> state (256 threads, the other waves leave)
+            __shared__ float gaps[1024];
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 256) {
+                const double mt = mean_term_block(g.ext.mu1, g.ext.mu2, d, g.ext.mean_dtype, gaps, red);
+                if (threadIdx.x == 0) g.ext.st->mean_term = mt;
+            }
+            return;
+        }
+    }
     if ((int)blockIdx.z >= g.gemm_z) {         // checker blocks: one live workgroup per problem
         // (the check is written for 256 threads; surplus waves leave, a finished wave no longer counts at s_barrier)
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 256) ns_check_block(g.chk, (int64_t)blockIdx.z - g.gemm_z, red);
@@ -190,7 +210,136 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     }
 
     double ss = 0.0;
-    if constexpr (KSPLIT) {
+    if constexpr (KSPLIT && MODE != 0) {
+        static_assert(MODE == 0 || (NW == 8 && FULL), "statistics epilogues: 512 threads, d % 64 == 0");
+        __shared__ double sred[8 * 5];
+        // operands of the epilogue, requested before the partial tiles are summed: element (rr, cc) of this tile, and for
+        // MODE 2 the element (cc, rr) of Z's mirror tile (tr(Z R) pairs R_ij with Z_ji)
+        double a_in[2]; float z_in[2]; double diag_in[2][2];
+        const float* Zf = nullptr;
+        if constexpr (MODE == 2) Zf = (g.sel && (*g.sel & 1)) ? g.ext.Z32_alt : g.ext.Z32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * NT, rr = e >> 5, cc = e & 31;
+            const int r = row0 + rr, c = col0 + cc;
+            a_in[q] = 0.0; z_in[q] = 0.f; diag_in[q][0] = 0.0; diag_in[q][1] = 0.0;
+            if constexpr (MODE == 2) {
+                a_in[q] = g.ext.A64[(int64_t)r * d + c];
+                z_in[q] = Zf[(int64_t)c * d + r];
+                if (r == c) diag_in[q][0] = (double)A32[(int64_t)r * d + r];                 // Y_rr
+            } else {
+                if (r == c) { diag_in[q][0] = A[(int64_t)r * d + r]; diag_in[q][1] = B[(int64_t)r * d + r]; }   // C1_rr, C2_rr
+            }
+        }
+        __syncthreads();
+        double* part = smem;                                   // [NW][32][33]
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    part[wave * (32 * 33) + (16 * fa + lk + 4 * reg) * 33 + 16 * fb + li] = acc[fa][fb][reg];
+        __syncthreads();
+        double vq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * NT, rr = e >> 5, cc = e & 31;
+            const double sum = ((part[rr * 33 + cc] + part[(32 * 33) + rr * 33 + cc]) +
+                                (part[2 * (32 * 33) + rr * 33 + cc] + part[3 * (32 * 33) + rr * 33 + cc])) +
+                               ((part[4 * (32 * 33) + rr * 33 + cc] + part[5 * (32 * 33) + rr * 33 + cc]) +
+                                (part[6 * (32 * 33) + rr * 33 + cc] + part[7 * (32 * 33) + rr * 33 + cc]));
+            vq[q] = alpha * sum;
+        }
+        __syncthreads();                                       // every partial has been read: the buffer is free
+        double* P = smem;                                      // [32][33]: the values whose |.| row / column sums are wanted
+        const int nb = gridDim.x;
+        double* rowabs = g.ext.stats;                          // [bj][d]
+        double* colabs = g.ext.stats + (int64_t)nb * d;        // [bi][d]
+        double v5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if constexpr (MODE == 1) {
+            double* scal = g.ext.stats + 2 * (int64_t)nb * d + (int64_t)8 * (ty * nb + tx);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + q * NT, rr = e >> 5, cc = e & 31;
+                const int r = row0 + rr, c = col0 + cc;
+                const double v = vq[q];
+                C[(int64_t)r * d + c] = v;
+                P[rr * 33 + cc] = v;
+                v5[0] += v * v;
+                if (r == c) { v5[2] += v; v5[3] += diag_in[q][0]; v5[4] += diag_in[q][1]; }
+            }
+            v5[1] = v5[0];      // slot of sum a_ij a_ji (tr A^2, needs the mirror tile): ||A||_F^2 >= tr A^2 stands in -- the two
+                                // differ by the non-normal part of A only and either is merely a guess of where the bulk sits
+            __syncthreads();
+            if (tid < 32) {
+                double t = 0.0;
+                for (int c = 0; c < 32; ++c) t += fabs(P[tid * 33 + c]);
+                rowabs[(int64_t)tx * d + row0 + tid] = t;
+            } else if (tid < 64) {
+                const int c = tid - 32;
+                double t = 0.0;
+                for (int rr = 0; rr < 32; ++rr) t += fabs(P[rr * 33 + c]);
+                colabs[(int64_t)ty * d + col0 + c] = t;
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v5[q] += __shfl_xor(v5[q], off);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) sred[wave * 5 + q] = v5[q];
+            }
+            __syncthreads();
+            if (tid < 5) {
+                double t = 0.0;
+                for (int w = 0; w < 8; ++w) t += sred[w * 5 + tid];
+                scal[tid] = t;
+            }
+        } else {
+            // R = A/c - G for this tile; the mirror tile of Z sits in z_in.  P holds Z's mirror tile (tx, ty) TRANSPOSED:
+            // P[rr][cc] = Z[col0 + cc][row0 + rr], so its row sums are column sums of that tile and vice versa.
+            double* scal = g.ext.stats + 2 * (int64_t)nb * d + (int64_t)8 * (ty * nb + tx);
+            const double inv = 1.0 / g.ext.st->c;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + q * NT, rr = e >> 5, cc = e & 31;
+                const int r = row0 + rr, c = col0 + cc;
+                const double R = a_in[q] * inv - vq[q];
+                const double z = (double)z_in[q];
+                P[rr * 33 + cc] = z;
+                v5[0] += z * R;                               // Z_ji R_ij
+                v5[1] += R * R;
+                if (r == c) v5[2] += diag_in[q][0];
+            }
+            __syncthreads();
+            if (tid < 32) {                                   // column tid of P = row (col0 + tid) of Z, its entries in columns row0..row0+31
+                double t = 0.0;
+                for (int rr = 0; rr < 32; ++rr) t += fabs(P[rr * 33 + tid]);
+                rowabs[(int64_t)ty * d + col0 + tid] = t;     // Z tile (bi = tx, bj = ty): rowabs[bj][row]
+            } else if (tid < 64) {                            // row (tid - 32) of P = column (row0 + tid - 32) of Z
+                const int rr = tid - 32;
+                double t = 0.0;
+                for (int c = 0; c < 32; ++c) t += fabs(P[rr * 33 + c]);
+                colabs[(int64_t)tx * d + row0 + rr] = t;      // colabs[bi][col]
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v5[q] += __shfl_xor(v5[q], off);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sred[wave * 5 + q] = v5[q];
+            }
+            __syncthreads();
+            if (tid < 3) {
+                double t = 0.0;
+                for (int w = 0; w < 8; ++w) t += sred[w * 5 + tid];
+                scal[tid] = t;
+            }
+        }
+        return;
+    } else if constexpr (KSPLIT) {
         // sum the waves' partial tiles through LDS, then a row-major (coalesced) store of C
         __syncthreads();
         double* part = smem;                                   // [NW][32][33]
@@ -310,18 +459,31 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
     return (int)slots;
 }
 
-// C = alpha * A32 * B32 in fp64 (operands fp32, d % 64 == 0, one problem): the correction product Y Y of the
-// mixed-precision Newton-Schulz.  `sel` (device, may be NULL) picks the *_alt operands when odd; `skip` as above.
-int gemm_f64_from_f32_launch(int d, const float* A, const float* B, const float* A_alt, const float* B_alt, const int* sel,
-                             double* C, double alpha, const int* skip, hipStream_t stream) {
-    if (d % KB != 0) return set_error(FAD_ERR_INVALID, "gemm_f64_from_f32: d=%d is not a multiple of %d", d, KB);
+int gemm_f64_product_stats_launch(int d, const double* C1, const double* C2, double* A, const int* skip, const NsProductExt& ext,
+                                  hipStream_t stream) {
+    if (d % KB != 0) return set_error(FAD_ERR_INVALID, "gemm_f64_product_stats: d=%d is not a multiple of %d", d, KB);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.C[0] = C; g.alpha[0] = alpha; g.ntypes = 1; g.remap = 1; g.gemm_z = 1;
+    g.A[0] = C1; g.B[0] = C2; g.C[0] = A; g.alpha[0] = 1.0; g.ntypes = 1; g.remap = 1; g.gemm_z = 1;
     g.skip = skip; g.skip_stride = 0;
-    g.A32 = A; g.B32 = B; g.A32_alt = A_alt; g.B32_alt = B_alt; g.sel = sel;
+    g.ext = ext;
     const unsigned t = (unsigned)(d / 32);
-    hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true, 8, float>), dim3(t, t, 1), dim3(512), 0, stream, d, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true, 8, double, 1>), dim3(t, t, 2), dim3(512), 0, stream, d, g);
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
+int gemm_f64_correction_launch(int d, const float* Y, const float* Y_alt, const int* sel, const int* skip, const NsProductExt& ext,
+                               hipStream_t stream) {
+    if (d % KB != 0) return set_error(FAD_ERR_INVALID, "gemm_f64_correction: d=%d is not a multiple of %d", d, KB);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.alpha[0] = 1.0; g.ntypes = 1; g.remap = 1; g.gemm_z = 1;
+    g.skip = skip; g.skip_stride = 0;
+    g.A32 = Y; g.B32 = Y; g.A32_alt = Y_alt; g.B32_alt = Y_alt; g.sel = sel;
+    g.ext = ext;
+    const unsigned t = (unsigned)(d / 32);
+    hipLaunchKernelGGL((gemm_f64_kernel<32, 1, true, true, 8, float, 2>), dim3(t, t, 1), dim3(512), 0, stream, d, g);
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
 }

@@ -34,14 +34,32 @@ struct Gemm32Args {
     double thr_pred;                     // bound on the NEXT residual below which the next iterate is taken as final
     const double* chk_partials;
     Ns32State* st;
-    const NsState* st64;                 // problem-level state (done = A was bad / zero)
+    const NsState* st64;                 // problem-level state (done = A was bad / zero; c = the scale)
+    const double* A64;                   // gemm_f32_first_launch: the fp64 product A = C1 C2 that iteration 0 starts from
 };
 
 
-int gemm_f64_from_f32_launch(int d, const float* A, const float* B, const float* A_alt, const float* B_alt, const int* sel,
-                             double* C, double alpha, const int* skip, hipStream_t stream);
+// Extras of the two fp64 products of the mixed-precision route whose epilogues also produce statistics (gemm_f64.hip,
+// gemm_f64_kernel MODE 1 / 2).  stats: tile statistics in the layout of ns_tilestats (frechet.hip).
+struct NsProductExt {
+    double* stats;
+    // MODE 1 (A = C1 C2): the spare workgroup's mean term
+    const double* mu1; const double* mu2; int mean_dtype; NsState* st;
+    // MODE 2 (G = Y Y): R = A64 / st->c - G, paired with Z (Z32_alt when *sel is odd)
+    const double* A64; const float* Z32; const float* Z32_alt;
+};
+
+// A = C1 C2 (fp64, d % 64 == 0, one problem) + tile statistics + mean term -> ext.st->mean_term.  skip as gemm_f64_launch.
+int gemm_f64_product_stats_launch(int d, const double* C1, const double* C2, double* A, const int* skip, const NsProductExt& ext,
+                                  hipStream_t stream);
+// The correction product Y Y on fp32 operands in fp64 with the statistics of R = A/c - Y Y and Z (nothing is stored but those).
+int gemm_f64_correction_launch(int d, const float* Y, const float* Y_alt, const int* sel, const int* skip, const NsProductExt& ext,
+                               hipStream_t stream);
 
 // launches the GEMM(s) of `g` (+ the checker block when g.check); returns the partial slots per GEMM or < 0
 int gemm_f32_launch(int d, const Gemm32Args& g, hipStream_t stream);
+// Iteration 0 in one launch: with Y0 = A64 / st64->c and T0 = (3 I - Y0) / 2 formed on the way into LDS,
+// C[0] = Y1 = Y0 T0 and C[1] = Z1 = T0 (Z0 = I needs no product).  skip as above.
+int gemm_f32_first_launch(int d, const Gemm32Args& g, hipStream_t stream);
 
 }  // namespace fad
