@@ -1,0 +1,1069 @@
+// Device side of the moments path (gfx950): the tile kernels, the reduce / presum kernels, the per-segment sums and the
+// small finishing kernels, with the launch descriptors they take.  Included by moments.hip only (which holds the overview,
+// the handle, the split planner and the C ABI); kept apart so that either file can be read on its own.
+#pragma once
+#include "fad_common.h"
+#include <type_traits>
+
+namespace fad {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kXcd = 8;
+constexpr int kMaxSets = 8;       // frame matrices per launch
+
+// Workgroup id -> work item such that consecutive items land on the SAME XCD (block b runs on
+// XCD b % 8): the tiles of one row-split then share that XCD's L2 for their slabs of E.
+__device__ __forceinline__ int xcd_contiguous(int b, int nwg) {
+    const int xcd = b % kXcd, idx = b / kXcd;
+    const int q = nwg / kXcd, r = nwg % kXcd;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void tile_coords(int tile, int nt, int& ta, int& tb) {
+    int a = 0, t = tile;
+    while (t >= nt - a) { t -= nt - a; ++a; }
+    ta = a; tb = a + t;
+}
+
+// One frame matrix of a launch and where its partial sums go.
+struct SegRun;
+struct TileSet {
+    const void* E;             // rows (device)
+    int64_t n, ld;             // frames, row pitch in elements
+    int64_t rows_per_split;    // split s sums rows [s * rows_per_split, ...)
+    int S;                     // row-splits
+    int item0;                 // first work item of this set; item = item0 + split * T + tile
+    void* partials;            // [S][T][tile stride]
+    double* colpart;           // [S][nt * BT] -- [runs][nt * BT] when `runs` is set
+    int* flag;                 // shift guard: raised by the fp16 kernels, gate of the fp64 redo (or nullptr)
+    // Segment-aligned splits (fad_moments_update_segmented on long files): split s sums the runs
+    // [split_first_run[s], split_first_run[s+1]), each run = rows of ONE file, and writes every run's column sums to
+    // its own colpart row -- the per-file sums fall out of the one pass over E (moments_tile_h16_tr only).
+    const SegRun* runs;
+    const int* split_first_run;
+};
+struct SegRun { int64_t r0; int32_t rows; int32_t seg; };
+struct TileLaunch {
+    TileSet set[kMaxSets];
+    int nsets, d, nt, T, total;
+};
+
+// work item -> (set, split, tile, row range).  `w` is wave-uniform, so the table is read with scalar loads.
+__device__ __forceinline__ const TileSet& locate(const TileLaunch& L, int w, int& split, int& tile, int64_t& k_begin,
+                                                 int64_t& k_end, int& run_lo, int& run_hi) {
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxSets; ++i)
+        if (i < L.nsets && w >= L.set[i].item0) si = i;
+    const TileSet& s = L.set[si];
+    const int local = w - s.item0;
+    split = local / L.T; tile = local - split * L.T;
+    k_begin = (int64_t)split * s.rows_per_split;
+    k_end = (k_begin + s.rows_per_split < s.n) ? k_begin + s.rows_per_split : s.n;
+    run_lo = 0; run_hi = 0;
+    if (s.runs) { run_lo = s.split_first_run[split]; run_hi = s.split_first_run[split + 1]; }
+    return s;
+}
+
+template <int KIND> __device__ __forceinline__ float h16_to_f32(uint32_t bits16) {
+    if constexpr (KIND == FAD_F16) {
+        _Float16 h; unsigned short s = (unsigned short)bits16; __builtin_memcpy(&h, &s, 2); return (float)h;
+    } else {
+        return __uint_as_float(bits16 << 16);
+    }
+}
+
+template <int KIND> __device__ __forceinline__ float sum8(const uint4& v) {
+    // sum of the 8 packed halfs/bfloats in fp32: four v_dot2c_f32_{f16,bf16} against (1, 1) -- the column sums
+    // ride on the diagonal tiles' waves, whose VALU time is on the kernel's critical path
+    float s = 0.f;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if constexpr (KIND == FAD_F16) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 a; __builtin_memcpy(&a, &w[q], 4);
+            const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+            s = __builtin_amdgcn_fdot2(a, one, s, false);
+        } else {
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            b2 a, one; __builtin_memcpy(&a, &w[q], 4);
+            const uint32_t ob = 0x3f803f80u; __builtin_memcpy(&one, &ob, 4);
+            s = __builtin_amdgcn_fdot2_f32_bf16(a, one, s, false);
+        }
+    }
+    return s;
+}
+
+template <int KIND> __device__ __forceinline__ f32x16 mfma_h16(const uint4& a, const uint4& b, const f32x16& c) {
+    if constexpr (KIND == FAD_F16) {
+        f16x8 va, vb; __builtin_memcpy(&va, &a, 16); __builtin_memcpy(&vb, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(va, vb, c, 0, 0, 0);
+    } else {
+        bf16x8 va, vb; __builtin_memcpy(&va, &a, 16); __builtin_memcpy(&vb, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, c, 0, 0, 0);
+    }
+}
+
+constexpr int H_BT = 128;     // tile edge
+constexpr int H_TS = H_BT * H_BT + 64;   // partial-tile stride (floats): +256 B so that the same element of
+                                         // consecutive tiles/splits does not alias onto one memory channel
+constexpr int H_KB = 32;      // rows per stage
+constexpr int H_NST = 4;      // LDS ring depth (stages): 4 x 16 KiB per workgroup, two workgroups per CU
+
+// Out-of-range rows / columns of an LDS-DMA load are redirected per lane to a 16-byte block of zeros.
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int outstanding_steps) {
+    // s_waitcnt vmcnt(outstanding_steps * N) for outstanding_steps in 0..7 (the count must be an immediate)
+    switch (outstanding_steps) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<N>(); break;
+        case 2: wait_vmcnt<2 * N>(); break;
+        case 3: wait_vmcnt<3 * N>(); break;
+        case 4: wait_vmcnt<4 * N>(); break;
+        case 5: wait_vmcnt<5 * N>(); break;
+        case 6: wait_vmcnt<6 * N>(); break;
+        default: wait_vmcnt<7 * N>(); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// moments_tile_h16_tr.  256 threads = 4 waves as 2x2; workgroup tile 128 x 128 of E^T E, wave tile 64 x 64 = 2x2
+// MFMA 32x32 tiles; 32 rows of E per LDS stage.
+//   * slabs of E go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip)
+//     through a ring of NST stages; waits are counted (s_waitcnt vmcnt(N), never 0 in steady state) and the barrier
+//     is a raw s_barrier so that younger stages stay in flight across it;
+//   * operand fragments by ds_read_b64_tr_b16 (LDS transpose read): in a 16-lane group lane t supplies the address
+//     of 4 consecutive columns of row t>>2 and receives 4 consecutive ROWS of column t -- exactly the k-contiguous
+//     fragment an MFMA wants from a row-major slab (semantics verified with scripts/probes/tr_probe.hip).
+// FAST = LDS-DMA loads issued as inline asm with a wave-uniform SGPR base (see issue_fast); used when the problem has
+// more than one tile (MFMA-bound shapes).  Single-tile problems (D <= 128, HBM-bound) measured slower with either
+// asm form (63 / 59 vs 53 us for 1M x 128) and keep the builtin loads throughout.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int NST, bool DIAG, bool FAST>
+__device__ __forceinline__ void tile_h16_tr_body(
+    const uint16_t* __restrict__ E, int64_t k_begin0, int64_t k_end0, int64_t ld, int d, int nt, int T,
+    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
+    uint4* smem, int* __restrict__ shift_flag, const SegRun* __restrict__ runs, int run_lo, int run_hi) {
+    constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
+    // uint4 per stage: A slab + B slab; a launch whose only tile is the diagonal one (FAST = false: D <= 128, the
+    // HBM-bound shape) has no B slab and spends the same 64 KiB on twice as many stages in flight
+    constexpr int STAGE = FAST ? 2 * H_KB * 16 : H_KB * 16;
+    static_assert(FAST || DIAG, "single-tile launches only have the diagonal tile");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (scalar branches around MFMAs)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, kg = lane >> 5;
+    // rows of the current run (the whole split unless `runs` is given); the lambdas below see these by reference
+    int64_t k_begin = k_begin0, k_end = k_end0;
+    int nkb = 0;
+
+    // LDS position (row, chunk p) holds global chunk p ^ 4*(row & 3): the transpose reads of four consecutive rows
+    // then fall into the four different 64-byte quarters of the bank space (conflict-free).  The swizzle is applied
+    // on the SOURCE address because global_load_lds writes lane-linear; rows sr and sr+16 share (row & 3).
+    const int sr = tid >> 4, sc = (tid & 15) ^ (((tid >> 4) & 3) << 2);
+    const bool col_ok_a = (ca + sc * 8) < d;
+    const bool col_ok_b = (cb + sc * 8) < d;
+    const uint16_t* ga = E + ca + sc * 8;
+    const uint16_t* gb = E + cb + sc * 8;
+    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
+    // transpose-read addressing: in each 16-lane group lane t points at (row t>>2, columns 4*(t&3)..+3) of a
+    // [4 rows][16 cols] block and receives column t of it (4 consecutive k).  Group g of the wave: rows 8*(g>>1),
+    // columns 16*(g&1) of the 32-column fragment.
+    const int t16 = lane & 15, grp = lane >> 4;
+    const int tr_row = 8 * (grp >> 1) + (t16 >> 2);                 // + ks*16 (+4 for the second read)
+    const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);              // + 32*frag + 64*wave-half, in columns
+
+    // part g of the loads of stage kb: off the diagonal (h, side) = (g >> 1, g & 1), on it h = g (A side only)
+    auto issue_part = [&](int kb, int g) {
+        uint4* st = smem + (kb % NST) * STAGE;
+        const int h = DIAG ? g : (g >> 1);
+        const int64_t r = k_begin + (int64_t)kb * H_KB + sr + 16 * h;
+        const bool ok = r < k_end;
+        // LDS destination = wave-uniform base + lane*16: rows 16h + 4*wave .. +3, 16 chunks each
+        const bool side_b = !DIAG && (g & 1);
+        const uint16_t* src = side_b ? ((ok && col_ok_b) ? gb + r * ld : zsrc) : ((ok && col_ok_a) ? ga + r * ld : zsrc);
+        uint4* dstp = st + 256 * h + 64 * wave + (side_b ? H_KB * 16 : 0);
+        if (FAST) {
+            // inline asm like the fast form below: ONE LDS-DMA builtin anywhere in the kernel and hipcc's hazard
+            // bookkeeping costs the hot loop its gain.  Per-lane 64-bit addresses (lanes may go to the zero block).
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)dstp);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dstp, 16, 0, 0);
+        }
+    };
+    auto issue = [&](int kb) {
+#pragma unroll
+        for (int g = 0; g < LPS; ++g) issue_part(kb, g);
+    };
+    // The same loads with a wave-uniform 64-bit base in SGPRs + a loop-invariant 32-bit lane offset
+    // (global_load_lds_dwordx4 v_off, s[base:base+1]; inline asm -- the builtin always produces 64-bit VGPR addresses).
+    // With per-lane 64-bit addresses a CU does not overlap LDS-DMA with MFMAs: independent loader and MFMA waves take
+    // the SUM of their times; with an SGPR base they overlap (scripts/probes/dma_mfma_mix.hip: 0.95 -> 0.56 ms where
+    // either alone takes 0.47; scripts/probes/stream_pipeline.hip: this kernel's skeleton 50.7 -> 34.6 us).  Only for
+    // stages whose 32 rows and 128 + 128 columns are all in range (no zero-source redirection), and kept in a loop of
+    // its own: with the builtin form in the same loop body the gain disappears.
+    const bool cols_full = (ca + H_BT <= d) && (cb + H_BT <= d) && ld < ((int64_t)1 << 26);
+    const uint32_t voff = (uint32_t)(((int64_t)sr * ld + sc * 8) * 2);
+    const uint32_t smem_lds = (uint32_t)(size_t)(lptr_t)smem;
+    auto issue_fast = [&](int kb) {
+#pragma unroll
+        for (int g = 0; g < LPS; ++g) {
+            const int h = DIAG ? g : (g >> 1);
+            const bool side_b = !DIAG && (g & 1);
+            const uint64_t sb = (uint64_t)(E + (k_begin + (int64_t)kb * H_KB + 16 * h) * ld + (side_b ? cb : ca));
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+            const uint64_t ub = ((uint64_t)hi << 32) | lo;
+            const uint32_t dst = smem_lds + (uint32_t)(((kb % NST) * STAGE + 256 * h + 64 * wave + (side_b ? H_KB * 16 : 0)) * 16);
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
+        }
+    };
+    int nfast = 0;                                 // stages [0, nfast) of the current run may be loaded the fast way
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
+    double csum[2] = {0.0, 0.0};                   // column sums of the current run
+    double ctot[2] = {0.0, 0.0};                   // ... of the whole split (shift guard)
+    const bool do_colsum = DIAG && (wr == wc);     // the diagonal waves also hold sum x^2 (diagonal of acc)
+
+    // fragment of one k-step (16 rows) of a slab: two transpose reads (rows r0..r0+3 and r0+4..r0+7 of the lane's
+    // 8-row half) give the 8 consecutive k that the 32x32x16 MFMA wants per lane
+    auto frag = [&](const char* slab, int ks, int col0) -> uint4 {
+        // byte address of (row, col): row*256 + ((col/8) ^ 4*(row&3))*16 + ((col/4)&1)*8
+        const int r0 = ks * 16 + tr_row, r1 = r0 + 4, col = col0 + tr_col;
+        const int o0 = r0 * 256 + (((col >> 3) ^ ((r0 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+        const int o1 = r1 * 256 + (((col >> 3) ^ ((r1 & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + o1));
+        uint4 f;
+        __builtin_memcpy(&f.x, &lo, 8);
+        __builtin_memcpy(&f.z, &hi, 8);
+        return f;
+    };
+    // F[0], F[1] = the wave's two A-side fragments, F[2], F[3] = its two B-side fragments of k-step (kb, ks)
+    auto load_frags = [&](int kb, int ks, uint4 (&F)[4]) {
+        const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
+        const char* sB = DIAG ? sA : sA + H_KB * 256;
+        F[0] = frag(sA, ks, 64 * wr); F[1] = frag(sA, ks, 64 * wr + 32);
+        F[2] = frag(sB, ks, 64 * wc); F[3] = frag(sB, ks, 64 * wc + 32);
+    };
+    auto mma = [&](const uint4 (&F)[4]) {
+        acc[0][0] = mfma_h16<KIND>(F[0], F[2], acc[0][0]);
+        acc[0][1] = mfma_h16<KIND>(F[0], F[3], acc[0][1]);
+        acc[1][0] = mfma_h16<KIND>(F[1], F[2], acc[1][0]);
+        acc[1][1] = mfma_h16<KIND>(F[1], F[3], acc[1][1]);
+    };
+    // A DIAGONAL tile is symmetric, so only 20 of the 32 MFMAs of a stage are issued:
+    //   * the waves on the tile's diagonal (wr == wc) own a symmetric 64 x 64 block: A and B fragments coincide
+    //     (8 transpose reads instead of 16) and the lower 32 x 32 block is skipped -- 3 MFMAs per k-step;
+    //   * the block (rows 0..63, columns 64..127) is shared by the two remaining waves: wave (0,1) takes k-step 0 of
+    //     every stage, wave (1,0) k-step 1 (4 MFMAs, 8 reads each); wave (1,0) stores its half-sum in the unused
+    //     lower-left slots of the partial tile and moments_reduce adds the two (reduce_body, "mirror").
+    const bool diag_wave = wr == wc;
+    auto stage_diag = [&](int kb) {
+        const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
+        if (diag_wave) {
+            uint4 A0[2], A1[2];
+            A0[0] = frag(sA, 0, 64 * wr); A0[1] = frag(sA, 0, 64 * wr + 32);
+            A1[0] = frag(sA, 1, 64 * wr); A1[1] = frag(sA, 1, 64 * wr + 32);
+            acc[0][0] = mfma_h16<KIND>(A0[0], A0[0], acc[0][0]);
+            acc[0][1] = mfma_h16<KIND>(A0[0], A0[1], acc[0][1]);
+            acc[1][1] = mfma_h16<KIND>(A0[1], A0[1], acc[1][1]);
+            acc[0][0] = mfma_h16<KIND>(A1[0], A1[0], acc[0][0]);
+            acc[0][1] = mfma_h16<KIND>(A1[0], A1[1], acc[0][1]);
+            acc[1][1] = mfma_h16<KIND>(A1[1], A1[1], acc[1][1]);
+            csum[0] += (double)sum8<KIND>(A0[0]) + (double)sum8<KIND>(A1[0]);
+            csum[1] += (double)sum8<KIND>(A0[1]) + (double)sum8<KIND>(A1[1]);
+        } else {
+            uint4 F[4];
+            F[0] = frag(sA, wr, 0); F[1] = frag(sA, wr, 32);       // wave (0,1): k-step 0, wave (1,0): k-step 1
+            F[2] = frag(sA, wr, 64); F[3] = frag(sA, wr, 96);
+            mma(F);
+        }
+    };
+
+    // one stage: wait for it, workgroup barrier, refill the freed slot, 16 transpose reads, 8 MFMAs
+    auto stage = [&](int kb, auto refill_tag) {
+        // stage kb must have landed; up to NST-2 younger stages may stay in flight
+        const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
+        wait_vmcnt_upto<LPS>(ahead);
+        __builtin_amdgcn_s_barrier();              // stage kb is in LDS; stage kb-1 is free
+        if (decltype(refill_tag)::value) issue_fast(kb + NST - 1);
+        else if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+        if constexpr (DIAG) {
+            stage_diag(kb);
+        } else {
+            // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
+            // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
+            uint4 F0[4], F1[4];
+            load_frags(kb, 0, F0);
+            load_frags(kb, 1, F1);
+            mma(F0);
+            mma(F1);
+        }
+    };
+    // One run = a range of rows streamed through the ring: prologue, hot loop (the stage to refill is a full one ->
+    // SGPR-base loads only), tail with the general loads.  A split is one run, or -- segment-aligned splits -- the
+    // runs of several files back to back: the accumulators carry over, the column sums are flushed per run.
+    double total_rows = 0.0;
+    const int n_runs = runs ? run_hi - run_lo : 1;
+    for (int ri = 0; ri < n_runs; ++ri) {
+        int64_t crow = split;                      // colpart row of this run
+        if (runs) {
+            const SegRun rn = runs[run_lo + ri];
+            k_begin = rn.r0; k_end = rn.r0 + rn.rows; crow = run_lo + ri;
+            if (ri) __builtin_amdgcn_s_barrier();  // every wave has left the previous run's last stage: its slots are free
+        }
+        nkb = (int)((k_end - k_begin + H_KB - 1) / H_KB);
+        nfast = (FAST && cols_full) ? (int)((k_end - k_begin) / H_KB) : 0;
+        total_rows += (double)(k_end - k_begin);
+        for (int s0 = 0; s0 < NST - 1 && s0 < nkb; ++s0) { if (s0 < nfast) issue_fast(s0); else issue(s0); }
+        const int hot = (nfast - (NST - 1) > 0) ? nfast - (NST - 1) : 0;
+        int kb = 0;
+        for (; kb < hot; ++kb) stage(kb, std::true_type{});
+        for (; kb < nkb; ++kb) stage(kb, std::false_type{});
+        if (do_colsum) {
+            csum[0] += __shfl_xor(csum[0], 32);
+            csum[1] += __shfl_xor(csum[1], 32);
+            if (kg == 0) {
+                double* cp = colpart + crow * (int64_t)(nt * H_BT) + cb + 64 * wc + li;
+                cp[0] = csum[0]; cp[32] = csum[1];
+            }
+            ctot[0] += csum[0]; ctot[1] += csum[1];
+            csum[0] = 0.0; csum[1] = 0.0;
+        }
+    }
+
+    // partial tile, fragment major: float4 index ((fa*4 + fb)*4 + q)*64 + lane holds registers 4q..4q+3 of the
+    // 32 x 32 block (fa, fb) = rows 32fa + 8q + 4(lane>>5) + 0..3 of column 32fb + (lane&31);
+    // a wave stores 1 KiB per instruction, 16 instructions instead of 64 scattered dword stores
+    float4* out = reinterpret_cast<float4*>(partials + ((int64_t)split * T + tile) * H_TS);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x16& a = acc[x][y];
+                out[(((2 * wr + x) * 4 + (2 * wc + y)) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+            }
+    if (do_colsum && shift_flag) {
+        // Shift guard (see moments_tile_f64): within this split's rows, is any column's mean^2 > 64 var?
+        // Then fp32 partial sums of x^2 cannot resolve the variance and the block is redone in fp64.
+        // sum x^2 of column (32 f + li) is the diagonal element acc[f][f][reg] of the lane whose C/D row
+        // (reg&3) + 8 (reg>>2) + 4 kg equals li: kg = (li>>2)&1, reg = (li&3) + 4 (li>>3).
+        const double nr = total_rows;
+        const int myreg = (li & 3) + 4 * (li >> 3);
+        const bool own = kg == ((li >> 2) & 1);
+        bool hit = false;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float dsel = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dsel = (r == myreg) ? acc[f][f][r] : dsel;
+            double s2 = own ? (double)dsel : 0.0;
+            s2 += __shfl_xor(s2, 32);
+            const double mean = ctot[f] / nr, var = s2 / nr - mean * mean;
+            const bool col_in = (cb + 64 * wc + 32 * f + li) < d;
+            if (col_in && !(mean * mean <= 64.0 * var) && !(ctot[f] == 0.0 && s2 == 0.0)) hit = true;
+        }
+        if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
+    }
+}
+
+template <int KIND, int NST, bool FAST>
+__global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
+    const int w = xcd_contiguous(blockIdx.x, L.total);
+    int split, tile, run_lo, run_hi; int64_t k_begin, k_end;
+    const TileSet& s = locate(L, w, split, tile, k_begin, k_end, run_lo, run_hi);
+    int ta, tb; tile_coords(tile, L.nt, ta, tb);
+    const uint16_t* E = static_cast<const uint16_t*>(s.E);
+    float* partials = static_cast<float*>(s.partials);
+    if (ta == tb)
+        tile_h16_tr_body<KIND, NST, true, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                partials, s.colpart, smem_dyn, s.flag, s.runs, run_lo, run_hi);
+    else if constexpr (FAST)
+        tile_h16_tr_body<KIND, NST, false, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                 partials, s.colpart, smem_dyn, nullptr, s.runs, run_lo, run_hi);
+}
+
+// ------------------------------------------------------------------------------------------
+// moments_tile_h16_wave: every wave owns a WHOLE 128 x 128 tile in 256 accumulator registers and streams its own
+// rows; the four waves of a workgroup take the 16-row k-steps round robin and their tiles are summed once, at
+// the end, through LDS.  Why (measured in round 1):
+//   * LDS transpose reads run at ~120 B/clk per CU.  With 64 x 64 wave tiles an MFMA needs 1 KiB of LDS reads,
+//     which makes the LDS port as busy as the matrix pipe, and the eight waves of a CU queue on it in lockstep.
+//     A 128 x 128 wave tile needs 0.5 KiB per MFMA.
+//   * One workgroup per CU halves the partial tiles (written, then read by the reduce kernel).
+//   * No workgroup barrier and no LDS sharing in the main loop: a wave waits only on its own LDS-DMA counter.
+// Per wave: ring of NSL slots of one k-step (16 rows x 128 columns of the A side, + the B side off the diagonal),
+// filled by global_load_lds with the same source-side XOR swizzle as above; per k-step 16 (8) transpose reads feed
+// 16 (10 on a diagonal tile: upper blocks only) MFMAs; the reads of step i+1 are issued right behind the first
+// MFMA of step i (the compiler only emits lgkmcnt(0) around ds_read_b64_tr_b16, so that is where a full wait is
+// harmless).  It loses to the kernel above at D = 512 (62 vs 51 us: with one wave per SIMD nothing fills the gaps the
+// loads leave) and wins on the HBM-bound single-tile stream (16.8M x 128: 0.80 vs 0.91 ms).
+// ------------------------------------------------------------------------------------------
+constexpr int W_RING = 32768;                                  // LDS ring bytes per wave
+constexpr int W_LDS = 4 * W_RING + 4 * H_BT * 8 + H_BT * 8;    // + per-wave column sums + their total
+
+template <int KIND, bool DIAG>
+__device__ __forceinline__ void tile_h16_wave_body(
+    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
+    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
+    char* smem, int* __restrict__ shift_flag) {
+    constexpr int NSL = DIAG ? 8 : 4;              // ring slots (k-steps in flight + the one being read)
+    constexpr int SLOTB = DIAG ? 4096 : 8192;      // bytes per slot
+    constexpr int LPS = DIAG ? 4 : 8;              // LDS-DMA instructions per k-step
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kg = lane >> 5;
+    const int nks = (int)((k_end - k_begin + 15) / 16);
+    const int nw = (nks > wave) ? (nks - wave + 3) / 4 : 0;          // this wave's k-steps: wave, wave + 4, ...
+    char* ring = smem + wave * W_RING;
+
+    // LDS-DMA: one instruction = 4 rows x 256 B; lane -> row lane>>4, 16-byte chunk (lane&15) ^ 4*(row&3)
+    const int srow = lane >> 4, sc = (lane & 15) ^ (srow << 2);
+    const bool col_ok_a = (ca + sc * 8) < d;
+    const bool col_ok_b = (cb + sc * 8) < d;
+    const uint16_t* ga = E + ca + sc * 8;
+    const uint16_t* gb = E + cb + sc * 8;
+    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
+    // part g of the loads of own k-step i: rows 4g..4g+3 of the A slab (g < 4) or of the B slab (g >= 4)
+    auto issue_part = [&](int i, int g) {
+        char* slot = ring + (i % NSL) * SLOTB;
+        const int h = g & 3;
+        const int64_t r = k_begin + (int64_t)(wave + 4 * i) * 16 + srow + 4 * h;
+        const bool ok = r < k_end;
+        if (g < 4) {
+            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)(slot + h * 1024), 16, 0, 0);
+        } else {
+            const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(slot + 4096 + h * 1024), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int i) {
+#pragma unroll
+        for (int g = 0; g < LPS; ++g) issue_part(i, g);
+    };
+
+    // transpose-read addressing (see above): byte offset of the lane's first read of 32-column fragment f
+    const int t16 = lane & 15, grp = lane >> 4;
+    const int tr_row = 8 * (grp >> 1) + (t16 >> 2);
+    const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);
+    int fo[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int col = 32 * f + tr_col;
+        fo[f] = tr_row * 256 + (((col >> 3) ^ ((tr_row & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
+    }
+    auto frag = [&](const char* slab, int f) -> uint4 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f] + 1024));
+        uint4 v;
+        __builtin_memcpy(&v.x, &lo, 8);
+        __builtin_memcpy(&v.z, &hi, 8);
+        return v;
+    };
+    constexpr int NFR = DIAG ? 4 : 8;              // fragments per k-step: A side 0..3 (+ B side 4..7)
+    auto load_frags = [&](int i, uint4 (&F)[NFR]) {
+        const char* slot = ring + (i % NSL) * SLOTB;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) F[f] = frag(slot, f);
+        if (!DIAG) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) F[4 + f] = frag(slot + 4096, f);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
+    double csum[4] = {0.0, 0.0, 0.0, 0.0};
+
+    auto mma_first = [&](const uint4 (&F)[NFR]) { acc[0][0] = mfma_h16<KIND>(F[0], F[DIAG ? 0 : 4], acc[0][0]); };
+    auto mma_rest = [&](const uint4 (&F)[NFR]) {
+#pragma unroll
+        for (int fa = 0; fa < 4; ++fa)
+#pragma unroll
+            for (int fb = (DIAG ? fa : 0); fb < 4; ++fb) {
+                if (fa == 0 && fb == 0) continue;
+                acc[fa][fb] = mfma_h16<KIND>(F[fa], F[DIAG ? fb : 4 + fb], acc[fa][fb]);
+            }
+        if (DIAG) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) csum[f] += (double)sum8<KIND>(F[f]);
+        }
+    };
+
+    const int n0 = nw < NSL ? nw : NSL;
+    for (int s = 0; s < n0; ++s) issue(s);
+    uint4 C[NFR], N[NFR];                          // fragments of the current / the next k-step
+    if (nw > 0) {
+        wait_vmcnt_upto<LPS>(n0 - 1);
+        load_frags(0, C);
+    }
+    for (int i = 0; i < nw; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        mma_first(C);                              // (lgkmcnt(0) before it: every read of step i has landed)
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + NSL < nw) issue(i + NSL);          // ... so its slot can be refilled
+        if (i + 1 < nw) {
+            const int newest = i + NSL;
+            const int youngest = (nw - 1 < newest) ? nw - 1 : newest;
+            wait_vmcnt_upto<LPS>(youngest - (i + 1));      // step i+1 is in LDS
+            load_frags(i + 1, N);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rest(C);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) C[f] = N[f];
+    }
+
+    // ---- epilogue: sum the four waves' tiles (fp64 sum of four fp32 values, rounded once) and store ------
+    __syncthreads();                               // every wave is done with its ring
+    float4* xch = reinterpret_cast<float4*>(smem);                   // [wave][2048] per half
+    double* colx = reinterpret_cast<double*>(smem + 4 * W_RING);     // [4][128] per-wave column sums
+    double* colt = colx + 4 * H_BT;                                  // [128] their total
+    if (DIAG) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            csum[f] += __shfl_xor(csum[f], 32);
+            if (kg == 0) colx[wave * H_BT + 32 * f + li] = csum[f];
+        }
+        __syncthreads();
+        if (tid < H_BT) {
+            const double t = (colx[tid] + colx[H_BT + tid]) + (colx[2 * H_BT + tid] + colx[3 * H_BT + tid]);
+            colt[tid] = t;
+            colpart[(int64_t)split * (nt * H_BT) + cb + tid] = t;
+        }
+    }
+    float4* out = reinterpret_cast<float4*>(partials + ((int64_t)split * T + tile) * H_TS);
+    const double nr = (double)(k_end - k_begin);
+    bool hit = false;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x16& a = acc[2 * half + fl][fb];
+                    xch[wave * 2048 + ((fl * 4 + fb) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+                }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 256 * j;
+            const float4 v0 = xch[e], v1 = xch[2048 + e], v2 = xch[4096 + e], v3 = xch[6144 + e];
+            const double s0 = ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            const double s1 = ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+            const double s2 = ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+            const double s3 = ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+            out[half * 2048 + e] = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
+            if (DIAG && shift_flag) {
+                // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?  The
+                // float4 of lane l, quad q of a diagonal block holds rows 8q + 4(l>>5) + 0..3 of column l&31: it
+                // contains the diagonal element (sum of x^2 of that column) iff (l&31)>>2 == 2q + (l>>5).
+                const int el = e & 63, eq = (e >> 6) & 3, efb = (e >> 8) & 3, efa = 2 * half + (e >> 10);
+                const int eli = el & 31;
+                if (efa == efb && (eli >> 2) == 2 * eq + (el >> 5)) {
+                    const int c = eli & 3, col = 32 * efb + eli;
+                    const double sq = (c == 0) ? s0 : (c == 1) ? s1 : (c == 2) ? s2 : s3;
+                    const double cs = colt[col];
+                    const double mean = cs / nr, var = sq / nr - mean * mean;
+                    if ((cb + col) < d && !(mean * mean <= 64.0 * var) && !(cs == 0.0 && sq == 0.0)) hit = true;
+                }
+            }
+        }
+        __syncthreads();                           // before the second half overwrites the exchange buffer
+    }
+    if (DIAG && shift_flag && hit) atomicOr(shift_flag, 1);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void moments_tile_h16_wave(TileLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) char smem_wave[];   // the ONLY LDS object: W_LDS bytes
+    const int w = xcd_contiguous(blockIdx.x, L.total);
+    int split, tile, run_lo, run_hi; int64_t k_begin, k_end;
+    const TileSet& s = locate(L, w, split, tile, k_begin, k_end, run_lo, run_hi);      // (runs are a moments_tile_h16_tr feature)
+    int ta, tb; tile_coords(tile, L.nt, ta, tb);
+    const uint16_t* E = static_cast<const uint16_t*>(s.E);
+    float* partials = static_cast<float*>(s.partials);
+    if (ta == tb)
+        tile_h16_wave_body<KIND, true>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT, partials,
+                                       s.colpart, smem_wave, s.flag);
+    else
+        tile_h16_wave_body<KIND, false>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT, partials,
+                                        s.colpart, smem_wave, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// Shift guard.  The fp16 pass sums exact products in fp32 over bounded runs; that is accurate
+// relative to sum x^2, not to the variance.  For a column with |mean| >> std (constant-ish features,
+// outlier dimensions of transformer states) the covariance is a small difference of large sums, so
+// the update is REDONE exactly (fp64 products and sums, like np.cov's centred dsyrk) when any column
+// has mean^2 > 64 var within some workgroup's run of rows.  No host round trip: the fp64 tile kernel
+// is launched unconditionally and exits at once when the flag is clear; one reduce launch serves both
+// sources.  Two flags alternate between updates so that the reduce of update k can clear the flag of
+// update k+1 without a memset.
+//
+// Generic tile kernel: any input dtype, any pitch/alignment.  Everything in fp64 on
+// v_mfma_f64_16x16x4_f64 (A: lane l holds A[i=l&15][k=l>>4]; B[k=l>>4][j=l&15];
+// D: col = l&15, row = (l>>4) + 4*reg).  Workgroup tile 64x64, wave tile 32x32, 16 rows/stage.
+// ------------------------------------------------------------------------------------------
+constexpr int G_BT = 64;
+constexpr int G_TS = G_BT * G_BT + 32;   // partial-tile stride (doubles), +256 B as for H_TS
+constexpr int G_KB = 16;
+constexpr int G_LDS = 80;     // padded row pitch (doubles): consecutive k rows hit the other bank half
+
+template <typename TIn> __device__ __forceinline__ double to_f64(TIn v);
+template <> __device__ __forceinline__ double to_f64<double>(double v) { return v; }
+template <> __device__ __forceinline__ double to_f64<float>(float v) { return (double)v; }
+struct raw_f16 { uint16_t b; };
+struct raw_bf16 { uint16_t b; };
+template <> __device__ __forceinline__ double to_f64<raw_f16>(raw_f16 v) { return (double)h16_to_f32<FAD_F16>(v.b); }
+template <> __device__ __forceinline__ double to_f64<raw_bf16>(raw_bf16 v) { return (double)h16_to_f32<FAD_BF16>(v.b); }
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void moments_tile_f64(TileLaunch L) {
+    __shared__ double smem[2][2][G_KB * G_LDS];      // 40 KiB
+    // one grid for all sets (sized for the longest); a set whose gate is clear has nothing to redo
+    const TileSet& s = L.set[blockIdx.y];
+    if ((int)blockIdx.x >= s.S * L.T) return;
+    if (s.flag && *s.flag == 0) return;              // shift guard: only runs when the fp16 pass flagged the block
+    const TIn* __restrict__ E = static_cast<const TIn*>(s.E);
+    const int64_t ld = s.ld;
+    const int d = L.d, nt = L.nt, T = L.T;
+
+    const int w = xcd_contiguous(blockIdx.x, s.S * T);
+    const int split = w / T, tile = w - split * T;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    const bool diag = (ta == tb);
+    const int ca = ta * G_BT, cb = tb * G_BT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+
+    const int64_t k_begin = (int64_t)split * s.rows_per_split;
+    const int64_t k_end = (k_begin + s.rows_per_split < s.n) ? k_begin + s.rows_per_split : s.n;
+    const int nkb = (int)((k_end - k_begin + G_KB - 1) / G_KB);
+
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+    double ra[4], rb[4];
+    auto fetch = [&](int kb) {
+        const int64_t r = k_begin + (int64_t)kb * G_KB + sr;
+        const bool ok = r < k_end;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int colA = ca + sc4 + q, colB = cb + sc4 + q;
+            ra[q] = (ok && colA < d) ? to_f64<TIn>(E[r * ld + colA]) : 0.0;
+            if (!diag) rb[q] = (ok && colB < d) ? to_f64<TIn>(E[r * ld + colB]) : 0.0;
+        }
+    };
+
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double csum[2] = {0.0, 0.0};
+    const bool do_colsum = diag && (wr == 0);
+
+    if (nkb > 0) fetch(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            smem[buf][0][sr * G_LDS + sc4 + q] = ra[q];
+            if (!diag) smem[buf][1][sr * G_LDS + sc4 + q] = rb[q];
+        }
+        __syncthreads();
+        if (kb + 1 < nkb) fetch(kb + 1);
+        const double* sA = smem[buf][0];
+        const double* sB = smem[buf][diag ? 0 : 1];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + lk;
+            double a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = sA[k * G_LDS + 32 * wr + 16 * f + li];
+                b[f] = sB[k * G_LDS + 32 * wc + 16 * f + li];
+            }
+#pragma unroll
+            for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+                    acc[fa][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fa], b[fb], acc[fa][fb], 0, 0, 0);
+            if (do_colsum) { csum[0] += b[0]; csum[1] += b[1]; }
+        }
+    }
+
+    double* out = static_cast<double*>(s.partials) + ((int64_t)split * T + tile) * G_TS;
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int a_local = 32 * wr + 16 * fa + lk + 4 * reg;
+                const int b_local = 32 * wc + 16 * fb + li;
+                out[a_local * G_BT + b_local] = acc[fa][fb][reg];
+            }
+    if (do_colsum) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            csum[f] += __shfl_xor(csum[f], 16);
+            csum[f] += __shfl_xor(csum[f], 32);
+        }
+        if (lk == 0) {
+            double* cp = s.colpart + (int64_t)split * (nt * G_BT) + cb + 32 * wc + li;
+            cp[0] = csum[0]; cp[16] = csum[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// partials -> packed fp64 accumulator (sum over splits in fp64, fixed order => deterministic).
+// One thread per 4 adjacent elements of one tile.
+// ------------------------------------------------------------------------------------------
+struct SplitPlan { int nt, T, S; int64_t rows_per_split; };
+
+// One source of partial sums for moments_reduce: `S` row-splits x `T` tiles (+ column partials).
+struct ReduceSrc {
+    const void* partials; const double* colpart;
+    int S, T, nt;
+    int SC;               // rows of colpart (= S, or the number of runs of segment-aligned splits)
+    int tile_blocks;      // workgroups that sum tiles; the following ceil(d/256) sum the columns and the row count
+    int layout;           // 0 row major, 1 fragment major (the fp16 kernels)
+    int sl;               // "split lanes" (1, 4 or 16), see below
+};
+
+// One set of a reduce launch: accumulator += (or =) the sum over splits of ONE of two sources: `prim` when *gate == 0
+// or there is no gate, else `alt` -- the fp64 redo of the block by moments_tile_f64 (shift guard).
+struct ReduceJob {
+    ReduceSrc prim, alt;
+    double* acc; double n_add;
+    const int* gate; int* clear_flag;
+    int overwrite;        // the accumulator was reset since its last update: store instead of add (saves the memset)
+};
+struct ReduceLaunch { ReduceJob job[kMaxSets]; int d; };
+
+// sl "split lanes" share one output group: thread (l, g) sums splits l, l+sl, ... and the sl partial
+// sums are combined through LDS in a fixed order.  With hundreds of row-splits (D = 128 uses every
+// workgroup slot for one tile) a single thread per output would walk all of them serially.
+template <typename PT, int BT>
+__device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* __restrict__ acc_packed, double n_add,
+                                            bool overwrite, int block, double* red) {
+    const PT* __restrict__ partials = static_cast<const PT*>(r.partials);
+    const int S = r.S, T = r.T, nt = r.nt, SL = r.sl;
+    const int G = 256 / SL;                        // output groups (4 values each) per block
+    const int per_tile = BT * BT / 4;
+    if (block >= r.tile_blocks) {                  // trailing blocks: column sums and the row count
+        const int a = (block - r.tile_blocks) * 256 + threadIdx.x;
+        if (a == 0) acc_packed[0] = overwrite ? n_add : acc_packed[0] + n_add;
+        if (a >= d) return;
+        const int dpad = nt * BT;
+        const double* __restrict__ colpart = r.colpart;
+        double s0 = 0.0, s1 = 0.0;
+        const int SC = r.SC;
+        int sp = 0;
+        for (; sp + 1 < SC; sp += 2) { s0 += colpart[(int64_t)sp * dpad + a]; s1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
+        if (sp < SC) s0 += colpart[(int64_t)sp * dpad + a];
+        acc_packed[1 + a] = overwrite ? s0 + s1 : acc_packed[1 + a] + (s0 + s1);
+        return;
+    }
+    const int sl = threadIdx.x / G, gl = threadIdx.x % G;
+    const int64_t g = (int64_t)block * G + gl;
+    const bool live = g < (int64_t)T * per_tile;
+    int tile = 0, a_local = 0, b_local = 0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        tile = (int)(g / per_tile);
+        const int e = (int)(g - (int64_t)tile * per_tile);
+        if (r.layout == 0) {               // row major: 4 adjacent columns of one row
+            a_local = e / (BT / 4); b_local = (e % (BT / 4)) * 4;
+        } else {                           // fragment major: 4 adjacent ROWS of one column
+            const int el = e & 63;
+            a_local = 32 * (e >> 10) + 8 * ((e >> 6) & 3) + 4 * (el >> 5);
+            b_local = 32 * ((e >> 8) & 3) + (el & 31);
+        }
+        constexpr int TS = (sizeof(PT) == 4) ? BT * BT + 64 : BT * BT + 32;      // H_TS / G_TS
+        const PT* p = partials + (int64_t)tile * TS + e * 4;
+        const int64_t stride = (int64_t)T * TS;
+        // "mirror": on a DIAGONAL tile moments_tile_h16_tr splits the k-steps of the block (rows 0..63, columns 64..127)
+        // between two waves; the second half-sum sits in the lower-left slots, 32 x 32 block (fa + 2, fb - 2) =
+        // 6 * 256 float4 further on (zeros when the wave kernel or a presum wrote the tile)
+        int nsrc = 1;
+        if (r.layout == 1) {
+            int ta0, tb0; tile_coords(tile, nt, ta0, tb0);
+            if (ta0 == tb0 && (e >> 10) < 2 && ((e >> 8) & 3) >= 2) nsrc = 2;
+        }
+        for (int h = 0; h < nsrc; ++h) {
+            const PT* ph = p + h * (6 * 256 * 4);
+            int sp = sl;
+            if constexpr (sizeof(PT) == 4) {           // four independent loads in flight per thread
+                for (; sp + 3 * SL < S; sp += 4 * SL) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(ph + sp * stride);
+                    const float4 v1 = *reinterpret_cast<const float4*>(ph + (sp + SL) * stride);
+                    const float4 v2 = *reinterpret_cast<const float4*>(ph + (sp + 2 * SL) * stride);
+                    const float4 v3 = *reinterpret_cast<const float4*>(ph + (sp + 3 * SL) * stride);
+                    s[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+                    s[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+                    s[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+                    s[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+                }
+            }
+            for (; sp < S; sp += SL) {
+                if constexpr (sizeof(PT) == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(ph + sp * stride);
+                    s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+                } else {
+                    const double2 v0 = *reinterpret_cast<const double2*>(ph + sp * stride);
+                    const double2 v1 = *reinterpret_cast<const double2*>(ph + sp * stride + 2);
+                    s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+                }
+            }
+        }
+    }
+    if (SL > 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(sl * G + gl) * 4 + q] = s[q];
+        __syncthreads();
+        if (sl != 0) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double t = 0.0;
+            for (int l = 0; l < SL; ++l) t += red[(l * G + gl) * 4 + q];
+            s[q] = t;
+        }
+    }
+    if (!live) return;
+    int ta, tb; tile_coords(tile, nt, ta, tb);
+    double* M = acc_packed + 1 + d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int a = ta * BT + a_local + (r.layout ? q : 0), b = tb * BT + b_local + (r.layout ? 0 : q);
+        if (a >= d || b >= d) continue;
+        const int64_t ab = (int64_t)a * d + b, ba = (int64_t)b * d + a;
+        if (ta != tb) {
+            M[ab] = overwrite ? s[q] : M[ab] + s[q];
+            M[ba] = overwrite ? s[q] : M[ba] + s[q];
+        } else if (a <= b) {            // diagonal tile: upper triangle is authoritative
+            M[ab] = overwrite ? s[q] : M[ab] + s[q];
+            if (a != b) M[ba] = overwrite ? s[q] : M[ba] + s[q];
+        }
+    }
+}
+
+// blockIdx.y = set; the grid's x extent is sized for the largest job.
+template <typename PTA, int BTA>
+__global__ __launch_bounds__(256) void moments_reduce(ReduceLaunch R) {
+    __shared__ double red[256 * 4];
+    const ReduceJob& j = R.job[blockIdx.y];
+    if (j.clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *j.clear_flag = 0;     // next update's flag
+    const int col_blocks = (R.d + 255) / 256;
+    if (j.gate && *j.gate != 0) {
+        if ((int)blockIdx.x < j.alt.tile_blocks + col_blocks)
+            reduce_body<double, 64>(j.alt, R.d, j.acc, j.n_add, j.overwrite != 0, (int)blockIdx.x, red);
+    } else if ((int)blockIdx.x < j.prim.tile_blocks + col_blocks) {
+        reduce_body<PTA, BTA>(j.prim, R.d, j.acc, j.n_add, j.overwrite != 0, (int)blockIdx.x, red);
+    }
+}
+
+// Stage 1 of the two-level reduce used when an update produced hundreds or thousands of partial tiles (long inputs
+// at small D: every run of <= 8192 rows is one split).  Block (x, c) sums the splits of chunk c for 256 output
+// groups (four loads in flight per thread) into fp64 partials laid out like moments_reduce<double, BT> expects;
+// trailing x-blocks do the same for the column partials.
+constexpr int PRESUM_CHUNK = 32;
+template <int BT>
+__global__ __launch_bounds__(256) void moments_presum(
+    const float* __restrict__ partials, const double* __restrict__ colpart, int S, int SC, int T, int nt, int group_blocks,
+    double* __restrict__ partials2, double* __restrict__ colpart2, const int* __restrict__ gate) {
+    if (gate && *gate != 0) return;                // the block is being redone in fp64: nothing to pre-sum
+    const int c = blockIdx.y;
+    const int s0 = c * PRESUM_CHUNK, s1 = (s0 + PRESUM_CHUNK < S) ? s0 + PRESUM_CHUNK : S;
+    const int dpad = nt * BT;
+    if ((int)blockIdx.x >= group_blocks) {
+        const int a = ((int)blockIdx.x - group_blocks) * 256 + threadIdx.x;
+        if (a >= dpad) return;
+        // the colpart rows (SC of them: one per split, or one per run) are shared out evenly over the chunks
+        const int per = (SC + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int c0 = c * per, c1 = (c0 + per < SC) ? c0 + per : SC;
+        double t0 = 0.0, t1 = 0.0;
+        int sp = c0;
+        for (; sp + 1 < c1; sp += 2) { t0 += colpart[(int64_t)sp * dpad + a]; t1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
+        if (sp < c1) t0 += colpart[(int64_t)sp * dpad + a];
+        colpart2[(int64_t)c * dpad + a] = t0 + t1;
+        return;
+    }
+    constexpr int per_tile = BT * BT / 4;
+    constexpr int TS32 = BT * BT + 64, TS64 = BT * BT + 32;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (int64_t)T * per_tile) return;
+    const int tile = (int)(g / per_tile), e = (int)(g - (int64_t)tile * per_tile);
+    const float* p = partials + (int64_t)tile * TS32 + e * 4;
+    const int64_t stride = (int64_t)T * TS32;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    int sp = s0;
+    for (; sp + 3 < s1; sp += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + sp * stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (sp + 1) * stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (sp + 2) * stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(p + (sp + 3) * stride);
+        s[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+        s[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+        s[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+    }
+    for (; sp < s1; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
+        s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+    }
+    double* o = partials2 + ((int64_t)c * T + tile) * TS64 + e * 4;
+    *reinterpret_cast<double2*>(o) = make_double2(s[0], s[1]);
+    *reinterpret_cast<double2*>(o + 2) = make_double2(s[2], s[3]);
+}
+
+static ReduceSrc reduce_src(const void* part, const double* colp, const SplitPlan& p, int bt, int layout) {
+    ReduceSrc r;
+    r.partials = part; r.colpart = colp; r.S = p.S; r.SC = p.S; r.T = p.T; r.nt = p.nt; r.layout = layout;
+    r.sl = (p.S > 64) ? 16 : (p.S > 8) ? 4 : 1;
+    r.tile_blocks = (int)cdiv((int64_t)p.T * (bt * bt / 4), 256 / r.sl);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-segment column sums (files / songs stored back to back): seg_sums[s][a] = sum over the rows of segment s of
+// E[r][a], fp64.  Two stages, deterministic: every "piece" (<= SEG_PIECE rows of ONE segment) is summed by one
+// workgroup whose threads each own 8 adjacent columns (16-byte loads of fp16 rows) of every (256 / lanes-per-row)-th
+// row; then one thread per (segment, column) adds that segment's pieces in order.  Short segments are single
+// pieces; a 2250-row file (config 4) is 9 pieces, so a batch of 64 files already fills the chip.
+// ------------------------------------------------------------------------------------------
+constexpr int SEG_PIECE = 256;
+struct SegPiece { int64_t r0; int rows; int seg; };
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void segment_piece_sums(
+    const TIn* __restrict__ E, int64_t ld, int d, const SegPiece* __restrict__ pieces, double* __restrict__ piece_sums) {
+    __shared__ double red[256 * 8];
+    const SegPiece pc = pieces[blockIdx.x];
+    const int cg = (d + 7) / 8;                    // column groups of 8
+    const int tid = threadIdx.x;
+    for (int g0 = 0; g0 < cg; g0 += 256) {         // d <= 2048: one pass
+        const int lanes = (cg - g0 < 256) ? cg - g0 : 256;          // threads that own a column group
+        const int rpi = 256 / lanes;                                // rows handled per iteration
+        const int g = g0 + tid % lanes, rl = tid / lanes;
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (rl < rpi) {
+            for (int r = rl; r < pc.rows; r += rpi) {
+                const TIn* p = E + (pc.r0 + r) * ld + g * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (g * 8 + q < d) s[q] += to_f64<TIn>(p[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[tid * 8 + q] = s[q];
+        __syncthreads();
+        if (tid < lanes) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double t = 0.0;
+                for (int l = 0; l < rpi; ++l) t += red[(l * lanes + tid) * 8 + q];
+                if (g * 8 + q < d) piece_sums[(int64_t)blockIdx.x * d + g * 8 + q] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(128) void segment_gather_sums(const double* __restrict__ piece_sums, int64_t pitch,
+                                                           const int64_t* __restrict__ seg_first_piece, int d,
+                                                           double* __restrict__ seg_sums) {
+    const int64_t seg = blockIdx.x;
+    const int a = blockIdx.y * 128 + threadIdx.x;
+    if (a >= d) return;
+    double t = 0.0;
+    for (int64_t p = seg_first_piece[seg]; p < seg_first_piece[seg + 1]; ++p) t += piece_sums[p * pitch + a];
+    seg_sums[seg * d + a] = t;
+}
+
+// Per-file mean rows of the online statistics (fadtk/utils.py:16, 36-40), see fad_moments_update_file_means:
+// exact[f] = sqrt(n_f) m_f, rounded[f] = sqrt(n_f) m~_f (m~ = the mean as np.mean returns it for `dtype`),
+// weighted[f] = n_f m~_f; empty files give zero rows.
+template <int DT>
+__device__ __forceinline__ double round_mean_like(double v) {
+    if constexpr (DT == FAD_F16) return (double)(float)(_Float16)(float)v;
+    else if constexpr (DT == FAD_BF16) {
+        uint32_t u = __float_as_uint((float)v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (double)__uint_as_float(u & 0xffff0000u);
+    } else if constexpr (DT == FAD_F32) return (double)(float)v;
+    else return v;
+}
+template <int DT>
+__global__ __launch_bounds__(256) void file_mean_rows(const double* __restrict__ seg_sums, const int64_t* __restrict__ sizes,
+                                                      int64_t n_files, int d, double* __restrict__ exact,
+                                                      double* __restrict__ rounded, double* __restrict__ weighted) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_files * d) return;
+    const int64_t f = g / d;
+    const double n = (double)sizes[f];
+    double m = 0.0, mr = 0.0;
+    if (n > 0.0) { m = seg_sums[g] / n; mr = round_mean_like<DT>(m); }
+    const double rt = sqrt(n);
+    exact[g] = rt * m; rounded[g] = rt * mr; weighted[g] = n * mr;
+}
+
+__global__ __launch_bounds__(256) void packed_axpy(double* __restrict__ dst, const double* __restrict__ src,
+                                                   int64_t len) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < len) dst[g] += src[g];
+}
+
+// mu = sum/n ; cov = (M - sum sum^T / n) / (n - ddof)
+__global__ __launch_bounds__(256) void moments_finalize_kernel(
+    const double* __restrict__ acc_packed, int d, int ddof, double* __restrict__ mu,
+    double* __restrict__ cov) {
+    const double n = acc_packed[0];
+    const double* sum = acc_packed + 1;
+    const double* M = acc_packed + 1 + d;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < d && mu) mu[g] = sum[g] / n;
+    if (g >= (int64_t)d * d) return;
+    const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
+    cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit
+}
+
+}  // namespace fad
