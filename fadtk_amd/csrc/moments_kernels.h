@@ -280,10 +280,13 @@ __device__ __forceinline__ void tile_h16_tr_body(
     //   * the block (rows 0..63, columns 64..127) is shared by the two remaining waves: wave (0,1) takes k-step 0 of
     //     every stage, wave (1,0) k-step 1 (4 MFMAs, 8 reads each); wave (1,0) stores its half-sum in the unused
     //     lower-left slots of the partial tile and moments_reduce adds the two (reduce_body, "mirror").
+    // The role is a COMPILE-TIME argument and the run loop below is entered once per role: with a (wave-uniform) run-time
+    // test inside one loop, hipcc kept the accumulators of the off-diagonal waves in a second register range and copied
+    // all 64 of them back and forth around their four MFMAs -- 80 v_accvgpr_mov per stage (found in the ISA, round 2).
     const bool diag_wave = wr == wc;
-    auto stage_diag = [&](int kb) {
+    auto stage_diag = [&](int kb, auto role_tag) {
         const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
-        if (diag_wave) {
+        if constexpr (decltype(role_tag)::value) {
             uint4 A0[2], A1[2];
             A0[0] = frag(sA, 0, 64 * wr); A0[1] = frag(sA, 0, 64 * wr + 32);
             A1[0] = frag(sA, 1, 64 * wr); A1[1] = frag(sA, 1, 64 * wr + 32);
@@ -304,7 +307,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     };
 
     // one stage: wait for it, workgroup barrier, refill the freed slot, 16 transpose reads, 8 MFMAs
-    auto stage = [&](int kb, auto refill_tag) {
+    auto stage = [&](int kb, auto refill_tag, auto role_tag) {
         // stage kb must have landed; up to NST-2 younger stages may stay in flight
         const int ahead = (nkb - 1 - kb < NST - 2) ? (nkb - 1 - kb) : (NST - 2);
         wait_vmcnt_upto<LPS>(ahead);
@@ -312,7 +315,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
         if (decltype(refill_tag)::value) issue_fast(kb + NST - 1);
         else if (kb + NST - 1 < nkb) issue(kb + NST - 1);
         if constexpr (DIAG) {
-            stage_diag(kb);
+            stage_diag(kb, role_tag);
         } else {
             // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
             // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
@@ -340,9 +343,13 @@ __device__ __forceinline__ void tile_h16_tr_body(
         total_rows += (double)(k_end - k_begin);
         for (int s0 = 0; s0 < NST - 1 && s0 < nkb; ++s0) { if (s0 < nfast) issue_fast(s0); else issue(s0); }
         const int hot = (nfast - (NST - 1) > 0) ? nfast - (NST - 1) : 0;
-        int kb = 0;
-        for (; kb < hot; ++kb) stage(kb, std::true_type{});
-        for (; kb < nkb; ++kb) stage(kb, std::false_type{});
+        auto run_stages = [&](auto role_tag) {
+            int kb = 0;
+            for (; kb < hot; ++kb) stage(kb, std::true_type{}, role_tag);
+            for (; kb < nkb; ++kb) stage(kb, std::false_type{}, role_tag);
+        };
+        if (DIAG && diag_wave) run_stages(std::true_type{});
+        else run_stages(std::false_type{});
         if (do_colsum) {
             csum[0] += __shfl_xor(csum[0], 32);
             csum[1] += __shfl_xor(csum[1], 32);
