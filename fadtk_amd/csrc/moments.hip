@@ -13,12 +13,12 @@
 //                          out over all sets, so every workgroup sums a longer run of rows and the per-workgroup
 //                          costs (a 64 KiB partial tile written and re-read, pipeline fill, launch) are paid once
 //                          for all of them.
-//   moments_tile_h16_wave  the same contract, one 128x128 tile per WAVE; wins on single-tile, HBM-bound shapes.
 //   moments_tile_f64       any dtype / any alignment -> fp64 partial tiles with v_mfma_f64_16x16x4_f64
 //                          (products and sums in fp64, like np.cov); also the exact redo of the shift guard.
 //   moments_reduce         partials (fp32|fp64) -> += packed fp64 accumulator, mirrored; all sets in one launch.
 //   moments_finalize       (n, sum, sumsq) -> mu, cov with ddof.
-// (Earlier generations of the tile kernel: scripts/probes/moments_generations.hip.)
+// (Earlier generations of the tile kernel, and the one-tile-per-wave kernel shipped through round 2:
+//  scripts/probes/moments_generations.hip.)
 //
 // Data layout in HBM
 //   E            row-major [N x ld], one frame per row (the layout of fadtk's .npy files)
@@ -48,7 +48,6 @@ struct fad_moments {
     int* shift_flag = nullptr;             // device int[2], ping-pong between updates
     unsigned update_seq = 0;
     int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0, read at creation)
-    int force_variant = 0;                 // FAD_MOMENTS_VARIANT=4|8 (read at creation): pin the fp16 tile kernel
     bool force_generic = false;            // FAD_MOMENTS_FORCE_GENERIC=1 (read at creation): always the fp64 kernel
     bool fresh = false;                    // reset since the last update: the next reduce stores instead of adding
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
@@ -86,9 +85,6 @@ static tile_kernel_t tr_kernel(int dtype, bool fast) {       // multi-tile: 4 st
     if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false>;
     return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, 2 * H_NST, false>;
 }
-static tile_kernel_t wave_kernel(int dtype) {
-    return dtype == FAD_F16 ? &moments_tile_h16_wave<FAD_F16> : &moments_tile_h16_wave<FAD_BF16>;
-}
 constexpr size_t kTrLds = (size_t)H_NST * 2 * H_KB * 16 * sizeof(uint4);
 static int ensure_kernel_attrs(int device) {
     static std::mutex mu;
@@ -100,8 +96,6 @@ static int ensure_kernel_attrs(int device) {
         for (bool fast : {false, true})
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
-        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wave_kernel(dt)),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     }
     done[device] = true;
     return FAD_OK;
@@ -212,15 +206,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
     R.d = d;
     if (use_h16) {
         FAD_TRY(ensure_kernel_attrs(h0->device));
-        int64_t total_rows = 0;
-        for (int i = 0; i < count; ++i) total_rows += n[i];
-        // default: the 4-wave kernel; the one-tile-per-wave kernel wins on the HBM-bound single-tile shape (16.8M x 128:
-        // 0.80 vs 0.91 ms) and loses at D = 512 (62 vs 51 us), see DESIGN.md section 4
-        int variant = h0->force_variant ? h0->force_variant : ((d <= H_BT && total_rows >= (1 << 22)) ? 8 : 4);
-        if (seg) variant = 4;                      // runs are a feature of the four-wave kernel
-        // wave kernel: one workgroup per CU, each wave sums at most 8192 rows in fp32 (4 waves per split)
-        if (variant == 8) plan_splits(count, n, d, H_BT, 64, h0->n_cu, 1, 256, 4 * 8192, plan);
-        else plan_splits(count, n, d, H_BT, H_KB, h0->n_cu, 2, 256, 8192, plan);
+        plan_splits(count, n, d, H_BT, H_KB, h0->n_cu, 2, 256, 8192, plan);
         if (seg) { plan[0].S = seg->S; plan[0].rows_per_split = seg->max_split_rows; }
         TileLaunch L;
         memset(&L, 0, sizeof(L));
@@ -246,10 +232,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         }
         L.total = item;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-        if (variant == 8)
-            hipLaunchKernelGGL(wave_kernel(dtype), dim3((unsigned)L.total), dim3(256), W_LDS, st, L);
-        else
-            hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
+        hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
 
         // shift guard: exact fp64 redo of every flagged set, one gated launch for all of them
@@ -447,8 +430,6 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     // the knobs are read once, here: nothing on the update path calls getenv
     const char* gs = getenv("FAD_MOMENTS_SHIFT_GUARD");
     h->guard = !(gs && gs[0] == '0');
-    const char* var = getenv("FAD_MOMENTS_VARIANT");
-    h->force_variant = (var && (var[0] == '4' || var[0] == '8')) ? (var[0] - '0') : 0;
     const char* fg = getenv("FAD_MOMENTS_FORCE_GENERIC");
     h->force_generic = fg && fg[0] == '1';
     *out = h;
@@ -581,7 +562,7 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
     const bool is16 = (dtype == FAD_F16 || dtype == FAD_BF16);
     const bool aligned = is16 && (d % 8 == 0) && (dld % 8 == 0) && ((reinterpret_cast<uintptr_t>(drows) & 15u) == 0) && !h->force_generic;
     bool fused = false;
-    if (want_sums && aligned && h->force_variant != 8) {
+    if (want_sums && aligned) {
         constexpr int64_t kCap = 8192;             // rows one workgroup may sum in fp32 (see plan_splits)
         int64_t n_runs = 0, covered = 0;
         for (int64_t sg = 0; sg < n_segments; ++sg) { const int64_t len = offsets[sg + 1] - offsets[sg]; n_runs += len > 0 ? cdiv(len, kCap) : 1; covered += len; }

@@ -417,223 +417,6 @@ __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
 }
 
 // ------------------------------------------------------------------------------------------
-// moments_tile_h16_wave: every wave owns a WHOLE 128 x 128 tile in 256 accumulator registers and streams its own
-// rows; the four waves of a workgroup take the 16-row k-steps round robin and their tiles are summed once, at
-// the end, through LDS.  Why (measured in round 1):
-//   * LDS transpose reads run at ~120 B/clk per CU.  With 64 x 64 wave tiles an MFMA needs 1 KiB of LDS reads,
-//     which makes the LDS port as busy as the matrix pipe, and the eight waves of a CU queue on it in lockstep.
-//     A 128 x 128 wave tile needs 0.5 KiB per MFMA.
-//   * One workgroup per CU halves the partial tiles (written, then read by the reduce kernel).
-//   * No workgroup barrier and no LDS sharing in the main loop: a wave waits only on its own LDS-DMA counter.
-// Per wave: ring of NSL slots of one k-step (16 rows x 128 columns of the A side, + the B side off the diagonal),
-// filled by global_load_lds with the same source-side XOR swizzle as above; per k-step 16 (8) transpose reads feed
-// 16 (10 on a diagonal tile: upper blocks only) MFMAs; the reads of step i+1 are issued right behind the first
-// MFMA of step i (the compiler only emits lgkmcnt(0) around ds_read_b64_tr_b16, so that is where a full wait is
-// harmless).  It loses to the kernel above at D = 512 (62 vs 51 us: with one wave per SIMD nothing fills the gaps the
-// loads leave) and wins on the HBM-bound single-tile stream (16.8M x 128: 0.80 vs 0.91 ms).
-// ------------------------------------------------------------------------------------------
-constexpr int W_RING = 32768;                                  // LDS ring bytes per wave
-constexpr int W_LDS = 4 * W_RING + 4 * H_BT * 8 + H_BT * 8;    // + per-wave column sums + their total
-
-template <int KIND, bool DIAG>
-__device__ __forceinline__ void tile_h16_wave_body(
-    const uint16_t* __restrict__ E, int64_t k_begin, int64_t k_end, int64_t ld, int d, int nt, int T,
-    int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
-    char* smem, int* __restrict__ shift_flag) {
-    constexpr int NSL = DIAG ? 8 : 4;              // ring slots (k-steps in flight + the one being read)
-    constexpr int SLOTB = DIAG ? 4096 : 8192;      // bytes per slot
-    constexpr int LPS = DIAG ? 4 : 8;              // LDS-DMA instructions per k-step
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kg = lane >> 5;
-    const int nks = (int)((k_end - k_begin + 15) / 16);
-    const int nw = (nks > wave) ? (nks - wave + 3) / 4 : 0;          // this wave's k-steps: wave, wave + 4, ...
-    char* ring = smem + wave * W_RING;
-
-    // LDS-DMA: one instruction = 4 rows x 256 B; lane -> row lane>>4, 16-byte chunk (lane&15) ^ 4*(row&3)
-    const int srow = lane >> 4, sc = (lane & 15) ^ (srow << 2);
-    const bool col_ok_a = (ca + sc * 8) < d;
-    const bool col_ok_b = (cb + sc * 8) < d;
-    const uint16_t* ga = E + ca + sc * 8;
-    const uint16_t* gb = E + cb + sc * 8;
-    const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
-    // part g of the loads of own k-step i: rows 4g..4g+3 of the A slab (g < 4) or of the B slab (g >= 4)
-    auto issue_part = [&](int i, int g) {
-        char* slot = ring + (i % NSL) * SLOTB;
-        const int h = g & 3;
-        const int64_t r = k_begin + (int64_t)(wave + 4 * i) * 16 + srow + 4 * h;
-        const bool ok = r < k_end;
-        if (g < 4) {
-            const uint16_t* srcA = (ok && col_ok_a) ? ga + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)(slot + h * 1024), 16, 0, 0);
-        } else {
-            const uint16_t* srcB = (ok && col_ok_b) ? gb + r * ld : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(slot + 4096 + h * 1024), 16, 0, 0);
-        }
-    };
-    auto issue = [&](int i) {
-#pragma unroll
-        for (int g = 0; g < LPS; ++g) issue_part(i, g);
-    };
-
-    // transpose-read addressing (see above): byte offset of the lane's first read of 32-column fragment f
-    const int t16 = lane & 15, grp = lane >> 4;
-    const int tr_row = 8 * (grp >> 1) + (t16 >> 2);
-    const int tr_col = 16 * (grp & 1) + 4 * (t16 & 3);
-    int fo[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int col = 32 * f + tr_col;
-        fo[f] = tr_row * 256 + (((col >> 3) ^ ((tr_row & 3) << 2)) << 4) + ((col >> 2) & 1) * 8;
-    }
-    auto frag = [&](const char* slab, int f) -> uint4 {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f]));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slab + fo[f] + 1024));
-        uint4 v;
-        __builtin_memcpy(&v.x, &lo, 8);
-        __builtin_memcpy(&v.z, &hi, 8);
-        return v;
-    };
-    constexpr int NFR = DIAG ? 4 : 8;              // fragments per k-step: A side 0..3 (+ B side 4..7)
-    auto load_frags = [&](int i, uint4 (&F)[NFR]) {
-        const char* slot = ring + (i % NSL) * SLOTB;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) F[f] = frag(slot, f);
-        if (!DIAG) {
-#pragma unroll
-            for (int f = 0; f < 4; ++f) F[4 + f] = frag(slot + 4096, f);
-        }
-    };
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.f;
-    double csum[4] = {0.0, 0.0, 0.0, 0.0};
-
-    auto mma_first = [&](const uint4 (&F)[NFR]) { acc[0][0] = mfma_h16<KIND>(F[0], F[DIAG ? 0 : 4], acc[0][0]); };
-    auto mma_rest = [&](const uint4 (&F)[NFR]) {
-#pragma unroll
-        for (int fa = 0; fa < 4; ++fa)
-#pragma unroll
-            for (int fb = (DIAG ? fa : 0); fb < 4; ++fb) {
-                if (fa == 0 && fb == 0) continue;
-                acc[fa][fb] = mfma_h16<KIND>(F[fa], F[DIAG ? fb : 4 + fb], acc[fa][fb]);
-            }
-        if (DIAG) {
-#pragma unroll
-            for (int f = 0; f < 4; ++f) csum[f] += (double)sum8<KIND>(F[f]);
-        }
-    };
-
-    const int n0 = nw < NSL ? nw : NSL;
-    for (int s = 0; s < n0; ++s) issue(s);
-    uint4 C[NFR], N[NFR];                          // fragments of the current / the next k-step
-    if (nw > 0) {
-        wait_vmcnt_upto<LPS>(n0 - 1);
-        load_frags(0, C);
-    }
-    for (int i = 0; i < nw; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
-        mma_first(C);                              // (lgkmcnt(0) before it: every read of step i has landed)
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + NSL < nw) issue(i + NSL);          // ... so its slot can be refilled
-        if (i + 1 < nw) {
-            const int newest = i + NSL;
-            const int youngest = (nw - 1 < newest) ? nw - 1 : newest;
-            wait_vmcnt_upto<LPS>(youngest - (i + 1));      // step i+1 is in LDS
-            load_frags(i + 1, N);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_rest(C);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < NFR; ++f) C[f] = N[f];
-    }
-
-    // ---- epilogue: sum the four waves' tiles (fp64 sum of four fp32 values, rounded once) and store ------
-    __syncthreads();                               // every wave is done with its ring
-    float4* xch = reinterpret_cast<float4*>(smem);                   // [wave][2048] per half
-    double* colx = reinterpret_cast<double*>(smem + 4 * W_RING);     // [4][128] per-wave column sums
-    double* colt = colx + 4 * H_BT;                                  // [128] their total
-    if (DIAG) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            csum[f] += __shfl_xor(csum[f], 32);
-            if (kg == 0) colx[wave * H_BT + 32 * f + li] = csum[f];
-        }
-        __syncthreads();
-        if (tid < H_BT) {
-            const double t = (colx[tid] + colx[H_BT + tid]) + (colx[2 * H_BT + tid] + colx[3 * H_BT + tid]);
-            colt[tid] = t;
-            colpart[(int64_t)split * (nt * H_BT) + cb + tid] = t;
-        }
-    }
-    float4* out = reinterpret_cast<float4*>(partials + ((int64_t)split * T + tile) * H_TS);
-    const double nr = (double)(k_end - k_begin);
-    bool hit = false;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int fl = 0; fl < 2; ++fl)
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x16& a = acc[2 * half + fl][fb];
-                    xch[wave * 2048 + ((fl * 4 + fb) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-                }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = tid + 256 * j;
-            const float4 v0 = xch[e], v1 = xch[2048 + e], v2 = xch[4096 + e], v3 = xch[6144 + e];
-            const double s0 = ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-            const double s1 = ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-            const double s2 = ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
-            const double s3 = ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
-            out[half * 2048 + e] = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
-            if (DIAG && shift_flag) {
-                // Shift guard (see moments_tile_f64): within this run of rows, is any column's mean^2 > 64 var?  The
-                // float4 of lane l, quad q of a diagonal block holds rows 8q + 4(l>>5) + 0..3 of column l&31: it
-                // contains the diagonal element (sum of x^2 of that column) iff (l&31)>>2 == 2q + (l>>5).
-                const int el = e & 63, eq = (e >> 6) & 3, efb = (e >> 8) & 3, efa = 2 * half + (e >> 10);
-                const int eli = el & 31;
-                if (efa == efb && (eli >> 2) == 2 * eq + (el >> 5)) {
-                    const int c = eli & 3, col = 32 * efb + eli;
-                    const double sq = (c == 0) ? s0 : (c == 1) ? s1 : (c == 2) ? s2 : s3;
-                    const double cs = colt[col];
-                    const double mean = cs / nr, var = sq / nr - mean * mean;
-                    if ((cb + col) < d && !(mean * mean <= 64.0 * var) && !(cs == 0.0 && sq == 0.0)) hit = true;
-                }
-            }
-        }
-        __syncthreads();                           // before the second half overwrites the exchange buffer
-    }
-    if (DIAG && shift_flag && hit) atomicOr(shift_flag, 1);
-}
-
-template <int KIND>
-__global__ __launch_bounds__(256) void moments_tile_h16_wave(TileLaunch L) {
-    extern __shared__ __attribute__((aligned(16))) char smem_wave[];   // the ONLY LDS object: W_LDS bytes
-    const int w = xcd_contiguous(blockIdx.x, L.total);
-    int split, tile, run_lo, run_hi; int64_t k_begin, k_end;
-    const TileSet& s = locate(L, w, split, tile, k_begin, k_end, run_lo, run_hi);      // (runs are a moments_tile_h16_tr feature)
-    int ta, tb; tile_coords(tile, L.nt, ta, tb);
-    const uint16_t* E = static_cast<const uint16_t*>(s.E);
-    float* partials = static_cast<float*>(s.partials);
-    if (ta == tb)
-        tile_h16_wave_body<KIND, true>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT, partials,
-                                       s.colpart, smem_wave, s.flag);
-    else
-        tile_h16_wave_body<KIND, false>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT, partials,
-                                        s.colpart, smem_wave, nullptr);
-}
-
-// ------------------------------------------------------------------------------------------
 // Shift guard.  The fp16 pass sums exact products in fp32 over bounded runs; that is accurate
 // relative to sum x^2, not to the variance.  For a column with |mean| >> std (constant-ish features,
 // outlier dimensions of transformer states) the covariance is a small difference of large sums, so
@@ -830,7 +613,7 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
         const int64_t stride = (int64_t)T * TS;
         // "mirror": on a DIAGONAL tile moments_tile_h16_tr splits the k-steps of the block (rows 0..63, columns 64..127)
         // between two waves; the second half-sum sits in the lower-left slots, 32 x 32 block (fa + 2, fb - 2) =
-        // 6 * 256 float4 further on (zeros when the wave kernel or a presum wrote the tile)
+        // 6 * 256 float4 further on (zeros when a presum wrote the tile)
         int nsrc = 1;
         if (r.layout == 1) {
             int ta0, tb0; tile_coords(tile, nt, ta0, tb0);
