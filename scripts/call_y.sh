@@ -1,4 +1,13 @@
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"
-timeout 300 python bench.py --steps 100 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('value',round(d['value'],1),'ms/step',round(d['ms_per_step'],4),'kernel_ms',round(d['roofline']['kernel_ms'],5),'frac',round(d['roofline']['frac'],4),'fad',d['fad'],d['breakdown_ms']);print({k:v for k,v in d['extra']['c4_moments'].items() if k!='includes'})"
+out=gpurun_out
+bash scripts/gpu_round.sh full 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" | tail -60
+echo "== kernel sequence"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$out/prof2 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --inflight 1 --no-cpu-baseline --no-extras > /dev/null 2>&1)
+db=$(find $out/prof2 -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py seq "$db" > $out/kernel_seq.csv; tail -30 $out/kernel_seq.csv | cut -c1-110
+echo "== pmc tile"
+bash scripts/pmc_tile.sh 2>&1 | tail -8
+echo "== c4 profile"
+rm -rf $out/prof3 && mkdir -p $out/prof3
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof3 -o c4 -- python $GRAFT_REPO_ROOT/scripts/probe_c4_prof.py 2>&1 | grep "group of")
+db=$(find $out/prof3 -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py stats "$db" > $out/c4_kernel_stats.csv; head -16 $out/c4_kernel_stats.csv | cut -c1-150
+find $out/prof $out/prof2 $out/prof3 $out/pmc -name "*.db" -delete 2>/dev/null

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU probe, run under rocprofv3 --kernel-trace: a few config-4 groups of 4096 files through OnlineStats (what bench.py's
-extra.c4_moments times) so that the kernel statistics show where a group's time goes; plus a plain read of the same bytes."""
+extra.c4_moments times) so that the kernel statistics show where a group's time goes (scripts/probes/hbm_read.hip gives
+the plain-read ceiling of the chip for the same bytes)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,11 +16,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): st.add_group(x, sizes)
 torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
 print(f"group of {files} files: {t*1e6:.1f} us = {x.numel()*2/t/1e12:.2f} TB/s")
-# how fast does a plain streaming read of the same bytes go on this chip?
-v = x.view(torch.int32)
-for _ in range(3): v.sum()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): v.sum()
-torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
-print(f"torch int32 sum over the same buffer: {t*1e6:.1f} us = {x.numel()*2/t/1e12:.2f} TB/s")
 st.close()
