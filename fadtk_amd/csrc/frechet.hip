@@ -1088,6 +1088,19 @@ int fad_frechet_end(fad_frechet_job_t* job, double* out_fad, fad_diag_t* diag) {
     return frechet_single(j.d, j.cov1, j.cov2, j.mu1, j.mu2, j.eps, 0, 0.0, j.mean_dtype, j.device, j.stream, ws, out_fad, diag, true);
 }
 
+int fad_frechet_cancel(fad_frechet_job_t* job) {
+    if (!job) return set_error(FAD_ERR_INVALID, "NULL argument");
+    Workspace& ws = *reinterpret_cast<Workspace*>(job);
+    if (!ws.busy) return FAD_OK;
+    DeviceGuard g(ws.job.device);
+    // the enqueued kernels still write into the slot's buffers: it may only be handed out again once they are through
+    if (ws.job.mixed && ws.done_ev) FAD_HIP_TRY(hipEventSynchronize(ws.done_ev));
+    else FAD_HIP_TRY(hipStreamSynchronize(ws.job.stream));
+    ws.busy = false;
+    ws.job = Workspace::Job();
+    return FAD_OK;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------

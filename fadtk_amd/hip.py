@@ -261,6 +261,18 @@ class FrechetJob:
         K.check(self._lib.fad_frechet_end(job, C.byref(out), C.byref(diag)), "fad_frechet_end")
         return float(out.value), diag.as_dict()
 
+    def cancel(self):
+        """Give the slot back without collecting the score (waits for the enqueued kernels)."""
+        if self._job is not None:
+            job, self._job = self._job, None
+            K.check(self._lib.fad_frechet_cancel(job), "fad_frechet_cancel")
+
+    def __del__(self):            # a job dropped without result(): its slot must not stay taken (8 per thread)
+        try:
+            self.cancel()
+        except Exception:         # noqa: BLE001  interpreter shutdown, library gone
+            pass
+
 
 def frechet_batched(mu_b, cov_b, rows, offsets: Sequence[int], mean_mode: int = 1, device: int = 0):
     """Per-song FAD against one baseline (``fad_frechet_batched_vs_baseline``).

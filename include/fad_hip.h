@@ -177,17 +177,19 @@ int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, i
                              int max_iter, double tol, int mean_dtype, void* stream, double* out_fad, fad_diag_t* diag);
 
 /* Several scores in flight.  The square-root chain of ONE score is a dozen dependent launches of small kernels: it is
- * bound by launch latency and leaves most of the GPU idle.  begin() enqueues the whole chain on `stream` and returns at
- * once; end() waits for it and delivers the same result (and the same errors) as fad_frechet_from_moments -- topping the
- * iteration up or falling back to the float64 iteration when the device says so.  Running consecutive scores on two to
- * four streams (each with its own pair of handles) lets their chains and moments passes overlap: 1.4-1.75x the scores/s
- * of the blocking call at config 3.  The score_inf loop (fad.py:325-341: 25 independent FAD evaluations) is the user.
- * A job must be collected by the host thread that began it (the slots are thread-local, 8 per thread and device); the
- * handles may be reset / fed again on `stream` as soon as begin() has returned. */
+ * bound by launch latency.  begin() puts (mu, Sigma) of both handles and the whole chain on `stream` and returns at once;
+ * end() waits for it and delivers the same result (and the same errors) as fad_frechet_from_moments -- topping the
+ * iteration up or falling back to the float64 iteration when the device says so.  A caller that begins score k+1 before it
+ * ends score k never leaves the device waiting between scores (bench.py: +10 % scores/s on ONE stream); with one stream
+ * per score the chains and moments passes of consecutive scores overlap as well (another +20-25 %).
+ * The handles may be reset / fed again ON `stream` as soon as begin() has returned (their statistics were copied out in
+ * stream order); on another stream only after end().  A job must be ended (or cancelled) by the host thread that began it:
+ * the slots are thread-local, 8 per thread and device.  cancel() gives the slot back without a result. */
 typedef struct fad_frechet_job fad_frechet_job_t;
 int fad_frechet_from_moments_begin(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps, int mean_dtype,
                                    void* stream, fad_frechet_job_t** job);
 int fad_frechet_end(fad_frechet_job_t* job, double* out_fad, fad_diag_t* diag);
+int fad_frechet_cancel(fad_frechet_job_t* job);
 
 /* ------------------------------------------------------------------ per-song FAD (--indiv)
  * Replaces the loop of score_individual (fadtk/fad.py:373-387): for every song s (rows

@@ -585,6 +585,13 @@ def test_frechet_jobs_in_flight_match_the_blocking_call(F):
         hip.FrechetJob(ma, mb)
     vals = [j.result()[0] for j in pending]
     assert len(set(vals)) == 1
+    # dropped or cancelled jobs give their slots back; the handles may be fed again on the same stream right after begin()
+    dropped = [hip.FrechetJob(ma, mb) for _ in range(8)]
+    dropped[0].cancel(); dropped[0].cancel()
+    del dropped
+    j1 = hip.FrechetJob(ma, mb)
+    ma.reset(); ma.update(cases[1][0][:, :128].contiguous()); mb.reset()          # same stream: ordered behind the job's copy
+    assert j1.result()[0] == vals[0]
     for ma, mb in handles:
         ma.close(); mb.close()
 
