@@ -181,6 +181,18 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
         if (!bad && !(c > 0.0)) {            // A == 0: its root is 0, nothing to iterate
             st->done = 1; st->finished = 1; st->conv = 1; st->final_iter = 0; st->c = 1.0;
         }
+        if (s32) {
+            // Is the float32 leg worth starting?  Its result is only accepted while ||Z|| ~ (lambda_min / c)^-1/2 stays below ~20
+            // (est is cubic in it), i.e. for spectra that are flat within a factor of a few hundred.  The participation
+            // ratio (tr A)^2 / ||A||_F^2 <= rank counts the eigenvalues that matter: d for a flat spectrum, 28 of 512 for
+            // covariances decaying like k^-1/2 (already rejected, after 12 iterations), a handful for real embeddings.
+            // Below d/4 the leg is switched off here -- every one of its launches skips -- and the host goes straight
+            // to the float64 iteration, which reuses this product and this state.  A rule on the inputs alone.
+            const bool hopeless = !bad && (c > 0.0) && (trA * trA < 0.25 * (double)d * fro2);
+            if (bad || !(c > 0.0) || hopeless) {
+                s32->done = 1; s32->finished = 1; s32->failed = 1; s32->upd_skip[0] = 1; s32->upd_skip[1] = 1;
+            }
+        }
     }
 }
 
@@ -250,14 +262,6 @@ __global__ void clear_states(NsState* st, int64_t B) {
     }
 }
 
-// after a rejected low-precision attempt: the fp64 iteration starts from a clean slate, too_few is kept
-__global__ void rearm_state(NsState* st) {
-    if (threadIdx.x == 0) {
-        st->done = 0; st->finished = 0; st->nonfinite = 0; st->conv = 0; st->final_iter = -1;
-        st->upd_skip[0] = 0; st->upd_skip[1] = 0;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 struct MixedResult;
 struct Workspace : NsWorkspace {
@@ -287,6 +291,7 @@ struct Pool {
     static constexpr int kSlots = 8;
     Workspace slot[kSlots];
     int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
+    int f64_iters = 0;                              // ... and the float64 iteration (single pair), 0 = not known yet
     int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
     double pred_thr = 0.0;                          // FAD_FRECHET_PRED_THR (read once; -1 = the built-in rule), see pred_threshold
     void release_all() { for (Workspace& w : slot) w.release_all(); }
@@ -326,8 +331,10 @@ static size_t ns_small_bytes(int d, int64_t B) {
 // Enqueue + run the batched iteration.  On return host_states (pinned, B entries) holds the final
 // per-problem state; the caller turns it into scores.  States must have been cleared by the caller
 // (so that pre-kernels like finalize_for_frechet can raise too_few).
+// reuse_prepared: A = C1 C2 (first matrix of ws.mats) and the armed state are those of a float32 attempt on the same problem
+// that just gave up (mixed_begin: same buffer, same ns_prepare) -- product, statistics and scale are not formed again.
 static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_t stream, Workspace& ws,
-                  NsState** host_states) {
+                  NsState** host_states, bool reuse_prepared = false) {
     const int d = pb.d;
     const int64_t B = pb.B, dd = (int64_t)d * d;
     if (max_iter <= 0) max_iter = 64;
@@ -357,21 +364,28 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     *host_states = hs;
 
     GemmType g[2];
-    g[0] = {pb.cov1, pb.s_cov1, pb.cov2, pb.s_cov2, A, dd, 1.0, 0.0, 0.0, nullptr};
-    int rc = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device);
-    if (rc < 0) return rc;
-    const unsigned nb = (unsigned)stat_blocks(d);
-    hipLaunchKernelGGL(ns_tilestats, dim3(nb, nb, (unsigned)B), dim3(256), 0, stream, A, d, pb.cov1, pb.s_cov1, pb.cov2,
-                       pb.s_cov2, tilestats, dstates);
-    hipLaunchKernelGGL(ns_prepare, dim3((unsigned)B), dim3(256), 0, stream, tilestats, d, (int)nb, pb.mu1, pb.s_mu1, pb.mu2,
-                       pb.s_mu2, pb.mean_dtype, dstates);
+    int rc;
+    if (!reuse_prepared) {
+        g[0] = {pb.cov1, pb.s_cov1, pb.cov2, pb.s_cov2, A, dd, 1.0, 0.0, 0.0, nullptr};
+        rc = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device);
+        if (rc < 0) return rc;
+        const unsigned nb = (unsigned)stat_blocks(d);
+        hipLaunchKernelGGL(ns_tilestats, dim3(nb, nb, (unsigned)B), dim3(256), 0, stream, A, d, pb.cov1, pb.s_cov1, pb.cov2,
+                           pb.s_cov2, tilestats, dstates);
+        hipLaunchKernelGGL(ns_prepare, dim3((unsigned)B), dim3(256), 0, stream, tilestats, d, (int)nb, pb.mu1, pb.s_mu1, pb.mu2,
+                           pb.s_mu2, pb.mean_dtype, dstates);
+    }
     // iteration 0 without GEMMs for T and Z (Z0 = I): Y0, T0, Z1 = T0, residual partials
     const int nslots0 = (int)cdiv(dd, 256);
     hipLaunchKernelGGL(ns_first, dim3((unsigned)nslots0, (unsigned)B), dim3(256), 0, stream, A, d, dstates, Y[0], T, Z[1],
                        dd, partials, pstride);
 
-    // launches are enqueued blind, `chunk` iterations at a time; 6 = what well-conditioned D=512 products take
+    // launches are enqueued blind, `chunk` iterations at a time: first what the previous single-pair call on this thread needed
+    // (+1 for the check that closes a predicted finish; 6 = what well-conditioned D=512 products take), then four at a time.
+    // Every host round trip in between costs the chain ~20-30 us; the decisions are the device's, so the count only sets how
+    // many launches end up skipped.
     int cur = 0, k = 0, chunk = 6;
+    if (B == 1 && ws.pool && ws.pool->f64_iters > 0) chunk = ws.pool->f64_iters + 1;
     bool all_done = false;
     NsCheckArgs chk;
     chk.max_iter = max_iter; chk.st_all = dstates; chk.partials_all = partials; chk.pstride = pstride; chk.stride = dd;
@@ -403,6 +417,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
         chunk = 4;
     }
     FAD_HIP_TRY(hipGetLastError());
+    if (B == 1 && ws.pool && hs[0].finished && hs[0].final_iter >= 0) ws.pool->f64_iters = hs[0].final_iter + 1;
     return FAD_OK;
 }
 
@@ -538,7 +553,7 @@ static int mixed_enqueue(Workspace& ws, int upto) {
             // (Z0 = I needs no product).  No check rides on it -- its residual ||I - Y0|| decides nothing a well-posed
             // problem cares about (a non-finite product was caught by ns_prepare); the first check is iteration 1's.
             g.C[0] = m.Y[1]; g.C[1] = m.Z[1]; g.alpha[0] = 1.0f; g.ntypes = 1; g.A64 = m.A; g.st64 = m.dstate;
-            g.skip = &m.dstate->done;
+            g.skip = &m.s32->done;               // (set by ns_prepare: bad / zero product, or a spectrum the float32 leg cannot serve)
             FAD_TRY(gemm_f32_first_launch(d, g, stream));
             continue;
         }
@@ -635,6 +650,7 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
                           Workspace& ws, double* out_fad, fad_diag_t* diag, bool check_few) {
     const int64_t dd = (int64_t)d * d;
     NsState* hs = nullptr;
+    bool reuse = false;
     NsProblem pb{d, 1, cov1, 0, cov2, 0, mu1, 0, mu2, 0, mean_dtype};
     if (mixed_eligible(ws, d, max_iter, tol)) {
         MixedResult r;
@@ -653,11 +669,11 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
             }
             return FAD_OK;
         }
-        // rejected: the state words the fp64 iteration relies on are re-armed by ns_prepare; only the skip words and
-        // `done` need clearing (too_few stays as finalize_for_frechet set it)
-        hipLaunchKernelGGL(rearm_state, dim3(1), dim3(64), 0, stream, static_cast<NsState*>(ws.small.p));
+        // rejected: the float64 iteration takes over from the product C1 C2 and the state ns_prepare armed for this very
+        // problem (nothing in the float32 leg writes to either)
+        reuse = true;
     }
-    FAD_TRY(run_ns(pb, max_iter, tol, device, stream, ws, &hs));
+    FAD_TRY(run_ns(pb, max_iter, tol, device, stream, ws, &hs, reuse));
     if (check_few && (hs->too_few[0] || hs->too_few[1]))
         return set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
     bool used_eps = false;

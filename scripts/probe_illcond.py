@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""GPU probe: the Frechet distance of ILL-conditioned covariance pairs (decaying spectra, as real embeddings have): which route
+runs (diag['converged']: 3 = float32 + correction, 1/2 = float64 iteration), how many iterations, how long."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from fadtk_amd import hip, _capi as K
+
+rng = np.random.default_rng(0)
+for d, n, decay in ((512, 100000, 0.0), (512, 100000, 0.5), (512, 100000, 1.0), (512, 100000, 2.0), (512, 20000, 3.0), (128, 50000, 2.0), (768, 100000, 1.5)):
+    lam = np.arange(1, d + 1) ** (-decay / 2.0)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    a = torch.from_numpy(((rng.standard_normal((n, d)) * lam) @ q.T).astype(np.float16)).cuda()
+    b = torch.from_numpy(((1.05 * rng.standard_normal((n, d)) * lam) @ q.T + 0.01).astype(np.float16)).cuda()
+    with hip.Moments(d) as ma, hip.Moments(d) as mb:
+        hip.Moments.update_multi([ma, mb], [a, b])
+        for _ in range(3): fad, diag = hip.frechet_from_moments(ma, mb, mean_dtype=K.FAD_F16)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): fad, diag = hip.frechet_from_moments(ma, mb, mean_dtype=K.FAD_F16)
+        t = (time.perf_counter() - t0) / 10
+    print(f"D={d} N={n} spectrum k^-{decay}: FAD {fad:.6g} route {diag['converged']} iterations {diag['iters']} residual {diag['residual']:.2e}: {t*1e3:.3f} ms", flush=True)
