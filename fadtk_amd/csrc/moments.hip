@@ -42,6 +42,7 @@ struct fad_moments {
     bool owns_acc = true;                  // false after fad_moments_bind: the caller's buffer
     fad::DevBuf partials, colpart, stage, seg_tab, seg_piece, seg_out, scratch;
     fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
+    fad::DevBuf cvec;                      // float16 rows: per-split column shifts for the guard's second pass
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
     void* tab_host = nullptr; size_t tab_host_cap = 0;     // pinned staging of the segment tables of update_segmented
     hipEvent_t tab_ev = nullptr;           // recorded behind the upload of tab_host: the next call waits before rewriting it
@@ -81,6 +82,9 @@ static int64_t packed_len(int d) { return 1 + (int64_t)d + (int64_t)d * d; }
 // The dynamic-LDS limit of the fp16 tile kernels is a per-device function attribute: set it once per device,
 // under a lock (two host threads may make their first update on different GPUs at the same time).
 typedef void (*tile_kernel_t)(TileLaunch);
+static tile_kernel_t tr_kernel_shift(bool fast) {          // second pass of the shift guard (float16 rows only)
+    return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false, true>;
+}
 static tile_kernel_t tr_kernel(int dtype, bool fast) {       // multi-tile: 4 stages of 16 KiB; single tile: 8 stages of 8 KiB
     if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false>;
     return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, 2 * H_NST, false>;
@@ -93,9 +97,13 @@ static int ensure_kernel_attrs(int device) {
     if (device < 0 || device >= 64) return set_error(FAD_ERR_INVALID, "device %d out of range", device);
     if (done[device]) return FAD_OK;
     for (int dt : {FAD_F16, FAD_BF16}) {
-        for (bool fast : {false, true})
+        for (bool fast : {false, true}) {
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
+            if (dt == FAD_F16)
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel_shift(fast)),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
+        }
     }
     done[device] = true;
     return FAD_OK;
@@ -212,6 +220,15 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         memset(&L, 0, sizeof(L));
         L.nsets = count; L.d = d; L.nt = plan[0].nt; L.T = plan[0].T;
         int item = 0, max_s = 0;
+        for (int i = 0; i < count; ++i) if (plan[i].S > max_s) max_s = plan[i].S;
+        // What a raised guard flag leads to: float16 rows in plain (not file-aligned) splits get a SECOND PASS of the tile kernel
+        // over x - c (tile_h16_tr_body, SHIFT) and are un-shifted where their partial tiles are first summed (moments_reduce,
+        // or moments_presum of the two-level reduce); everything else is redone by the fp64 kernel.
+        // ... Short inputs (fewer than 16 rows per column) keep the fp64 redo, which costs next to nothing there: their
+        // covariances are rank-deficient, sqrt(Sigma1 Sigma2) then moves with the SQUARE ROOT of a perturbation, and only sums
+        // that are exact to the last bit reproduce the reference's value to 1e-4 (the VGGish pipeline tests: 10 files x 10 frames).
+        bool second_pass = dtype == FAD_F16 && !seg;
+        for (int i = 0; i < count; ++i) second_pass = second_pass && n[i] >= 16 * (int64_t)d;
         for (int i = 0; i < count; ++i) {
             fad_moments* h = hs[i];
             const SplitPlan& p = plan[i];
@@ -222,13 +239,16 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
             if (seg) { s.runs = seg->runs; s.split_first_run = seg->split_first_run; }
             s.partials = h->partials.p; s.colpart = static_cast<double*>(h->colpart.p);
             s.flag = nullptr;
+            if (h->guard && second_pass) {
+                FAD_TRY(h->cvec.reserve((size_t)p.S * p.nt * H_BT * sizeof(uint16_t)));
+                s.cvec = static_cast<uint16_t*>(h->cvec.p);
+            }
             if (h->guard) {
                 s.flag = h->shift_flag + (h->update_seq & 1u);
                 R.job[i].clear_flag = h->shift_flag + ((h->update_seq + 1u) & 1u);
                 h->update_seq++;
             }
             item += p.S * p.T;
-            if (p.S > max_s) max_s = p.S;
         }
         L.total = item;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
@@ -243,7 +263,11 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         SplitPlan q[kMaxSets];
         int max_items64 = 0;
         for (int i = 0; i < count; ++i) any_guard = any_guard || (L.set[i].flag != nullptr);
-        if (any_guard) {
+        if (any_guard && second_pass) {
+            // same launch geometry, gated per set by its flag; it overwrites the flagged sets' partial tiles and column partials
+            hipLaunchKernelGGL(tr_kernel_shift(L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
+            for (int i = 0; i < count; ++i) R.job[i].gate = L.set[i].flag;
+        } else if (any_guard) {
             plan_splits(count, n, d, G_BT, G_KB, h0->n_cu, 2, 128, 0, q);
             G.nt = q[0].nt; G.T = q[0].T;
             for (int i = 0; i < count; ++i) {
@@ -279,11 +303,14 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
                 double* pc = static_cast<double*>(h->presum_col.p);
                 const int gb = (int)cdiv((int64_t)p.T * (H_BT * H_BT / 4), 256);
                 hipLaunchKernelGGL((moments_presum<H_BT>), dim3((unsigned)(gb + cdiv(p.nt * H_BT, 256)), (unsigned)p2.S), dim3(256),
-                                   0, st, part, colp, p.S, seg ? seg->n_runs : p.S, p.T, p.nt, gb, ps, pc, (const int*)L.set[i].flag);
+                                   0, st, part, colp, p.S, seg ? seg->n_runs : p.S, p.T, p.nt, gb, ps, pc, (const int*)L.set[i].flag,
+                                   (const uint16_t*)L.set[i].cvec, (int64_t)p.rows_per_split, (int64_t)n[i]);
                 j.prim = reduce_src(ps, pc, p2, H_BT, 1);
+                if (second_pass && L.set[i].cvec) j.gate = nullptr;      // un-shifted already: the second stage always takes these sums
             } else {
                 j.prim = reduce_src(part, colp, p, H_BT, 1);
                 if (seg) j.prim.SC = seg->n_runs;
+                if (second_pass && L.set[i].cvec) { j.prim.cvec = L.set[i].cvec; j.prim.rows_per_split = p.rows_per_split; j.prim.n_rows = n[i]; }
             }
             if (!j.gate) j.alt = j.prim;
             j.acc = h->acc; j.n_add = (double)n[i]; j.overwrite = h->fresh ? 1 : 0;
@@ -441,7 +468,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     DeviceGuard g(h->device);
     if (h->acc && h->owns_acc) (void)hipFree(h->acc);
     if (h->shift_flag) (void)hipFree(h->shift_flag);
-    h->partials64.release(); h->colpart64.release(); h->presum.release(); h->presum_col.release();
+    h->partials64.release(); h->colpart64.release(); h->cvec.release(); h->presum.release(); h->presum_col.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
     h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release();
     if (h->tab_host) (void)hipHostFree(h->tab_host);

@@ -40,7 +40,8 @@ struct TileSet {
     int item0;                 // first work item of this set; item = item0 + split * T + tile
     void* partials;            // [S][T][tile stride]
     double* colpart;           // [S][nt * BT] -- [runs][nt * BT] when `runs` is set
-    int* flag;                 // shift guard: raised by the fp16 kernels, gate of the fp64 redo (or nullptr)
+    int* flag;                 // shift guard: raised by the fp16 kernels, gate of the second pass / the fp64 redo (or nullptr)
+    uint16_t* cvec;            // shift guard, fp16 rows: [S][nt * BT] per-split column shifts (float16 bits), see tile_h16_tr_body
     // Segment-aligned splits (fad_moments_update_segmented on long files): split s sums the runs
     // [split_first_run[s], split_first_run[s+1]), each run = rows of ONE file, and writes every run's column sums to
     // its own colpart row -- the per-file sums fall out of the one pass over E (moments_tile_h16_tr only).
@@ -153,11 +154,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int outstanding
 // more than one tile (MFMA-bound shapes).  Single-tile problems (D <= 128, HBM-bound) measured slower with either
 // asm form (63 / 59 vs 53 us for 1M x 128) and keep the builtin loads throughout.
 // ------------------------------------------------------------------------------------------
-template <int KIND, int NST, bool DIAG, bool FAST>
+// SHIFT: the second pass of the shift guard (float16 rows).  The first pass found a column whose mean^2 exceeds 64 x its
+// variance inside some split -- float32 partial sums of x_i x_j cannot resolve the covariance there -- and left, per split and
+// for EVERY column, c_j = float16(mean_j) (0 where mean^2 <= var: nothing to gain) in `cvec`.  This pass streams the same rows
+// again and feeds x - c to the MFMAs as an error-free pair of float16 values: x - c = x' + e with x' = fl(x - c) and e the
+// rounding error of that subtraction (TwoSum; e = 0 whenever x and c are within a factor of two of each other -- always, on
+// the columns that tripped the guard).  Products are exact in float32 as before, three MFMAs per block instead of one
+// (x'x' + x'e + ex'; ee is below 2^-22 of it), and what is summed is CENTRED: float32-sum accuracy relative to the variance
+// of every column, tripped or not.  moments_reduce restores the raw moments in float64: sum x_i x_j = S'_ij + c_i s'_j +
+// s'_i c_j + n c_i c_j with s' the column sums of x - c.  Two passes of this kernel + a few loads per split in the reduce
+// instead of the float64 kernel over the whole block: ~10x faster when the guard fires (scripts/probe_guard.py).
+template <int KIND, int NST, bool DIAG, bool FAST, bool SHIFT = false>
 __device__ __forceinline__ void tile_h16_tr_body(
     const uint16_t* __restrict__ E, int64_t k_begin0, int64_t k_end0, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
-    uint4* smem, int* __restrict__ shift_flag, const SegRun* __restrict__ runs, int run_lo, int run_hi) {
+    uint4* smem, int* __restrict__ shift_flag, const SegRun* __restrict__ runs, int run_lo, int run_hi,
+    uint16_t* __restrict__ cvec = nullptr) {
+    static_assert(!SHIFT || KIND == FAD_F16, "the shifted pass is written for float16 rows");
     constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
     // uint4 per stage: A slab + B slab; a launch whose only tile is the diagonal one (FAST = false: D <= 128, the
     // HBM-bound shape) has no B slab and spends the same 64 KiB on twice as many stages in flight
@@ -261,18 +274,67 @@ __device__ __forceinline__ void tile_h16_tr_body(
         __builtin_memcpy(&f.z, &hi, 8);
         return f;
     };
+    // SHIFT: x - c = x' + e on a fragment (8 consecutive rows of ONE column per lane: one scalar c, packed TwoSum);
+    // `rows_left` = rows of the run left at the fragment's first row: elements past the end were loaded as zeros and must
+    // stay zero (only the last stage of a run can have them; the hot loop passes 8).
+    auto split2 = [&](uint4 f, uint32_t c2, int64_t rows_left, uint4& xs, uint4& es) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        uint32_t w[4] = {f.x, f.y, f.z, f.w}, x[4], e[4];
+        h2 c; __builtin_memcpy(&c, &c2, 4);
+        const h2 b = -c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h2 a; __builtin_memcpy(&a, &w[q], 4);
+            const h2 sm = a + b;                       // Knuth's TwoSum: a + b = sm + er exactly
+            const h2 bb = sm - a;
+            const h2 er = (a - (sm - bb)) + (b - bb);
+            __builtin_memcpy(&x[q], &sm, 4);
+            __builtin_memcpy(&e[q], &er, 4);
+            if (rows_left < 8) {
+                const uint32_t m = ((2 * q < rows_left) ? 0xffffu : 0u) | ((2 * q + 1 < rows_left) ? 0xffff0000u : 0u);
+                x[q] &= m; e[q] &= m;
+            }
+        }
+        xs = make_uint4(x[0], x[1], x[2], x[3]);
+        es = make_uint4(e[0], e[1], e[2], e[3]);
+    };
+    // this lane's shifts (packed twice) for the fragments it reads: off the diagonal / diagonal waves: columns
+    // 64 wr + {0, 32} + li of the A side and 64 wc + {0, 32} + li of the B side; the other two waves of a diagonal tile:
+    // columns {0, 32, 64, 96} + li of the (only) slab
+    uint32_t cs[4] = {0u, 0u, 0u, 0u};
+    if constexpr (SHIFT) {
+        const uint16_t* cv = cvec + (int64_t)split * (nt * H_BT);
+        const bool four = DIAG && (wr != wc);
+        const int col[4] = {four ? ca + li : ca + 64 * wr + li, four ? ca + 32 + li : ca + 64 * wr + 32 + li,
+                            four ? ca + 64 + li : cb + 64 * wc + li, four ? ca + 96 + li : cb + 64 * wc + 32 + li};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t h = cv[col[q]]; cs[q] = h | (h << 16); }
+    }
+    auto rows_left_at = [&](int kb, int ks) -> int64_t { return k_end - (k_begin + (int64_t)kb * H_KB + ks * 16 + 8 * kg); };
     // F[0], F[1] = the wave's two A-side fragments, F[2], F[3] = its two B-side fragments of k-step (kb, ks)
-    auto load_frags = [&](int kb, int ks, uint4 (&F)[4]) {
+    auto load_frags = [&](int kb, int ks, uint4 (&F)[4], uint4 (&R)[4], bool full) {
         const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
         const char* sB = DIAG ? sA : sA + H_KB * 256;
         F[0] = frag(sA, ks, 64 * wr); F[1] = frag(sA, ks, 64 * wr + 32);
         F[2] = frag(sB, ks, 64 * wc); F[3] = frag(sB, ks, 64 * wc + 32);
+        if constexpr (SHIFT) {
+            const int64_t left = full ? 8 : rows_left_at(kb, ks);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split2(F[q], cs[q], left, F[q], R[q]);
+        }
     };
     auto mma = [&](const uint4 (&F)[4]) {
         acc[0][0] = mfma_h16<KIND>(F[0], F[2], acc[0][0]);
         acc[0][1] = mfma_h16<KIND>(F[0], F[3], acc[0][1]);
         acc[1][0] = mfma_h16<KIND>(F[1], F[2], acc[1][0]);
         acc[1][1] = mfma_h16<KIND>(F[1], F[3], acc[1][1]);
+    };
+    // SHIFT: + x' e + e x' (R = the rounding errors that go with F)
+    auto mma_err = [&](const uint4 (&F)[4], const uint4 (&R)[4]) {
+        acc[0][0] = mfma_h16<KIND>(F[0], R[2], acc[0][0]); acc[0][0] = mfma_h16<KIND>(R[0], F[2], acc[0][0]);
+        acc[0][1] = mfma_h16<KIND>(F[0], R[3], acc[0][1]); acc[0][1] = mfma_h16<KIND>(R[0], F[3], acc[0][1]);
+        acc[1][0] = mfma_h16<KIND>(F[1], R[2], acc[1][0]); acc[1][0] = mfma_h16<KIND>(R[1], F[2], acc[1][0]);
+        acc[1][1] = mfma_h16<KIND>(F[1], R[3], acc[1][1]); acc[1][1] = mfma_h16<KIND>(R[1], F[3], acc[1][1]);
     };
     // A DIAGONAL tile is symmetric, so only 20 of the 32 MFMAs of a stage are issued:
     //   * the waves on the tile's diagonal (wr == wc) own a symmetric 64 x 64 block: A and B fragments coincide
@@ -284,12 +346,26 @@ __device__ __forceinline__ void tile_h16_tr_body(
     // test inside one loop, hipcc kept the accumulators of the off-diagonal waves in a second register range and copied
     // all 64 of them back and forth around their four MFMAs -- 80 v_accvgpr_mov per stage (found in the ISA, round 2).
     const bool diag_wave = wr == wc;
-    auto stage_diag = [&](int kb, auto role_tag) {
+    auto stage_diag = [&](int kb, auto role_tag, bool full) {
         const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
         if constexpr (decltype(role_tag)::value) {
             uint4 A0[2], A1[2];
             A0[0] = frag(sA, 0, 64 * wr); A0[1] = frag(sA, 0, 64 * wr + 32);
             A1[0] = frag(sA, 1, 64 * wr); A1[1] = frag(sA, 1, 64 * wr + 32);
+            if constexpr (SHIFT) {
+                const int64_t l0 = full ? 8 : rows_left_at(kb, 0), l1 = full ? 8 : rows_left_at(kb, 1);
+                uint4 E0[2], E1[2];
+                split2(A0[0], cs[0], l0, A0[0], E0[0]); split2(A0[1], cs[1], l0, A0[1], E0[1]);
+                split2(A1[0], cs[0], l1, A1[0], E1[0]); split2(A1[1], cs[1], l1, A1[1], E1[1]);
+                acc[0][0] = mfma_h16<KIND>(A0[0], E0[0], acc[0][0]); acc[0][0] = mfma_h16<KIND>(E0[0], A0[0], acc[0][0]);
+                acc[0][1] = mfma_h16<KIND>(A0[0], E0[1], acc[0][1]); acc[0][1] = mfma_h16<KIND>(E0[0], A0[1], acc[0][1]);
+                acc[1][1] = mfma_h16<KIND>(A0[1], E0[1], acc[1][1]); acc[1][1] = mfma_h16<KIND>(E0[1], A0[1], acc[1][1]);
+                acc[0][0] = mfma_h16<KIND>(A1[0], E1[0], acc[0][0]); acc[0][0] = mfma_h16<KIND>(E1[0], A1[0], acc[0][0]);
+                acc[0][1] = mfma_h16<KIND>(A1[0], E1[1], acc[0][1]); acc[0][1] = mfma_h16<KIND>(E1[0], A1[1], acc[0][1]);
+                acc[1][1] = mfma_h16<KIND>(A1[1], E1[1], acc[1][1]); acc[1][1] = mfma_h16<KIND>(E1[1], A1[1], acc[1][1]);
+                csum[0] += (double)sum8<KIND>(E0[0]) + (double)sum8<KIND>(E1[0]);
+                csum[1] += (double)sum8<KIND>(E0[1]) + (double)sum8<KIND>(E1[1]);
+            }
             acc[0][0] = mfma_h16<KIND>(A0[0], A0[0], acc[0][0]);
             acc[0][1] = mfma_h16<KIND>(A0[0], A0[1], acc[0][1]);
             acc[1][1] = mfma_h16<KIND>(A0[1], A0[1], acc[1][1]);
@@ -302,6 +378,13 @@ __device__ __forceinline__ void tile_h16_tr_body(
             uint4 F[4];
             F[0] = frag(sA, wr, 0); F[1] = frag(sA, wr, 32);       // wave (0,1): k-step 0, wave (1,0): k-step 1
             F[2] = frag(sA, wr, 64); F[3] = frag(sA, wr, 96);
+            if constexpr (SHIFT) {
+                const int64_t left = full ? 8 : rows_left_at(kb, wr);
+                uint4 R[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split2(F[q], cs[q], left, F[q], R[q]);
+                mma_err(F, R);
+            }
             mma(F);
         }
     };
@@ -314,16 +397,18 @@ __device__ __forceinline__ void tile_h16_tr_body(
         __builtin_amdgcn_s_barrier();              // stage kb is in LDS; stage kb-1 is free
         if (decltype(refill_tag)::value) issue_fast(kb + NST - 1);
         else if (kb + NST - 1 < nkb) issue(kb + NST - 1);
+        constexpr bool full = decltype(refill_tag)::value;      // hot loop: this stage and the refilled one are whole
         if constexpr (DIAG) {
-            stage_diag(kb, role_tag);
+            stage_diag(kb, role_tag, full);
         } else {
             // all 16 transpose reads of the stage are issued up front (the compiler waits with lgkmcnt(0) before the
             // first MFMA; software-pipelining the reads one k-step or one stage ahead measured no gain -- DESIGN.md)
-            uint4 F0[4], F1[4];
-            load_frags(kb, 0, F0);
-            load_frags(kb, 1, F1);
+            uint4 F0[4], F1[4], R0[4], R1[4];
+            load_frags(kb, 0, F0, R0, full);
+            load_frags(kb, 1, F1, R1, full);
             mma(F0);
             mma(F1);
+            if constexpr (SHIFT) { mma_err(F0, R0); mma_err(F1, R1); }
         }
     };
     // One run = a range of rows streamed through the ring: prologue, hot loop (the stage to refill is a full one ->
@@ -393,27 +478,39 @@ __device__ __forceinline__ void tile_h16_tr_body(
             s2 += __shfl_xor(s2, 32);
             const double mean = ctot[f] / nr, var = s2 / nr - mean * mean;
             const bool col_in = (cb + 64 * wc + 32 * f + li) < d;
-            if (col_in && !(mean * mean <= 64.0 * var) && !(ctot[f] == 0.0 && s2 == 0.0)) hit = true;
+            const bool hit_f = col_in && !(mean * mean <= 64.0 * var) && !(ctot[f] == 0.0 && s2 == 0.0);
+            hit = hit || hit_f;
+            if (cvec && kg == 0) {          // this split's shift for the second pass: the column's mean on the float16 grid, or none
+                const bool worth = col_in && (mean * mean > var) && (mean == mean) && !isinf(mean) && fabs(mean) < 65000.0;
+                const _Float16 ch = worth ? (_Float16)(float)mean : (_Float16)0.0f;
+                uint16_t bits; __builtin_memcpy(&bits, &ch, 2);
+                cvec[(int64_t)split * (nt * H_BT) + cb + 64 * wc + 32 * f + li] = bits;
+            }
         }
         if (__any(hit) && lane == 0) atomicOr(shift_flag, 1);
     }
 }
 
-template <int KIND, int NST, bool FAST>
+template <int KIND, int NST, bool FAST, bool SHIFT = false>
 __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
     const int w = xcd_contiguous(blockIdx.x, L.total);
     int split, tile, run_lo, run_hi; int64_t k_begin, k_end;
     const TileSet& s = locate(L, w, split, tile, k_begin, k_end, run_lo, run_hi);
+    if constexpr (SHIFT) {
+        if (!s.flag || *s.flag == 0) return;       // second pass of the shift guard: only for sets whose first pass raised the flag
+    }
     int ta, tb; tile_coords(tile, L.nt, ta, tb);
     const uint16_t* E = static_cast<const uint16_t*>(s.E);
     float* partials = static_cast<float*>(s.partials);
+    // (the second pass neither re-examines the columns nor rewrites the shifts: no flag, but the shifts to read)
     if (ta == tb)
-        tile_h16_tr_body<KIND, NST, true, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
-                                                partials, s.colpart, smem_dyn, s.flag, s.runs, run_lo, run_hi);
+        tile_h16_tr_body<KIND, NST, true, FAST, SHIFT>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                       partials, s.colpart, smem_dyn, SHIFT ? nullptr : s.flag, s.runs, run_lo, run_hi,
+                                                       s.cvec);
     else if constexpr (FAST)
-        tile_h16_tr_body<KIND, NST, false, FAST>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
-                                                 partials, s.colpart, smem_dyn, nullptr, s.runs, run_lo, run_hi);
+        tile_h16_tr_body<KIND, NST, false, FAST, SHIFT>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                        partials, s.colpart, smem_dyn, nullptr, s.runs, run_lo, run_hi, s.cvec);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -557,10 +654,15 @@ struct ReduceSrc {
     int tile_blocks;      // workgroups that sum tiles; the following ceil(d/256) sum the columns and the row count
     int layout;           // 0 row major, 1 fragment major (the fp16 kernels)
     int sl;               // "split lanes" (1, 4 or 16), see below
+    // second pass of the shift guard (tile_h16_tr_body, SHIFT): when the gate is up the partials are sums over x - c and the
+    // raw moments come back as S' + c s'^T + s' c^T + n c c^T per split (cvec = the shifts, colpart = s', rows per split below)
+    const uint16_t* cvec;
+    int64_t rows_per_split, n_rows;
 };
 
 // One set of a reduce launch: accumulator += (or =) the sum over splits of ONE of two sources: `prim` when *gate == 0
-// or there is no gate, else `alt` -- the fp64 redo of the block by moments_tile_f64 (shift guard).
+// or there is no gate, else `alt` -- the fp64 redo of the block by moments_tile_f64 (shift guard) -- or, when prim.cvec is
+// set, `prim` again, rewritten by the second pass and un-shifted here.
 struct ReduceJob {
     ReduceSrc prim, alt;
     double* acc; double n_add;
@@ -572,9 +674,11 @@ struct ReduceLaunch { ReduceJob job[kMaxSets]; int d; };
 // sl "split lanes" share one output group: thread (l, g) sums splits l, l+sl, ... and the sl partial
 // sums are combined through LDS in a fixed order.  With hundreds of row-splits (D = 128 uses every
 // workgroup slot for one tile) a single thread per output would walk all of them serially.
+__device__ __forceinline__ double f16_bits_to_f64(uint16_t b) { _Float16 h; __builtin_memcpy(&h, &b, 2); return (double)(float)h; }
+
 template <typename PT, int BT>
 __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* __restrict__ acc_packed, double n_add,
-                                            bool overwrite, int block, double* red) {
+                                            bool overwrite, int block, double* red, bool unshift = false) {
     const PT* __restrict__ partials = static_cast<const PT*>(r.partials);
     const int S = r.S, T = r.T, nt = r.nt, SL = r.sl;
     const int G = 256 / SL;                        // output groups (4 values each) per block
@@ -590,6 +694,13 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
         int sp = 0;
         for (; sp + 1 < SC; sp += 2) { s0 += colpart[(int64_t)sp * dpad + a]; s1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
         if (sp < SC) s0 += colpart[(int64_t)sp * dpad + a];
+        if (unshift) {                             // sum x = s' + n c, split by split
+            for (int q = 0; q < SC; ++q) {
+                const int64_t left = r.n_rows - (int64_t)q * r.rows_per_split;
+                const double nq = (double)(left < r.rows_per_split ? left : r.rows_per_split);
+                s1 += nq * f16_bits_to_f64(r.cvec[(int64_t)q * dpad + a]);
+            }
+        }
         acc_packed[1 + a] = overwrite ? s0 + s1 : acc_packed[1 + a] + (s0 + s1);
         return;
     }
@@ -646,6 +757,24 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
             }
         }
     }
+    if (unshift && live) {
+        // + c_a s'_b + s'_a c_b + n c_a c_b for this thread's splits (fp64; the shifts are zero on ordinary columns)
+        int ta0, tb0; tile_coords(tile, nt, ta0, tb0);
+        const int dpad = nt * BT;
+        const int ga = ta0 * BT + a_local, gb = tb0 * BT + b_local;      // layout 1: rows ga..ga+3 of column gb
+        for (int sp = sl; sp < S; sp += SL) {
+            const int64_t left = r.n_rows - (int64_t)sp * r.rows_per_split;
+            const double nq = (double)(left < r.rows_per_split ? left : r.rows_per_split);
+            const uint16_t* cv = r.cvec + (int64_t)sp * dpad;
+            const double* sv = r.colpart + (int64_t)sp * dpad;
+            const double cb_ = f16_bits_to_f64(cv[gb]), sb_ = sv[gb];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double ca_ = f16_bits_to_f64(cv[ga + q]), sa_ = sv[ga + q];
+                s[q] += ca_ * sb_ + sa_ * cb_ + nq * ca_ * cb_;
+            }
+        }
+    }
     if (SL > 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[(sl * G + gl) * 4 + q] = s[q];
@@ -683,7 +812,10 @@ __global__ __launch_bounds__(256) void moments_reduce(ReduceLaunch R) {
     const ReduceJob& j = R.job[blockIdx.y];
     if (j.clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *j.clear_flag = 0;     // next update's flag
     const int col_blocks = (R.d + 255) / 256;
-    if (j.gate && *j.gate != 0) {
+    if (j.gate && *j.gate != 0 && j.prim.cvec) {
+        if ((int)blockIdx.x < j.prim.tile_blocks + col_blocks)
+            reduce_body<PTA, BTA>(j.prim, R.d, j.acc, j.n_add, j.overwrite != 0, (int)blockIdx.x, red, true);
+    } else if (j.gate && *j.gate != 0) {
         if ((int)blockIdx.x < j.alt.tile_blocks + col_blocks)
             reduce_body<double, 64>(j.alt, R.d, j.acc, j.n_add, j.overwrite != 0, (int)blockIdx.x, red);
     } else if ((int)blockIdx.x < j.prim.tile_blocks + col_blocks) {
@@ -699,8 +831,16 @@ constexpr int PRESUM_CHUNK = 32;
 template <int BT>
 __global__ __launch_bounds__(256) void moments_presum(
     const float* __restrict__ partials, const double* __restrict__ colpart, int S, int SC, int T, int nt, int group_blocks,
-    double* __restrict__ partials2, double* __restrict__ colpart2, const int* __restrict__ gate) {
-    if (gate && *gate != 0) return;                // the block is being redone in fp64: nothing to pre-sum
+    double* __restrict__ partials2, double* __restrict__ colpart2, const int* __restrict__ gate,
+    const uint16_t* __restrict__ cvec, int64_t rows_per_split, int64_t n_rows) {
+    // gate up: the block is being redone in fp64 (nothing to pre-sum) -- or, with `cvec`, the partials are the second pass's
+    // sums over x - c and are un-shifted here, split by split (see reduce_body)
+    const bool unshift = gate && *gate != 0 && cvec;
+    if (gate && *gate != 0 && !cvec) return;
+    auto rows_of = [&](int sp) -> double {
+        const int64_t left = n_rows - (int64_t)sp * rows_per_split;
+        return (double)(left < rows_per_split ? left : rows_per_split);
+    };
     const int c = blockIdx.y;
     const int s0 = c * PRESUM_CHUNK, s1 = (s0 + PRESUM_CHUNK < S) ? s0 + PRESUM_CHUNK : S;
     const int dpad = nt * BT;
@@ -714,6 +854,8 @@ __global__ __launch_bounds__(256) void moments_presum(
         int sp = c0;
         for (; sp + 1 < c1; sp += 2) { t0 += colpart[(int64_t)sp * dpad + a]; t1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
         if (sp < c1) t0 += colpart[(int64_t)sp * dpad + a];
+        if (unshift)
+            for (int q = c0; q < c1; ++q) t1 += rows_of(q) * f16_bits_to_f64(cvec[(int64_t)q * dpad + a]);
         colpart2[(int64_t)c * dpad + a] = t0 + t1;
         return;
     }
@@ -740,6 +882,28 @@ __global__ __launch_bounds__(256) void moments_presum(
         const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
         s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
     }
+    if (unshift) {
+        int ta0, tb0; tile_coords(tile, nt, ta0, tb0);
+        // (the lower-left 64 x 64 block of a DIAGONAL tile holds the second half-sums of its upper-right block -- "mirror",
+        // added by the second stage under the upper-right coordinates -- or nothing: no correction there)
+        const bool mirror_slot = ta0 == tb0 && (e >> 10) >= 2 && ((e >> 8) & 3) < 2;
+        if (!mirror_slot) {
+            const int el = e & 63;
+            const int ga = ta0 * BT + 32 * (e >> 10) + 8 * ((e >> 6) & 3) + 4 * (el >> 5);
+            const int gb = tb0 * BT + 32 * ((e >> 8) & 3) + (el & 31);
+            for (int q = s0; q < s1; ++q) {
+                const double nq = rows_of(q);
+                const uint16_t* cv = cvec + (int64_t)q * dpad;
+                const double* sv = colpart + (int64_t)q * dpad;
+                const double cb_ = f16_bits_to_f64(cv[gb]), sb_ = sv[gb];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double ca_ = f16_bits_to_f64(cv[ga + k]), sa_ = sv[ga + k];
+                    s[k] += ca_ * sb_ + sa_ * cb_ + nq * ca_ * cb_;
+                }
+            }
+        }
+    }
     double* o = partials2 + ((int64_t)c * T + tile) * TS64 + e * 4;
     *reinterpret_cast<double2*>(o) = make_double2(s[0], s[1]);
     *reinterpret_cast<double2*>(o + 2) = make_double2(s[2], s[3]);
@@ -747,6 +911,7 @@ __global__ __launch_bounds__(256) void moments_presum(
 
 static ReduceSrc reduce_src(const void* part, const double* colp, const SplitPlan& p, int bt, int layout) {
     ReduceSrc r;
+    r.cvec = nullptr; r.rows_per_split = 0; r.n_rows = 0;
     r.partials = part; r.colpart = colp; r.S = p.S; r.SC = p.S; r.T = p.T; r.nt = p.nt; r.layout = layout;
     r.sl = (p.S > 64) ? 16 : (p.S > 8) ? 4 : 1;
     r.tile_blocks = (int)cdiv((int64_t)p.T * (bt * bt / 4), 256 / r.sl);

@@ -111,8 +111,10 @@ def test_moments_mfma_and_generic_kernels_agree(F, monkeypatch):
 
 
 def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
-    """|mean| >> std: the covariance is a tiny difference of huge raw moments.  The guard must notice
-    and redo the block in fp64 so that the result matches np.cov's centred computation."""
+    """|mean| >> std: the covariance is a tiny difference of huge raw moments.  The guard must notice; float16 rows then get a
+    second pass over x - c (c = the column's mean on the float16 grid, exact by Sterbenz) and the raw moments are restored in
+    float64 -- the covariance must come out as accurately as for well-centred data, i.e. to float32-sum accuracy RELATIVE TO
+    THE VARIANCES, not to the raw moments."""
     from fadtk_amd.hip import Moments
     rng = np.random.default_rng(77)
     n, d = 6000, 256
@@ -122,8 +124,9 @@ def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
     x = x.astype(np.float16)
     _, cov_o = O.embd_statistics(x)
     mu, cov = F.calc_embd_statistics(x)
-    assert np.abs(cov - cov_o).max() <= 1e-9 * np.abs(cov_o).max() + 1e-12
-    assert abs(cov[64, 64]) < 1e-12 and np.abs(cov[:64, :64] - cov_o[:64, :64]).max() < 1e-10
+    assert np.abs(cov - cov_o).max() <= 1e-6 * np.abs(cov_o).max()
+    assert abs(cov[64, 64]) < 1e-12 and np.abs(cov[:64, :64] - cov_o[:64, :64]).max() < 1e-6 * np.abs(cov_o[:64, :64]).max()
+    np.testing.assert_allclose(mu.astype(np.float64), x.astype(np.float64).mean(0), rtol=1e-3)
     with Moments(d) as m:                          # guard decisions are per update: a benign block stays on the MFMA path
         m.set_timing(True)
         m.update(x[:, 128:].repeat(2, axis=1)[:, :d].copy())
@@ -131,6 +134,46 @@ def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
     monkeypatch.setenv("FAD_MOMENTS_SHIFT_GUARD", "0")     # without the guard the fp32 partial sums show
     _, cov_fast = F.calc_embd_statistics(x)
     assert np.abs(cov_fast[:64, :64] - cov_o[:64, :64]).max() > 1e-7
+
+
+@pytest.mark.parametrize("d,sizes,outliers", [(512, (100000, 70001), (0, 5, 300, 511)), (128, (50013,), (7, 100)),
+                                              (768, (9000, 33, 8193), (1, 2, 3, 700)), (200, (4099,), (0, 199))])
+def test_moments_guard_second_pass_raw_moments(F, d, sizes, outliers):
+    """The second pass (x - c through the fp16 MFMA kernel, un-shifted in the reduce) must give the RAW moments of the rows:
+    several sets in one launch of which only some are flagged, ragged last stages (rows not a multiple of 32), columns past a
+    partial last tile, accumulation over two updates, a column that is constant and one whose mean is negative."""
+    import torch
+    from fadtk_amd.hip import Moments
+    rng = np.random.default_rng(d + len(sizes))
+    blocks, refs = [], []
+    for k, n in enumerate(sizes):
+        x = rng.standard_normal((n, d)) * (0.5 + rng.random(d))
+        if k != 1:                                       # the second set (if any) stays benign
+            for c in outliers:
+                x[:, c] = (-1) ** c * (20.0 + 3.0 * c / d) + 0.02 * x[:, c]
+            x[:, outliers[0]] = 12.5                     # constant
+        x = x.astype(np.float16)
+        blocks.append(torch.from_numpy(x).cuda()); refs.append(x.astype(np.float64))
+    accs = [Moments(d) for _ in sizes]
+    try:
+        Moments.update_multi(accs, blocks)
+        Moments.update_multi(accs, [b[: b.shape[0] // 3] for b in blocks])       # on top: a second, shorter update
+        for a, x in zip(accs, refs):
+            p = a.export()
+            xx = np.concatenate([x, x[: x.shape[0] // 3]])
+            nn = xx.shape[0]
+            assert p[0] == nn
+            np.testing.assert_allclose(p[1:1 + d], xx.sum(0), rtol=1e-6, atol=1e-6 * nn)
+            mu_, cov_ = p[1:1 + d] / nn, None
+            cov = (p[1 + d:].reshape(d, d) - np.outer(p[1:1 + d], p[1:1 + d]) / nn) / (nn - 1)
+            ref = np.cov(xx, rowvar=False)
+            scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-30
+            assert np.abs(cov - ref).max() <= 1e-6 * np.abs(ref).max()
+            ok = np.diag(ref) > 0
+            assert (np.abs(cov - ref)[np.ix_(ok, ok)] / scale[np.ix_(ok, ok)]).max() <= 2e-4     # entry by entry, in units of sigma_i sigma_j
+    finally:
+        for a in accs:
+            a.close()
 
 
 def test_moments_tile_kernel_structured_rows(F):
@@ -192,7 +235,7 @@ def test_moments_update_multi_shift_guard_is_per_set(F):
     for m, x in ((ma, good), (mb, bad)):
         mu, cov, n = m.finalize()
         _, cov_o = O.embd_statistics(x)
-        tol = 1e-9 if x is bad else 2e-6
+        tol = 2e-6             # (the flagged set takes the second pass: float32-sum accuracy relative to the variances, like the others)
         assert np.abs(cov - cov_o).max() <= tol * np.abs(cov_o).max() + 1e-12
         m.close()
 
