@@ -156,10 +156,12 @@ def extra_c5(torch, hip, device):
             "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": 8, "kind": "port",
                              "sample": f"{n_cpu} of the same songs through the oracle (eig + sqrtm per song, fad.py:373-378) on a "
                                        "thread pool of 8 (fad.py:387, BLAS threads as numpy finds them), one pass", "seconds": dt_cpu},
-            "roofline": {"kernel": "pair_quadform (whole batched call timed)", "bound": "fp64 mfma", "achieved": flops / dt5 / 1e12,
+            "roofline": {"kernel": "gemm_f64_kernel<64> (W = Dm Sigma_b, 14 problems of 768^3; whole batched call timed)", "bound": "fp64 mfma", "achieved": flops / dt5 / 1e12,
                          "peak": 78.6, "unit": "TFLOP/s", "frac": flops / dt5 / 1e12 / 78.6,
                          "note": "2 n_songs D^2 flops; peak = fp64 matrix datasheet figure (the guide lists none); measured "
-                                 "v_mfma_f64_16x16x4 ceiling on this chip 45-47 TFLOP/s (scripts/probes/mfma_rate.hip)"}}
+                                 "v_mfma_f64_16x16x4 ceiling on this chip 45-47 TFLOP/s (scripts/probes/mfma_rate.hip). The product itself runs "
+                                 "at that ceiling (250 us, profiles/r02b README); the rest of the call is the upload of the 4.7 MB baseline, "
+                                 "song_stats, the difference rows and the row dots"}}
 
 
 def main():

@@ -782,83 +782,9 @@ __global__ __launch_bounds__(256) void song_cov(const TIn* __restrict__ rows, in
     cov_out[slot * (int64_t)d * d + (int64_t)a * d + b] = acc / (double)(r1 - r0 - 1);
 }
 
-// Two-frame songs: q_s = d_s^T Sigma_b d_s with d_s = x1 - x2, 16 songs per workgroup on
-// v_mfma_f64_16x16x4_f64.  The 16 difference rows are staged in LDS (k-chunks of <= 1024, pitch
-// KC+2 doubles: conflict-free ds_read_b64 for the A fragment); per column block of 16,
-//   W[16 songs x 16 cols] = Dm[16 x KC] Sigma_b[KC x 16 cols],  q += sum_col W .* Dm[:, col].
-// Sigma_b is read straight from L2 (shared by every workgroup, 128-byte row segments).
-constexpr int PQ_KC = 1024;
-template <typename TIn>
-__global__ __launch_bounds__(256) void pair_quadform(const TIn* __restrict__ rows, int64_t ld, int d,
-                                                     const int64_t* __restrict__ offsets,
-                                                     const int64_t* __restrict__ song_ids, int64_t n_pairs,
-                                                     const double* __restrict__ cov_b, int kc_len,
-                                                     double* __restrict__ q_out) {
-    extern __shared__ __attribute__((aligned(16))) double sD[];      // [16][kc_len + 2] then red[4][16]
-    const int P = kc_len + 2;
-    double* red = sD + 16 * P;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int64_t slot0 = (int64_t)blockIdx.x * 16;
-    double qacc[4] = {0.0, 0.0, 0.0, 0.0};            // rows lk + 4*reg of W
-    int64_t rW[4]; bool okW[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int64_t sl = slot0 + lk + 4 * reg;
-        okW[reg] = sl < n_pairs;
-        rW[reg] = okW[reg] ? offsets[song_ids[sl]] : 0;
-    }
-    const int ncb = (d + 15) / 16;
-    for (int kc0 = 0; kc0 < d; kc0 += kc_len) {
-        const int len = (d - kc0 < kc_len) ? d - kc0 : kc_len;
-        const int len4 = (len + 3) & ~3;
-        __syncthreads();
-        for (int sg = 0; sg < 16; ++sg) {
-            const int64_t sl = slot0 + sg;
-            const bool ok = sl < n_pairs;
-            const int64_t r = ok ? offsets[song_ids[sl]] : 0;
-            for (int k = tid; k < len4; k += 256) {
-                double v = 0.0;
-                if (ok && k < len) v = ld_f64<TIn>(rows, r * ld + kc0 + k) - ld_f64<TIn>(rows, (r + 1) * ld + kc0 + k);
-                sD[sg * P + k] = v;
-            }
-        }
-        __syncthreads();
-        for (int cb = wave; cb < ncb; cb += 4) {
-            const int col = cb * 16 + li;
-            const bool col_ok = col < d;
-            f64x4 w = (f64x4){0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < len4; k0 += 4) {
-                const int k = k0 + lk;
-                const double a = sD[li * P + k];
-                const double b = (col_ok && k < len) ? cov_b[(int64_t)(kc0 + k) * d + col] : 0.0;
-                w = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, w, 0, 0, 0);
-            }
-            if (col_ok) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    if (okW[reg]) {
-                        const double dv = ld_f64<TIn>(rows, rW[reg] * ld + col) - ld_f64<TIn>(rows, (rW[reg] + 1) * ld + col);
-                        qacc[reg] += w[reg] * dv;
-                    }
-            }
-        }
-    }
-    // reduce over the 16 column lanes, then over the 4 waves (fixed order)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) qacc[reg] += __shfl_xor(qacc[reg], off);
-        if (li == 0) red[wave * 16 + lk + 4 * reg] = qacc[reg];
-    }
-    __syncthreads();
-    if (tid < 16 && slot0 + tid < n_pairs)
-        q_out[slot0 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
-}
-
 // Two-frame songs through the batched GEMM: Dm[r] = x1 - x2 (fp64, exact), W = Dm Sigma_b (rows packed D at a
-// time, Sigma_b shared), q[r] = W[r] . Dm[r].  The 16-songs-per-workgroup kernel above (pair_quadform) re-reads all of
-// Sigma_b per workgroup and ran at ~4 TFLOP/s; kept for reference behind FAD_PAIR_GEMM=0.
+// time, Sigma_b shared), q[r] = W[r] . Dm[r].  (Round 1's 16-songs-per-workgroup kernel re-read all of Sigma_b per
+// workgroup and ran at ~4 TFLOP/s; this product runs at the fp64 MFMA ceiling: 12.7 GFLOP in 250 us at config 5.)
 template <typename TIn>
 __global__ __launch_bounds__(256) void pair_diff_rows(const TIn* __restrict__ rows, int64_t ld, int d,
                                                       const int64_t* __restrict__ offsets, const int64_t* __restrict__ song_ids,
@@ -1156,8 +1082,7 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
 
     // ---- two-frame songs: closed form  tr sqrt = sqrt(d^T Sigma_b d / 2)
     std::vector<double> h_q(pairs.size());
-    static const bool pair_gemm = [] { const char* e = getenv("FAD_PAIR_GEMM"); return !(e && e[0] == '0'); }();
-    if (!pairs.empty() && pair_gemm) {
+    if (!pairs.empty()) {
         const int64_t budget_rows = std::max<int64_t>(d, ((int64_t)1 << 30) / ((int64_t)d * 16));
         for (size_t p0 = 0; p0 < pairs.size(); p0 += (size_t)budget_rows) {
             const int64_t P = (int64_t)std::min<size_t>((size_t)budget_rows, pairs.size() - p0);
@@ -1177,15 +1102,6 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             FAD_HIP_TRY(hipMemcpyAsync(h_q.data() + p0, qd, P * sizeof(double), hipMemcpyDeviceToHost, st));
             FAD_HIP_TRY(hipStreamSynchronize(st));
         }
-    } else if (!pairs.empty()) {
-        FAD_HIP_TRY(hipMemcpyAsync(ids_dev, pairs.data(), pairs.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        const int kc_len = (int)std::min<int64_t>(PQ_KC, cdiv(d, 32) * 32);
-        const size_t lds = ((size_t)16 * (kc_len + 2) + 64) * sizeof(double);
-        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_quadform<TIn>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((pair_quadform<TIn>), dim3((unsigned)cdiv((int64_t)pairs.size(), 16)), dim3(256), lds, st,
-                           drows, ld, d, d_off, ids_dev, (int64_t)pairs.size(), dcov_b, kc_len, qdev);
-        FAD_HIP_TRY(hipMemcpyAsync(h_q.data(), qdev, pairs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     FAD_HIP_TRY(hipStreamSynchronize(st));
     double tr_b = 0.0;

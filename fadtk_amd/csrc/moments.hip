@@ -203,7 +203,12 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
     bool aligned = is16 && (d % 8 == 0);
     for (int i = 0; i < count && aligned; ++i)
         aligned = (ld[i] % 8 == 0) && ((reinterpret_cast<uintptr_t>(rows[i]) & 15u) == 0);
-    const bool use_h16 = aligned && !h0->force_generic;
+    // Short inputs (every set with fewer than 16 rows per column) take the exact fp64 kernel: it costs next to nothing at that
+    // size, and covariances of so few rows are (nearly) rank-deficient -- the Frechet distance then moves with the SQUARE ROOT of
+    // a perturbation of the moments, so float32 partial sums (1e-7) could cost parity (1e-4) there.
+    int64_t n_max = 0;
+    for (int i = 0; i < count; ++i) if (n[i] > n_max) n_max = n[i];
+    const bool use_h16 = aligned && !h0->force_generic && (n_max >= 16 * (int64_t)d || seg);
 
     hipEvent_t* ev = nullptr;
     FAD_TRY(timing_events(h0, &ev));
