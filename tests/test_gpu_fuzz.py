@@ -47,6 +47,43 @@ def test_fuzz_moments_against_numpy(seed, monkeypatch):
                                    err_msg=what)
 
 
+def test_fuzz_moments_guard_second_pass(monkeypatch):
+    """Columns with |mean| >> std (the shift guard) on float16 rows long enough for the second pass (>= 16 rows per column):
+    random shapes, chunkings and column patterns; the covariance must come out to float32-sum accuracy IN UNITS OF
+    sigma_i sigma_j for every entry -- raw second moments are 1e2..1e4 times larger here."""
+    import torch
+    from fadtk_amd.hip import Moments
+    rng = np.random.default_rng(2024)
+    for case in range(18):
+        d = int(rng.choice([64, 128, 200, 256, 512, 640]))
+        n = int(rng.choice([16 * d, 16 * d + 7, 30000, 70001]))
+        sig = 0.2 + rng.random(d)
+        x64 = rng.standard_normal((n, d)) * sig
+        k = int(rng.choice([1, 3, d // 8, d // 2]))
+        cols = rng.choice(d, size=k, replace=False)
+        x64[:, cols] += rng.choice([-1.0, 1.0], size=k) * sig[cols] * rng.uniform(10.0, 60.0, size=k)
+        if rng.random() < 0.5:
+            x64[:, cols[0]] = 7.25                                          # a constant column
+        x = torch.from_numpy(x64).to(torch.float16).cuda()
+        ref = x.double().cpu().numpy()
+        with Moments(d) as m:
+            cuts = sorted(set([0, n] + [int(c) for c in rng.integers(16 * d, n + 1, size=int(rng.choice([0, 1, 2])))]))
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                if hi - lo > 0:
+                    m.update(x[lo:hi])
+            mu, cov, cnt = m.finalize()
+        what = f"case {case}: n={n} d={d} outlier columns {k} cuts={cuts}"
+        want = np.cov(ref, rowvar=False)
+        sd = np.sqrt(np.diag(want))
+        scale = np.outer(sd, sd)
+        live = sd > 0
+        assert cnt == n, what
+        np.testing.assert_allclose(mu, ref.mean(0), rtol=1e-6, atol=1e-7, err_msg=what)
+        err = np.abs(cov - want)
+        assert (err[np.ix_(live, live)] / scale[np.ix_(live, live)]).max() <= 5e-6, what
+        assert err[~live].max(initial=0.0) <= 1e-9 and err[:, ~live].max(initial=0.0) <= 1e-9, what
+
+
 def _random_cov(rng, d, n, decay, scale):
     """Sample covariance of n rows with spectrum ~ k^-decay (n <= d gives a rank-deficient matrix)."""
     lam = np.arange(1, d + 1, dtype=np.float64) ** (-decay)
