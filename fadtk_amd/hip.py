@@ -90,7 +90,7 @@ class Moments:
         if want_sums and n_seg > 0:
             if on_dev:
                 import torch
-                sums_dev = torch.zeros((n_seg, self.d), dtype=torch.float64, device=keep.device)
+                sums_dev = torch.empty((n_seg, self.d), dtype=torch.float64, device=keep.device)   # every entry is written (segment_gather_sums)
                 sums_ptr = sums_dev.data_ptr()
             else:
                 sums = np.zeros((n_seg, self.d), dtype=np.float64)
