@@ -164,6 +164,37 @@ def extra_c5(torch, hip, device):
                                  "song_stats, the difference rows and the row dots"}}
 
 
+def extra_c5_frames(torch, hip, device):
+    """Config 5, encoder-frame variant: songs of [1500 x 768] float16 frames (Whisper-small's encoder output per
+    clip) against a baseline from a synthetic [20000 x 768]; every song is a full D x D problem (n - 1 >= D: per-song covariance,
+    batched float64 Newton-Schulz against the shared baseline).  CPU baseline = 2 of the songs through the oracle."""
+    from oracle import fad_oracle as O
+    nsongs, frames, d5 = 32, 1500, 768
+    g5 = torch.Generator(device=device); g5.manual_seed(55)
+    scale = 0.5 + torch.rand((d5,), generator=g5, device=device)
+    songs = (torch.randn((nsongs * frames, d5), generator=g5, device=device) * scale).to(torch.float16)
+    base = torch.randn((20000, d5), generator=g5, device=device, dtype=torch.float64) * scale.double() * 1.05 + 0.01
+    mu5 = base.mean(0).cpu().numpy(); cov5 = torch.cov(base.T).cpu().numpy()
+    offs = np.arange(0, nsongs * frames + 1, frames)
+    hip.frechet_batched(mu5, cov5, songs, offs)
+    torch.cuda.synchronize(); t5 = time.perf_counter()
+    sc5, st5 = hip.frechet_batched(mu5, cov5, songs, offs)
+    torch.cuda.synchronize(); dt5 = time.perf_counter() - t5
+    n_cpu = 2
+    sample = songs[: n_cpu * frames].cpu().numpy()
+    t0 = time.perf_counter()
+    want = [O.individual_scores(mu5, cov5, [sample[i * frames:(i + 1) * frames]], run_sqrtm=True)[0] for i in range(n_cpu)]
+    dt_cpu = time.perf_counter() - t0
+    want = np.array([np.nan if w is None else float(w) for w in want])
+    rel = float(np.nanmax(np.abs(sc5[:n_cpu] - want) / np.abs(want)))
+    return {"songs": nsongs, "dim": d5, "frames_per_song": frames, "ms": dt5 * 1e3, "songs_per_s": nsongs / dt5, "ok": int((st5 == 0).sum()),
+            "max_rel_err_vs_oracle_sample": rel,
+            "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": "BLAS threads as numpy finds them", "kind": "port",
+                             "sample": f"{n_cpu} of the same songs through the oracle (np.cov + eig + sqrtm per song, fad.py:373-378), "
+                                       "one after the other", "seconds": dt_cpu},
+            "note": "per song: covariance of [1500 x 768] + a 768^3 float64 Newton-Schulz against the shared baseline (batched over the songs)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -299,7 +330,8 @@ def main():
     extra = {}
     if rank == 0 and not distributed and not args.no_extras:
         for name, fn in (("c4_moments", lambda: extra_c4(torch, hip, device, local_rank)),
-                         ("per_song_config5_shape", lambda: extra_c5(torch, hip, device))):
+                         ("per_song_config5_shape", lambda: extra_c5(torch, hip, device)),
+                         ("per_song_config5_encoder_frames", lambda: extra_c5_frames(torch, hip, device))):
             try:
                 extra[name] = fn()
             except Exception as e:      # noqa: BLE001  side measurements must never break the bench line
