@@ -49,7 +49,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0           # dense, /opt/skills/guides/MI355X_MICRO
 MFMA_F32_PEAK_TFLOPS = 157.3            # f32-input MFMA = the fp32 vector rate, same guide
 HBM_PEAK_GBS = 8000.0
 FAD_F16 = 0                             # fad_dtype code: the reference's float16 mean term
-DEFAULT_INFLIGHT = 2
+DEFAULT_INFLIGHT = 3
 
 
 def make_sets(torch, device, rank):
@@ -202,8 +202,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=DEFAULT_INFLIGHT,
                     help="scores in flight: consecutive steps alternate over this many pairs of accumulators (each with its own "
-                         "Frechet job), and step k+1 is enqueued before the score of step k is collected; 1 = every step waits "
-                         "for its score before the next one starts")
+                         "Frechet job); the moments of step i and the Frechet chain of step i-1 are enqueued before the score of "
+                         "step i-N is collected (3 or more keep the device busy); 1 = every step waits for its score")
     ap.add_argument("--lane-streams", action="store_true",
                     help="one HIP stream per score in flight instead of one stream for all of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -240,12 +240,14 @@ def main():
     a, b = make_sets(torch, device, rank)
     # both handles of a score keep their statistics in ONE device buffer: the exchange of the path -- the sum of the ranks'
     # sufficient statistics -- is a single in-place all-reduce over it (the product's --gpus path uses the same class).
-    # One such buffer per score in flight ("lane").  By default the lanes share ONE stream: the host enqueues step k+1
-    # before it collects step k, so the device never waits for the host between steps, and the kernels of different steps
-    # never overlap (the HIP-event duration of the tile kernel stays a clean single-kernel measurement).  --lane-streams
+    # One such buffer per score in flight ("lane").  By default the lanes share ONE stream: the host enqueues steps ahead of
+    # the score it collects (run_steps), so the device never waits for the host between steps, and the kernels of different
+    # steps never overlap (the HIP-event duration of the tile kernel stays a clean single-kernel measurement).  --lane-streams
     # gives every lane its own stream: more scores/s (the latency-bound Frechet chain of one step overlaps the tile kernel
     # of the next), at the price of per-kernel durations that include the contention.
     n_lanes = max(1, min(int(args.inflight), 8))
+
+    comm_stream = torch.cuda.Stream(device=device) if distributed else None
 
     class Lane:
         def __init__(self, k):
@@ -254,14 +256,27 @@ def main():
             self.shared = fdist.SharedStats(DIM, SETS, local_rank)
             self.ma, self.mb = self.shared.moments
             self.job = None
+            self.fed = torch.cuda.Event(); self.reduced = torch.cuda.Event()
 
-        def launch(self):
-            """Enqueue one whole step on this lane's stream; nothing is waited for."""
+        def feed(self):
+            """Phase 1 of a step: moments of both sets (one launch of each kernel); with several ranks the exchange -- ONE in-place
+            all-reduce over the buffer that holds both sets' statistics -- starts on a stream of its own as soon as they are
+            there, so that it runs under the NEXT step's moments instead of in front of this step's square root."""
             with torch.cuda.stream(self.stream):
                 self.ma.reset(); self.mb.reset()
-                hip.Moments.update_multi([self.ma, self.mb], [a, b])     # both sets: one launch of each kernel
+                hip.Moments.update_multi([self.ma, self.mb], [a, b])
                 if distributed:
-                    dist.all_reduce(self.shared.buffer)                  # (SharedStats.allreduce minus the settle calls: both sets were just fed)
+                    self.fed.record()
+                    with torch.cuda.stream(comm_stream):
+                        comm_stream.wait_event(self.fed)
+                        dist.all_reduce(self.shared.buffer)              # (SharedStats.allreduce minus the settle calls: both sets were just fed)
+                        self.reduced.record()
+
+        def score(self):
+            """Phase 2: [wait for the exchange,] enqueue the whole Frechet chain; nothing is waited for on the host."""
+            with torch.cuda.stream(self.stream):
+                if distributed:
+                    torch.cuda.current_stream().wait_event(self.reduced)
                 self.job = hip.FrechetJob(self.ma, self.mb, mean_dtype=FAD_F16)
 
         def collect(self):
@@ -273,21 +288,35 @@ def main():
     ma, mb = lanes[0].ma, lanes[0].mb
 
     def run_steps(count, marks=None):
-        """`count` steps, at most n_lanes of them in flight; every one of them is collected before this returns."""
-        out = None
+        """`count` steps, at most n_lanes of them in flight; every one of them is collected before this returns.  Order of the
+        enqueues: feed(i), score(i-1), so the device sees  moments(i) | Frechet(i-1) | moments(i+1) | Frechet(i) ...  and the
+        host collects score(i - n_lanes) before it reuses that lane -- with three lanes two more steps are queued behind the
+        one it waits for, so the device never runs dry."""
+        out, fed = None, None
+
+        def collect(lane):
+            nonlocal out
+            out = lane.collect()
+            if marks is not None:
+                marks.append(time.perf_counter())
+
         for i in range(count):
             lane = lanes[i % n_lanes]
             if lane.job is not None:
-                out = lane.collect()
-                if marks is not None:
-                    marks.append(time.perf_counter())
-            lane.launch()
+                collect(lane)
+            lane.feed()
+            if n_lanes == 1:
+                lane.score()
+            else:
+                if fed is not None:
+                    fed.score()
+                fed = lane
+        if fed is not None:
+            fed.score()
         for k in range(n_lanes):                                         # drain, oldest first
             lane = lanes[(count + k) % n_lanes]
             if lane.job is not None:
-                out = lane.collect()
-                if marks is not None:
-                    marks.append(time.perf_counter())
+                collect(lane)
         return out
 
     def fence():
