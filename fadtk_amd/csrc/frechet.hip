@@ -782,6 +782,100 @@ __global__ __launch_bounds__(256) void song_cov(const TIn* __restrict__ rows, in
     cov_out[slot * (int64_t)d * d + (int64_t)a * d + b] = acc / (double)(r1 - r0 - 1);
 }
 
+// The same on the fp64 MFMA for songs of many frames (Encodec: [2250 x 128] per song, CLAP: hundreds x 512): one workgroup per
+// upper-triangular 64 x 64 tile of one song's covariance, 4 waves as 2 x 2 each owning 2 x 2 v_mfma_f64_16x16x4_f64 tiles,
+// 16-row stages of (x - mean) staged through LDS as doubles (the layout of moments_tile_f64, moments_kernels.h), both
+// triangles written.  The scalar kernel above ran at ~4 TFLOP/s and was half of the D x D route's time at those shapes
+// (scripts/probe_songs_general.py).  grid (tiles, 1, songs).
+constexpr int SC_LDS = 80;                 // padded row pitch (doubles), as G_LDS of the moments kernels
+template <typename TIn>
+__global__ __launch_bounds__(256) void song_cov_mfma(const TIn* __restrict__ rows, int64_t ld, int d, int nt,
+                                                     const int64_t* __restrict__ offsets, const int64_t* __restrict__ song_ids,
+                                                     const double* __restrict__ mean_exact, double* __restrict__ cov_out) {
+    __shared__ double smem[2][2][16 * SC_LDS];      // [buffer][A | B][row][col]
+    const int64_t slot = blockIdx.z;
+    const int64_t s = song_ids[slot];
+    int ta = 0, t = blockIdx.x;
+    while (t >= nt - ta) { t -= nt - ta; ++ta; }
+    const int tb = ta + t;
+    const bool diag = ta == tb;
+    const int ca = ta * 64, cb = tb * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t r0 = offsets[s], r1 = offsets[s + 1];
+    const int nkb = (int)((r1 - r0 + 15) / 16);
+    const double* mean = mean_exact + s * d;
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+    double ma[4], mb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ma[q] = (ca + sc4 + q < d) ? mean[ca + sc4 + q] : 0.0;
+        mb[q] = (cb + sc4 + q < d) ? mean[cb + sc4 + q] : 0.0;
+    }
+    double ra[4], rb[4];
+    auto fetch = [&](int kb) {
+        const int64_t r = r0 + (int64_t)kb * 16 + sr;
+        const bool ok = r < r1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int colA = ca + sc4 + q, colB = cb + sc4 + q;
+            ra[q] = (ok && colA < d) ? ld_f64<TIn>(rows, r * ld + colA) - ma[q] : 0.0;
+            if (!diag) rb[q] = (ok && colB < d) ? ld_f64<TIn>(rows, r * ld + colB) - mb[q] : 0.0;
+        }
+    };
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    if (nkb > 0) fetch(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            smem[buf][0][sr * SC_LDS + sc4 + q] = ra[q];
+            if (!diag) smem[buf][1][sr * SC_LDS + sc4 + q] = rb[q];
+        }
+        __syncthreads();
+        if (kb + 1 < nkb) fetch(kb + 1);
+        const double* sA = smem[buf][0];
+        const double* sB = smem[buf][diag ? 0 : 1];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + lk;
+            double a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = sA[k * SC_LDS + 32 * wr + 16 * f + li];
+                b[f] = sB[k * SC_LDS + 32 * wc + 16 * f + li];
+            }
+#pragma unroll
+            for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+                    acc[fa][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fa], b[fb], acc[fa][fb], 0, 0, 0);
+        }
+    }
+    const double inv = 1.0 / (double)(r1 - r0 - 1);
+    double* out = cov_out + slot * (int64_t)d * d;
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int a_ = ca + 32 * wr + 16 * fa + lk + 4 * reg;
+                const int b_ = cb + 32 * wc + 16 * fb + li;
+                if (a_ < d && b_ < d) {
+                    const double v = acc[fa][fb][reg] * inv;
+                    out[(int64_t)a_ * d + b_] = v;
+                    if (!diag) out[(int64_t)b_ * d + a_] = v;
+                }
+            }
+}
+
 // Two-frame songs through the batched GEMM: Dm[r] = x1 - x2 (fp64, exact), W = Dm Sigma_b (rows packed D at a
 // time, Sigma_b shared), q[r] = W[r] . Dm[r].  (Round 1's 16-songs-per-workgroup kernel re-read all of Sigma_b per
 // workgroup and ran at ~4 TFLOP/s; this product runs at the fp64 MFMA ceiling: 12.7 GFLOP in 250 us at config 5.)
@@ -1177,8 +1271,14 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         for (size_t g0 = 0; g0 < general.size(); g0 += (size_t)sub) {
             const int64_t B = (int64_t)std::min<size_t>((size_t)sub, general.size() - g0);
             FAD_HIP_TRY(hipMemcpyAsync(ids_dev, general.data() + g0, B * sizeof(int64_t), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL((song_cov<TIn>), dim3(t16, t16, (unsigned)B), dim3(256), 0, st, drows, ld, d, d_off,
-                               ids_dev, mean_exact, covs);
+            if (d >= 64) {
+                const int nt64 = (int)cdiv(d, 64);
+                hipLaunchKernelGGL((song_cov_mfma<TIn>), dim3((unsigned)(nt64 * (nt64 + 1) / 2), 1, (unsigned)B), dim3(256), 0, st, drows,
+                                   ld, d, nt64, d_off, ids_dev, mean_exact, covs);
+            } else {
+                hipLaunchKernelGGL((song_cov<TIn>), dim3(t16, t16, (unsigned)B), dim3(256), 0, st, drows, ld, d, d_off,
+                                   ids_dev, mean_exact, covs);
+            }
             // gather the reference-rounded means of this sub-batch contiguously: reuse q area? keep simple:
             // mean_ref rows of the sub-batch are not contiguous, so run NS with mu2 = mu_b (mean term = 0)
             // and take the mean term from song_stats instead.
