@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(int d, Gemm32Args g) {
     // prefetch distance every stage pays that latency again.  Hence ALL loads of up to PF = 8 stages (the whole k
     // range at D = 512) are issued before anything else -- even before the skip word is looked at (a skipped launch
     // wastes them, a live one has one exposed latency per PF stages instead of two).
-    constexpr int PF = FIRST ? 4 : 8;                            // (FIRST: fp64 operands, twice the registers per stage)
+    constexpr int PF = 8;                                        // (FIRST: fp64 operands, twice the registers per stage)
     typedef double d2v __attribute__((ext_vector_type(2)));
     float4 ra[PF], rb[PF];
     d2v da[FIRST ? PF : 1][2], db[FIRST ? PF : 1][2];
