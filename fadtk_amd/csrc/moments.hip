@@ -54,7 +54,7 @@ struct fad_moments {
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
     // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
     static constexpr int kRing = 256;
-    bool timing = false;
+    int timing = 0;                        // 0 off, 1 all three events, 2 tile kernel only (no event behind the reduce)
     hipEvent_t* ev = nullptr;              // [kRing][3]
     int ev_count = 0;                      // entries recorded since the last query
     int last_variant = -1;                 // 0: h16 MFMA tile kernel, 1: generic fp64 kernel
@@ -327,7 +327,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         }
         if (two_level) hipLaunchKernelGGL((moments_reduce<double, H_BT>), dim3((unsigned)max_blocks, (unsigned)count), dim3(256), 0, st, R);
         else hipLaunchKernelGGL((moments_reduce<float, H_BT>), dim3((unsigned)max_blocks, (unsigned)count), dim3(256), 0, st, R);
-        if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
+        if (ev && h0->timing == 1) FAD_HIP_TRY(hipEventRecord(ev[2], st));
     } else {
         plan_splits(count, n, d, G_BT, G_KB, h0->n_cu, 2, 128, 0, plan);
         TileLaunch L;
@@ -357,7 +357,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         FAD_TRY(launch_generic_dtype(L, max_items, dtype, st));
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL((moments_reduce<double, G_BT>), dim3((unsigned)max_blocks, (unsigned)count), dim3(256), 0, st, R);
-        if (ev) FAD_HIP_TRY(hipEventRecord(ev[2], st));
+        if (ev && h0->timing == 1) FAD_HIP_TRY(hipEventRecord(ev[2], st));
     }
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
@@ -820,7 +820,7 @@ int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* c
 
 int fad_moments_set_timing(fad_moments_t* h, int enabled) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
-    h->timing = enabled != 0;
+    h->timing = (enabled == 2) ? 2 : (enabled != 0 ? 1 : 0);
     h->ev_count = 0;
     return FAD_OK;
 }
@@ -834,13 +834,14 @@ int fad_moments_last_timing(fad_moments_t* h, float* ms_main, float* ms_reduce, 
     DeviceGuard g(h->device);
     const int total = h->ev_count;
     const int m = total < fad_moments::kRing ? total : fad_moments::kRing;
-    FAD_HIP_TRY(hipEventSynchronize(h->ev[3 * ((total - 1) % fad_moments::kRing) + 2]));
+    const bool with_reduce = h->timing == 1;
+    FAD_HIP_TRY(hipEventSynchronize(h->ev[3 * ((total - 1) % fad_moments::kRing) + (with_reduce ? 2 : 1)]));
     double a = 0.0, b = 0.0;
     for (int i = total - m; i < total; ++i) {
         hipEvent_t* e = h->ev + 3 * (i % fad_moments::kRing);
         float x = 0.f, y = 0.f;
         FAD_HIP_TRY(hipEventElapsedTime(&x, e[0], e[1]));
-        FAD_HIP_TRY(hipEventElapsedTime(&y, e[1], e[2]));
+        if (with_reduce) FAD_HIP_TRY(hipEventElapsedTime(&y, e[1], e[2]));
         a += x; b += y;
     }
     if (ms_main) *ms_main = (float)(a / m);

@@ -201,8 +201,9 @@ class Moments:
         return mu, cov, int(n.value)
 
     # -- timing of the dominant kernel (bench.py)
-    def set_timing(self, on: bool = True):
-        K.check(self._lib.fad_moments_set_timing(self._h, 1 if on else 0))
+    def set_timing(self, on=True):
+        """True / 1: events around the tile kernel and behind the reduce; 2: around the tile kernel only; False / 0: off."""
+        K.check(self._lib.fad_moments_set_timing(self._h, 2 if on == 2 else (1 if on else 0)))
 
     def last_timing(self):
         a, b, v = C.c_float(), C.c_float(), C.c_int()

@@ -136,7 +136,10 @@ int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* c
  * its tile kernel on the caller's stream (no synchronisation); last_timing() returns the AVERAGE
  * duration in ms of the tile kernel and of the reduce kernels over the updates recorded since the
  * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA, 1 = generic fp64).
- * A fad_moments_update_multi call is ONE update recorded on hs[0]: its tile-kernel time covers all sets. */
+ * A fad_moments_update_multi call is ONE update recorded on hs[0]: its tile-kernel time covers all sets.
+ * enabled = 2 records the two events around the tile kernel only (ms_reduce comes back 0): an event record between two
+ * kernels costs the stream a few microseconds, and the one behind the reduce sits in front of whatever the caller
+ * enqueues next. */
 int fad_moments_set_timing(fad_moments_t* h, int enabled);
 int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_reduce_kernel,
                             int* kernel_variant);
