@@ -765,6 +765,50 @@ __global__ __launch_bounds__(256) void song_stats(const TIn* __restrict__ rows, 
     if (threadIdx.x == 0) { scal[2 * s] = mt; scal[2 * s + 1] = (n > 1) ? ts / (double)(n - 1) : 0.0; }
 }
 
+// The same for songs of many frames: the four waves of the workgroup take every fourth row each (64 columns at a time) and
+// their partial sums meet in LDS -- one thread per column walking 2250 rows twice made this kernel 15 % of the per-song route at
+// the Encodec shape.  (Songs of a few frames keep the kernel above: there the columns are the parallelism.)
+template <typename TIn>
+__global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ rows, int64_t ld, int d,
+                                                       const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
+                                                       int mean_mode, double* __restrict__ mean_exact,
+                                                       double* __restrict__ mean_ref, double* __restrict__ scal /*[S][2]*/) {
+    __shared__ double part[4][64];
+    __shared__ double red[4];
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = offsets[s], r1 = offsets[s + 1];
+    const int64_t n = r1 - r0;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double mt = 0.0, ts = 0.0;
+    for (int a0 = 0; a0 < d; a0 += 64) {
+        const int a = a0 + cl;
+        const bool ok = a < d;
+        double sum = 0.0;
+        if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) sum += ld_f64<TIn>(rows, r * ld + a);
+        part[rl][cl] = sum;
+        __syncthreads();
+        const double tot = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        const double m = (n > 0) ? tot / (double)n : 0.0;
+        __syncthreads();
+        double sq = 0.0;
+        if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) { const double c = ld_f64<TIn>(rows, r * ld + a) - m; sq += c * c; }
+        part[rl][cl] = sq;
+        __syncthreads();
+        if (rl == 0 && ok) {
+            const double mr = mean_mode ? round_like_input<TIn>(m) : m;
+            mean_exact[s * d + a] = m;
+            mean_ref[s * d + a] = mr;
+            ts += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+            const double df = mu_b[a] - mr;
+            mt += df * df;
+        }
+        __syncthreads();
+    }
+    mt = block_sum(mt, red);
+    ts = block_sum(ts, red);
+    if (threadIdx.x == 0) { scal[2 * s] = mt; scal[2 * s + 1] = (n > 1) ? ts / (double)(n - 1) : 0.0; }
+}
+
 // Sigma_s = Xc^T Xc / (n-1) with the exact fp64 mean (np.cov), 16x16 threads per 16x16 tile; grid (t, t, songs)
 template <typename TIn>
 __global__ __launch_bounds__(256) void song_cov(const TIn* __restrict__ rows, int64_t ld, int d,
@@ -1156,8 +1200,12 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
     double* scal = mean_ref + (size_t)n_songs * d;
     double* qdev = scal + 2 * (size_t)n_songs;
     int64_t* ids_dev = reinterpret_cast<int64_t*>(qdev + n_songs);
-    hipLaunchKernelGGL((song_stats<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
-                       mean_mode, mean_exact, mean_ref, scal);
+    if (n_songs > 0 && (h_off[n_songs] - h_off[0]) / n_songs >= 64)
+        hipLaunchKernelGGL((song_stats_long<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
+                           mean_mode, mean_exact, mean_ref, scal);
+    else
+        hipLaunchKernelGGL((song_stats<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
+                           mean_mode, mean_exact, mean_ref, scal);
 
     // baseline trace (fp64, on device via a 1-problem prepare would be overkill): small D2H of the diagonal
     std::vector<int64_t> pairs, gram, general;
