@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Ablation of the moments tile kernel (v4): which of {MFMA, LDS transpose reads, global->LDS loads, barrier}
+"""HISTORICAL (round 1): the FAD_MOM_* compile-time switches this script drives were moved out of the library with the kernel
+generations they belonged to (scripts/probes/moments_generations.hip); it no longer builds anything useful and is kept for the
+record of how the table in DESIGN.md 4.1 was obtained.
+
+Ablation of the moments tile kernel (v4): which of {MFMA, LDS transpose reads, global->LDS loads, barrier}
 bounds it?  `python scripts/probe_ablate.py build` (CPU box, hipcc) makes one library per mask under
 scripts/probes/ablate/; `python scripts/probe_ablate.py` (GPU box) times the tile kernel of each at config 3.
 Mask bits 8..10 select the LDS ring depth of v4 (256 * NST; 0 = default 4), bit 11 (2048) spreads v8's loads
