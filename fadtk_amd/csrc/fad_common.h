@@ -86,6 +86,7 @@ struct GemmType {
     double* C; int64_t sc;
     double alpha, beta_eye, gamma;
     double* partials;
+    int b_upper = 0;        // B is upper triangular (zeros stored below the diagonal): column tile j stops at k < (j + 1) * tile
 };
 // returns the number of partial slots per problem (>0) or a negative fad_status
 // `check` (optional): one extra workgroup per problem runs ns_check_block (ns_check.h) beside the GEMM tiles.

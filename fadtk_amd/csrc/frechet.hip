@@ -266,6 +266,7 @@ __global__ void clear_states(NsState* st, int64_t B) {
 struct MixedResult;
 struct Workspace : NsWorkspace {
     DevBuf rows, offs, songbuf, songmat, rows2;     // per-song path
+    void* song_pin = nullptr; size_t song_pin_cap = 0;      // ... and its pinned staging: offsets going up, scores coming down
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats)
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
     bool busy = false;
@@ -281,6 +282,15 @@ struct Workspace : NsWorkspace {
     void release_all() {
         release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release();
         if (done_ev) { (void)hipEventDestroy(done_ev); done_ev = nullptr; }
+        if (song_pin) { (void)hipHostFree(song_pin); song_pin = nullptr; song_pin_cap = 0; }
+    }
+    int reserve_song_pin(size_t bytes) {
+        if (song_pin && song_pin_cap >= bytes) return FAD_OK;
+        if (song_pin) (void)hipHostFree(song_pin);
+        song_pin = nullptr; song_pin_cap = 0;
+        FAD_HIP_TRY(hipHostMalloc(&song_pin, bytes + bytes / 2 + 4096, hipHostMallocDefault));
+        song_pin_cap = bytes + bytes / 2 + 4096;
+        return FAD_OK;
     }
 };
 
@@ -741,7 +751,7 @@ template <typename TIn>
 __global__ __launch_bounds__(256) void song_stats(const TIn* __restrict__ rows, int64_t ld, int d,
                                                   const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
                                                   int mean_mode, double* __restrict__ mean_exact,
-                                                  double* __restrict__ mean_ref, double* __restrict__ scal /*[S][2]*/) {
+                                                  double* __restrict__ scal /*[S][2]*/) {
     __shared__ double red[4];
     const int64_t s = blockIdx.x;
     const int64_t r0 = offsets[s], r1 = offsets[s + 1];
@@ -752,8 +762,7 @@ __global__ __launch_bounds__(256) void song_stats(const TIn* __restrict__ rows, 
         for (int64_t r = r0; r < r1; ++r) sum += ld_f64<TIn>(rows, r * ld + a);
         const double m = (n > 0) ? sum / (double)n : 0.0;
         const double mr = mean_mode ? round_like_input<TIn>(m) : m;
-        mean_exact[s * d + a] = m;
-        mean_ref[s * d + a] = mr;
+        if (mean_exact) mean_exact[s * d + a] = m;
         double sq = 0.0;
         for (int64_t r = r0; r < r1; ++r) { const double c = ld_f64<TIn>(rows, r * ld + a) - m; sq += c * c; }
         ts += sq;
@@ -772,7 +781,7 @@ template <typename TIn>
 __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ rows, int64_t ld, int d,
                                                        const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
                                                        int mean_mode, double* __restrict__ mean_exact,
-                                                       double* __restrict__ mean_ref, double* __restrict__ scal /*[S][2]*/) {
+                                                       double* __restrict__ scal /*[S][2]*/) {
     __shared__ double part[4][64];
     __shared__ double red[4];
     const int64_t s = blockIdx.x;
@@ -796,8 +805,7 @@ __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ r
         __syncthreads();
         if (rl == 0 && ok) {
             const double mr = mean_mode ? round_like_input<TIn>(m) : m;
-            mean_exact[s * d + a] = m;
-            mean_ref[s * d + a] = mr;
+            if (mean_exact) mean_exact[s * d + a] = m;
             ts += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
             const double df = mu_b[a] - mr;
             mt += df * df;
@@ -923,25 +931,70 @@ __global__ __launch_bounds__(256) void song_cov_mfma(const TIn* __restrict__ row
 // Two-frame songs through the batched GEMM: Dm[r] = x1 - x2 (fp64, exact), W = Dm Sigma_b (rows packed D at a
 // time, Sigma_b shared), q[r] = W[r] . Dm[r].  (Round 1's 16-songs-per-workgroup kernel re-read all of Sigma_b per
 // workgroup and ran at ~4 TFLOP/s; this product runs at the fp64 MFMA ceiling: 12.7 GFLOP in 250 us at config 5.)
+// pair_stats_diff reads the two frames ONCE: the difference row for the product and the song's scalars (||mu_b - mean||^2 with
+// the mean as the reference sees it, tr Sigma_s) -- as a separate statistics kernel plus a difference kernel the rows were read
+// twice and two S x D float64 mean arrays nobody needed were written (63 us of a 340 us chain at config 5).
 template <typename TIn>
-__global__ __launch_bounds__(256) void pair_diff_rows(const TIn* __restrict__ rows, int64_t ld, int d,
-                                                      const int64_t* __restrict__ offsets, const int64_t* __restrict__ song_ids,
-                                                      int64_t n_pairs, double* __restrict__ dm) {
+__global__ __launch_bounds__(256) void pair_stats_diff(const TIn* __restrict__ rows, int64_t ld, int d,
+                                                       const int64_t* __restrict__ offsets, const int64_t* __restrict__ song_ids,
+                                                       int64_t n_pairs, const double* __restrict__ mu_b, int mean_mode,
+                                                       double* __restrict__ dm, double* __restrict__ scal /*[S][2]*/) {
+    __shared__ double red[4];
     const int64_t r = blockIdx.x;
-    const bool live = r < n_pairs;
-    const int64_t r0 = live ? offsets[song_ids[r]] : 0;
-    for (int a = threadIdx.x; a < d; a += 256)
-        dm[r * d + a] = live ? ld_f64<TIn>(rows, r0 * ld + a) - ld_f64<TIn>(rows, (r0 + 1) * ld + a) : 0.0;
+    if (r >= n_pairs) {                                             // padding rows of the last D-row problem
+        for (int a = threadIdx.x; a < d; a += 256) dm[r * d + a] = 0.0;
+        return;
+    }
+    const int64_t s = song_ids ? song_ids[r] : r;
+    const int64_t r0 = offsets[s];
+    double mt = 0.0, ts = 0.0;
+    for (int a = threadIdx.x; a < d; a += 256) {
+        const double x1 = ld_f64<TIn>(rows, r0 * ld + a), x2 = ld_f64<TIn>(rows, (r0 + 1) * ld + a);
+        dm[r * d + a] = x1 - x2;
+        const double m = (x1 + x2) / 2.0;
+        const double mr = mean_mode ? round_like_input<TIn>(m) : m;
+        const double c1 = x1 - m, c2 = x2 - m;
+        ts += c1 * c1 + c2 * c2;
+        const double df = mu_b[a] - mr;
+        mt += df * df;
+    }
+    mt = block_sum(mt, red);
+    ts = block_sum(ts, red);
+    if (threadIdx.x == 0) { scal[2 * s] = mt; scal[2 * s + 1] = ts; }
 }
 
-__global__ __launch_bounds__(256) void pair_rowdot(const double* __restrict__ w, const double* __restrict__ dm, int d,
-                                                   double* __restrict__ q) {
+// t[r] = W[r] . Dm[r] (W = Dm U, so t = q / 2), and with it the song's score: mean term + tr Sigma_b + tr Sigma_s - 2 sqrt(q / 2)
+__global__ __launch_bounds__(256) void pair_rowdot_score(const double* __restrict__ w, const double* __restrict__ dm, int d,
+                                                         const int64_t* __restrict__ song_ids, const double* __restrict__ scal,
+                                                         const double* __restrict__ tr_b, double* __restrict__ score) {
     __shared__ double red[4];
     const int64_t r = blockIdx.x;
     double t = 0.0;
     for (int a = threadIdx.x; a < d; a += 256) t += w[r * d + a] * dm[r * d + a];
     t = block_sum(t, red);
-    if (threadIdx.x == 0) q[r] = t;
+    if (threadIdx.x == 0) {
+        const int64_t s = song_ids ? song_ids[r] : r;
+        const double root = t > 0.0 ? sqrt(t) : 0.0;             // t = d^T U d = (d^T Sigma_b d) / 2
+        score[s] = (t == t) ? scal[2 * s] + *tr_b + scal[2 * s + 1] - 2.0 * root : t;
+    }
+}
+
+// d^T S d = 2 d^T U d  with  U = strict upper triangle of (S + S^T)/2 plus half its diagonal: the product W = Dm U then skips
+// the zero half of U (gemm b_upper) -- 13/24 of the flops of Dm S at D = 768, and it is the flops that bound this route.
+__global__ __launch_bounds__(256) void upper_half(const double* __restrict__ m, int d, double* __restrict__ u) {
+    const int64_t i = blockIdx.x;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const double v = 0.5 * (m[i * d + j] + m[(int64_t)j * d + i]);
+        u[i * d + j] = (j > i) ? v : (j == i ? 0.5 * v : 0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void diag_trace(const double* __restrict__ m, int d, double* __restrict__ out) {
+    __shared__ double red[4];
+    double t = 0.0;
+    for (int a = threadIdx.x; a < d; a += 256) t += m[(size_t)a * d + a];
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) *out = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1191,23 +1244,6 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
                         const int64_t* h_off, const int64_t* d_off, int64_t n_songs, int mean_mode, int device,
                         hipStream_t st, Workspace& ws, double* out_scores, int32_t* out_status) {
     const int64_t dd = (int64_t)d * d;
-    // ---- per-song scalars and means
-    // songbuf: mean_exact [S*d] | mean_ref [S*d] | scal [S*2] | q [S] | ids (int64) [S]
-    const size_t sb_doubles = (size_t)n_songs * (2 * d + 3);
-    FAD_TRY(ws.songbuf.reserve(sb_doubles * sizeof(double) + (size_t)n_songs * sizeof(int64_t) + 64));
-    double* mean_exact = static_cast<double*>(ws.songbuf.p);
-    double* mean_ref = mean_exact + (size_t)n_songs * d;
-    double* scal = mean_ref + (size_t)n_songs * d;
-    double* qdev = scal + 2 * (size_t)n_songs;
-    int64_t* ids_dev = reinterpret_cast<int64_t*>(qdev + n_songs);
-    if (n_songs > 0 && (h_off[n_songs] - h_off[0]) / n_songs >= 64)
-        hipLaunchKernelGGL((song_stats_long<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
-                           mean_mode, mean_exact, mean_ref, scal);
-    else
-        hipLaunchKernelGGL((song_stats<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
-                           mean_mode, mean_exact, mean_ref, scal);
-
-    // baseline trace (fp64, on device via a 1-problem prepare would be overkill): small D2H of the diagonal
     std::vector<int64_t> pairs, gram, general;
     static const bool gram_on = [] { const char* e = getenv("FAD_SONG_GRAM"); return !(e && e[0] == '0'); }();
     for (int64_t s = 0; s < n_songs; ++s) {
@@ -1217,44 +1253,70 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         else if (gram_on && n <= GRAM_MAX && n - 1 < d) { out_status[s] = FAD_OK; gram.push_back(s); }
         else { out_status[s] = FAD_OK; general.push_back(s); }
     }
-    std::vector<double> h_scal((size_t)2 * n_songs), h_diag((size_t)d);
-    FAD_HIP_TRY(hipMemcpy2DAsync(h_diag.data(), sizeof(double), dcov_b, (size_t)(d + 1) * sizeof(double), sizeof(double), d,
-                                 hipMemcpyDeviceToHost, st));
-    FAD_HIP_TRY(hipMemcpyAsync(h_scal.data(), scal, h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    const bool others = !gram.empty() || !general.empty();
 
-    // ---- two-frame songs: closed form  tr sqrt = sqrt(d^T Sigma_b d / 2)
-    std::vector<double> h_q(pairs.size());
+    // ---- per-song scalars and means
+    // songbuf: scal [S*2] | score [S] | tr_b [1] | ids (int64) [S] | mean_exact [S*d] (only when a song has more than two frames)
+    FAD_TRY(ws.songbuf.reserve(((size_t)n_songs * 4 + 2 + (others ? (size_t)n_songs * d : 0)) * sizeof(double) + 64));
+    double* scal = static_cast<double*>(ws.songbuf.p);
+    double* score_dev = scal + 2 * (size_t)n_songs;
+    double* trb_dev = score_dev + n_songs;
+    int64_t* ids_dev = reinterpret_cast<int64_t*>(trb_dev + 1);
+    double* mean_exact = others ? reinterpret_cast<double*>(ids_dev + n_songs) : nullptr;
+    hipLaunchKernelGGL(diag_trace, dim3(1), dim3(256), 0, st, dcov_b, d, trb_dev);
+    std::vector<double> h_scal;
+    double tr_b = 0.0;
+    if (others) {                       // (two-frame songs get their scalars from pair_stats_diff)
+        if ((h_off[n_songs] - h_off[0]) / n_songs >= 64)
+            hipLaunchKernelGGL((song_stats_long<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
+                               mean_mode, mean_exact, scal);
+        else
+            hipLaunchKernelGGL((song_stats<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
+                               mean_mode, mean_exact, scal);
+        h_scal.resize((size_t)2 * n_songs);
+        FAD_HIP_TRY(hipMemcpyAsync(h_scal.data(), scal, h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        FAD_HIP_TRY(hipMemcpyAsync(&tr_b, trb_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+
+    // ---- two-frame songs: closed form  tr sqrt = sqrt(d^T Sigma_b d / 2); the score is finished on the device and comes
+    // back as ONE copy into pinned memory (the scalars, the row dots and the diagonal used to travel separately)
     if (!pairs.empty()) {
+        const bool identity = (int64_t)pairs.size() == n_songs;            // every song has two frames: row r IS song r
         const int64_t budget_rows = std::max<int64_t>(d, ((int64_t)1 << 30) / ((int64_t)d * 16));
         for (size_t p0 = 0; p0 < pairs.size(); p0 += (size_t)budget_rows) {
             const int64_t P = (int64_t)std::min<size_t>((size_t)budget_rows, pairs.size() - p0);
             const int64_t nb = cdiv(P, d), Ppad = nb * d;
-            FAD_TRY(ws.songmat.reserve(((size_t)2 * Ppad * d + P) * sizeof(double)));
+            FAD_TRY(ws.songmat.reserve(((size_t)2 * Ppad * d + dd) * sizeof(double)));
             double* dm = static_cast<double*>(ws.songmat.p);
             double* wmat = dm + (size_t)Ppad * d;
-            double* qd = wmat + (size_t)Ppad * d;
-            FAD_TRY(ws.rows2.reserve((size_t)P * sizeof(int64_t)));
-            int64_t* d_ids = static_cast<int64_t*>(ws.rows2.p);
-            FAD_HIP_TRY(hipMemcpyAsync(d_ids, pairs.data() + p0, P * sizeof(int64_t), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL((pair_diff_rows<TIn>), dim3((unsigned)Ppad), dim3(256), 0, st, drows, ld, d, d_off, d_ids, P, dm);
-            GemmType gt{dm, dd, dcov_b, 0, wmat, dd, 1.0, 0.0, 0.0, nullptr};
+            double* uhalf = wmat + (size_t)Ppad * d;
+            hipLaunchKernelGGL(upper_half, dim3((unsigned)d), dim3(256), 0, st, dcov_b, d, uhalf);
+            const int64_t* d_ids = nullptr;
+            if (!identity) {
+                FAD_HIP_TRY(hipMemcpyAsync(ids_dev + p0, pairs.data() + p0, P * sizeof(int64_t), hipMemcpyHostToDevice, st));
+                d_ids = ids_dev + p0;
+            }
+            const int64_t* d_off_chunk = identity ? d_off + p0 : d_off;     // identity: chunk row r is song p0 + r
+            double* scal_chunk = identity ? scal + 2 * p0 : scal;
+            double* score_chunk = identity ? score_dev + p0 : score_dev;
+            hipLaunchKernelGGL((pair_stats_diff<TIn>), dim3((unsigned)Ppad), dim3(256), 0, st, drows, ld, d, d_off_chunk, d_ids, P,
+                               dmu_b, mean_mode, dm, scal_chunk);
+            GemmType gt{dm, dd, uhalf, 0, wmat, dd, 1.0, 0.0, 0.0, nullptr, 1};
             const int rc = gemm_f64_launch(d, &gt, 1, nb, nullptr, 0, st, device);
             if (rc < 0) return rc;
-            hipLaunchKernelGGL(pair_rowdot, dim3((unsigned)P), dim3(256), 0, st, wmat, dm, d, qd);
-            FAD_HIP_TRY(hipMemcpyAsync(h_q.data() + p0, qd, P * sizeof(double), hipMemcpyDeviceToHost, st));
-            FAD_HIP_TRY(hipStreamSynchronize(st));
+            hipLaunchKernelGGL(pair_rowdot_score, dim3((unsigned)P), dim3(256), 0, st, wmat, dm, d, d_ids, scal_chunk, trb_dev,
+                               score_chunk);
+        }
+        double* h_score = static_cast<double*>(ws.song_pin) + (n_songs + 1);       // behind the offsets (reserved by the caller)
+        FAD_HIP_TRY(hipMemcpyAsync(h_score, score_dev, (size_t)n_songs * sizeof(double), hipMemcpyDeviceToHost, st));
+        FAD_HIP_TRY(hipStreamSynchronize(st));
+        for (const int64_t s : pairs) {
+            const double v = h_score[s];
+            out_scores[s] = v;
+            if (!(v == v)) out_status[s] = FAD_ERR_NOT_FINITE;
         }
     }
-    FAD_HIP_TRY(hipStreamSynchronize(st));
-    double tr_b = 0.0;
-    for (int i = 0; i < d; ++i) tr_b += h_diag[i];
-    for (size_t i = 0; i < pairs.size(); ++i) {
-        const int64_t s = pairs[i];
-        const double q = h_q[i];
-        if (!(q == q) || !(tr_b == tr_b)) { out_status[s] = FAD_ERR_NOT_FINITE; out_scores[s] = __builtin_nan(""); continue; }
-        const double root = q > 0.0 ? sqrt(0.5 * q) : 0.0;
-        out_scores[s] = h_scal[2 * s] + tr_b + h_scal[2 * s + 1] - 2.0 * root;
-    }
+    if (others) FAD_HIP_TRY(hipStreamSynchronize(st));            // h_scal, tr_b
 
     // ---- songs with 3..64 frames: n x n Gram matrix + Jacobi eigenvalues
     if (!gram.empty()) {
@@ -1386,7 +1448,9 @@ extern "C" int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const 
         drows = ws.rows.p; dld = d;
     }
     FAD_TRY(ws.offs.reserve((size_t)(n_songs + 1) * sizeof(int64_t)));
-    FAD_HIP_TRY(hipMemcpyAsync(ws.offs.p, offsets, (size_t)(n_songs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    FAD_TRY(ws.reserve_song_pin((size_t)(2 * n_songs + 2) * sizeof(double)));        // offsets up | scores down
+    memcpy(ws.song_pin, offsets, (size_t)(n_songs + 1) * sizeof(int64_t));
+    FAD_HIP_TRY(hipMemcpyAsync(ws.offs.p, ws.song_pin, (size_t)(n_songs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
     const int64_t* d_off = static_cast<const int64_t*>(ws.offs.p);
 
     switch (dtype) {

@@ -36,6 +36,7 @@ struct GemmArgs {
     int remap;                           // XCD-aware tile map on/off
     int pstride;                         // partial slots reserved per problem
     int gemm_z;                          // blockIdx.z >= gemm_z: checker blocks (problem = blockIdx.z - gemm_z)
+    int tri;                             // B upper triangular: the k loop of column tile tx ends with the tile's last column
     // fp32 operands (TIn = float instantiation: the fp64 correction product of the mixed-precision Newton-Schulz):
     // A32/B32 replace A/B; when `sel` is given and *sel is odd the *_alt pointers are used (the final iterate of
     // the low-precision iteration lives in one of two ping-pong buffers, known only on the device)
@@ -100,7 +101,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
         return;
     }
     const int zi = (g.ntypes == 2) ? (blockIdx.z & 1) : 0;
-    const int64_t zb = (g.ntypes == 2) ? (blockIdx.z >> 1) : blockIdx.z;
+    int64_t zb = (g.ntypes == 2) ? (blockIdx.z >> 1) : blockIdx.z;
+    int ty = blockIdx.y, tx = blockIdx.x;
+    if (g.tri) {
+        // column tile j of a triangular B costs j + 1 stages: hand the tiles out longest first (workgroups start in the order of
+        // their linear index), so that the tail of the launch is made of the one-stage tiles
+        const int64_t L = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int64_t per = (int64_t)gridDim.y * g.gemm_z;
+        tx = (int)(gridDim.x - 1 - L / per);
+        const int64_t rem = L % per;
+        zb = rem / gridDim.y; ty = (int)(rem % gridDim.y);
+    }
     if (g.skip && g.skip[zb * g.skip_stride] != 0) return;
     const double* A = g.A[zi] + zb * g.sa[zi];
     const double* B = g.B[zi] + zb * g.sb[zi];
@@ -112,7 +123,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     const double alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
 
     // ---- tile coordinates (XCD-aware when the tile grid splits evenly into 2 x 4 blocks)
-    int ty = blockIdx.y, tx = blockIdx.x;
     const int t = gridDim.x;
     if (g.remap && (t & 3) == 0) {
         const int b = blockIdx.y * t + blockIdx.x;
@@ -129,7 +139,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     const int li = lane & 15, lk = lane >> 4;
     const int row0 = ty * BT, col0 = tx * BT;
     const bool vec = ((d & 1) == 0);         // 16-byte loads need even d (row starts stay 16-B aligned)
-    const int nkb = (d + KB - 1) / KB;
+    int nkb = (d + KB - 1) / KB;
+    if (g.tri) nkb = min(nkb, (min(col0 + BT, d) + KB - 1) / KB);        // rows k > the tile's last column of B are zeros
 
     // three named register sets (an array of arrays indexed in a loop ends up in scratch memory, which
     // forces a wait on every prefetch right after it is issued)
@@ -433,7 +444,9 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
         g.skip_stride = skip_stride; g.ntypes = ntypes;
         static const int env_remap = [] { const char* e = getenv("FAD_GEMM_REMAP"); return e ? atoi(e) : 1; }();
         static const int env_depth = [] { const char* e = getenv("FAD_GEMM_DEPTH"); return e ? atoi(e) : 1; }();
-        g.remap = env_remap;
+        g.tri = (ntypes == 1) ? types[0].b_upper : 0;
+        g.remap = g.tri ? 0 : env_remap;            // (the XCD map hands whole column blocks to an XCD: with a triangular B
+                                                    //  those blocks cost 1x .. 5x -- plain order mixes them)
         g.pstride = partial_stride > 0 ? partial_stride : (int)slots;
         g.gemm_z = (int)(m * ntypes);
         if (check) {

@@ -282,12 +282,21 @@ def frechet_batched(mu_b, cov_b, rows, offsets: Sequence[int], mean_mode: int = 
     """
     lib = K.load_library()
     K.require_gpu(device)
-    mu_b = K.f64_host(mu_b)
-    d = mu_b.shape[0]
-    cov_b = K.f64_host(cov_b, (d, d))
+    base_on_dev = K._is_torch(mu_b) and K._is_torch(cov_b) and mu_b.is_cuda and cov_b.is_cuda
+    if base_on_dev:                 # a baseline that already lives in HBM (float64) is used in place: no 8 D^2-byte upload per call
+        import torch
+        mu_t = mu_b.to(torch.float64).contiguous(); cov_t = cov_b.to(torch.float64).contiguous()
+        d = int(mu_t.shape[0])
+        assert tuple(cov_t.shape) == (d, d)
+    else:
+        mu_b = K.f64_host(mu_b)
+        d = mu_b.shape[0]
+        cov_b = K.f64_host(cov_b, (d, d))
     ptr, n, dd, ld, code, on_dev, keep = K.rows_view(rows)
     if n > 0 and dd != d:
         raise AssertionError(f"songs have {dd} features, baseline has {d}")
+    if base_on_dev and not on_dev:
+        mu_b, cov_b, base_on_dev = mu_t.cpu().numpy(), cov_t.cpu().numpy(), False      # host rows: the library stages everything itself
     off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
     n_songs = off.shape[0] - 1
     scores = np.full(max(n_songs, 0), np.nan, dtype=np.float64)
@@ -295,8 +304,11 @@ def frechet_batched(mu_b, cov_b, rows, offsets: Sequence[int], mean_mode: int = 
     if on_dev:
         # baseline must live where the rows live
         import torch
-        mu_t = torch.from_numpy(mu_b).to(keep.device)
-        cov_t = torch.from_numpy(cov_b).to(keep.device)
+        if not base_on_dev:
+            mu_t = torch.from_numpy(mu_b).to(keep.device)
+            cov_t = torch.from_numpy(cov_b).to(keep.device)
+        elif mu_t.device != keep.device:
+            mu_t, cov_t = mu_t.to(keep.device), cov_t.to(keep.device)
         mu_p, cov_p = mu_t.data_ptr(), cov_t.data_ptr()
     else:
         mu_p, cov_p = mu_b.ctypes.data, cov_b.ctypes.data

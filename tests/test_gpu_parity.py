@@ -823,6 +823,12 @@ def test_two_frame_songs_config5_shape_g8(F, golden):
     import torch
     scores_dev, _ = hip.frechet_batched(mu_b, cov_b, torch.from_numpy(rows).cuda(), offs, mean_mode=1)
     np.testing.assert_allclose(scores_dev, scores, rtol=1e-12)
+    # a baseline that already lives in HBM is used in place (no upload per call); with host rows it is brought back
+    mu_d, cov_d = torch.from_numpy(mu_b).cuda(), torch.from_numpy(cov_b).cuda()
+    scores_res, st = hip.frechet_batched(mu_d, cov_d, torch.from_numpy(rows).cuda(), offs, mean_mode=1)
+    assert (st == 0).all() and np.array_equal(scores_res, scores_dev)
+    scores_mix, _ = hip.frechet_batched(mu_d, cov_d, rows, offs, mean_mode=1)
+    assert np.array_equal(scores_mix, scores)
 
 
 def test_multi_frame_songs_g8(F, golden):
