@@ -201,6 +201,8 @@ int fad_frechet_cancel(fad_frechet_job_t* job);
  * score (the reference drops them, fad.py:380-391).
  * mean_mode: 0 = song mean in float64; 1 = round the song mean to the input dtype first, as
  * np.mean does for float16 (model_loader.py:47-48 + fad.py:48).
+ * on_device = 1: rows, mu_b and cov_b are DEVICE pointers (a caller scoring many batches against one baseline uploads it
+ * once); offsets, out_scores and out_status are host pointers either way.  cov_b is read as (cov_b + cov_b^T)/2.
  */
 int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const double* cov_b,
                                     const void* rows, int64_t n_rows, int64_t ld, int dtype,
