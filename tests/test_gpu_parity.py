@@ -863,6 +863,28 @@ def test_gram_path_matches_oracle_for_3_to_64_frames(F):
     np.testing.assert_allclose(scores, want, rtol=1e-6)
 
 
+def test_per_song_routes_mixed_in_one_call(F):
+    """Two-frame songs (closed form, scored on the device), Gram-route songs, a D x D song and songs that cannot be scored, interleaved
+    in one call: every route writes only its own songs, with host rows, device rows and a device-resident baseline alike."""
+    import torch
+    from fadtk_amd import hip
+    d = 96
+    mu_b, cov_b = R.baseline_stats(51, 6 * d, d)
+    rows_per_song = [2, 5, 2, 1, 130, 2, 0, 33, 2]
+    sg = R.songs(52, len(rows_per_song), rows_per_song, d)
+    rows = np.concatenate([s for s in sg if s.shape[0]])
+    offs = np.concatenate([[0], np.cumsum(rows_per_song)])
+    ok = [i for i, n in enumerate(rows_per_song) if n >= 2]
+    want = O.individual_scores(mu_b, cov_b, [sg[i] for i in ok], run_sqrtm=False)
+    dev_rows = torch.from_numpy(rows).cuda()
+    for base, rr in ((( mu_b, cov_b), rows), ((mu_b, cov_b), dev_rows),
+                     ((torch.from_numpy(mu_b).cuda(), torch.from_numpy(cov_b).cuda()), dev_rows)):
+        scores, status = hip.frechet_batched(base[0], base[1], rr, offs, mean_mode=1)
+        assert status[3] == -6 and status[6] == -6 and np.isnan(scores[3]) and np.isnan(scores[6])
+        assert (status[ok] == 0).all()
+        np.testing.assert_allclose(scores[ok], want, rtol=1e-6)
+
+
 def test_score_inf_golden_g6(F, golden, tmp_path):
     g = golden["g6"]
     mu_b, cov_b = R.baseline_stats(g["base_seed"], g["base_n"], g["d"])
