@@ -1237,6 +1237,100 @@ int fad_frechet_cancel(fad_frechet_job_t* job) {
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------
+// Songs with 64 < n <= D frames (n - 1 < D): the same Gram identity, but an n x n matrix no longer fits one workgroup's LDS.
+// G = W Xc^T / (n - 1) is formed by a batched MFMA kernel and its root trace comes from the batched Newton-Schulz iteration
+// on n_pad x n_pad problems (n_pad = the sub-batch's longest song, rounded up to 64) instead of on the rank-deficient D x D
+// product Sigma_b Sigma_s (10-second clips of a 50-frames-per-second D = 768 model: 499 frames).  G itself is singular -- the
+// centred frames sum to zero, G 1 = 0 -- so the iteration runs on
+//     G' = diag(G + (alpha / n) 1 1^T,  alpha I_pad),     alpha = tr G / n,
+// whose extra eigenvalues are exactly alpha (1 is an exact null vector of G):  tr sqrt(G) = tr sqrt(G') - (1 + pad) sqrt(alpha).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_trace(const double* __restrict__ xc, const double* __restrict__ w, int d,
+                                                  const int64_t* __restrict__ first_row, const int* __restrict__ n_rows,
+                                                  double* __restrict__ tr_g) {
+    __shared__ double red[4];
+    const int64_t k = blockIdx.x;
+    const int64_t base = first_row[k] * d, len = (int64_t)n_rows[k] * d;
+    double t = 0.0;
+    for (int64_t e = threadIdx.x; e < len; e += 256) t += w[base + e] * xc[base + e];
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) tr_g[k] = t / (double)(n_rows[k] - 1);
+}
+
+// grid (np/64, np/64, songs): one 64 x 64 tile of G' per workgroup, four waves of 32 x 32 on v_mfma_f64_16x16x4_f64, 16-deep k stages
+__global__ __launch_bounds__(256) void gram_big(const double* __restrict__ xc, const double* __restrict__ w, int d, int np,
+                                                const int64_t* __restrict__ first_row, const int* __restrict__ n_rows,
+                                                const double* __restrict__ tr_g, double* __restrict__ gout) {
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    constexpr int P = 18;                                   // LDS pitch (doubles)
+    __shared__ double sA[64 * P], sB[64 * P];
+    const int64_t k = blockIdx.z;
+    const int n = n_rows[k];
+    const int64_t f = first_row[k];
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
+    const double trg = tr_g[k];
+    const bool dead = !(trg > 0.0);                         // no spread at all (or not finite): the host scores it without a root
+    const double alpha = dead ? 1.0 : trg / (double)n;
+    double* G = gout + k * (int64_t)np * np;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    if (!dead && row0 < n && col0 < n) {
+        const int lr = tid >> 2, lc = (tid & 3) * 4;        // this thread stages 4 consecutive k of one row of each operand
+        const bool okA = row0 + lr < n, okB = col0 + lr < n;
+        const double* pa = w + (f + row0 + lr) * d;
+        const double* pb = xc + (f + col0 + lr) * d;
+        for (int k0 = 0; k0 < d; k0 += 16) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kk = k0 + lc + q;
+                sA[lr * P + lc + q] = (okA && kk < d) ? pa[kk] : 0.0;
+                sB[lr * P + lc + q] = (okB && kk < d) ? pb[kk] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                double a[2], b[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    a[q] = sA[(wr * 32 + 16 * q + li) * P + ks * 4 + lk];
+                    b[q] = sB[(wc * 32 + 16 * q + li) * P + ks * 4 + lk];
+                }
+#pragma unroll
+                for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb)
+                        acc[fa][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fa], b[fb], acc[fa][fb], 0, 0, 0);
+            }
+        }
+    }
+    const double inv = 1.0 / (double)(n - 1), shift = alpha / (double)n;
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = row0 + wr * 32 + 16 * fa + lk + 4 * reg, c = col0 + wc * 32 + 16 * fb + li;
+                double v;
+                if (dead) v = (r == c) ? 1.0 : 0.0;
+                else if (r < n && c < n) v = acc[fa][fb][reg] * inv + shift;
+                else v = (r == c) ? alpha : 0.0;
+                G[(int64_t)r * np + c] = v;
+            }
+}
+
+__global__ __launch_bounds__(256) void identity_and_zeros(double* __restrict__ eye, int np, double* __restrict__ zeros) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < (int64_t)np * np) eye[e] = (e / np == e % np) ? 1.0 : 0.0;
+    if (e < np) zeros[e] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
 namespace fad {
 
 template <typename TIn>
@@ -1244,16 +1338,17 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
                         const int64_t* h_off, const int64_t* d_off, int64_t n_songs, int mean_mode, int device,
                         hipStream_t st, Workspace& ws, double* out_scores, int32_t* out_status) {
     const int64_t dd = (int64_t)d * d;
-    std::vector<int64_t> pairs, gram, general;
+    std::vector<int64_t> pairs, gram, gram_ns, general;
     static const bool gram_on = [] { const char* e = getenv("FAD_SONG_GRAM"); return !(e && e[0] == '0'); }();
     for (int64_t s = 0; s < n_songs; ++s) {
         const int64_t n = h_off[s + 1] - h_off[s];
         if (n < 2) { out_status[s] = FAD_ERR_TOO_FEW_ROWS; out_scores[s] = __builtin_nan(""); }
         else if (n == 2) { out_status[s] = FAD_OK; pairs.push_back(s); }
         else if (gram_on && n <= GRAM_MAX && n - 1 < d) { out_status[s] = FAD_OK; gram.push_back(s); }
+        else if (gram_on && n - 1 < d) { out_status[s] = FAD_OK; gram_ns.push_back(s); }
         else { out_status[s] = FAD_OK; general.push_back(s); }
     }
-    const bool others = !gram.empty() || !general.empty();
+    const bool others = !gram.empty() || !gram_ns.empty() || !general.empty();
 
     // ---- per-song scalars and means
     // songbuf: scal [S*2] | score [S] | tr_b [1] | ids (int64) [S] | mean_exact [S*d] (only when a song has more than two frames)
@@ -1362,6 +1457,81 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
                 const double t = h_tr[k];
                 if (!(t == t) || !(tr_b == tr_b) || t > 1e300) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
                 out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * t;
+            }
+            g0 = g1;
+        }
+    }
+
+    // ---- songs with 65..D frames: n x n Gram matrix + batched Newton-Schulz on it (see gram_big)
+    if (!gram_ns.empty()) {
+        const int64_t budget_rows = std::max<int64_t>(d, ((int64_t)1 << 30) / ((int64_t)d * 16));     // ~1 GiB of Xc + W
+        const size_t budget_mats = (size_t)3 << 30;                                                   // Newton-Schulz matrices
+        size_t g0 = 0;
+        while (g0 < gram_ns.size()) {
+            std::vector<int64_t> src_row, row_song, first_row;
+            std::vector<int> nrows;
+            size_t g1 = g0;
+            int n_max = 0;
+            while (g1 < gram_ns.size()) {
+                const int64_t sg = gram_ns[g1], n = h_off[sg + 1] - h_off[sg];
+                const int64_t np_try = cdiv(std::max<int64_t>(n_max, n), 64) * 64;
+                if (!src_row.empty() && ((int64_t)src_row.size() + n > budget_rows ||
+                                         (size_t)(g1 - g0 + 1) * 7 * np_try * np_try * sizeof(double) > budget_mats)) break;
+                first_row.push_back((int64_t)src_row.size()); nrows.push_back((int)n);
+                if ((int)n > n_max) n_max = (int)n;
+                for (int64_t r = 0; r < n; ++r) { src_row.push_back(h_off[sg] + r); row_song.push_back(sg); }
+                ++g1;
+            }
+            const int64_t R = (int64_t)src_row.size(), nb = cdiv(R, d), Rpad = nb * d, ns = (int64_t)(g1 - g0);
+            const int np = (int)(cdiv(n_max, 64) * 64);
+            const int64_t npp = (int64_t)np * np;
+            // device scratch: xc [Rpad*d] | w [Rpad*d] | G' [ns*np*np] | I [np*np] | zeros [np] | tr G [ns]
+            FAD_TRY(ws.songmat.reserve(((size_t)2 * Rpad * d + (size_t)(ns + 1) * npp + np + ns) * sizeof(double)));
+            double* xc = static_cast<double*>(ws.songmat.p);
+            double* wmat = xc + (size_t)Rpad * d;
+            double* gmat = wmat + (size_t)Rpad * d;
+            double* eye = gmat + (size_t)ns * npp;
+            double* zeros = eye + npp;
+            double* trg = zeros + np;
+            FAD_TRY(ws.rows2.reserve(((size_t)2 * R + ns) * sizeof(int64_t) + (size_t)ns * sizeof(int) + 64));
+            int64_t* d_src = static_cast<int64_t*>(ws.rows2.p);
+            int64_t* d_song = d_src + R;
+            int64_t* d_first = d_song + R;
+            int* d_n = reinterpret_cast<int*>(d_first + ns);
+            FAD_HIP_TRY(hipMemcpyAsync(d_src, src_row.data(), R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipMemcpyAsync(d_song, row_song.data(), R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipMemcpyAsync(d_first, first_row.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipMemcpyAsync(d_n, nrows.data(), ns * sizeof(int), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((gram_center_rows<TIn>), dim3((unsigned)Rpad), dim3(256), 0, st, drows, ld, d, d_src, d_song,
+                               mean_exact, R, xc);
+            GemmType gt{xc, dd, dcov_b, 0, wmat, dd, 1.0, 0.0, 0.0, nullptr};          // W = Xc Sigma_b, D rows per problem
+            const int rc = gemm_f64_launch(d, &gt, 1, nb, nullptr, 0, st, device);
+            if (rc < 0) return rc;
+            hipLaunchKernelGGL(gram_trace, dim3((unsigned)ns), dim3(256), 0, st, xc, wmat, d, d_first, d_n, trg);
+            hipLaunchKernelGGL(gram_big, dim3((unsigned)(np / 64), (unsigned)(np / 64), (unsigned)ns), dim3(256), 0, st, xc, wmat, d, np,
+                               d_first, d_n, trg, gmat);
+            hipLaunchKernelGGL(identity_and_zeros, dim3((unsigned)cdiv(npp, 256)), dim3(256), 0, st, eye, np, zeros);
+            std::vector<double> h_trg((size_t)ns);
+            FAD_HIP_TRY(hipMemcpyAsync(h_trg.data(), trg, ns * sizeof(double), hipMemcpyDeviceToHost, st));
+            FAD_TRY(ws.small.reserve(ns_small_bytes(np, ns)));
+            NsState* dstates = static_cast<NsState*>(ws.small.p);
+            hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(ns, 64)), dim3(64), 0, st, dstates, ns);
+            NsState* hs = nullptr;
+            NsProblem pb{np, ns, gmat, npp, eye, 0, zeros, 0, zeros, 0, -1};            // A = G' I
+            FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));                          // (synchronises: the index vectors may go)
+            for (int64_t k = 0; k < ns; ++k) {
+                const int64_t sg = gram_ns[g0 + k];
+                const double tg = h_trg[k];
+                if (!(tg == tg) || !(tr_b == tr_b) || tg > 1e300) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
+                double tr_sqrt = 0.0;
+                if (tg > 0.0) {
+                    if (hs[k].nonfinite) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
+                    const double alpha = tg / (double)nrows[k];
+                    tr_sqrt = sqrt(hs[k].c) * hs[k].tr_last - (double)(1 + np - nrows[k]) * sqrt(alpha);
+                    if (tr_sqrt < 0.0) tr_sqrt = 0.0;
+                    if (hs[k].conv == 0) out_status[sg] = FAD_ERR_NOT_CONVERGED;
+                }
+                out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * tr_sqrt;
             }
             g0 = g1;
         }

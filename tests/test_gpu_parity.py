@@ -864,13 +864,13 @@ def test_gram_path_matches_oracle_for_3_to_64_frames(F):
 
 
 def test_per_song_routes_mixed_in_one_call(F):
-    """Two-frame songs (closed form, scored on the device), Gram-route songs, a D x D song and songs that cannot be scored, interleaved
+    """Two-frame songs (closed form, scored on the device), songs of both Gram routes, a D x D song and songs that cannot be scored, interleaved
     in one call: every route writes only its own songs, with host rows, device rows and a device-resident baseline alike."""
     import torch
     from fadtk_amd import hip
     d = 96
     mu_b, cov_b = R.baseline_stats(51, 6 * d, d)
-    rows_per_song = [2, 5, 2, 1, 130, 2, 0, 33, 2]
+    rows_per_song = [2, 5, 2, 1, 130, 2, 0, 80, 2, 33]
     sg = R.songs(52, len(rows_per_song), rows_per_song, d)
     rows = np.concatenate([s for s in sg if s.shape[0]])
     offs = np.concatenate([[0], np.cumsum(rows_per_song)])
@@ -883,6 +883,28 @@ def test_per_song_routes_mixed_in_one_call(F):
         assert status[3] == -6 and status[6] == -6 and np.isnan(scores[3]) and np.isnan(scores[6])
         assert (status[ok] == 0).all()
         np.testing.assert_allclose(scores[ok], want, rtol=1e-6)
+
+
+def test_gram_iteration_path_matches_oracle_for_65_to_d_frames(F):
+    """64 < n <= D frames: the n x n Gram matrix goes through the batched Newton-Schulz iteration (padded to the longest song of
+    the call, deflated by the null vector of the centring) instead of the rank-deficient D x D product: songs of different
+    lengths in one call, one with repeated frames (extra rank deficiency), one whose frames are all equal (no spread at all)."""
+    from fadtk_amd import hip
+    d = 256
+    mu_b, cov_b = R.baseline_stats(61, 5 * d, d)
+    rows_per_song = [65, 100, 128, 129, 200, 256, 90, 70]
+    sg = R.songs(62, len(rows_per_song), rows_per_song, d)
+    sg[6][40:] = sg[6][39]                                            # 51 copies of one frame
+    sg[7][:] = sg[7][0]                                               # a constant song: Sigma_s = 0
+    rows = np.concatenate(sg)
+    offs = np.concatenate([[0], np.cumsum(rows_per_song)])
+    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+    assert (status == 0).all(), status
+    want = O.individual_scores(mu_b, cov_b, sg, run_sqrtm=False)
+    # the reference's eig on a rank-deficient product returns the D - n + 1 zero eigenvalues as +-1e-16 and takes their roots
+    # (fad.py:91-92): it is itself only good to a few 1e-8 here
+    np.testing.assert_allclose(scores[:6], want[:6], rtol=2e-7)
+    np.testing.assert_allclose(scores[6:], want[6:], rtol=1e-6)
 
 
 def test_score_inf_golden_g6(F, golden, tmp_path):
