@@ -774,47 +774,58 @@ __global__ __launch_bounds__(256) void song_stats(const TIn* __restrict__ rows, 
     if (threadIdx.x == 0) { scal[2 * s] = mt; scal[2 * s + 1] = (n > 1) ? ts / (double)(n - 1) : 0.0; }
 }
 
-// The same for songs of many frames: the four waves of the workgroup take every fourth row each (64 columns at a time) and
-// their partial sums meet in LDS -- one thread per column walking 2250 rows twice made this kernel 15 % of the per-song route at
-// the Encodec shape.  (Songs of a few frames keep the kernel above: there the columns are the parallelism.)
+// The same for songs of many frames: one workgroup per (song, 64 columns); its four waves take every fourth row each and their
+// partial sums meet in LDS -- one thread per column walking 2250 rows twice made this kernel 15 % of the per-song route at the
+// Encodec shape, and one workgroup per song left a call of 64 long songs with 64 workgroups.  The chunks' shares of the two
+// scalars are summed by song_scal_sum.  (Songs of a few frames keep the kernel above: there the columns are the parallelism.)
 template <typename TIn>
 __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ rows, int64_t ld, int d,
                                                        const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
                                                        int mean_mode, double* __restrict__ mean_exact,
-                                                       double* __restrict__ scal /*[S][2]*/) {
-    __shared__ double part[4][64];
+                                                       double* __restrict__ part /*[S][chunks][2]*/) {
+    __shared__ double psum[4][64];
     __shared__ double red[4];
     const int64_t s = blockIdx.x;
     const int64_t r0 = offsets[s], r1 = offsets[s + 1];
     const int64_t n = r1 - r0;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int a = blockIdx.y * 64 + cl;
+    const bool ok = a < d;
     double mt = 0.0, ts = 0.0;
-    for (int a0 = 0; a0 < d; a0 += 64) {
-        const int a = a0 + cl;
-        const bool ok = a < d;
-        double sum = 0.0;
-        if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) sum += ld_f64<TIn>(rows, r * ld + a);
-        part[rl][cl] = sum;
-        __syncthreads();
-        const double tot = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
-        const double m = (n > 0) ? tot / (double)n : 0.0;
-        __syncthreads();
-        double sq = 0.0;
-        if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) { const double c = ld_f64<TIn>(rows, r * ld + a) - m; sq += c * c; }
-        part[rl][cl] = sq;
-        __syncthreads();
-        if (rl == 0 && ok) {
-            const double mr = mean_mode ? round_like_input<TIn>(m) : m;
-            if (mean_exact) mean_exact[s * d + a] = m;
-            ts += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
-            const double df = mu_b[a] - mr;
-            mt += df * df;
-        }
-        __syncthreads();
+    double sum = 0.0;
+    if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) sum += ld_f64<TIn>(rows, r * ld + a);
+    psum[rl][cl] = sum;
+    __syncthreads();
+    const double tot = (psum[0][cl] + psum[1][cl]) + (psum[2][cl] + psum[3][cl]);
+    const double m = (n > 0) ? tot / (double)n : 0.0;
+    __syncthreads();
+    double sq = 0.0;
+    if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) { const double c = ld_f64<TIn>(rows, r * ld + a) - m; sq += c * c; }
+    psum[rl][cl] = sq;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        const double mr = mean_mode ? round_like_input<TIn>(m) : m;
+        if (mean_exact) mean_exact[s * d + a] = m;
+        ts = (psum[0][cl] + psum[1][cl]) + (psum[2][cl] + psum[3][cl]);
+        const double df = mu_b[a] - mr;
+        mt = df * df;
     }
     mt = block_sum(mt, red);
     ts = block_sum(ts, red);
-    if (threadIdx.x == 0) { scal[2 * s] = mt; scal[2 * s + 1] = (n > 1) ? ts / (double)(n - 1) : 0.0; }
+    if (threadIdx.x == 0) {
+        double* o = part + 2 * (s * gridDim.y + blockIdx.y);
+        o[0] = mt; o[1] = (n > 1) ? ts / (double)(n - 1) : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void song_scal_sum(const double* __restrict__ part, int chunks, int64_t n_songs,
+                                                     double* __restrict__ scal /*[S][2]*/) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (song, which scalar)
+    if (e >= 2 * n_songs) return;
+    const int64_t s = e >> 1; const int w = (int)(e & 1);
+    double t = 0.0;
+    for (int c = 0; c < chunks; ++c) t += part[2 * (s * chunks + c) + w];
+    scal[e] = t;
 }
 
 // Sigma_s = Xc^T Xc / (n-1) with the exact fp64 mean (np.cov), 16x16 threads per 16x16 tile; grid (t, t, songs)
@@ -1245,22 +1256,30 @@ int fad_frechet_cancel(fad_frechet_job_t* job) {
 //     G' = diag(G + (alpha / n) 1 1^T,  alpha I_pad),     alpha = tr G / n,
 // whose extra eigenvalues are exactly alpha (1 is an exact null vector of G):  tr sqrt(G) = tr sqrt(G') - (1 + pad) sqrt(alpha).
 // ------------------------------------------------------------------------------------------
+constexpr int GRAM_TR_PARTS = 16;
 __global__ __launch_bounds__(256) void gram_trace(const double* __restrict__ xc, const double* __restrict__ w, int d,
                                                   const int64_t* __restrict__ first_row, const int* __restrict__ n_rows,
-                                                  double* __restrict__ tr_g) {
+                                                  double* __restrict__ tr_part /*[songs][GRAM_TR_PARTS]*/) {
     __shared__ double red[4];
     const int64_t k = blockIdx.x;
     const int64_t base = first_row[k] * d, len = (int64_t)n_rows[k] * d;
+    const int64_t per = (len + GRAM_TR_PARTS - 1) / GRAM_TR_PARTS, e0 = blockIdx.y * per, e1 = (e0 + per < len) ? e0 + per : len;
     double t = 0.0;
-    for (int64_t e = threadIdx.x; e < len; e += 256) t += w[base + e] * xc[base + e];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) t += w[base + e] * xc[base + e];
     t = block_sum(t, red);
-    if (threadIdx.x == 0) tr_g[k] = t / (double)(n_rows[k] - 1);
+    if (threadIdx.x == 0) tr_part[k * GRAM_TR_PARTS + blockIdx.y] = t;
+}
+// tr G of one song from its partials -- the same sum, in the same order, on the device (gram_big) and on the host
+__host__ __device__ inline double gram_trace_total(const double* part, int n) {
+    double t = 0.0;
+    for (int q = 0; q < GRAM_TR_PARTS; ++q) t += part[q];
+    return t / (double)(n - 1);
 }
 
 // grid (np/64, np/64, songs): one 64 x 64 tile of G' per workgroup, four waves of 32 x 32 on v_mfma_f64_16x16x4_f64, 16-deep k stages
 __global__ __launch_bounds__(256) void gram_big(const double* __restrict__ xc, const double* __restrict__ w, int d, int np,
                                                 const int64_t* __restrict__ first_row, const int* __restrict__ n_rows,
-                                                const double* __restrict__ tr_g, double* __restrict__ gout) {
+                                                const double* __restrict__ tr_part, double* __restrict__ gout) {
     typedef double f64x4 __attribute__((ext_vector_type(4)));
     constexpr int P = 18;                                   // LDS pitch (doubles)
     __shared__ double sA[64 * P], sB[64 * P];
@@ -1269,7 +1288,7 @@ __global__ __launch_bounds__(256) void gram_big(const double* __restrict__ xc, c
     const int64_t f = first_row[k];
     const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
-    const double trg = tr_g[k];
+    const double trg = gram_trace_total(tr_part + k * GRAM_TR_PARTS, n);
     const bool dead = !(trg > 0.0);                         // no spread at all (or not finite): the host scores it without a root
     const double alpha = dead ? 1.0 : trg / (double)n;
     double* G = gout + k * (int64_t)np * np;
@@ -1362,10 +1381,14 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
     std::vector<double> h_scal;
     double tr_b = 0.0;
     if (others) {                       // (two-frame songs get their scalars from pair_stats_diff)
-        if ((h_off[n_songs] - h_off[0]) / n_songs >= 64)
-            hipLaunchKernelGGL((song_stats_long<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
-                               mean_mode, mean_exact, scal);
-        else
+        if ((h_off[n_songs] - h_off[0]) / n_songs >= 64) {
+            const int chunks = (int)cdiv(d, 64);
+            FAD_TRY(ws.rows2.reserve((size_t)2 * n_songs * chunks * sizeof(double)));
+            double* part = static_cast<double*>(ws.rows2.p);
+            hipLaunchKernelGGL((song_stats_long<TIn>), dim3((unsigned)n_songs, (unsigned)chunks), dim3(256), 0, st, drows, ld, d, d_off,
+                               dmu_b, mean_mode, mean_exact, part);
+            hipLaunchKernelGGL(song_scal_sum, dim3((unsigned)cdiv(2 * n_songs, 256)), dim3(256), 0, st, part, chunks, n_songs, scal);
+        } else
             hipLaunchKernelGGL((song_stats<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,
                                mean_mode, mean_exact, scal);
         h_scal.resize((size_t)2 * n_songs);
@@ -1485,8 +1508,8 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             const int64_t R = (int64_t)src_row.size(), nb = cdiv(R, d), Rpad = nb * d, ns = (int64_t)(g1 - g0);
             const int np = (int)(cdiv(n_max, 64) * 64);
             const int64_t npp = (int64_t)np * np;
-            // device scratch: xc [Rpad*d] | w [Rpad*d] | G' [ns*np*np] | I [np*np] | zeros [np] | tr G [ns]
-            FAD_TRY(ws.songmat.reserve(((size_t)2 * Rpad * d + (size_t)(ns + 1) * npp + np + ns) * sizeof(double)));
+            // device scratch: xc [Rpad*d] | w [Rpad*d] | G' [ns*np*np] | I [np*np] | zeros [np] | tr G partials [ns*16]
+            FAD_TRY(ws.songmat.reserve(((size_t)2 * Rpad * d + (size_t)(ns + 1) * npp + np + ns * GRAM_TR_PARTS) * sizeof(double)));
             double* xc = static_cast<double*>(ws.songmat.p);
             double* wmat = xc + (size_t)Rpad * d;
             double* gmat = wmat + (size_t)Rpad * d;
@@ -1507,12 +1530,12 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             GemmType gt{xc, dd, dcov_b, 0, wmat, dd, 1.0, 0.0, 0.0, nullptr};          // W = Xc Sigma_b, D rows per problem
             const int rc = gemm_f64_launch(d, &gt, 1, nb, nullptr, 0, st, device);
             if (rc < 0) return rc;
-            hipLaunchKernelGGL(gram_trace, dim3((unsigned)ns), dim3(256), 0, st, xc, wmat, d, d_first, d_n, trg);
+            hipLaunchKernelGGL(gram_trace, dim3((unsigned)ns, GRAM_TR_PARTS), dim3(256), 0, st, xc, wmat, d, d_first, d_n, trg);
             hipLaunchKernelGGL(gram_big, dim3((unsigned)(np / 64), (unsigned)(np / 64), (unsigned)ns), dim3(256), 0, st, xc, wmat, d, np,
                                d_first, d_n, trg, gmat);
             hipLaunchKernelGGL(identity_and_zeros, dim3((unsigned)cdiv(npp, 256)), dim3(256), 0, st, eye, np, zeros);
-            std::vector<double> h_trg((size_t)ns);
-            FAD_HIP_TRY(hipMemcpyAsync(h_trg.data(), trg, ns * sizeof(double), hipMemcpyDeviceToHost, st));
+            std::vector<double> h_trg((size_t)ns * GRAM_TR_PARTS);
+            FAD_HIP_TRY(hipMemcpyAsync(h_trg.data(), trg, h_trg.size() * sizeof(double), hipMemcpyDeviceToHost, st));
             FAD_TRY(ws.small.reserve(ns_small_bytes(np, ns)));
             NsState* dstates = static_cast<NsState*>(ws.small.p);
             hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(ns, 64)), dim3(64), 0, st, dstates, ns);
@@ -1521,7 +1544,7 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));                          // (synchronises: the index vectors may go)
             for (int64_t k = 0; k < ns; ++k) {
                 const int64_t sg = gram_ns[g0 + k];
-                const double tg = h_trg[k];
+                const double tg = gram_trace_total(h_trg.data() + k * GRAM_TR_PARTS, nrows[k]);
                 if (!(tg == tg) || !(tr_b == tr_b) || tg > 1e300) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
                 double tr_sqrt = 0.0;
                 if (tg > 0.0) {
