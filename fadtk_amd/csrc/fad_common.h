@@ -87,6 +87,8 @@ struct GemmType {
     double alpha, beta_eye, gamma;
     double* partials;
     int b_upper = 0;        // B is upper triangular (zeros stored below the diagonal): column tile j stops at k < (j + 1) * tile
+    int sym = 0;            // the product is known to be symmetric (commuting symmetric factors): only the tiles on and above the
+                            // diagonal are computed, each off-diagonal tile is stored twice (a hint: honoured by the 64 x 64 kernel)
 };
 // returns the number of partial slots per problem (>0) or a negative fad_status
 // `check` (optional): one extra workgroup per problem runs ns_check_block (ns_check.h) beside the GEMM tiles.

@@ -328,6 +328,7 @@ struct NsProblem {                  // B problems of dimension d; strides in ele
     const double* mu1; int64_t s_mu1;
     const double* mu2; int64_t s_mu2;
     int mean_dtype;                 // ns_prepare: dtype whose rounding the mean term reproduces, or -1 (float64)
+    int sym = 0;                    // cov1 cov2 is symmetric (then so is every iterate): the products may skip the mirrored tiles
 };
 
 static int ns_pstride(int d) {                       // partial slots per problem: GEMM tiles or ns_first blocks
@@ -376,7 +377,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     GemmType g[2];
     int rc;
     if (!reuse_prepared) {
-        g[0] = {pb.cov1, pb.s_cov1, pb.cov2, pb.s_cov2, A, dd, 1.0, 0.0, 0.0, nullptr};
+        g[0] = {pb.cov1, pb.s_cov1, pb.cov2, pb.s_cov2, A, dd, 1.0, 0.0, 0.0, nullptr, 0, pb.sym};
         rc = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device);
         if (rc < 0) return rc;
         const unsigned nb = (unsigned)stat_blocks(d);
@@ -405,14 +406,14 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
         for (; k < stop; ++k) {
             int nslots = nslots0;
             if (k > 0) {
-                g[0] = {Z[cur], dd, Y[cur], dd, T, dd, -0.5, 1.5, 1.0, partials};
+                g[0] = {Z[cur], dd, Y[cur], dd, T, dd, -0.5, 1.5, 1.0, partials, 0, pb.sym};
                 nslots = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device, pstride);
                 if (nslots < 0) return nslots;
             }
             // update GEMMs of iteration k + its convergence check as one extra workgroup per problem
             chk.k = k; chk.nslots = nslots; chk.Yall = Y[cur];
-            g[0] = {Y[cur], dd, T, dd, Y[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
-            g[1] = {T, dd, Z[cur], dd, Z[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr};
+            g[0] = {Y[cur], dd, T, dd, Y[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr, 0, pb.sym};
+            g[1] = {T, dd, Z[cur], dd, Z[cur ^ 1], dd, 1.0, 0.0, 0.0, nullptr, 0, pb.sym};
             rc = gemm_f64_launch(d, g, k == 0 ? 1 : 2, B, &dstates[0].upd_skip[k & 1], kStateInts, stream, device, 0,
                                  &chk);                                                               // Z1 = T0 is in place
             if (rc < 0) return rc;
@@ -1540,7 +1541,8 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             NsState* dstates = static_cast<NsState*>(ws.small.p);
             hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(ns, 64)), dim3(64), 0, st, dstates, ns);
             NsState* hs = nullptr;
-            NsProblem pb{np, ns, gmat, npp, eye, 0, zeros, 0, zeros, 0, -1};            // A = G' I
+            static const int sym_on = [] { const char* e = getenv("FAD_SONG_SYM"); return (e && e[0] == '0') ? 0 : 1; }();
+            NsProblem pb{np, ns, gmat, npp, eye, 0, zeros, 0, zeros, 0, -1, sym_on};    // A = G' I, symmetric like every iterate
             FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));                          // (synchronises: the index vectors may go)
             for (int64_t k = 0; k < ns; ++k) {
                 const int64_t sg = gram_ns[g0 + k];

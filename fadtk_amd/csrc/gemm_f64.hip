@@ -36,6 +36,7 @@ struct GemmArgs {
     int remap;                           // XCD-aware tile map on/off
     int pstride;                         // partial slots reserved per problem
     int gemm_z;                          // blockIdx.z >= gemm_z: checker blocks (problem = blockIdx.z - gemm_z)
+    int sym;                             // GemmType::sym (all types of the launch)
     int tri;                             // B upper triangular: the k loop of column tile tx ends with the tile's last column
     // fp32 operands (TIn = float instantiation: the fp64 correction product of the mixed-precision Newton-Schulz):
     // A32/B32 replace A/B; when `sel` is given and *sel is odd the *_alt pointers are used (the final iterate of
@@ -126,12 +127,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     const int t = gridDim.x;
     if (g.remap && (t & 3) == 0) {
         const int b = blockIdx.y * t + blockIdx.x;
-        const int xcd = b & 7, idx = b >> 3;
+        // (symmetric products: the blocks below the diagonal have no work, so problem zb gives block (h + zb) % 8 to XCD h --
+        //  over a batch every XCD gets every block; measured without the rotation: no gain at all from skipping 28 of 64 tiles)
+        const int xcd = (b + (g.sym ? (int)(zb & 7) : 0)) & 7, idx = b >> 3;
         const int R = t >> 1, Cc = t >> 2;
         ty = (xcd >> 2) * R + idx / Cc;
         tx = (xcd & 3) * Cc + idx % Cc;
     }
     const int slot = ty * t + tx;
+    if constexpr (!KSPLIT && MODE == 0) {
+        if (g.sym && tx < ty) {              // mirror image of a tile another workgroup computes; its residual slot reads as zero
+            if (g.partials[zi] && threadIdx.x == 0) g.partials[zi][zb * g.pstride + slot] = 0.0;
+            return;
+        }
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: plain k-loop, no exec masking
@@ -390,10 +399,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
                     if (r < d && c < d) {
                         const double v = alpha * acc[fa][fb][reg] + (r == c ? beta_eye : 0.0);
                         C[(int64_t)r * d + c] = v;
+                        if (g.sym && tx > ty) C[(int64_t)c * d + r] = v;
                         const double e = v - (r == c ? gamma : 0.0);
                         ss += e * e;
                     }
                 }
+        if (g.sym && tx > ty) ss *= 2.0;         // the mirrored tile's share of the residual
     }
     double* partials = g.partials[zi];
     if (partials) {
@@ -410,8 +421,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
     }
 }
 
-static int pick_bt(int d, int64_t count, int device) {
-    const int64_t t64 = cdiv(d, 64) * cdiv(d, 64) * count;
+static int pick_bt(int d, int64_t count, int device, bool sym = false) {
+    const int64_t t = cdiv(d, 64);
+    const int64_t t64 = (sym ? t * (t + 1) / 2 : t * t) * count;            // tiles that do work
     return (t64 >= num_cus(device)) ? 64 : 32;
 }
 
@@ -425,7 +437,8 @@ int gemm_f64_slots_max(int d) { const int64_t t = cdiv(d, 32); return (int)(t * 
 int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, const int* skip, int skip_stride,
                     hipStream_t stream, int device, int partial_stride, const NsCheckArgs* check) {
     if (ntypes < 1 || ntypes > 2 || batch < 1) return set_error(FAD_ERR_INVALID, "gemm: ntypes=%d batch=%lld", ntypes, (long long)batch);
-    const int bt = pick_bt(d, (int64_t)ntypes * batch, device);
+    const bool sym = types[0].sym && (ntypes == 1 || types[1].sym);
+    const int bt = pick_bt(d, (int64_t)ntypes * batch, device, sym);
     const int64_t t = cdiv(d, bt);
     const int64_t slots = t * t;
     const int64_t max_b = 65535 / (ntypes + (check ? 1 : 0));
@@ -444,6 +457,7 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
         g.skip_stride = skip_stride; g.ntypes = ntypes;
         static const int env_remap = [] { const char* e = getenv("FAD_GEMM_REMAP"); return e ? atoi(e) : 1; }();
         static const int env_depth = [] { const char* e = getenv("FAD_GEMM_DEPTH"); return e ? atoi(e) : 1; }();
+        g.sym = (sym && bt == 64) ? 1 : 0;
         g.tri = (ntypes == 1) ? types[0].b_upper : 0;
         g.remap = g.tri ? 0 : env_remap;            // (the XCD map hands whole column blocks to an XCD: with a triangular B
                                                     //  those blocks cost 1x .. 5x -- plain order mixes them)
