@@ -266,6 +266,7 @@ __global__ void clear_states(NsState* st, int64_t B) {
 struct MixedResult;
 struct Workspace : NsWorkspace {
     DevBuf rows, offs, songbuf, songmat, rows2;     // per-song path
+    DevBuf base_root;                               // ... sqrt(Sigma_b) | I | zeros of the symmetric D x D route
     void* song_pin = nullptr; size_t song_pin_cap = 0;      // ... and its pinned staging: offsets going up, scores coming down
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats)
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
@@ -280,7 +281,7 @@ struct Workspace : NsWorkspace {
     hipEvent_t done_ev = nullptr;
     struct Pool* pool = nullptr;
     void release_all() {
-        release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release();
+        release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release(); base_root.release();
         if (done_ev) { (void)hipEventDestroy(done_ev); done_ev = nullptr; }
         if (song_pin) { (void)hipHostFree(song_pin); song_pin = nullptr; song_pin_cap = 0; }
     }
@@ -345,7 +346,7 @@ static size_t ns_small_bytes(int d, int64_t B) {
 // reuse_prepared: A = C1 C2 (first matrix of ws.mats) and the armed state are those of a float32 attempt on the same problem
 // that just gave up (mixed_begin: same buffer, same ns_prepare) -- product, statistics and scale are not formed again.
 static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_t stream, Workspace& ws,
-                  NsState** host_states, bool reuse_prepared = false) {
+                  NsState** host_states, bool reuse_prepared = false, double** y_bufs = nullptr) {
     const int d = pb.d;
     const int64_t B = pb.B, dd = (int64_t)d * d;
     if (max_iter <= 0) max_iter = 64;
@@ -358,6 +359,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
     double* Y[2] = {A + dd * B, A + 2 * dd * B};
     double* Z[2] = {A + 3 * dd * B, A + 4 * dd * B};
     double* T = A + 5 * dd * B;
+    if (y_bufs) { y_bufs[0] = Y[0]; y_bufs[1] = Y[1]; }      // the answer of problem b is sqrt(c) Y[final_iter & 1] (ns_check.h)
     NsState* dstates = static_cast<NsState*>(ws.small.p);
     double* partials = reinterpret_cast<double*>(dstates + B);
     const int pstride = ns_pstride(d);
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(256) void song_cov_mfma(const TIn* __restrict__ row
                                                      const double* __restrict__ mean_exact, double* __restrict__ cov_out) {
     __shared__ double smem[2][2][16 * SC_LDS];      // [buffer][A | B][row][col]
     const int64_t slot = blockIdx.z;
-    const int64_t s = song_ids[slot];
+    const int64_t s = song_ids ? song_ids[slot] : slot;
     int ta = 0, t = blockIdx.x;
     while (t >= nt - ta) { t -= nt - ta; ++ta; }
     const int tb = ta + t;
@@ -870,13 +872,13 @@ __global__ __launch_bounds__(256) void song_cov_mfma(const TIn* __restrict__ row
     const int li = lane & 15, lk = lane >> 4;
     const int64_t r0 = offsets[s], r1 = offsets[s + 1];
     const int nkb = (int)((r1 - r0 + 15) / 16);
-    const double* mean = mean_exact + s * d;
+    const double* mean = mean_exact ? mean_exact + s * d : nullptr;          // nullptr: the rows are centred already
     const int sr = tid >> 4, sc4 = (tid & 15) * 4;
     double ma[4], mb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        ma[q] = (ca + sc4 + q < d) ? mean[ca + sc4 + q] : 0.0;
-        mb[q] = (cb + sc4 + q < d) ? mean[cb + sc4 + q] : 0.0;
+        ma[q] = (mean && ca + sc4 + q < d) ? mean[ca + sc4 + q] : 0.0;
+        mb[q] = (mean && cb + sc4 + q < d) ? mean[cb + sc4 + q] : 0.0;
     }
     double ra[4], rb[4];
     auto fetch = [&](int kb) {
@@ -1344,6 +1346,15 @@ __global__ __launch_bounds__(256) void gram_big(const double* __restrict__ xc, c
             }
 }
 
+// sqrt(A) of problem 0 of a finished iteration: sqrt(c) Y[final_iter & 1], symmetrised
+__global__ __launch_bounds__(256) void root_from_state(const NsState* __restrict__ st, const double* __restrict__ y0,
+                                                       const double* __restrict__ y1, int d, double* __restrict__ out) {
+    const double* y = (st->final_iter & 1) ? y1 : y0;
+    const double sc = sqrt(st->c);
+    const int64_t i = blockIdx.x;
+    for (int j = threadIdx.x; j < d; j += 256) out[i * d + j] = 0.5 * sc * (y[i * d + j] + y[(int64_t)j * d + i]);
+}
+
 __global__ __launch_bounds__(256) void identity_and_zeros(double* __restrict__ eye, int np, double* __restrict__ zeros) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e < (int64_t)np * np) eye[e] = (e / np == e % np) ? 1.0 : 0.0;
@@ -1559,6 +1570,87 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
                 out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * tr_sqrt;
             }
             g0 = g1;
+        }
+    }
+
+    // ---- songs of D + 1 .. 8 D frames (D >= 64): the symmetric form of the D x D problem.  With B = sqrt(Sigma_b) (ONE
+    // Newton-Schulz problem per call) the product Sigma_b Sigma_s is similar to B Sigma_s B = cov(Xc B), so the song's matrix is
+    // the covariance of its transformed frames -- symmetric, like every iterate of its root, and the iteration's products skip
+    // the mirrored tiles (GemmType::sym); the D x D product Sigma_b Sigma_s is never formed.  Costs one [n x D][D x D] product
+    // per song: longer songs (Encodec: 2250 frames at D = 128) and baselines whose root does not converge keep the route below.
+    static const bool symroute_on = [] { const char* e = getenv("FAD_SONG_SYM"); return !(e && e[0] == '0'); }();
+    if (symroute_on && d >= 64 && !general.empty()) {
+        std::vector<int64_t> sym_songs, rest;
+        for (const int64_t sg : general) ((h_off[sg + 1] - h_off[sg] <= (int64_t)8 * d) ? sym_songs : rest).push_back(sg);
+        bool have_root = false;
+        double *broot = nullptr, *eye = nullptr, *zeros = nullptr;
+        if (!sym_songs.empty()) {
+            FAD_TRY(ws.base_root.reserve((size_t)(2 * dd + d) * sizeof(double)));
+            broot = static_cast<double*>(ws.base_root.p); eye = broot + dd; zeros = eye + dd;
+            hipLaunchKernelGGL(identity_and_zeros, dim3((unsigned)cdiv(dd, 256)), dim3(256), 0, st, eye, d, zeros);
+            FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
+            NsState* dstates = static_cast<NsState*>(ws.small.p);
+            hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, st, dstates, (int64_t)1);
+            NsState* hsb = nullptr;
+            double* yb[2] = {nullptr, nullptr};
+            NsProblem pbb{d, 1, dcov_b, 0, eye, 0, zeros, 0, zeros, 0, -1, 0};
+            FAD_TRY(run_ns(pbb, 0, 0.0, device, st, ws, &hsb, false, yb));
+            have_root = hsb[0].conv == 1 && !hsb[0].nonfinite && hsb[0].final_iter >= 0;
+            if (have_root) hipLaunchKernelGGL(root_from_state, dim3((unsigned)d), dim3(256), 0, st, dstates, yb[0], yb[1], d, broot);
+        }
+        if (have_root) {
+            const int64_t budget_rows = std::max<int64_t>(d, ((int64_t)1 << 30) / ((int64_t)d * 16));     // ~1 GiB of Xc + Xc B
+            const size_t budget_mats = (size_t)3 << 30;
+            const int nt64 = (int)cdiv(d, 64);
+            size_t g0 = 0;
+            while (g0 < sym_songs.size()) {
+                std::vector<int64_t> src_row, row_song, first_row;
+                size_t g1 = g0;
+                while (g1 < sym_songs.size()) {
+                    const int64_t sg = sym_songs[g1], n = h_off[sg + 1] - h_off[sg];
+                    if (!src_row.empty() && ((int64_t)src_row.size() + n > budget_rows ||
+                                             (size_t)(g1 - g0 + 1) * 7 * dd * sizeof(double) > budget_mats || g1 - g0 >= 4096)) break;
+                    first_row.push_back((int64_t)src_row.size());
+                    for (int64_t r = 0; r < n; ++r) { src_row.push_back(h_off[sg] + r); row_song.push_back(sg); }
+                    ++g1;
+                }
+                first_row.push_back((int64_t)src_row.size());
+                const int64_t R = (int64_t)src_row.size(), nb = cdiv(R, d), Rpad = nb * d, B = (int64_t)(g1 - g0);
+                // device scratch: xc [Rpad*d] | xc B [Rpad*d] | covariances [B*d*d]
+                FAD_TRY(ws.songmat.reserve(((size_t)2 * Rpad * d + (size_t)B * dd) * sizeof(double)));
+                double* xc = static_cast<double*>(ws.songmat.p);
+                double* xp = xc + (size_t)Rpad * d;
+                double* covs = xp + (size_t)Rpad * d;
+                FAD_TRY(ws.rows2.reserve(((size_t)2 * R + B + 1) * sizeof(int64_t) + 64));
+                int64_t* d_src = static_cast<int64_t*>(ws.rows2.p);
+                int64_t* d_song = d_src + R;
+                int64_t* d_first = d_song + R;
+                FAD_HIP_TRY(hipMemcpyAsync(d_src, src_row.data(), R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+                FAD_HIP_TRY(hipMemcpyAsync(d_song, row_song.data(), R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+                FAD_HIP_TRY(hipMemcpyAsync(d_first, first_row.data(), (B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL((gram_center_rows<TIn>), dim3((unsigned)Rpad), dim3(256), 0, st, drows, ld, d, d_src, d_song,
+                                   mean_exact, R, xc);
+                GemmType gt{xc, dd, broot, 0, xp, dd, 1.0, 0.0, 0.0, nullptr};              // Xc B, D rows per problem
+                const int rc = gemm_f64_launch(d, &gt, 1, nb, nullptr, 0, st, device);
+                if (rc < 0) return rc;
+                hipLaunchKernelGGL((song_cov_mfma<double>), dim3((unsigned)(nt64 * (nt64 + 1) / 2), 1, (unsigned)B), dim3(256), 0, st, xp,
+                                   (int64_t)d, d, nt64, d_first, (const int64_t*)nullptr, (const double*)nullptr, covs);
+                FAD_TRY(ws.small.reserve(ns_small_bytes(d, B)));
+                NsState* dstates = static_cast<NsState*>(ws.small.p);
+                hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, dstates, B);
+                NsState* hs = nullptr;
+                NsProblem pb{d, B, covs, dd, eye, 0, zeros, 0, zeros, 0, -1, 1};            // A = cov(Xc B) I
+                FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));                          // (synchronises: the index vectors may go)
+                for (int64_t b = 0; b < B; ++b) {
+                    const int64_t sg = sym_songs[g0 + b];
+                    if (hs[b].nonfinite || !(tr_b == tr_b)) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
+                    const double tr_sqrt = sqrt(hs[b].c) * hs[b].tr_last;
+                    out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * tr_sqrt;
+                    if (hs[b].conv == 0) out_status[sg] = FAD_ERR_NOT_CONVERGED;
+                }
+                g0 = g1;
+            }
+            general.swap(rest);
         }
     }
 
