@@ -196,7 +196,7 @@ def extra_c5_frames(torch, hip, device):
             "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": "BLAS threads as numpy finds them", "kind": "port",
                              "sample": f"{n_cpu} of the same songs through the oracle (np.cov + eig + sqrtm per song, fad.py:373-378), "
                                        "one after the other", "seconds": dt_cpu},
-            "note": "per song: covariance of [1500 x 768] + a 768^3 float64 Newton-Schulz against the shared baseline (batched over the songs)"}
+            "note": "per song: frames times sqrt(Sigma_b) (one root per call), covariance of the [1500 x 768] result, a 768^3 float64 Newton-Schulz on that symmetric matrix (batched over the songs, mirrored tiles skipped)"}
 
 
 def main():

@@ -907,6 +907,26 @@ def test_gram_iteration_path_matches_oracle_for_65_to_d_frames(F):
     np.testing.assert_allclose(scores[6:], want[6:], rtol=1e-6)
 
 
+def test_symmetric_dxd_route_and_its_fallbacks(F):
+    """Songs of D+1 .. 8D frames take the symmetric form (B = sqrt(Sigma_b) once, cov(Xc B) per song); longer songs in the same
+    call, and every song when Sigma_b is singular (its root does not converge), keep the product Sigma_b Sigma_s: all of them must
+    agree with the oracle."""
+    from fadtk_amd import hip
+    d = 64
+    rows_per_song = [100, 600, 65, 513, 512, 300]                    # 600 and 513 frames: more than 8 D
+    sg = R.songs(72, len(rows_per_song), rows_per_song, d)
+    rows = np.concatenate(sg)
+    offs = np.concatenate([[0], np.cumsum(rows_per_song)])
+    mu_b, cov_b = R.baseline_stats(71, 5 * d, d)
+    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+    assert (status == 0).all(), status
+    np.testing.assert_allclose(scores, O.individual_scores(mu_b, cov_b, sg, run_sqrtm=False), rtol=1e-9)
+    mu_s, cov_s = R.baseline_stats(73, d // 2, d)                     # 32 rows at D = 64: a singular baseline
+    scores, status = hip.frechet_batched(mu_s, cov_s, rows, offs, mean_mode=1)
+    assert (status == 0).all(), status
+    np.testing.assert_allclose(scores, O.individual_scores(mu_s, cov_s, sg, run_sqrtm=False), rtol=1e-6)
+
+
 def test_score_inf_golden_g6(F, golden, tmp_path):
     g = golden["g6"]
     mu_b, cov_b = R.baseline_stats(g["base_seed"], g["base_n"], g["d"])
