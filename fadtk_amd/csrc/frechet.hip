@@ -1581,7 +1581,8 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
     static const bool symroute_on = [] { const char* e = getenv("FAD_SONG_SYM"); return !(e && e[0] == '0'); }();
     if (symroute_on && d >= 64 && !general.empty()) {
         std::vector<int64_t> sym_songs, rest;
-        for (const int64_t sg : general) ((h_off[sg + 1] - h_off[sg] <= (int64_t)8 * d) ? sym_songs : rest).push_back(sg);
+        static const int64_t max_mult = [] { const char* e = getenv("FAD_SONG_SYM_MAX_FRAMES_PER_DIM"); return e ? (int64_t)atoll(e) : (int64_t)8; }();
+        for (const int64_t sg : general) ((h_off[sg + 1] - h_off[sg] <= max_mult * d) ? sym_songs : rest).push_back(sg);
         bool have_root = false;
         double *broot = nullptr, *eye = nullptr, *zeros = nullptr;
         if (!sym_songs.empty()) {
