@@ -1406,6 +1406,7 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         h_scal.resize((size_t)2 * n_songs);
         FAD_HIP_TRY(hipMemcpyAsync(h_scal.data(), scal, h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         FAD_HIP_TRY(hipMemcpyAsync(&tr_b, trb_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+        FAD_HIP_TRY(hipStreamSynchronize(st));       // here, not later: an error return below must not leave a copy into this frame in flight
     }
 
     // ---- two-frame songs: closed form  tr sqrt = sqrt(d^T Sigma_b d / 2); the score is finished on the device and comes
@@ -1446,8 +1447,6 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             if (!(v == v)) out_status[s] = FAD_ERR_NOT_FINITE;
         }
     }
-    if (others) FAD_HIP_TRY(hipStreamSynchronize(st));            // h_scal, tr_b
-
     // ---- songs with 3..64 frames: n x n Gram matrix + Jacobi eigenvalues
     if (!gram.empty()) {
         const int64_t budget_rows = std::max<int64_t>(d, ((int64_t)1 << 30) / ((int64_t)d * 16));     // ~1 GiB of Xc + W
@@ -1546,8 +1545,6 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             hipLaunchKernelGGL(gram_big, dim3((unsigned)(np / 64), (unsigned)(np / 64), (unsigned)ns), dim3(256), 0, st, xc, wmat, d, np,
                                d_first, d_n, trg, gmat);
             hipLaunchKernelGGL(identity_and_zeros, dim3((unsigned)cdiv(npp, 256)), dim3(256), 0, st, eye, np, zeros);
-            std::vector<double> h_trg((size_t)ns * GRAM_TR_PARTS);
-            FAD_HIP_TRY(hipMemcpyAsync(h_trg.data(), trg, h_trg.size() * sizeof(double), hipMemcpyDeviceToHost, st));
             FAD_TRY(ws.small.reserve(ns_small_bytes(np, ns)));
             NsState* dstates = static_cast<NsState*>(ws.small.p);
             hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(ns, 64)), dim3(64), 0, st, dstates, ns);
@@ -1555,6 +1552,8 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             static const int sym_on = [] { const char* e = getenv("FAD_SONG_SYM"); return (e && e[0] == '0') ? 0 : 1; }();
             NsProblem pb{np, ns, gmat, npp, eye, 0, zeros, 0, zeros, 0, -1, sym_on};    // A = G' I, symmetric like every iterate
             FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));                          // (synchronises: the index vectors may go)
+            std::vector<double> h_trg((size_t)ns * GRAM_TR_PARTS);
+            FAD_HIP_TRY(hipMemcpy(h_trg.data(), trg, h_trg.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (int64_t k = 0; k < ns; ++k) {
                 const int64_t sg = gram_ns[g0 + k];
                 const double tg = gram_trace_total(h_trg.data() + k * GRAM_TR_PARTS, nrows[k]);
