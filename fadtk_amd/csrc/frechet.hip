@@ -317,10 +317,6 @@ static Workspace* free_slot(int device) {
         if (!w.busy) { w.pool = &p; return &w; }
     return nullptr;
 }
-static Workspace& thread_ws(int device) {           // synchronous entry points: any slot that is not in flight
-    Workspace* w = free_slot(device);
-    return w ? *w : thread_pool(device).slot[0];
-}
 
 struct NsProblem {                  // B problems of dimension d; strides in elements (0 = shared)
     int d; int64_t B;
@@ -1717,7 +1713,10 @@ extern "C" int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const 
     DeviceGuard g(device);
     if (!g.ok) return set_error(FAD_ERR_HIP, "cannot select device %d", device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    Workspace& ws = thread_ws(device);
+    // a slot that no score in flight owns: the kernels of fad_frechet_from_moments_begin jobs still read and write their slots' buffers
+    Workspace* wsp = free_slot(device);
+    if (!wsp) return set_error(FAD_ERR_INVALID, "all %d Frechet slots of this thread are in flight: collect one with fad_frechet_end", Pool::kSlots);
+    Workspace& ws = *wsp;
     const int64_t dd = (int64_t)d * d;
     const size_t es = dtype_size(dtype);
 

@@ -319,7 +319,6 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
             }
             if (!j.gate) j.alt = j.prim;
             j.acc = h->acc; j.n_add = (double)n[i]; j.overwrite = h->fresh ? 1 : 0;
-            h->fresh = false;
             int blocks = j.prim.tile_blocks + col_blocks;
             if (j.gate && j.alt.tile_blocks + col_blocks > blocks) blocks = j.alt.tile_blocks + col_blocks;
             if (blocks > max_blocks) max_blocks = blocks;
@@ -348,7 +347,6 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
             j.prim = reduce_src(s.partials, s.colpart, p, G_BT, 0);
             j.alt = j.prim;
             j.acc = h->acc; j.n_add = (double)n[i]; j.overwrite = h->fresh ? 1 : 0;
-            h->fresh = false;
             if (j.prim.tile_blocks + col_blocks > max_blocks) max_blocks = j.prim.tile_blocks + col_blocks;
             h->last_variant = 1;
         }
@@ -360,6 +358,9 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         if (ev && h0->timing == 1) FAD_HIP_TRY(hipEventRecord(ev[2], st));
     }
     FAD_HIP_TRY(hipGetLastError());
+    // the deferred reset is consumed only now that the reduce which stores (instead of adds) is on the stream: an error return
+    // above leaves every handle "fresh", so a retry still overwrites whatever the accumulator holds
+    for (int i = 0; i < count; ++i) hs[i]->fresh = false;
     return FAD_OK;
 }
 

@@ -158,11 +158,16 @@ class FrechetAudioDistance:
         return embd_lst, files
 
     # ------------------------------------------------------------------ statistics
-    def load_stats(self, path: PathLike):
+    def load_stats(self, path: PathLike, collective: bool = False):
         """Resolve a dataset spec to (mu, cov) in the reference's order (fad.py:245-290):
         bundled ``stats/<name>.npz`` -> an .npz file with ``<model>.mu/.cov`` -> the cached
         ``<dir>/stats/<model>/{mu,cov}.npy`` -> compute from ``<dir>/embeddings/<model>/*.npy``
-        on the GPU and write that cache (float64)."""
+        on the GPU and write that cache (float64).
+
+        ``collective=False`` (the default, and what ``score`` / ``score_inf`` use) runs no collective at all: under
+        ``--gpus N`` only rank 0 scores, the other ranks have left by then.  ``collective=True`` is for callers that
+        EVERY rank of the job goes through (``score_individual``): rank 0 decides whether the cache is there, computes and
+        writes it if not (atomic renames), everybody else waits at the barrier and then reads it."""
         if isinstance(path, str):
             bundled = Path(__file__).parent / "stats" / (path.lower() + ".npz")
             if bundled.exists():
@@ -185,9 +190,9 @@ class FrechetAudioDistance:
         def cached():
             return (cache_dir / "mu.npy").exists() and (cache_dir / "cov.npy").exists()
 
-        # Several ranks (--gpus N --indiv) ask for the same statistics: rank 0 decides whether the cache is there,
-        # computes and writes it if not (atomic renames), everybody else waits at the barrier and then reads it.
-        have = dist.broadcast_object(cached() if dist.rank() == 0 else None)
+        together = collective and dist.world_size() > 1
+        leader = dist.rank() == 0 or not together
+        have = dist.broadcast_object(cached() if dist.rank() == 0 else None) if together else cached()
         if have:
             log.info(f"Embedding statistics is already cached for {path}, loading...")
             return np.load(cache_dir / "mu.npy"), np.load(cache_dir / "cov.npy")
@@ -196,15 +201,16 @@ class FrechetAudioDistance:
             log.error(f"The dataset you want to use ({path}) is not a directory nor a file.")
             exit(1)
 
-        if dist.rank() == 0:
+        if leader:
             log.info(f"Loading embedding files from {path}...")
             mu, cov = calculate_embd_statistics_online(list(emb_dir.glob("*.npy")), device=self.device_index,
                                                        workers=self.audio_load_worker)
             log.info("> Embeddings statistics calculated.")
             write_stats_cache(cache_dir, mu, cov)
-        dist.barrier()
-        if dist.rank() != 0:
-            mu, cov = np.load(cache_dir / "mu.npy"), np.load(cache_dir / "cov.npy")
+        if together:
+            dist.barrier()
+            if not leader:
+                mu, cov = np.load(cache_dir / "mu.npy"), np.load(cache_dir / "cov.npy")
         return mu, cov
 
     # ------------------------------------------------------------------ scores
@@ -267,7 +273,7 @@ class FrechetAudioDistance:
             return csv
 
         from . import dist
-        mu, cov = self.load_stats(baseline)
+        mu, cov = self.load_stats(baseline, collective=True)          # every rank of the job comes through here
         all_files = sorted(Path(eval_dir).glob("*.*")) if dist.world_size() > 1 else list(Path(eval_dir).glob("*.*"))
         _files = dist.shard(all_files) if dist.world_size() > 1 else all_files      # songs are independent: shard them
 
@@ -303,8 +309,8 @@ class FrechetAudioDistance:
         pairs = [p for p in zip(_files, scores) if p[1] is not None]
         if dist.world_size() > 1:                      # rank-ordered gather keeps the file order; rank 0 writes
             pairs = [p for part in dist.gather_objects(pairs) for p in part]
-            if dist.rank() != 0:
-                return csv
-        pairs = sorted(pairs, key=lambda x: np.abs(x[1]))
-        write(csv, "\n".join(",".join(str(x).replace(",", "_") for x in row) for row in pairs))
+        if dist.rank() == 0:
+            pairs = sorted(pairs, key=lambda x: np.abs(x[1]))
+            write(csv, "\n".join(",".join(str(x).replace(",", "_") for x in row) for row in pairs))
+        dist.barrier()                                 # no rank returns before the CSV is there
         return csv

@@ -47,10 +47,10 @@ class _DeviceFeeder:
         if not self.pending:
             return
         import torch
-        sizes = [int(t.shape[0]) for t in self.pending]
-        rows = torch.cat(self.pending, dim=0) if len(self.pending) > 1 else self.pending[0]
+        pending, self.pending, self.bytes = self.pending, [], 0       # whatever happens below, this group is not retried
+        sizes = [int(t.shape[0]) for t in pending]
+        rows = torch.cat(pending, dim=0) if len(pending) > 1 else pending[0]
         self.stats.add_group(rows.contiguous(), sizes)
-        self.pending, self.bytes = [], 0
 
 
 def _cache_embedding_batch(fs, ml, workers: int = 8, feeder=None, **kwargs):
@@ -81,18 +81,22 @@ def _cache_embedding_batch(fs, ml, workers: int = 8, feeder=None, **kwargs):
                     feeder.add_host(np.load(cache))
                 continue
             log.info(f"Loading {f} using {ml.name}")
-            try:
+            dev = None
+            try:                                 # only the embedding of THIS file is the file's own business
                 if feeder is not None:           # keep the frames on the device: fp16 exactly as stored, then moments
                     import torch
                     dev = ml._get_embedding(fut.result()).detach()
-                    dev = dev.to(torch.float16) if dev.dtype == torch.float32 else dev
-                    feeder.add(dev.contiguous())
+                    dev = (dev.to(torch.float16) if dev.dtype == torch.float32 else dev).contiguous()
                     embd = dev.cpu().numpy()     # the embedding cache file is part of the contract (fad.py:188-201)
                 else:
                     embd = ml.get_embedding(fut.result())
             except Exception as e:      # noqa: BLE001  a bad file must not take the shard down
                 log.error(f"Embedding {f} with {ml.name} failed: {e}")
                 continue
+            if dev is not None:
+                # a GPU / library error of a group flush (64 files) is not this file's fault: it propagates, the shard
+                # stops at once instead of embedding everything that follows for nothing
+                feeder.add(dev)
             cache.parent.mkdir(parents=True, exist_ok=True)
             np.save(cache, embd)
     if feeder is not None:

@@ -244,19 +244,32 @@ def frechet_from_moments(m1: Moments, m2: Moments, ddof: int = 1, eps: float = 1
 
 class FrechetJob:
     """A score in flight (``fad_frechet_from_moments_begin``): the whole square-root chain is enqueued on the stream that
-    was current when it was created; ``result()`` waits for it -> (fad, diag dict).  Collect it on the creating thread."""
+    was current when it was created; ``result()`` waits for it -> (fad, diag dict).
+
+    The slot behind a job belongs to the host thread that created it (the library keeps its workspaces per thread and frees
+    them when the thread ends), so ``result()`` / ``cancel()`` from another thread raise, and a job that is garbage-collected
+    on another thread -- or after its thread has gone -- is left alone instead of touching a workspace that may no longer
+    exist."""
 
     def __init__(self, m1: Moments, m2: Moments, ddof: int = 1, eps: float = 1e-6, mean_dtype: int = -1):
+        import threading
         self._lib = K.load_library()
+        self._owner = threading.get_ident()
         job = C.c_void_p()
         K.check(self._lib.fad_frechet_from_moments_begin(m1._h, m2._h, int(ddof), float(eps), int(mean_dtype),
                                                          K.current_stream_ptr(m1.device), C.byref(job)),
                 "fad_frechet_from_moments_begin")
         self._job = job
 
+    def _on_owner_thread(self) -> bool:
+        import threading
+        return threading.get_ident() == self._owner
+
     def result(self):
         if self._job is None:
             raise RuntimeError("this job was collected already")
+        if not self._on_owner_thread():
+            raise RuntimeError("a FrechetJob must be collected by the thread that created it (its slot is thread-local)")
         out, diag = C.c_double(), K.FadDiag()
         job, self._job = self._job, None
         K.check(self._lib.fad_frechet_end(job, C.byref(out), C.byref(diag)), "fad_frechet_end")
@@ -265,12 +278,15 @@ class FrechetJob:
     def cancel(self):
         """Give the slot back without collecting the score (waits for the enqueued kernels)."""
         if self._job is not None:
+            if not self._on_owner_thread():
+                raise RuntimeError("a FrechetJob must be cancelled by the thread that created it (its slot is thread-local)")
             job, self._job = self._job, None
             K.check(self._lib.fad_frechet_cancel(job), "fad_frechet_cancel")
 
     def __del__(self):            # a job dropped without result(): its slot must not stay taken (8 per thread)
         try:
-            self.cancel()
+            if getattr(self, "_job", None) is not None and self._on_owner_thread():
+                self.cancel()
         except Exception:         # noqa: BLE001  interpreter shutdown, library gone
             pass
 

@@ -116,14 +116,19 @@ class OnlineStats:
         """``rows`` = the frames of ``len(sizes)`` files stored back to back (numpy on the host, or a torch CUDA tensor that
         stays in HBM); one dtype per group."""
         sizes = np.asarray(sizes, dtype=np.int64)
-        self.n_files += len(sizes)
-        self.n_short += int((sizes < 2).sum())
-        self.n_empty += int((sizes < 1).sum())
+
+        def count():                                 # the file counters move only once the GPU calls of the group went through
+            self.n_files += len(sizes)
+            self.n_short += int((sizes < 2).sum())
+            self.n_empty += int((sizes < 1).sum())
+
         if int(sizes.sum()) == 0:
+            count()
             return
         offs = np.concatenate([[0], np.cumsum(sizes)])
         if not self.compat:
             self.frames.update(rows)
+            count()
             return
         on_dev = type(rows).__module__.split(".")[0] == "torch" and rows.is_cuda
         sums = self.frames.update_segmented(rows, offs, want_sums=True, sums_on_device=on_dev)
@@ -133,6 +138,7 @@ class OnlineStats:
         else:
             code = _DT_CODES.get(np.asarray(rows).dtype, 3)
         type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code)
+        count()
 
     def pieces(self):
         """(packed frames, sum_f n_f m~_f, sum_f n_f m_f m_f^T, sum_f n_f m~_f m~_f^T) as host arrays."""

@@ -64,3 +64,38 @@ def test_two_rank_reduce_of_sufficient_statistics(tmp_path, golden_dir):
     z = np.load(golden_dir / "g3_online.npz")
     np.testing.assert_allclose(cov, z["cov"], rtol=0, atol=1e-4 * np.abs(z["cov"]).max())   # Q1: per-file fp16 means
     assert list(np.load(tmp_path / "order.npy")) == list(range(37))      # rank-ordered gather keeps file order
+
+
+def _stats_worker(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as td
+    from fadtk_amd import dist
+    from fadtk_amd.fad import FrechetAudioDistance
+
+    class _Loader:                                   # load_stats only needs the model's name
+        name = "toy"
+
+    assert dist.init("gloo")
+    fad = FrechetAudioDistance(_Loader(), load_model=False)
+    mu, cov = fad.load_stats(Path(tmp), collective=True)            # every rank: rank 0 answers "is it cached?" for all
+    assert mu.shape == (4,) and cov.shape == (4, 4)
+    dist.barrier()
+    if rank != 0:                                    # `fadtk <model> <base> <eval> --gpus 2`: the other ranks leave here ...
+        td.destroy_process_group()
+        return
+    mu0, cov0 = fad.load_stats(Path(tmp))            # ... and rank 0 resolves the statistics ALONE: no collective may run
+    assert np.array_equal(mu0, mu) and np.array_equal(cov0, cov)
+    np.save(Path(tmp) / "rank0_done.npy", np.array([1]))
+    td.destroy_process_group()
+
+
+def test_load_stats_runs_no_collective_unless_asked(tmp_path):
+    """with several ranks `score` / `score_inf` are rank 0's alone (cli.score_main) -- load_stats must not wait for
+    ranks that have left; only the `collective=True` form (score_individual: every rank calls it) may synchronise."""
+    cache = tmp_path / "stats" / "toy"
+    cache.mkdir(parents=True)
+    np.save(cache / "mu.npy", np.arange(4.0)); np.save(cache / "cov.npy", np.eye(4))
+    mp.spawn(_stats_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "rank0_done.npy").exists()

@@ -86,3 +86,40 @@ def test_two_ranks_on_one_gpu_match_the_oracle_on_the_union(tmp_path):
         assert p[0] == 4001
         np.testing.assert_allclose(p[1:129], rows.sum(0), rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(p[129:].reshape(128, 128), rows.T @ rows, rtol=0, atol=1e-6 * np.abs(rows.T @ rows).max())
+
+
+def _cli_rank_main(rank, world, port, tmp, extra):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      FAD_DIST_BACKEND="gloo", FADTK_AMD_RANDOM_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from fadtk_amd import cli
+    tmp = Path(tmp)
+    sys.argv = ["fadtk", "encodec-emb", str(tmp / "base"), str(tmp / "eval"), str(tmp / f"out{extra}.csv"), "-w", "2"] + \
+        (["--inf"] if extra == "inf" else [])
+    cli.score_main()                                 # ranks != 0 return after the embedding barrier; rank 0 scores alone
+
+
+@pytest.mark.parametrize("extra", ["", "inf"])
+def test_plain_score_cli_with_two_ranks(tmp_path, extra):
+    """`fadtk <model> <base> <eval> --gpus 2` -- plain score and --inf -- used to leave rank 0 alone inside
+    the collectives of load_stats.  Two ranks (gloo, one GPU) run the launcher's main; the CSV line must match the oracle."""
+    import torch.multiprocessing as mp
+    from fadtk_amd import audio
+    n_eval = 12 if extra == "inf" else 4
+    for name, n, seed, gain in (("base", 6, 1800, 1.0), ("eval", n_eval, 1900, 0.8)):
+        (tmp_path / name).mkdir()
+        for i in range(n):
+            audio.write_pcm16(tmp_path / name / f"clip{i:03d}.wav", gain * R.audio_clip(seed + i, int((2.0 + 0.5 * (i % 3)) * 24000), 24000), 24000)
+    mp.spawn(_cli_rank_main, args=(2, _free_port(), str(tmp_path), extra), nprocs=2, join=True)
+    header, line = (tmp_path / f"out{extra}.csv").read_text().strip().split("\n")
+    assert header == "model,baseline,eval,score,inf_r2,time"
+    score = float(line.split(",")[3])
+    if extra == "":
+        stats = []
+        for name in ("base", "eval"):
+            blocks = [np.load(p) for p in sorted((tmp_path / name / "embeddings" / "encodec-emb").glob("*.npy"))]
+            stats.append(O.statistics_online(blocks))
+        ref = O.frechet_distance(*stats[0], *stats[1], run_sqrtm=False)
+        assert abs(score - ref) / abs(ref) < 1e-4
+    else:
+        assert np.isfinite(score) and line.split(",")[4] != "None"
