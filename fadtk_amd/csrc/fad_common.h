@@ -31,6 +31,11 @@ int set_error(int code, const char* fmt, ...);
 int check_device(int device);         // FAD_OK if `device` is a gfx950 GPU
 int num_cus(int device);
 
+// Host (pageable) -> device copy of `rows` rows of `width` bytes through pinned, multi-threaded staging (host_stage.cpp).
+// On return every read of `src` is done and the copy is ordered before later work on `st`; the device is never waited for.
+int host_to_device_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, int device,
+                      hipStream_t st);
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t dtype_size(int dt) {
     switch (dt) { case FAD_F16: case FAD_BF16: return 2; case FAD_F32: return 4; case FAD_F64: return 8; }

@@ -1730,7 +1730,7 @@ extern "C" int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const 
         const int64_t row_bytes = (int64_t)d * es;
         FAD_TRY(ws.rows.reserve((size_t)(n_rows > 0 ? n_rows : 1) * row_bytes + 16));
         if (n_rows > 0)
-            FAD_HIP_TRY(hipMemcpy2DAsync(ws.rows.p, row_bytes, rows, ld * es, row_bytes, n_rows, hipMemcpyHostToDevice, st));
+            FAD_TRY(host_to_device_2d(ws.rows.p, (size_t)row_bytes, rows, (size_t)(ld * es), (size_t)row_bytes, (size_t)n_rows, device, st));
         drows = ws.rows.p; dld = d;
     }
     FAD_TRY(ws.offs.reserve((size_t)(n_songs + 1) * sizeof(int64_t)));

@@ -368,7 +368,9 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
     return update_device_multi(1, &h, &rows, &n, &ld, dtype, st);
 }
 
-// Host rows -> staged through h->stage in bounded chunks (PCIe), then update_device.
+// Host rows -> HBM staging area of the handle in blocks of at most 1 GiB (host_to_device_2d: pinned, pipelined chunks), then
+// update_device on each block.  Nothing is synchronised: the copy of block k + 1 waits ON THE DEVICE for the kernels that
+// still read block k out of the same staging area.
 static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, int dtype, int on_device,
                       hipStream_t st) {
     if (on_device) return update_device(h, rows, n, ld, dtype, st);
@@ -377,15 +379,12 @@ static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, i
     int64_t chunk_rows = ((int64_t)1 << 30) / (row_bytes > 0 ? row_bytes : 1);
     if (chunk_rows < 1024) chunk_rows = 1024;
     chunk_rows = (chunk_rows / 32) * 32;
+    FAD_TRY(h->stage.reserve((size_t)(n < chunk_rows ? n : chunk_rows) * row_bytes + 16));
     for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
         const int64_t m = (n - r0 < chunk_rows) ? n - r0 : chunk_rows;
-        FAD_TRY(h->stage.reserve((size_t)m * row_bytes + 16));
         const char* src = static_cast<const char*>(rows) + r0 * ld * es;
-        FAD_HIP_TRY(hipMemcpy2DAsync(h->stage.p, row_bytes, src, ld * es, row_bytes, m,
-                                     hipMemcpyHostToDevice, st));
+        FAD_TRY(host_to_device_2d(h->stage.p, (size_t)row_bytes, src, (size_t)(ld * es), (size_t)row_bytes, (size_t)m, h->device, st));
         FAD_TRY(update_device(h, h->stage.p, m, h->d, dtype, st));
-        // the staging buffer is reused by the next chunk: wait for the kernels that read it
-        if (r0 + m < n) FAD_HIP_TRY(hipStreamSynchronize(st));
     }
     return FAD_OK;
 }
@@ -579,7 +578,7 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
     if (!on_device) {      // one staged copy serves both kernels (bounded by caller: host blocks are per-batch)
         const int64_t row_bytes = (int64_t)h->d * es;
         FAD_TRY(h->stage.reserve((size_t)n * row_bytes + 16));
-        FAD_HIP_TRY(hipMemcpy2DAsync(h->stage.p, row_bytes, rows, ld * es, row_bytes, n, hipMemcpyHostToDevice, st));
+        FAD_TRY(host_to_device_2d(h->stage.p, (size_t)row_bytes, rows, (size_t)(ld * es), (size_t)row_bytes, (size_t)n, h->device, st));
         drows = h->stage.p; dld = h->d;
     }
     double* dout = seg_sums;

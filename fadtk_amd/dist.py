@@ -49,9 +49,20 @@ def world_size() -> int:
     return 1
 
 
+def _forced() -> bool:
+    """FAD_DIST_FORCE=1: take the multi-rank code path (process group, collectives) even with ONE rank -- how the RCCL route
+    of `--gpus N` is exercised on a single-GPU box (tests/test_gpu_dist.py)."""
+    return os.environ.get("FAD_DIST_FORCE") == "1"
+
+
+def _active() -> bool:
+    """Do collectives have to run?  (several ranks, or a forced one-rank group)"""
+    return is_initialized() and (world_size() > 1 or _forced())
+
+
 def init(backend: str = None) -> bool:
     """Join the job described by RANK / WORLD_SIZE / MASTER_* (torchrun).  No-op for a single process."""
-    if env_world() <= 1 or is_initialized():
+    if (env_world() <= 1 and not (_forced() and "RANK" in os.environ)) or is_initialized():
         return is_initialized()
     import torch
     import torch.distributed as dist
@@ -80,7 +91,7 @@ def shard(items: Sequence, r: int = None, w: int = None) -> list:
 def allreduce_packed(packed, device=None):
     """Sum a packed float64 statistics vector (numpy or torch) over all ranks; returns the same kind.
     RCCL reduces device tensors in place; under gloo (CPU collectives) a device tensor takes the host route."""
-    if world_size() <= 1:
+    if not _active():
         return packed
     import torch
     import torch.distributed as dist
@@ -149,7 +160,7 @@ def allreduce_moments(moments: Sequence) -> None:
 
 def broadcast_object(obj, src: int = 0):
     """Rank ``src``'s python object on every rank (file lists: every rank must shard the SAME list)."""
-    if world_size() <= 1:
+    if not _active():
         return obj
     import torch.distributed as dist
     box = [obj if rank() == src else None]
@@ -159,7 +170,7 @@ def broadcast_object(obj, src: int = 0):
 
 def gather_objects(obj) -> List:
     """All ranks' python objects in rank order (per-song score lists are tiny)."""
-    if world_size() <= 1:
+    if not _active():
         return [obj]
     import torch.distributed as dist
     out = [None] * world_size()
@@ -168,6 +179,6 @@ def gather_objects(obj) -> List:
 
 
 def barrier():
-    if world_size() > 1:
+    if _active():
         import torch.distributed as dist
         dist.barrier()

@@ -123,3 +123,65 @@ def test_plain_score_cli_with_two_ranks(tmp_path, extra):
         assert abs(score - ref) / abs(ref) < 1e-4
     else:
         assert np.isfinite(score) and line.split(",")[4] != "None"
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path -- process group over RCCL, comm stream, fed / reduced events, ONE in-place
+    all_reduce over the buffer that holds both sets' statistics -- runs in no other automated test.  FAD_BENCH_FORCE_DIST=1 takes
+    it with a one-rank RCCL communicator; the JSON line must carry the driver's fields, say which backend and how many ranks the
+    collective saw, and give the same score as the plain path on the same frames."""
+    import json
+    import subprocess
+    import torch
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from fadtk_amd import hip
+    env = dict(os.environ, FAD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"]["collective_backend"] == "nccl" and out["config"]["collective_ranks"] == 1
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+    a, b = bench.make_sets(torch, torch.device("cuda", 0), 0, 0)
+    with hip.Moments(bench.DIM) as ma, hip.Moments(bench.DIM) as mb:
+        hip.Moments.update_multi([ma, mb], [a, b])
+        want, _ = hip.frechet_from_moments(ma, mb, mean_dtype=bench.FAD_F16)
+    assert abs(out["fad"] - want) <= 1e-9 * abs(want)
+
+
+def test_fused_stats_cli_under_torchrun_with_rccl(tmp_path):
+    """`fadtk <model> <base> <eval> <csv> --fused-stats` relaunched the way `--gpus N` relaunches it (torch.distributed.run),
+    with a ONE-rank RCCL group (FAD_DIST_FORCE=1): embed_and_accumulate's shared buffer goes through the nccl all_reduce, rank 0
+    writes the statistics cache and scores.  Checked against the oracle's online statistics of the cached embeddings."""
+    import subprocess
+    from fadtk_amd import audio
+    for name, n, seed, gain in (("base", 7, 2800, 1.0), ("eval", 5, 2900, 0.75)):
+        (tmp_path / name).mkdir()
+        for i in range(n):
+            audio.write_pcm16(tmp_path / name / f"clip{i:03d}.wav", gain * R.audio_clip(seed + i, int((2.0 + 0.5 * (i % 3)) * 24000), 24000), 24000)
+    env = dict(os.environ, FAD_DIST_FORCE="1", FADTK_AMD_RANDOM_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=str(ROOT))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FAD_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "fadtk_amd", "encodec-emb", str(tmp_path / "base"), str(tmp_path / "eval"),
+           str(tmp_path / "out.csv"), "--fused-stats", "-w", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "accumulated on 1 GPU(s)" in r.stderr + r.stdout
+    header, line = (tmp_path / "out.csv").read_text().strip().split("\n")
+    score = float(line.split(",")[3])
+    stats = []
+    for name in ("base", "eval"):
+        blocks = [np.load(p) for p in sorted((tmp_path / name / "embeddings" / "encodec-emb").glob("*.npy"))]
+        stats.append(O.statistics_online(blocks))
+        assert (tmp_path / name / "stats" / "encodec-emb" / "cov.npy").exists()
+    ref = O.frechet_distance(*stats[0], *stats[1], run_sqrtm=False)
+    assert abs(score - ref) / abs(ref) < 1e-4
