@@ -1,14 +1,19 @@
-// Host (pageable) rows -> HBM at PCIe speed: the host side of fad_moments_update / _update_segmented / the per-song call when the
-// caller hands numpy arrays, as fadtk's own callers do (fad.py:42-48 calc_embd_statistics(embd_lst), utils.py:13-16 np.load).
+// Host (pageable) rows -> HBM: the host side of fad_moments_update / _update_segmented / the per-song call when the caller hands
+// numpy arrays, as fadtk's own callers do (fad.py:42-48 calc_embd_statistics(embd_lst), utils.py:13-16 np.load).
 //
-// A pageable hipMemcpy2DAsync goes through the runtime's single staging path: measured 34 GB/s on the MI355X box (round 2:
-// 3.0 ms per [100000 x 512] float16 set, 154 scores/s end to end), well under what PCIe Gen5 x16 carries (63 GB/s spec).  Here
-// the copy is cut into chunks of a few MiB; T host threads each own two PINNED buffers and one copy stream: memcpy of chunk
-// c + 2 into the pinned buffer overlaps the DMA of chunk c, and the T streams keep several SDMA transfers in flight.  When the
-// call returns every read of the caller's buffer is done (the threads are joined), the device copy is ordered in front of
-// whatever the caller enqueues on `st` next, and nothing was synchronised with the device.
+// Three routes, FAD_H2D_MODE (read once per thread):
+//   pageable (default)  one hipMemcpy2DAsync from the caller's pageable buffer: the runtime's own pinned staging
+//   threads             chunks of a few MiB; T host threads each own two PINNED buffers and one copy stream -- the memcpy of
+//                       chunk c + 2 overlaps the DMA of chunk c, several SDMA transfers in flight
+//   register            hipHostRegister the caller's pages in place, one DMA, unregister
+// Measured on the MI355X box, [100000 x 512] float16 = 102.4 MB (scripts/probe_host_path.py, round 3): pageable 2.04 ms =
+// 50.1 GB/s, register 2.01 ms = 51.1 GB/s, threads 2.10-2.42 ms = 42-49 GB/s (4 / 8 / 16 threads, 1-16 MiB chunks) with 9 ms
+// outliers when the workers are scheduled late.  PCIe Gen5 x16 carries ~50 GB/s here whichever way the bytes are staged, so
+// the runtime's route stays the default (round 2's "34 GB/s" was the whole calc_embd_statistics call -- handle creation, the
+// finalize kernel and the 2 MB covariance coming back included -- not the copy); the other two stay selectable for hosts whose
+// runtime path is slower.  In every mode the call returns with all reads of the caller's buffer done and the copy ordered in
+// front of whatever follows on `st`; only `register` waits for the device (the unregister must).
 //
-// FAD_H2D_MODE   threads (default) | register (hipHostRegister the caller's buffer, one DMA, unregister) | pageable (round 2)
 // FAD_H2D_THREADS  1..16 (default 8)      FAD_H2D_CHUNK_KB  (default 4096)
 #include "fad_common.h"
 
@@ -51,7 +56,7 @@ struct Stager {
     int configure() {
         if (mode >= 0) return FAD_OK;
         const char* m = getenv("FAD_H2D_MODE");
-        mode = (m && m[0] == 'r') ? 1 : (m && m[0] == 'p') ? 2 : 0;
+        mode = (m && m[0] == 'r') ? 1 : (m && m[0] == 't') ? 0 : 2;
         const char* t = getenv("FAD_H2D_THREADS");
         int want = t ? atoi(t) : 8;
         if (want < 1) want = 1;

@@ -385,6 +385,9 @@ static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, i
         const char* src = static_cast<const char*>(rows) + r0 * ld * es;
         FAD_TRY(host_to_device_2d(h->stage.p, (size_t)row_bytes, src, (size_t)(ld * es), (size_t)row_bytes, (size_t)m, h->device, st));
         FAD_TRY(update_device(h, h->stage.p, m, h->d, dtype, st));
+        // inputs above 1 GiB reuse the staging area: the runtime's pageable route makes no promise to order its staging copies
+        // behind the kernels that still read the previous block (the pinned routes of host_stage.cpp wait on the device)
+        if (r0 + m < n) FAD_HIP_TRY(hipStreamSynchronize(st));
     }
     return FAD_OK;
 }
