@@ -95,5 +95,26 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+NATIVE_TESTS = PKG.parent / "tests" / "native"
+
+
+def build_native_tests(force: bool = False, verbose: bool = True) -> list:
+    """tests/native/*.hip -> tests/native/<name> (gfx950 executables that check single kernels of csrc/ against host
+    arithmetic; run by `pytest -m gpu`).  Test infrastructure, not part of the library."""
+    out = []
+    for src in sorted(NATIVE_TESTS.glob("*.hip")):
+        exe = src.with_suffix("")
+        if force or _stale(exe, [src, *HEADERS]):
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-o", str(exe), str(src)]
+            if verbose:
+                print("[fadtk_amd.build]", " ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))
+    print(build_native_tests(force="--force" in sys.argv))

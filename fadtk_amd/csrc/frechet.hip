@@ -27,6 +27,7 @@
 #include "ns_check.h"
 #include "ns32.h"
 #include "ns_mean.h"
+#include "ns_fast.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -263,17 +264,18 @@ __global__ void clear_states(NsState* st, int64_t B) {
 }
 
 // ------------------------------------------------------------------------------------------
-struct MixedResult;
 struct Workspace : NsWorkspace {
     DevBuf rows, offs, songbuf, songmat, rows2;     // per-song path
     DevBuf base_root;                               // ... sqrt(Sigma_b) | I | zeros of the symmetric D x D route
     void* song_pin = nullptr; size_t song_pin_cap = 0;      // ... and its pinned staging: offsets going up, scores coming down
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats)
+    DevBuf fast;                                    // the nine-launch chain (ns_fast.h): header, digit planes, split planes
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
     bool busy = false;
     struct Job {
         int d = 0, device = 0, k = 0, mean_dtype = -1, ddof = 1;
         bool mixed = false;                         // the low-precision chain was enqueued (else: end() runs the synchronous path)
+        bool fast = false;                          // ... in its nine-launch form (ns_fast.h); nsf_prepare has staged (mu, Sigma)
         double eps = 0.0;
         hipStream_t stream = nullptr;
         const double *cov1 = nullptr, *cov2 = nullptr, *mu1 = nullptr, *mu2 = nullptr;
@@ -281,7 +283,7 @@ struct Workspace : NsWorkspace {
     hipEvent_t done_ev = nullptr;
     struct Pool* pool = nullptr;
     void release_all() {
-        release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release(); base_root.release();
+        release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release(); base_root.release(); fast.release();
         if (done_ev) { (void)hipEventDestroy(done_ev); done_ev = nullptr; }
         if (song_pin) { (void)hipHostFree(song_pin); song_pin = nullptr; song_pin_cap = 0; }
     }
@@ -304,6 +306,7 @@ struct Pool {
     int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
     int f64_iters = 0;                              // ... and the float64 iteration (single pair), 0 = not known yet
     int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
+    int fast = -1;                                  // FAD_FRECHET_FAST (read once): 0 = round 2's twelve-launch float32 chain
     double pred_thr = 0.0;                          // FAD_FRECHET_PRED_THR (read once; -1 = the built-in rule), see pred_threshold
     void release_all() { for (Workspace& w : slot) w.release_all(); }
 };
@@ -444,12 +447,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
 // is written straight into pinned host memory.  The number of blind iterations is the count the previous call on
 // this thread needed (scores of one run need the same count; a short batch is topped up two at a time).
 // ==========================================================================================
-struct MixedResult {
-    int status;            // 0: low-precision iteration not finished yet, 1: accepted, 2: rejected -> fp64 iteration,
-                           // 4: a PREDICTED final iterate was rejected -> iterate on from `iters` with the strict threshold
-    int iters, decided_at, nonfinite, too_few0, too_few1;
-    double tr_scaled, c, tr1, tr2, mean_term, res, est;
-};
+typedef nsf::FastResult MixedResult;      // status / pieces of the result as the closing kernel leaves them in pinned host memory
 
 // One block: reduce the partials, decide, write the result where the host reads it (pinned host memory).
 __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ stats, int d, int nb,
@@ -483,7 +481,7 @@ __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ st
     o.status = 0; o.iters = s32->final_iter; o.decided_at = s32->decided_at; o.nonfinite = st->nonfinite;
     o.too_few0 = st->too_few[0]; o.too_few1 = st->too_few[1];
     o.c = st->c; o.tr1 = st->tr1; o.tr2 = st->tr2; o.mean_term = st->mean_term;
-    o.tr_scaled = 0.0; o.res = 0.0; o.est = 0.0;
+    o.tr_scaled = 0.0; o.res = 0.0; o.est = 0.0; o.prepared = 1; o.pad = 0;
     if (st->done || s32->failed) {
         o.status = 2;                                 // bad / zero product or fp32 gave up: the fp64 path decides
     } else if (live) {
@@ -595,6 +593,147 @@ static int mixed_enqueue(Workspace& ws, int upto) {
     return FAD_OK;
 }
 
+// ==========================================================================================
+// The nine-launch form of the chain (ns_fast.h): exact products on the int8 MFMA, iteration on split-float16 operands.
+// D in {256, 512, 768, 1024}; FAD_FRECHET_FAST=0 keeps round 2's float32 chain (the two are compared in the tests).
+// ==========================================================================================
+static bool mixed_eligible(Workspace& ws, int d, int max_iter, double tol);
+static bool fast_dim(int d) { return d == 256 || d == 512 || d == 768 || d == 1024; }
+static bool fast_eligible(Workspace& ws, int d, int max_iter, double tol) {
+    Pool* p = ws.pool;
+    if (p && p->fast < 0) { const char* e = getenv("FAD_FRECHET_FAST"); p->fast = (e && e[0] == '0') ? 0 : 1; }
+    return (!p || p->fast) && fast_dim(d) && mixed_eligible(ws, d, max_iter, tol);
+}
+
+struct FastBufs {
+    nsf::FastHdr* hdr;
+    int8_t* digC[2];
+    float *P, *Pt;
+    nsf::SplitMat Y[2], Z[2], T;
+    int8_t *digY[2], *digYt[2];
+};
+static size_t fast_bytes(int d) {
+    const size_t dd = (size_t)d * d;
+    return 256 + 2 * 6 * dd + 2 * 4 * dd + 5 * 4 * 2 * dd + 4 * 6 * dd + 256;
+}
+static FastBufs fast_bufs(Workspace& ws, int d) {
+    const size_t dd = (size_t)d * d;
+    char* p = static_cast<char*>(ws.fast.p);
+    FastBufs f;
+    f.hdr = reinterpret_cast<nsf::FastHdr*>(p); p += 256;
+    for (int i = 0; i < 2; ++i) { f.digC[i] = reinterpret_cast<int8_t*>(p); p += 6 * dd; }
+    f.P = reinterpret_cast<float*>(p); p += 4 * dd;
+    f.Pt = reinterpret_cast<float*>(p); p += 4 * dd;
+    nsf::SplitMat* mats[5] = {&f.Y[0], &f.Y[1], &f.Z[0], &f.Z[1], &f.T};
+    for (nsf::SplitMat* m : mats) {
+        m->h = reinterpret_cast<_Float16*>(p); p += 2 * dd;
+        m->l = reinterpret_cast<_Float16*>(p); p += 2 * dd;
+        m->th = reinterpret_cast<_Float16*>(p); p += 2 * dd;
+        m->tl = reinterpret_cast<_Float16*>(p); p += 2 * dd;
+    }
+    for (int i = 0; i < 2; ++i) { f.digY[i] = reinterpret_cast<int8_t*>(p); p += 6 * dd; f.digYt[i] = reinterpret_cast<int8_t*>(p); p += 6 * dd; }
+    return f;
+}
+
+// K1 on `stream`: (mu, Sigma) of both sets into the slot's staging area (from packed moments, or the caller's device matrices
+// when acc1 == nullptr), state reset, scales, digit planes.
+static int fast_prepare(Workspace& ws, int d, int ddof, const double* acc1, const double* acc2, const double* cov1, const double* cov2,
+                        double* mus, double* covs, hipStream_t st) {
+    FAD_TRY(ws.fast.reserve(fast_bytes(d)));
+    FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
+    FastBufs f = fast_bufs(ws, d);
+    nsf::PrepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.acc[0] = acc1; a.acc[1] = acc2; a.cov_in[0] = cov1; a.cov_in[1] = cov2; a.d = d; a.ddof = ddof; a.mus = mus; a.covs = covs;
+    a.dig[0] = f.digC[0]; a.dig[1] = f.digC[1];
+    a.st = static_cast<NsState*>(ws.small.p);
+    a.s32 = nullptr; a.hdr = f.hdr;
+    hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)((int64_t)d * d / 4096), 2), dim3(256), 0, st, a);
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
+template <int NS> static void fast_launch_split(int mode, unsigned t, const nsf::SplitArgs& g, hipStream_t st) {
+    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_FIRST>), dim3(t, t, 1), dim3(512), 0, st, g);
+    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_T>), dim3(t, t, 1), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_U>), dim3(t, t, 3), dim3(512), 0, st, g);
+}
+static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st) {
+    const unsigned t = (unsigned)(d / 32);
+    switch (d) {
+        case 256: fast_launch_split<2>(mode, t, g, st); break;
+        case 512: fast_launch_split<4>(mode, t, g, st); break;
+        case 768: fast_launch_split<6>(mode, t, g, st); break;
+        default: fast_launch_split<8>(mode, t, g, st); break;
+    }
+}
+template <int NS8> static void fast_launch_i8(int mode, unsigned t, const nsf::I8Args& g, hipStream_t st) {
+    if (mode == nsf::I8_A) hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_A>), dim3(t, t, 2), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_G>), dim3(t, t, 1), dim3(512), 0, st, g);
+}
+static void fast_i8(int d, int mode, const nsf::I8Args& g, hipStream_t st) {
+    const unsigned t = (unsigned)(d / 32);
+    switch (d) {
+        case 256: fast_launch_i8<1>(mode, t, g, st); break;
+        case 512: fast_launch_i8<2>(mode, t, g, st); break;
+        case 768: fast_launch_i8<3>(mode, t, g, st); break;
+        default: fast_launch_i8<4>(mode, t, g, st); break;
+    }
+}
+
+// iterations [ws.job.k, upto) of the chain, then the closing kernels (exact correction, result -> pinned host)
+static int fast_enqueue(Workspace& ws, int upto) {
+    const int d = ws.job.d;
+    hipStream_t stream = ws.job.stream;
+    MixedBufs m = mixed_bufs(ws, d);
+    FastBufs f = fast_bufs(ws, d);
+    const int nslots = (d / 32) * (d / 32);
+    for (int& k = ws.job.k; k < upto; ++k) {
+        nsf::SplitArgs g;
+        memset(&g, 0, sizeof(g));
+        g.d = d; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
+        if (k == 0) {
+            // A = C1 C2 (exact) + its statistics + the mean term, then iteration 0: Y1 = Y0 T0, Z1 = T0
+            nsf::I8Args a;
+            memset(&a, 0, sizeof(a));
+            a.Adig = f.digC[0]; a.Bdig = f.digC[1]; a.d = d; a.hdr = f.hdr; a.stats = m.tilestats;
+            a.A64 = m.A; a.P = f.P; a.Pt = f.Pt; a.st = m.dstate; a.mu1 = ws.job.mu1; a.mu2 = ws.job.mu2; a.mean_dtype = ws.job.mean_dtype;
+            fast_i8(d, nsf::I8_A, a, stream);
+            g.C[0] = f.Y[1]; g.C[1] = f.Z[1]; g.Cdig[0] = f.digY[1]; g.Cdig_t[0] = f.digYt[1];
+            g.P = f.P; g.Pt = f.Pt; g.statsA = m.tilestats;
+            fast_split(d, nsf::SP_FIRST, g, stream);
+            continue;
+        }
+        const int cur = k & 1;
+        // T = (3I - Z Y)/2 and the residual partials of iteration k
+        g.A[0] = f.Z[cur]; g.B[0] = f.Y[cur]; g.C[0] = f.T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f;
+        g.partials = m.partials; g.skip = &m.s32->done;
+        fast_split(d, nsf::SP_T, g, stream);
+        // Y <- Y T, Z <- T Z + the check of iteration k as an extra workgroup
+        memset(&g, 0, sizeof(g));
+        g.d = d; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
+        g.A[0] = f.Y[cur]; g.B[0] = f.T; g.C[0] = f.Y[cur ^ 1];
+        g.A[1] = f.T; g.B[1] = f.Z[cur]; g.C[1] = f.Z[cur ^ 1];
+        g.Cdig[0] = f.digY[cur ^ 1]; g.Cdig_t[0] = f.digYt[cur ^ 1];
+        g.skip = &m.s32->upd_skip[k & 1];
+        g.k = k; g.max_low = kMaxLow; g.nslots = nslots; g.chk_partials = m.partials;
+        g.thr_pred = pred_threshold(ws.pool, d);
+        fast_split(d, nsf::SP_U, g, stream);
+    }
+    // exact correction on the final iterate (which of the ping-pong buffers: known on the device only)
+    nsf::I8Args a;
+    memset(&a, 0, sizeof(a));
+    a.Adig = f.digY[0]; a.Bdig = f.digYt[0]; a.Adig_alt = f.digY[1]; a.Bdig_alt = f.digYt[1]; a.sel = &m.s32->final_iter;
+    a.d = d; a.hdr = f.hdr; a.skip = &m.s32->skip_corr; a.stats = m.tilestats; a.st = m.dstate; a.A64in = m.A;
+    a.Y[0] = f.Y[0]; a.Y[1] = f.Y[1]; a.Z[0] = f.Z[0]; a.Z[1] = f.Z[1];
+    fast_i8(d, nsf::I8_G, a, stream);
+    hipLaunchKernelGGL(nsf::nsf_finish, dim3(1), dim3(256), 0, stream, m.tilestats, d, (int)m.nb, f.hdr, m.dstate, m.s32, m.hres, kMaxLow);
+    FAD_HIP_TRY(hipGetLastError());
+    if (!ws.done_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&ws.done_ev, hipEventDisableTiming));
+    FAD_HIP_TRY(hipEventRecord(ws.done_ev, stream));
+    return FAD_OK;
+}
+
 // Enqueue the whole low-precision chain of ONE problem on `stream` (nothing is waited for): C1 C2, statistics, scale,
 // iteration 0, the blind batch of iterations, the closing kernels.  The state words must have been cleared.
 static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Workspace& ws) {
@@ -612,6 +751,13 @@ static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Work
     MixedBufs m = mixed_bufs(ws, d);
     m.hres->status = -1;
     ws.job.d = d; ws.job.device = device; ws.job.stream = stream; ws.job.k = 0;
+    if (ws.job.fast) {                           // (nsf_prepare is on the stream already: fast_prepare)
+        ws.job.mu1 = pb.mu1; ws.job.mu2 = pb.mu2; ws.job.mean_dtype = pb.mean_dtype;
+        int want = ws.pool ? ws.pool->lp_iters : 5;
+        if (want < 2) want = 2;
+        if (want > kMaxLow) want = kMaxLow;
+        return fast_enqueue(ws, want);
+    }
     // A = C1 C2 with its tile statistics from the epilogue and the mean term from a spare workgroup (one launch instead of
     // product + ns_tilestats), then the scale
     NsProductExt ext;
@@ -639,7 +785,8 @@ static int mixed_finish(Workspace& ws, MixedResult* res) {
             break;
         }
         if (ws.job.k >= kMaxLow) break;
-        FAD_TRY(mixed_enqueue(ws, (ws.job.k + 2 < kMaxLow) ? ws.job.k + 2 : kMaxLow));
+        const int upto = (ws.job.k + 2 < kMaxLow) ? ws.job.k + 2 : kMaxLow;
+        FAD_TRY(ws.job.fast ? fast_enqueue(ws, upto) : mixed_enqueue(ws, upto));
     }
     *res = *m.hres;
     if (res->status == 0) res->status = 2;
@@ -678,9 +825,9 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
             }
             return FAD_OK;
         }
-        // rejected: the float64 iteration takes over from the product C1 C2 and the state ns_prepare armed for this very
-        // problem (nothing in the float32 leg writes to either)
-        reuse = true;
+        // rejected: the float64 iteration takes over from the product C1 C2 and the state that was armed for this very
+        // problem (nothing in the low-precision leg writes to either) -- unless the chain never got that far (prepared = 0)
+        reuse = r.prepared != 0;
     }
     FAD_TRY(run_ns(pb, max_iter, tol, device, stream, ws, &hs, reuse));
     if (check_few && (hs->too_few[0] || hs->too_few[1]))
@@ -1140,7 +1287,8 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
     Workspace& ws = *wsp;
     ws.job = Workspace::Job();
     FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
-    hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, st, static_cast<NsState*>(ws.small.p), (int64_t)1);
+    const bool fast = fast_eligible(ws, d, max_iter, tol);
+    if (!fast) hipLaunchKernelGGL(clear_states, dim3(1), dim3(64), 0, st, static_cast<NsState*>(ws.small.p), (int64_t)1);
     const int64_t dd = (int64_t)d * d;
     const double *dc1 = cov1, *dc2 = cov2, *dm1 = mu1, *dm2 = mu2;
     if (!on_device) {
@@ -1152,6 +1300,10 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
         FAD_HIP_TRY(hipMemcpyAsync(s + 2 * dd + d, mu2, d * sizeof(double), hipMemcpyHostToDevice, st));
         dc1 = s; dc2 = s + dd; dm1 = s + 2 * dd; dm2 = s + 2 * dd + d;
     }
+    if (fast) {                                    // state reset, scales and digit planes from the caller's matrices
+        ws.job.fast = true;
+        FAD_TRY(fast_prepare(ws, d, 1, nullptr, nullptr, dc1, dc2, nullptr, nullptr, st));
+    }
     return frechet_single(d, dc1, dc2, dm1, dm2, eps, max_iter, tol, -1, device, st, ws, out_fad, diag, false);
 }
 
@@ -1159,7 +1311,7 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
 // area and the iteration state is cleared.  (Forming Sigma inside the first product instead -- from the packed statistics,
 // between registers and LDS -- was measured: 18.7 us against 12.4 + 4.8 for product + this launch; dropped.)
 static int stage_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps, int mean_dtype,
-                              hipStream_t st, Workspace& ws) {
+                              hipStream_t st, Workspace& ws, int max_iter = 0, double tol = 0.0) {
     if (!h1 || !h2) return set_error(FAD_ERR_INVALID, "NULL argument");
     const int d = moments_dim(h1), device = moments_device(h1);
     if (moments_dim(h2) != d)
@@ -1174,6 +1326,10 @@ static int stage_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, 
     ws.job = Workspace::Job();
     ws.job.d = d; ws.job.device = device; ws.job.stream = st; ws.job.eps = eps; ws.job.mean_dtype = mean_dtype; ws.job.ddof = ddof;
     ws.job.cov1 = s; ws.job.cov2 = s + dd; ws.job.mu1 = s + 2 * dd; ws.job.mu2 = s + 2 * dd + d;
+    if (fast_eligible(ws, d, max_iter, tol)) {     // the nine-launch chain: its first kernel does this staging as well
+        ws.job.fast = true;
+        return fast_prepare(ws, d, ddof, moments_packed(h1), moments_packed(h2), nullptr, nullptr, s + 2 * dd, s, st);
+    }
     hipLaunchKernelGGL(finalize_for_frechet, dim3((unsigned)cdiv(dd, 256), 2), dim3(256), 0, st, moments_packed(h1), moments_packed(h2),
                        d, ddof, s + 2 * dd, s, static_cast<NsState*>(ws.small.p));
     FAD_HIP_TRY(hipGetLastError());
@@ -1190,7 +1346,7 @@ int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, i
     if (!wsp) return set_error(FAD_ERR_INVALID, "all %d Frechet slots of this thread are in flight: collect one with fad_frechet_end", Pool::kSlots);
     Workspace& ws = *wsp;
     ws.pool = &thread_pool(device);
-    FAD_TRY(stage_from_moments(h1, h2, ddof, eps, mean_dtype, st, ws));
+    FAD_TRY(stage_from_moments(h1, h2, ddof, eps, mean_dtype, st, ws, max_iter, tol));
     const Workspace::Job j = ws.job;
     return frechet_single(j.d, j.cov1, j.cov2, j.mu1, j.mu2, eps, max_iter, tol, mean_dtype, device, st, ws, out_fad, diag, true);
 }

@@ -1002,3 +1002,76 @@ def test_moments_bind_keeps_statistics_in_callers_buffer(F):
         torch.cuda.synchronize()
         # (two blocks group the fp32 partial sums differently: fp32-level agreement, as in the streaming test)
         np.testing.assert_allclose(buf[:plen].cpu().numpy(), want, rtol=0, atol=1e-6 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("d,n", [(256, 3000), (512, 6000), (768, 9000), (1024, 12000)])
+def test_frechet_nine_launch_chain_matches_float32_chain_and_oracle(F, monkeypatch, d, n):
+    """Round 3: for D in {256, 512, 768, 1024} the square root runs as nine launches -- exact products on the int8 MFMA, iteration
+    on split-float16 operands (csrc/ns_fast.h).  From packed moments (the bench's route, float16 frames, the reference's float16
+    mean term) and from host matrices it must give what round 2's float32 chain gives (FAD_FRECHET_FAST=0, new thread = new
+    workspace), what the all-float64 iteration gives, and the oracle's value far below the 1e-4 bar."""
+    import threading
+    import torch
+    from fadtk_amd import hip
+    rng = np.random.default_rng(3 * d + n)
+    a = (rng.standard_normal((n, d)) * (0.6 + 0.8 * rng.random(d))).astype(np.float16)
+    b = (1.04 * rng.standard_normal((n, d)) * (0.6 + 0.8 * rng.random(d)) + 0.015).astype(np.float16)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+
+    def from_moments():
+        with hip.Moments(d) as ma, hip.Moments(d) as mb:
+            hip.Moments.update_multi([ma, mb], [ta, tb])
+            return hip.frechet_from_moments(ma, mb, mean_dtype=0)
+
+    fad, diag = from_moments()
+    assert diag["converged"] == 3, diag
+    fad2, diag2 = from_moments()                       # batch sized by the first call: same decisions, same bits
+    assert fad2 == fad and diag2["iters"] == diag["iters"]
+    out = {}
+
+    def other(key):
+        out[key] = from_moments()
+    monkeypatch.setenv("FAD_FRECHET_FAST", "0")
+    t = threading.Thread(target=other, args=("f32",)); t.start(); t.join()
+    monkeypatch.setenv("FAD_FRECHET_MIXED", "0")
+    t = threading.Thread(target=other, args=("f64",)); t.start(); t.join()
+    assert out["f32"][1]["converged"] == 3 and out["f64"][1]["converged"] in (1, 2)
+    for key in ("f32", "f64"):
+        assert abs(diag["tr_sqrt"] - out[key][1]["tr_sqrt"]) <= 2e-10 * abs(diag["tr_sqrt"]), (key, diag, out[key][1])
+        assert abs(diag["tr1"] - out[key][1]["tr1"]) <= 1e-12 * abs(diag["tr1"]) and diag["mean_term"] == out[key][1]["mean_term"]
+    ref = O.fad_between(a, b)                          # the reference's path on the same float16 frames (float16 mean term)
+    assert abs(fad - ref) <= 2e-6 * abs(ref), (fad, ref)
+    # host matrices through fad_frechet (caller-given Sigma: no moments, the kernels digitise the matrices as they come)
+    monkeypatch.delenv("FAD_FRECHET_FAST"); monkeypatch.delenv("FAD_FRECHET_MIXED")
+    m1, c1, m2, c2 = _pair_stats(a.astype(np.float64), b.astype(np.float64))
+    fad_h, diag_h = hip.frechet(m1, c1, m2, c2)
+    assert diag_h["converged"] == 3
+    ref_h = O.frechet_distance(m1, c1, m2, c2, run_sqrtm=False)
+    assert abs(fad_h - ref_h) <= 1e-7 * abs(ref_h)
+
+
+def test_frechet_nine_launch_chain_degenerate_inputs(F):
+    """What must NOT stay on the fast chain: a zero covariance, NaNs, a hopeless spectrum, fewer than two rows -- the same
+    answers / errors as before, through the float64 route."""
+    import torch
+    from fadtk_amd import hip
+    d = 256
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2000, d))
+    m, c = x.mean(0), np.cov(x, rowvar=False)
+    fad, diag = hip.frechet(m, c, m, np.zeros((d, d)))                       # zero product: root 0
+    assert abs(fad - np.trace(c)) <= 1e-9 * np.trace(c)
+    cn = c.copy(); cn[3, 4] = np.nan
+    with pytest.raises(ValueError):
+        hip.frechet(m, cn, m, c)
+    y = (x * (np.arange(1, d + 1) ** -1.5)).astype(np.float64)             # decaying spectrum: participation ratio far below d/4
+    my, cy = y.mean(0), np.cov(y, rowvar=False)
+    fad_y, diag_y = hip.frechet(my, cy, 1.01 * my, 1.1 * cy)
+    assert diag_y["converged"] in (1, 2)
+    ref = O.frechet_distance(my, cy, 1.01 * my, 1.1 * cy, run_sqrtm=False)
+    assert abs(fad_y - ref) <= 1e-6 * abs(ref)
+    with hip.Moments(d) as ma, hip.Moments(d) as mb:
+        ma.update(torch.from_numpy(x.astype(np.float16)).cuda())
+        mb.update(torch.from_numpy(x[:1].astype(np.float16)).cuda())
+        with pytest.raises(AssertionError):
+            hip.frechet_from_moments(ma, mb)
