@@ -231,6 +231,46 @@ def extra_c5_frames(torch, hip, device):
             "note": "per song: frames times sqrt(Sigma_b) (one root per call), covariance of the [1500 x 768] result, a 768^3 Newton-Schulz on that symmetric matrix (batched over the songs, mirrored tiles skipped)"}
 
 
+def extra_score_inf(fadtk_amd, a_host, b_host):
+    """FAD-inf at config-3 size (fad.py:304-351): 25 resampled sizes of the [100000 x 512] float16 eval set against the
+    baseline's statistics.  Batched device route (frames in HBM, eight resamples per moments launch, square-root chains in
+    flight) vs the point-by-point route through the public functions (host gather, PCIe per point: what round 2 shipped),
+    and 2 of the 25 points through the CPU oracle."""
+    from oracle import fad_oracle as O
+
+    class _M:
+        name = "bench"
+    fad = fadtk_amd.FrechetAudioDistance(_M(), load_model=False)
+    mu_b, cov_b = fadtk_amd.calc_embd_statistics(a_host)
+    mu_b = mu_b.astype(np.float64)
+    ns = [int(n) for n in np.linspace(500, b_host.shape[0], 25)]
+    rng = np.random.default_rng(25)
+    picks = [rng.integers(0, b_host.shape[0], size=n) for n in ns]
+    fad._score_inf_points_on_device(mu_b, cov_b, b_host, picks[:3])        # warm-up (allocations)
+    ms_dev, vals = [], None
+    for _ in range(3):
+        t0 = time.perf_counter(); vals = fad._score_inf_points_on_device(mu_b, cov_b, b_host, picks); ms_dev.append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter(); seq = fad._score_inf_points_sequential(mu_b, cov_b, b_host, picks); ms_seq = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    want = []
+    for k in (2, 12):
+        mu_e, cov_e = O.embd_statistics(b_host[picks[k]])
+        want.append(O.frechet_distance(mu_b, cov_b, mu_e, cov_e, run_sqrtm=True))
+    dt_cpu = time.perf_counter() - t0
+    rel = max(abs(vals[k] - w) / abs(w) for k, w in zip((2, 12), want))
+    xs = 1.0 / np.array(ns)
+    slope, intercept = np.polyfit(xs, np.array(vals), 1)
+    return {"points": 25, "rows": int(b_host.shape[0]), "dim": int(b_host.shape[1]), "resampled_rows_total": int(sum(ns)),
+            "ms_batched_device_route": float(np.median(ms_dev)), "ms_spread": spread(ms_dev), "points_per_s": 25e3 / float(np.median(ms_dev)),
+            "ms_point_by_point_route": ms_seq, "speedup_vs_point_by_point": ms_seq / float(np.median(ms_dev)),
+            "max_rel_diff_between_routes": float(np.max(np.abs(np.array(vals) - np.array(seq)) / np.abs(np.array(seq)))),
+            "fad_inf": float(intercept), "max_rel_err_vs_oracle_sample": float(rel),
+            "cpu_baseline": {"value": 2.0 / dt_cpu, "unit": "points/s", "cores": "BLAS threads as numpy finds them", "kind": "port",
+                             "sample": f"2 of the 25 points (n = {ns[2]} and {ns[12]} resampled rows) through the oracle: fancy-index gather, np.cov, eig + sqrtm",
+                             "seconds": dt_cpu},
+            "note": "includes the upload of the [100000 x 512] eval frames (102 MB) once per call and the 25 index vectors"}
+
+
 def extra_host(fadtk_amd, a_host, b_host, fad_ref):
     """SURVEY 8-d3 'with H2D copy': the same score from PAGEABLE numpy arrays through the reference's own call sequence --
     calc_embd_statistics(A), calc_embd_statistics(B), calc_frechet_distance (fad.py:42-120) -- i.e. 2 x 102.4 MB over PCIe inside
@@ -536,6 +576,10 @@ def main():
                 out.setdefault("extra", {})["host_resident"] = extra_host(fadtk_amd, a_host, b_host, fad0)
             except Exception as e:      # noqa: BLE001
                 out.setdefault("extra", {})["host_resident"] = {"error": repr(e)}
+            try:
+                out["extra"]["score_inf_c3"] = extra_score_inf(fadtk_amd, a_host, b_host)
+            except Exception as e:      # noqa: BLE001
+                out["extra"]["score_inf_c3"] = {"error": repr(e)}
         base, fad_cpu = cpu_baseline(a_host, b_host)
         out["cpu_baseline"] = base
         out["speedup_vs_cpu"] = out["value"] / base["value"]

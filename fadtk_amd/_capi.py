@@ -28,6 +28,7 @@ FAD_ERR_NOT_FINITE = -7
 FAD_ERR_NOT_CONVERGED = -8
 
 FAD_F16, FAD_BF16, FAD_F32, FAD_F64 = 0, 1, 2, 3
+FAD_MEAN_SECOND_ONLY = 16     # | dtype: fad_frechet_from_moments' mean term with only the second mean rounded (include/fad_hip.h)
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libfad_hip.so"
 

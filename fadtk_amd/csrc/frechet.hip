@@ -30,6 +30,7 @@
 #include "ns_fast.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -269,13 +270,15 @@ struct Workspace : NsWorkspace {
     DevBuf base_root;                               // ... sqrt(Sigma_b) | I | zeros of the symmetric D x D route
     void* song_pin = nullptr; size_t song_pin_cap = 0;      // ... and its pinned staging: offsets going up, scores coming down
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats)
-    DevBuf fast;                                    // the nine-launch chain (ns_fast.h): header, digit planes, split planes
+    DevBuf fast;                                    // the eight-launch chain (ns_fast.h): header, digit planes, split planes
+    int fast_gen = 0;                               // per-score token of that chain (FastHdr::flag_gen)
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
     bool busy = false;
     struct Job {
         int d = 0, device = 0, k = 0, mean_dtype = -1, ddof = 1;
         bool mixed = false;                         // the low-precision chain was enqueued (else: end() runs the synchronous path)
-        bool fast = false;                          // ... in its nine-launch form (ns_fast.h); nsf_prepare has staged (mu, Sigma)
+        bool fast = false;                          // ... in its eight-launch form (ns_fast.h); nsf_prepare has staged (mu, Sigma)
+        int gen = 0;                                // ... and this is its token
         double eps = 0.0;
         hipStream_t stream = nullptr;
         const double *cov1 = nullptr, *cov2 = nullptr, *mu1 = nullptr, *mu2 = nullptr;
@@ -447,7 +450,14 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
 // is written straight into pinned host memory.  The number of blind iterations is the count the previous call on
 // this thread needed (scores of one run need the same count; a short batch is topped up two at a time).
 // ==========================================================================================
-typedef nsf::FastResult MixedResult;      // status / pieces of the result as the closing kernel leaves them in pinned host memory
+struct MixedResult {       // status / pieces of the result, in pinned host memory (written by ns32_finish, or by fast_decide on the host)
+    int status;            // 0: low-precision iteration not finished yet, 1: accepted, 2: rejected -> fp64 iteration,
+                           // 4: a PREDICTED final iterate was rejected -> iterate on from `iters` with the strict threshold
+    int iters, decided_at, nonfinite, too_few0, too_few1;
+    double tr_scaled, c, tr1, tr2, mean_term, res, est;
+    int prepared;          // A = C1 C2 (float64) and the armed state are valid: the float64 route may start from them
+    int pad;
+};
 
 // One block: reduce the partials, decide, write the result where the host reads it (pinned host memory).
 __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ stats, int d, int nb,
@@ -594,7 +604,7 @@ static int mixed_enqueue(Workspace& ws, int upto) {
 }
 
 // ==========================================================================================
-// The nine-launch form of the chain (ns_fast.h): exact products on the int8 MFMA, iteration on split-float16 operands.
+// The eight-launch form of the chain (ns_fast.h): exact products on the int8 MFMA, iteration on split-float16 operands.
 // D in {256, 512, 768, 1024}; FAD_FRECHET_FAST=0 keeps round 2's float32 chain (the two are compared in the tests).
 // ==========================================================================================
 static bool mixed_eligible(Workspace& ws, int d, int max_iter, double tol);
@@ -607,48 +617,63 @@ static bool fast_eligible(Workspace& ws, int d, int max_iter, double tol) {
 
 struct FastBufs {
     nsf::FastHdr* hdr;
-    int8_t* digC[2];
-    float *P, *Pt;
-    nsf::SplitMat Y[2], Z[2], T;
-    int8_t *digY[2], *digYt[2];
+    uint4* digC[2];
+    nsf::SplitMat P, Y[2], Z[2], T;
+    uint4 *digY[2], *digYt[2];
+    // pinned host memory behind NsState + MixedResult: what the correction kernel leaves for fast_decide
+    int* host_words; double* host_vals; double* host_stats;
 };
 static size_t fast_bytes(int d) {
     const size_t dd = (size_t)d * d;
-    return 256 + 2 * 6 * dd + 2 * 4 * dd + 5 * 4 * 2 * dd + 4 * 6 * dd + 256;
+    return 256 + 2 * 6 * dd + 6 * 8 * dd + 4 * 6 * dd + 256;
+}
+static size_t fast_pinned_bytes(int d) {
+    const size_t nb = (size_t)d / 32;
+    return sizeof(NsState) + sizeof(MixedResult) + 64 + nsf::kHostWords * sizeof(int) + nsf::kHostVals * sizeof(double) +
+           (nsf::kTileStats + 2) * nb * nb * sizeof(double) + 64;
 }
 static FastBufs fast_bufs(Workspace& ws, int d) {
     const size_t dd = (size_t)d * d;
     char* p = static_cast<char*>(ws.fast.p);
     FastBufs f;
     f.hdr = reinterpret_cast<nsf::FastHdr*>(p); p += 256;
-    for (int i = 0; i < 2; ++i) { f.digC[i] = reinterpret_cast<int8_t*>(p); p += 6 * dd; }
-    f.P = reinterpret_cast<float*>(p); p += 4 * dd;
-    f.Pt = reinterpret_cast<float*>(p); p += 4 * dd;
-    nsf::SplitMat* mats[5] = {&f.Y[0], &f.Y[1], &f.Z[0], &f.Z[1], &f.T};
+    for (int i = 0; i < 2; ++i) { f.digC[i] = reinterpret_cast<uint4*>(p); p += 6 * dd; }
+    nsf::SplitMat* mats[6] = {&f.P, &f.Y[0], &f.Y[1], &f.Z[0], &f.Z[1], &f.T};
     for (nsf::SplitMat* m : mats) {
-        m->h = reinterpret_cast<_Float16*>(p); p += 2 * dd;
-        m->l = reinterpret_cast<_Float16*>(p); p += 2 * dd;
-        m->th = reinterpret_cast<_Float16*>(p); p += 2 * dd;
-        m->tl = reinterpret_cast<_Float16*>(p); p += 2 * dd;
+        m->a = reinterpret_cast<uint4*>(p); p += 4 * dd;
+        m->at = reinterpret_cast<uint4*>(p); p += 4 * dd;
     }
-    for (int i = 0; i < 2; ++i) { f.digY[i] = reinterpret_cast<int8_t*>(p); p += 6 * dd; f.digYt[i] = reinterpret_cast<int8_t*>(p); p += 6 * dd; }
+    for (int i = 0; i < 2; ++i) { f.digY[i] = reinterpret_cast<uint4*>(p); p += 6 * dd; f.digYt[i] = reinterpret_cast<uint4*>(p); p += 6 * dd; }
+    char* h = static_cast<char*>(ws.pinned);
+    f.host_words = nullptr; f.host_vals = nullptr; f.host_stats = nullptr;
+    if (h && ws.pinned_cap >= fast_pinned_bytes(d)) {
+        h += ((sizeof(NsState) + sizeof(MixedResult) + 63) / 64) * 64;
+        f.host_vals = reinterpret_cast<double*>(h); h += nsf::kHostVals * sizeof(double);
+        f.host_stats = reinterpret_cast<double*>(h); h += (nsf::kTileStats + 2) * ((size_t)d / 32) * ((size_t)d / 32) * sizeof(double);
+        f.host_words = reinterpret_cast<int*>(h);
+    }
     return f;
 }
 
-// K1 on `stream`: (mu, Sigma) of both sets into the slot's staging area (from packed moments, or the caller's device matrices
-// when acc1 == nullptr), state reset, scales, digit planes.
+// K1 on `stream`: mu of both sets and (from packed moments) their covariances into the slot's staging area, state reset, scales,
+// digit planes.  acc1 == nullptr: the caller's device matrices cov1 / cov2 are used as they are.
 static int fast_prepare(Workspace& ws, int d, int ddof, const double* acc1, const double* acc2, const double* cov1, const double* cov2,
                         double* mus, double* covs, hipStream_t st) {
+    void* const before = ws.fast.p;
     FAD_TRY(ws.fast.reserve(fast_bytes(d)));
     FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
     FastBufs f = fast_bufs(ws, d);
+    if (ws.fast.p != before) FAD_HIP_TRY(hipMemsetAsync(f.hdr, 0, 256, st));       // a fresh header: no stale token in its flag words
+    ws.job.gen = ++ws.fast_gen;
+    if (ws.fast_gen > (1 << 30)) ws.fast_gen = 1;
     nsf::PrepArgs a;
     memset(&a, 0, sizeof(a));
-    a.acc[0] = acc1; a.acc[1] = acc2; a.cov_in[0] = cov1; a.cov_in[1] = cov2; a.d = d; a.ddof = ddof; a.mus = mus; a.covs = covs;
+    a.acc[0] = acc1; a.acc[1] = acc2; a.cov_in[0] = cov1; a.cov_in[1] = cov2; a.d = d; a.ddof = ddof; a.gen = ws.job.gen;
+    a.mus = mus; a.covs = covs;
     a.dig[0] = f.digC[0]; a.dig[1] = f.digC[1];
     a.st = static_cast<NsState*>(ws.small.p);
-    a.s32 = nullptr; a.hdr = f.hdr;
-    hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)((int64_t)d * d / 4096), 2), dim3(256), 0, st, a);
+    a.hdr = f.hdr;
+    hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)((int64_t)d * d / 2048), 2), dim3(128), 0, st, a);
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
 }
@@ -681,26 +706,27 @@ static void fast_i8(int d, int mode, const nsf::I8Args& g, hipStream_t st) {
     }
 }
 
-// iterations [ws.job.k, upto) of the chain, then the closing kernels (exact correction, result -> pinned host)
+// iterations [ws.job.k, upto) of the chain, then the exact correction, whose partials land in pinned host memory
 static int fast_enqueue(Workspace& ws, int upto) {
     const int d = ws.job.d;
     hipStream_t stream = ws.job.stream;
     MixedBufs m = mixed_bufs(ws, d);
     FastBufs f = fast_bufs(ws, d);
+    if (!f.host_words) return set_error(FAD_ERR_ALLOC, "pinned result area of the fast Frechet chain is missing");
     const int nslots = (d / 32) * (d / 32);
     for (int& k = ws.job.k; k < upto; ++k) {
         nsf::SplitArgs g;
         memset(&g, 0, sizeof(g));
-        g.d = d; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
+        g.d = d; g.gen = ws.job.gen; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
         if (k == 0) {
             // A = C1 C2 (exact) + its statistics + the mean term, then iteration 0: Y1 = Y0 T0, Z1 = T0
             nsf::I8Args a;
             memset(&a, 0, sizeof(a));
-            a.Adig = f.digC[0]; a.Bdig = f.digC[1]; a.d = d; a.hdr = f.hdr; a.stats = m.tilestats;
-            a.A64 = m.A; a.P = f.P; a.Pt = f.Pt; a.st = m.dstate; a.mu1 = ws.job.mu1; a.mu2 = ws.job.mu2; a.mean_dtype = ws.job.mean_dtype;
+            a.Adig = f.digC[0]; a.Bdig = f.digC[1]; a.d = d; a.gen = ws.job.gen; a.hdr = f.hdr; a.stats = m.tilestats;
+            a.A64 = m.A; a.P = f.P; a.st = m.dstate; a.mu1 = ws.job.mu1; a.mu2 = ws.job.mu2; a.mean_dtype = ws.job.mean_dtype;
             fast_i8(d, nsf::I8_A, a, stream);
-            g.C[0] = f.Y[1]; g.C[1] = f.Z[1]; g.Cdig[0] = f.digY[1]; g.Cdig_t[0] = f.digYt[1];
-            g.P = f.P; g.Pt = f.Pt; g.statsA = m.tilestats;
+            g.A[0] = f.P; g.B[0] = f.P; g.C[0] = f.Y[1]; g.C[1] = f.Z[1]; g.Cdig[0] = f.digY[1]; g.Cdig_t[0] = f.digYt[1];
+            g.A64 = m.A; g.statsA = m.tilestats;
             fast_split(d, nsf::SP_FIRST, g, stream);
             continue;
         }
@@ -711,7 +737,7 @@ static int fast_enqueue(Workspace& ws, int upto) {
         fast_split(d, nsf::SP_T, g, stream);
         // Y <- Y T, Z <- T Z + the check of iteration k as an extra workgroup
         memset(&g, 0, sizeof(g));
-        g.d = d; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
+        g.d = d; g.gen = ws.job.gen; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
         g.A[0] = f.Y[cur]; g.B[0] = f.T; g.C[0] = f.Y[cur ^ 1];
         g.A[1] = f.T; g.B[1] = f.Z[cur]; g.C[1] = f.Z[cur ^ 1];
         g.Cdig[0] = f.digY[cur ^ 1]; g.Cdig_t[0] = f.digYt[cur ^ 1];
@@ -724,13 +750,67 @@ static int fast_enqueue(Workspace& ws, int upto) {
     nsf::I8Args a;
     memset(&a, 0, sizeof(a));
     a.Adig = f.digY[0]; a.Bdig = f.digYt[0]; a.Adig_alt = f.digY[1]; a.Bdig_alt = f.digYt[1]; a.sel = &m.s32->final_iter;
-    a.d = d; a.hdr = f.hdr; a.skip = &m.s32->skip_corr; a.stats = m.tilestats; a.st = m.dstate; a.A64in = m.A;
+    a.d = d; a.gen = ws.job.gen; a.hdr = f.hdr; a.skip = &m.s32->skip_corr; a.stats = f.host_stats; a.st = m.dstate; a.A64in = m.A;
     a.Y[0] = f.Y[0]; a.Y[1] = f.Y[1]; a.Z[0] = f.Z[0]; a.Z[1] = f.Z[1];
+    a.s32 = m.s32; a.host_words = f.host_words; a.host_vals = f.host_vals;
+    f.host_words[12] = 0;                          // (the kernel stamps the snapshot with this score's token)
     fast_i8(d, nsf::I8_G, a, stream);
-    hipLaunchKernelGGL(nsf::nsf_finish, dim3(1), dim3(256), 0, stream, m.tilestats, d, (int)m.nb, f.hdr, m.dstate, m.s32, m.hres, kMaxLow);
     FAD_HIP_TRY(hipGetLastError());
     if (!ws.done_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&ws.done_ev, hipEventDisableTiming));
     FAD_HIP_TRY(hipEventRecord(ws.done_ev, stream));
+    return FAD_OK;
+}
+
+// The closing decision, on the host (the enqueued chain has been waited for): reduce the correction's per-tile partials, bound the
+// neglected terms, accept / reject -- what ns32_finish does on the device for the float32 chain, minus a launch.  Fills *m.hres.
+static int fast_decide(Workspace& ws) {
+    const int d = ws.job.d, nb = d / 32;
+    MixedBufs m = mixed_bufs(ws, d);
+    FastBufs f = fast_bufs(ws, d);
+    const int* hw = f.host_words; const double* hv = f.host_vals; const double* hsx = f.host_stats;
+    if (hw[12] != ws.job.gen) return set_error(FAD_ERR_HIP, "the correction kernel of the fast Frechet chain left no result");
+    MixedResult o;
+    memset(&o, 0, sizeof(o));
+    const bool bad = hw[0] != 0;
+    o.status = 0; o.iters = hw[7]; o.decided_at = hw[8]; o.nonfinite = hw[2]; o.too_few0 = hw[3]; o.too_few1 = hw[4];
+    o.c = hv[0]; o.tr1 = hv[1]; o.tr2 = hv[2]; o.mean_term = hv[3];
+    o.prepared = bad ? 0 : 1;
+    const bool ok = hw[5] != 0, failed = hw[6] != 0, strict = hw[9] != 0;
+    if (bad || hw[1] || failed) {
+        o.status = 2;                                // bad / zero product or the low-precision leg gave up: the float64 route decides
+    } else if (ok && !hw[11]) {
+        double corr = 0.0, r2 = 0.0, tr = 0.0, zinf = 0.0, zone = 0.0;
+        for (int t = 0; t < nb * nb; ++t) { corr += hsx[nsf::kTileStats * t]; r2 += hsx[nsf::kTileStats * t + 1]; tr += hsx[nsf::kTileStats * t + 2]; }
+        const double* zmax = hsx + (size_t)nsf::kTileStats * nb * nb;     // [ty * nb + tx]: (row part, column part) of |Z|, rows block tx, columns block ty
+        for (int x = 0; x < nb; ++x) {
+            double rs = 0.0, cs = 0.0;
+            for (int y = 0; y < nb; ++y) { rs += zmax[2 * (y * nb + x)]; cs += zmax[2 * (x * nb + y) + 1]; }
+            if (rs > zinf) zinf = rs;                // >= the largest row sum of |Z| over row block x
+            if (cs > zone) zone = cs;                // >= the largest column sum over column block x
+        }
+        const int fi = hw[7], fm = fi < 16 ? (fi < 0 ? 0 : fi) : 15;
+        double res = hv[4 + fm];
+        if (hw[8] == fi - 1) { const double rp = hv[4 + (fi - 1 < 16 ? (fi - 1 < 0 ? 0 : fi - 1) : 15)]; res = 0.75 * rp * rp + 0.25 * rp * rp * rp; if (res < 2e-6) res = 2e-6; }
+        const double zn = std::sqrt(zinf * zone), rn = std::sqrt(r2);
+        const double trs = tr + 0.5 * corr;
+        const double est = zn * zn * zn * rn * rn / 8.0 + zn * res * rn / 2.0;
+        const bool finite = std::isfinite(trs) && std::isfinite(est);
+        o.tr_scaled = trs; o.res = res; o.est = est;
+        // accepted when the bound on the neglected terms is below 1e-9 of the trace, or moves the DISTANCE by less than 1e-6 of
+        // itself (100x inside the 1e-4 bar; the bound overestimates the true error 10..10^4 times, most for spread spectra where
+        // ||Z|| is large: scripts/ns_emulate_split.py)
+        const double fad = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs;
+        const bool accept = finite && (est <= 1e-9 * std::fabs(trs) || 2.0 * std::sqrt(o.c) * est <= 1e-6 * std::fabs(fad));
+        o.status = accept ? 1 : 2;
+        if (!accept && finite && !strict && hw[8] == fi - 1 && fi + 1 < kMaxLow) {
+            // the iterate was taken as final on a PREDICTED residual and the correction cannot absorb it: nothing is lost --
+            // (Y_f, Z_f) are intact, the iteration goes on from there and only the float32 floor ends it now
+            o.status = 4;
+            hipLaunchKernelGGL(nsf::nsf_rearm, dim3(1), dim3(64), 0, ws.job.stream, m.s32);
+            FAD_HIP_TRY(hipGetLastError());
+        }
+    }
+    *m.hres = o;
     return FAD_OK;
 }
 
@@ -741,7 +821,7 @@ static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Work
     const int64_t dd = (int64_t)d * d;
     FAD_TRY(ws.mats.reserve((size_t)(6 * dd) * sizeof(double)));
     FAD_TRY(ws.mats32.reserve((size_t)(5 * dd) * sizeof(float)));
-    const size_t hbytes = sizeof(NsState) + sizeof(MixedResult);
+    const size_t hbytes = ws.job.fast ? fast_pinned_bytes(d) : sizeof(NsState) + sizeof(MixedResult);
     if (!ws.pinned || ws.pinned_cap < hbytes) {
         if (ws.pinned) (void)hipHostFree(ws.pinned);
         ws.pinned = nullptr; ws.pinned_cap = 0;
@@ -778,6 +858,7 @@ static int mixed_finish(Workspace& ws, MixedResult* res) {
     MixedBufs m = mixed_bufs(ws, ws.job.d);
     for (;;) {
         FAD_HIP_TRY(hipEventSynchronize(ws.done_ev));
+        if (ws.job.fast) FAD_TRY(fast_decide(ws));
         if (m.hres->status == 4) {                 // predicted final iterate rejected: go on from it (state re-armed on the device)
             ws.job.k = m.hres->iters;
             m.hres->status = 0;
@@ -1326,7 +1407,7 @@ static int stage_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, 
     ws.job = Workspace::Job();
     ws.job.d = d; ws.job.device = device; ws.job.stream = st; ws.job.eps = eps; ws.job.mean_dtype = mean_dtype; ws.job.ddof = ddof;
     ws.job.cov1 = s; ws.job.cov2 = s + dd; ws.job.mu1 = s + 2 * dd; ws.job.mu2 = s + 2 * dd + d;
-    if (fast_eligible(ws, d, max_iter, tol)) {     // the nine-launch chain: its first kernel does this staging as well
+    if (fast_eligible(ws, d, max_iter, tol)) {     // the eight-launch chain: its first kernel does this staging as well
         ws.job.fast = true;
         return fast_prepare(ws, d, ddof, moments_packed(h1), moments_packed(h2), nullptr, nullptr, s + 2 * dd, s, st);
     }

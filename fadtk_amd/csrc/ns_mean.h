@@ -22,6 +22,19 @@ __device__ __forceinline__ double mean_term_block(const double* __restrict__ mu1
                                                   int mean_dtype, float* gaps, double* red) {
     const int tid = threadIdx.x;
     double mt = 0.0;
+    if (mean_dtype >= 16) {
+        // FAD_MEAN_SECOND_ONLY | dtype: only the SECOND mean carries the dtype's rounding, the arithmetic stays float64 -- what
+        // score_inf does (fad.py:333-341): mu_base comes from the statistics cache in float64, mu_eval = np.mean of the resampled
+        // float16 frames is float16, and numpy promotes their difference to float64.
+        const int dt = mean_dtype & 3;
+        for (int i = tid; i < d; i += 256) {
+            const double m2 = (dt == FAD_F16) ? round_f16(mu2[i]) : (dt == FAD_BF16) ? round_bf16(mu2[i])
+                              : (dt == FAD_F32) ? (double)(float)mu2[i] : mu2[i];
+            const double df = mu1[i] - m2;
+            mt += df * df;
+        }
+        return block_sum(mt, red);
+    }
     for (int i = tid; i < d; i += 256) { const double df = mu1[i] - mu2[i]; mt += df * df; }
     double mean_term = block_sum(mt, red);             // NaNs/Infs propagate through the sum
     if (mean_dtype == FAD_F16 || mean_dtype == FAD_BF16) {

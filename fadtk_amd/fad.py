@@ -253,27 +253,16 @@ class FrechetAudioDistance:
         max_n = len(embeds)
         ns = [int(n) for n in np.linspace(min_n, max_n, steps)]
 
-        gpu_rows = None
-        try:                                         # keep the frame matrix resident in HBM and gather there
-            import torch
-            if torch.cuda.is_available() and embeds.dtype in (np.float16, np.float32, np.float64):
-                gpu_rows = torch.from_numpy(embeds).to(f"cuda:{self.device_index}")
-        except Exception:       # noqa: BLE001
-            gpu_rows = None
-
-        results = []
-        for n in tq(ns, desc="Calculating FAD-inf"):
-            indices = np.random.choice(embeds.shape[0], size=n, replace=True)
-            if gpu_rows is not None:
-                import torch
-                picked = gpu_rows.index_select(0, torch.from_numpy(indices).to(gpu_rows.device))
-                with hip.Moments(embeds.shape[1], self.device_index) as acc:
-                    acc.update(picked)
-                    mu64, cov_eval, _ = acc.finalize()
-                mu_eval = mu64.astype(np.float32).astype(embeds.dtype) if embeds.dtype != np.float64 else mu64
-            else:
-                mu_eval, cov_eval = calc_embd_statistics(embeds[indices], device=self.device_index)
-            results.append([n, calc_frechet_distance(mu_base, cov_base, mu_eval, cov_eval, device=self.device_index)])
+        # numpy's global RNG is drawn in the reference's order (one choice() per point, fad.py:333) before anything runs
+        picks = [np.random.choice(embeds.shape[0], size=n, replace=True) for n in ns]
+        values = None
+        try:                                          # (both routes run on the HIP library; only WHERE the frames live differs)
+            values = self._score_inf_points_on_device(mu_base, cov_base, embeds, picks)
+        except ImportError:                           # no torch to hold the frames in HBM: host arrays, one point at a time
+            values = None
+        if values is None:
+            values = self._score_inf_points_sequential(mu_base, cov_base, embeds, picks)
+        results = [[n, v] for n, v in zip(ns, values)]
 
         ys = np.array(results)
         xs = 1 / np.array(ns)
@@ -281,6 +270,59 @@ class FrechetAudioDistance:
         fit = slope * xs + intercept
         r2 = 1 - np.sum((ys[:, 1] - fit) ** 2) / np.sum((ys[:, 1] - np.mean(ys[:, 1])) ** 2)
         return FADInfResults(score=intercept, slope=slope, r2=r2, points=results)
+
+    def _score_inf_points_sequential(self, mu_base, cov_base, embeds, picks):
+        """One point after the other through the public functions, as the reference does it (fad.py:333-341): every point gathers
+        on the host, crosses PCIe, and brings (mu, Sigma) back before its distance is taken.  Kept as the fallback of the batched
+        route and as what bench.py compares it with."""
+        out = []
+        for idx in tq(picks, desc="Calculating FAD-inf"):
+            mu_eval, cov_eval = calc_embd_statistics(embeds[idx], device=self.device_index)
+            out.append(calc_frechet_distance(mu_base, cov_base, mu_eval, cov_eval, device=self.device_index))
+        return out
+
+    def _score_inf_points_on_device(self, mu_base, cov_base, embeds, picks):
+        """All points of FAD-inf with the frames resident in HBM: gather-with-replacement on the device, the moments of up to eight
+        resamples per launch (``fad_moments_update_multi``), every distance straight from the accumulators with its square-root
+        chain in flight (``fad_frechet_from_moments_begin``) -- no (mu, Sigma) crosses PCIe.  The baseline's (mu, Sigma) enter as
+        the sufficient statistics of a two-frame pseudo-dataset with exactly that mean and covariance; ``mean_dtype`` asks for
+        the reference's arithmetic of the mean term here: a float64 baseline mean against np.mean of the resampled frames,
+        which keeps their dtype (float16)."""
+        import torch
+        if not torch.cuda.is_available() or embeds.dtype not in (np.float16, np.float32, np.float64):
+            return None
+        dev = torch.device("cuda", self.device_index)
+        d = int(embeds.shape[1])
+        rows = torch.from_numpy(np.ascontiguousarray(embeds)).to(dev)
+        mu_b = np.asarray(mu_base, dtype=np.float64).reshape(-1)
+        cov_b = np.asarray(cov_base, dtype=np.float64)
+        packed = np.concatenate([[2.0], 2.0 * mu_b, (cov_b + 2.0 * np.outer(mu_b, mu_b)).reshape(-1)])
+        code = {np.dtype(np.float16): hip.K.FAD_F16, np.dtype(np.float32): hip.K.FAD_F32}.get(embeds.dtype)
+        mean_dtype = -1 if code is None else (hip.K.FAD_MEAN_SECOND_ONLY | code)
+        budget = 2 << 30                             # bytes of gathered frames alive at once
+        values = []
+        with torch.cuda.device(dev):
+            base = hip.Moments(d, self.device_index).import_(packed)
+            accs = [hip.Moments(d, self.device_index) for _ in range(8)]
+            try:
+                k = 0
+                while k < len(picks):
+                    group, nbytes = [], 0
+                    while k < len(picks) and len(group) < 8 and (not group or nbytes + picks[k].size * d * rows.element_size() <= budget):
+                        group.append(picks[k]); nbytes += picks[k].size * d * rows.element_size(); k += 1
+                    gathered = [rows.index_select(0, torch.from_numpy(idx).to(dev)) for idx in group]
+                    for a in accs[:len(group)]:
+                        a.reset()
+                    hip.Moments.update_multi(accs[:len(group)], gathered)
+                    jobs = [hip.FrechetJob(base, a, mean_dtype=mean_dtype) for a in accs[:len(group)]]
+                    for job in jobs:
+                        fad, _ = job.result()
+                        values.append(np.float64(fad))
+            finally:
+                base.close()
+                for a in accs:
+                    a.close()
+        return values
 
     def score_individual(self, baseline: PathLike, eval_dir: PathLike, csv_name: Union[Path, str]) -> Path:
         """Per-file FAD against the baseline, written as ``path,score`` lines sorted by |score|

@@ -175,7 +175,11 @@ int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2,
  * mean_dtype: how ||mu1 - mu2||^2 is formed.  FAD_F16 / FAD_BF16 / FAD_F32 = as the reference does for embeddings
  * of that dtype: np.mean keeps the dtype (fad.py:48 on the float16 arrays of model_loader.py:47-48), so the means are
  * rounded to it, subtracted in it, and diff.dot(diff) (fad.py:83, 119) is accumulated in float32 and rounded to it
- * (float16: bit for bit what numpy returns).  Anything else (FAD_F64, -1): float64 means. */
+ * (float16: bit for bit what numpy returns).  Anything else (FAD_F64, -1): float64 means.
+ * FAD_MEAN_SECOND_ONLY | dtype: only the mean of the SECOND handle is rounded to the dtype, difference and dot product stay in
+ * float64 -- score_inf's case (fad.py:333-341): a float64 baseline mean from the statistics cache against np.mean of resampled
+ * float16 frames. */
+#define FAD_MEAN_SECOND_ONLY 16
 int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
                              int max_iter, double tol, int mean_dtype, void* stream, double* out_fad, fad_diag_t* diag);
 

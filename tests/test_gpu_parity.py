@@ -131,8 +131,10 @@ def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
         m.set_timing(True)
         m.update(x[:, 128:].repeat(2, axis=1)[:, :d].copy())
         assert m.last_timing()[2] == 0
-    monkeypatch.setenv("FAD_MOMENTS_SHIFT_GUARD", "0")     # without the guard the fp32 partial sums show
-    _, cov_fast = F.calc_embd_statistics(x)
+    monkeypatch.setenv("FAD_MOMENTS_SHIFT_GUARD", "0")     # without the guard the fp32 partial sums show (the knob is read when a
+    with Moments(d) as m:                                  # handle is created; calc_embd_statistics keeps its handle per thread)
+        m.update(x)
+        _, cov_fast, _ = m.finalize()
     assert np.abs(cov_fast[:64, :64] - cov_o[:64, :64]).max() > 1e-7
 
 
@@ -1075,3 +1077,25 @@ def test_frechet_nine_launch_chain_degenerate_inputs(F):
         mb.update(torch.from_numpy(x[:1].astype(np.float16)).cuda())
         with pytest.raises(AssertionError):
             hip.frechet_from_moments(ma, mb)
+
+
+@pytest.mark.parametrize("d,dtype", [(512, np.float16), (128, np.float16), (64, np.float32)])
+def test_score_inf_points_on_device_match_the_sequential_route(F, d, dtype):
+    """score_inf's batched route (frames in HBM, gather on the device, eight resamples per moments launch, distances straight from
+    the accumulators with only the resample's mean rounded to the frames' dtype) against the point-by-point route through
+    calc_embd_statistics / calc_frechet_distance and against the oracle's arithmetic (fad.py:333-341)."""
+    rng = np.random.default_rng(d)
+    rows = (1.1 * rng.standard_normal((6000, d)) * (0.5 + rng.random(d)) + 0.3).astype(dtype)
+    base = rng.standard_normal((8000, d)) * (0.5 + rng.random(d)) + 0.25
+    mu_b, cov_b = base.mean(0), np.cov(base, rowvar=False)
+    fad = F.FrechetAudioDistance(_Toy("toy"), load_model=False)
+    ns = [int(n) for n in np.linspace(500, rows.shape[0], 11)]
+    picks = [rng.integers(0, rows.shape[0], size=n) for n in ns]
+    got = fad._score_inf_points_on_device(mu_b, cov_b, rows, picks)
+    assert got is not None and len(got) == len(picks)
+    seq = fad._score_inf_points_sequential(mu_b, cov_b, rows, picks)
+    np.testing.assert_allclose(got, seq, rtol=2e-6)
+    for idx, v in list(zip(picks, got))[::5]:
+        mu_e, cov_e = O.embd_statistics(rows[idx])
+        ref = O.frechet_distance(mu_b, cov_b, mu_e, cov_e, run_sqrtm=False)
+        assert abs(v - ref) <= FAD_BAR / 10 * abs(ref)
