@@ -50,8 +50,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kDigits = 6;             // balanced base-128 digits per value
-constexpr int kUmin = 3;               // digit pairs (p, q) with p + q >= kUmin are multiplied (weight 2^(7 (p + q) - 80))
-constexpr int kGroups = 2 * (kDigits - 1) - kUmin + 1;      // accumulators: p + q = 3 .. 10
+// digit pairs (p, q) with p + q >= UMIN are multiplied (weight 2^(7 (p + q) - 80)); pairs of equal p + q share an accumulator.
+// UMIN = 3 (30 pairs) reproduces the product of the grid values to ~1e-15 (A = C1 C2, whose scale c may be small); UMIN = 4 (26
+// pairs) to ~1e-12 -- enough for G = Y Y, whose entries are O(1) (scripts/ns_emulate_split.py)
+constexpr int kUminA = 3, kUminG = 4;
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 constexpr int kTileStats = 4;          // doubles per tile in the statistics K2 / K8 leave
 
@@ -156,54 +158,73 @@ __device__ __forceinline__ double hdr_inv_s12(const FastHdr* h) { return 1.0 / (
 struct SplitMat { uint4* a; uint4* at; };
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// K1: means, traces, scales and digit planes of both covariances from the packed moments (or the caller's matrices).
-// grid (d * d / 2048, 2), 128 threads: a thread owns one 16-byte piece of every digit plane = 16 consecutive columns of one row.
+// K1: means, mean term, traces, scales and digit planes of both covariances from the packed moments (or the caller's matrices).
+// grid (d * d / 2048 + 1, 2), 512 threads: a thread owns 4 consecutive columns of one row = one dword of every digit plane;
+// the extra workgroup of set 0 forms both means and the mean term ||mu1 - mu2||^2 (the reference's dtype quirk included).
 struct PrepArgs {
-    const double* acc[2];            // packed moments [n | sum | sum xxT], or nullptr: the caller's Sigma is used as it is
+    const double* acc[2];            // packed moments [n | sum | sum xxT], or nullptr: the caller's (mu, Sigma) are used as they are
     const double* cov_in[2];         // ... then these (device)
-    int d, ddof, gen;
+    const double* mu_in[2];
+    int d, ddof, gen, mean_dtype;
     double* mus;                     // [2][d]          (written only with acc)
     double* covs;                    // [2][d * d]      (written only with acc: what the float64 route reads if it has to take over)
     uint4* dig[2];                   // digit planes of s_1 Sigma_1 (A operand) and of (s_2 Sigma_2)^T (B operand)
     NsState* st; FastHdr* hdr;
 };
 
-__global__ __launch_bounds__(128) void nsf_prepare(PrepArgs a) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
+    __shared__ double red[8 * 2];
+    __shared__ double mu_lds[2 * 1024];
+    __shared__ float gaps[1024];
     const int set = blockIdx.y, tid = threadIdx.x, d = a.d;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the spare workgroup: means of both sets -> global (with acc) and LDS, then the mean term -> state
+        if (set != 0 || tid >= 256) return;
+        for (int q = 0; q < 2; ++q) {
+            const double* acq = a.acc[q];
+            for (int i = tid; i < d; i += 256) {
+                const double m = acq ? acq[1 + i] / acq[0] : a.mu_in[q][i];       // (sum / n: bit for bit what finalize_for_frechet writes)
+                mu_lds[q * 1024 + i] = m;
+                if (acq) a.mus[(int64_t)q * d + i] = m;
+            }
+        }
+        __syncthreads();
+        const double mt = mean_term_block(mu_lds, mu_lds + 1024, d, a.mean_dtype, gaps, red);
+        if (tid == 0) a.st->mean_term = mt;
+        return;
+    }
     const double* acc = a.acc[set];
     const double n = acc ? acc[0] : 2.0;
     const double* sum = acc ? acc + 1 : nullptr;
     const double* M = acc ? acc + 1 + d : a.cov_in[set];
     const double inv_n = 1.0 / n, inv_nd = 1.0 / (n - (double)a.ddof);
-    // this thread's piece: lane (r, g) of k-step ks of row block rb -- consecutive threads are consecutive lanes
-    const int T = blockIdx.x * 128 + tid;
-    const int r = T & 31, g = (T >> 5) & 1, ksrb = T >> 6, ks = ksrb % (d >> 5), rb = ksrb / (d >> 5);
-    const int row = 32 * rb + r, k0 = 32 * ks + 16 * g;
-    // its 16 elements are requested first; the scale is found while they travel.  (The packed moments start at an odd
-    // double: 8-byte loads.)
-    double m[16];
+    // this thread's dword: quarter qd of the piece of lane (r, g), k-step ks, row block rb -- consecutive threads write
+    // consecutive dwords of consecutive pieces
+    const int T = blockIdx.x * 512 + tid;
+    const int qd = T & 3, piece = T >> 2;
+    const int r = piece & 31, g = (piece >> 5) & 1, ksrb = piece >> 6, ks = ksrb % (d >> 5), rb = ksrb / (d >> 5);
+    const int row = 32 * rb + r, k0 = 32 * ks + 16 * g + 4 * qd;
+    // its elements are requested first; the scale is found while they travel.  (The packed moments start at an odd double:
+    // 8-byte loads.)
+    double m[4], sk[4], sr = 0.0;
     const double* Mrow = M + (int64_t)row * d + k0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) m[q] = Mrow[q];
-    double sr = 0.0, sk[16];
+    for (int q = 0; q < 4; ++q) m[q] = Mrow[q];
     if (acc) {
         sr = sum[row];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) sk[q] = sum[k0 + q];
+        for (int q = 0; q < 4; ++q) sk[q] = sum[k0 + q];
     }
     // every workgroup finds the scale itself: trace and largest diagonal entry (a NaN / Inf on the diagonal shows in the trace)
-    double tr = 0.0, mx = 0.0;
-    for (int i = tid; i < d; i += 128) {
+    double tr1[1] = {0.0}, mx = 0.0;
+    for (int i = tid; i < d; i += 512) {
         const double md = M[(int64_t)i * d + i];
         const double v = acc ? (md - (sum[i] * sum[i]) * inv_n) * inv_nd : md;
-        tr += v; mx = fmax(mx, v);
+        tr1[0] += v; mx = fmax(mx, v);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { tr += __shfl_xor(tr, off); mx = fmax(mx, __shfl_xor(mx, off)); }
-    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = tr; red[(tid >> 6) * 2 + 1] = mx; }
-    __syncthreads();
-    tr = red[0] + red[2]; mx = fmax(red[1], red[3]);
+    mx = wg8_max(mx, red);
+    wg8_sum<1>(tr1, red);
+    const double tr = tr1[0];
     const bool few = acc && n < 2.0;
     const bool bad = few || !(tr == tr) || isinf(tr) || !(mx > 0.0) || isinf(mx);
     int ex = 0;
@@ -217,17 +238,15 @@ __global__ __launch_bounds__(128) void nsf_prepare(PrepArgs a) {
             a.st->upd_skip[0] = 0; a.st->upd_skip[1] = 0;
         }
     }
-    if (acc && blockIdx.x == 0)
-        for (int i = tid; i < d; i += 128) a.mus[(int64_t)set * d + i] = sum[i] / n;      // (bit for bit what finalize_for_frechet writes)
     // (Sigma_2 is used as its own transpose: the moments give a bit-for-bit symmetric matrix; for caller-given matrices the
     //  product formed is Sigma_1 Sigma_2^T, which differs from Sigma_1 Sigma_2 by the asymmetry of the caller's Sigma_2 only)
-    uint32_t w[kDigits][4];
+    uint32_t w[kDigits];
 #pragma unroll
-    for (int p = 0; p < kDigits; ++p) { w[p][0] = 0u; w[p][1] = 0u; w[p][2] = 0u; w[p][3] = 0u; }
+    for (int p = 0; p < kDigits; ++p) w[p] = 0u;
     bool off_grid = false;
     double* cov_out = acc ? a.covs + (int64_t)set * d * d + (int64_t)row * d + k0 : nullptr;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 4; ++q) {
         // Sigma[row][k0 + q]: the expression of moments_finalize_kernel up to the reciprocals (symmetric bit for bit)
         const double c0 = acc ? (m[q] - (sr * sk[q]) * inv_n) * inv_nd : m[q];
         if (acc) cov_out[q] = c0;
@@ -237,12 +256,12 @@ __global__ __launch_bounds__(128) void nsf_prepare(PrepArgs a) {
         int dg[kDigits];
         digits_of<double>((bad || !fits) ? 0.0 : v, dg);
 #pragma unroll
-        for (int p = 0; p < kDigits; ++p) w[p][q >> 2] |= ((uint32_t)dg[p] & 0xffu) << (8 * (q & 3));
+        for (int p = 0; p < kDigits; ++p) w[p] |= ((uint32_t)dg[p] & 0xffu) << (8 * q);
     }
     if (off_grid) a.hdr->flag_gen[set] = a.gen;          // (every raiser writes the same value)
     uint4* out = a.dig[set];
 #pragma unroll
-    for (int p = 0; p < kDigits; ++p) out[dg_idx(rb, ks, p, 32 * g + r, d)] = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
+    for (int p = 0; p < kDigits; ++p) reinterpret_cast<uint32_t*>(out + dg_idx(rb, ks, p, 32 * g + r, d))[qd] = w[p];
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -307,7 +326,7 @@ struct I8Args {
     double* stats;                               // I8_A: [nb * nb][4] (device);  I8_G: [nb * nb][4] then [nb * nb][2] (PINNED HOST memory)
     // I8_A
     double* A64; SplitMat P;
-    NsState* st; const double* mu1; const double* mu2; int mean_dtype;
+    NsState* st;
     // I8_G
     const double* A64in;
     SplitMat Y[2], Z[2];
@@ -321,17 +340,9 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     __shared__ __attribute__((aligned(16))) double part[8 * 32 * 33];
     __shared__ float fin[32 * 33];
     __shared__ double red[8 * 4];
+    constexpr int kUmin = (MODE == I8_A) ? kUminA : kUminG;
+    constexpr int kGroups = 2 * (kDigits - 1) - kUmin + 1;
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
-    if constexpr (MODE == I8_A) {
-        if (blockIdx.z == 1) {                   // the spare workgroup: mean term -> state
-            __shared__ float gaps[1024];
-            if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 256) {
-                const double mt = mean_term_block(g.mu1, g.mu2, d, g.mean_dtype, gaps, red);
-                if (tid == 0) g.st->mean_term = mt;
-            }
-            return;
-        }
-    }
     const bool bad = hdr_bad(g.hdr, g.gen);
     const bool skipped = bad || (g.skip && *g.skip != 0);
     if constexpr (MODE == I8_G) {
@@ -554,19 +565,23 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     double2 a2 = make_double2(0.0, 0.0);
     if constexpr (MODE == SP_FIRST) {
         a2 = *reinterpret_cast<const double2*>(g.A64 + (int64_t)(row0 + rr) * d + col0 + 2 * cp);    // this thread's elements of A
-        // ---- the scale (what ns_prepare did in a launch of its own): every workgroup, identically, from K2's tile statistics
+        // ---- the scale (what ns_prepare did in a launch of its own): every workgroup, identically, from K2's tile statistics.
+        // One record per thread goes through LDS (a per-thread loop over a row of records is a chain of dependent cache misses).
         const int nb = gridDim.x;
         const double* scal = g.statsA;
+        double* tmax = reinterpret_cast<double*>(part);              // [2][nb * nb]: largest row / column sum of |a| per tile
         double v2[2] = {0.0, 0.0};
-        for (int k = tid; k < nb * nb; k += 512) { v2[0] += scal[kTileStats * k]; v2[1] += scal[kTileStats * k + 1]; }
+        for (int k = tid; k < nb * nb; k += 512) {
+            const double2 r0 = *reinterpret_cast<const double2*>(scal + kTileStats * k), r1 = *reinterpret_cast<const double2*>(scal + kTileStats * k + 2);
+            v2[0] += r0.x; v2[1] += r0.y;
+            tmax[k] = (r1.x == r1.x) ? r1.x : 1e300; tmax[nb * nb + k] = (r1.y == r1.y) ? r1.y : 1e300;
+        }
+        __syncthreads();
         // ||A||_inf <= max over row blocks of (sum over column blocks of the tile's largest row sum); ||A||_1 likewise
         double bnd = 0.0;
         if (tid < 2 * nb) {
             const int line = tid % nb; const bool col = tid >= nb;
-            for (int q = 0; q < nb; ++q) {
-                const double t = col ? scal[kTileStats * (q * nb + line) + 3] : scal[kTileStats * (line * nb + q) + 2];
-                bnd += (t == t) ? t : 1e300;
-            }
+            for (int q = 0; q < nb; ++q) bnd += col ? tmax[nb * nb + q * nb + line] : tmax[line * nb + q];
         }
         const double inf_b = wg8_max((tid < nb) ? bnd : 0.0, red);
         const double one_b = wg8_max((tid >= nb && tid < 2 * nb) ? bnd : 0.0, red);
@@ -575,14 +590,17 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         double u = sqrt(fro2);
         if (inf_b < u) u = inf_b;
         if (one_b < u) u = one_b;
-        double c = u / 2.5;                              // every eigenvalue of A/c below 3 (above, Y converges to a NEGATIVE root)
+        // every eigenvalue of A/c must stay below 3 (above, Y converges to a NEGATIVE root): c = u / 2.9 is safe because u bounds
+        // the spectral radius; the tile bounds are ~15 % above the true norms of a noise-like matrix, which round 2 divided by 2.5
+        double c = u / 2.9;
         const double wmean = (trA > 0.0) ? fro2 / trA : 0.0;      // where the bulk of a flat spectrum sits (||A||_F^2 stands in for tr A^2)
         if (wmean > c && wmean <= u) c = wmean;
         const double mean_term = g.st->mean_term, tr1 = g.hdr->tr[0], tr2 = g.hdr->tr[1];
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
         // the float32-class iteration only serves spectra that are flat within a few hundred: participation ratio (tr A)^2 / ||A||_F^2 >= d/4
-        const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2);
+        // ... and whose bulk is not far below the largest covariance entries: A lives on a fixed-point grid of 2^-41 relative to those
+        const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
             NsState* st = g.st; Ns32State* s32 = g.s32;
             st->c = zero ? 1.0 : c * hdr_inv_s12(g.hdr);     // in the caller's units: A / st->c = (s1 s2 A) / c

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, visit b: the nine-launch Frechet chain -- kernel checks, parity, bench, kernel sequence
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-out=gpurun_out/r03c; mkdir -p $out
+out=gpurun_out/r03d; mkdir -p $out
 echo "== native kernel checks"
 timeout 600 tests/native/nsfast_check 512 256 768 1024 > $out/nsfast_check.txt 2>&1; echo "nsfast rc=$?"; grep -E "FAIL|==|passed|FAILED|error" $out/nsfast_check.txt | head -60
 echo "== parity tests of the Frechet routes"
@@ -11,7 +11,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 
 import json
 for name in ("bench_fast",):
     try:
-        o = json.load(open(f"gpurun_out/r03c/{name}.json"))
+        o = json.load(open(f"gpurun_out/r03d/{name}.json"))
         print(name, "value", o["value"], "ms/step", o["ms_per_step"], "breakdown", o["breakdown_ms"], "fad", o["fad"], "iters", o["newton_schulz_iters"], o["ns_converged"], "repeat", o["value_repeat_blocks"]["median"], "frac", o["roofline"]["frac"])
     except Exception as e:
         print(name, "unreadable", e)
@@ -19,7 +19,7 @@ PY
 tail -3 $out/bench_fast.err
 FAD_FRECHET_FAST=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $out/bench_f32chain.json 2>/dev/null; python - <<'PY'
 import json
-o = json.load(open("gpurun_out/r03c/bench_f32chain.json"))
+o = json.load(open("gpurun_out/r03d/bench_f32chain.json"))
 print("f32 chain: value", o["value"], "ms/step", o["ms_per_step"], "breakdown", o["breakdown_ms"], "fad", o["fad"], "repeat", o["value_repeat_blocks"]["median"])
 PY
 echo "== rocprofv3 kernel trace of the bench"

@@ -140,7 +140,7 @@ static void run_split(int d, int mode, const SplitArgs& g) {
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
 }
 template <int NS8> static void launch_i8(int mode, unsigned t, const I8Args& g) {
-    if (mode == I8_A) hipLaunchKernelGGL((nsf_i8<NS8, I8_A>), dim3(t, t, 2), dim3(512), 0, 0, g);
+    if (mode == I8_A) hipLaunchKernelGGL((nsf_i8<NS8, I8_A>), dim3(t, t, 1), dim3(512), 0, 0, g);
     else hipLaunchKernelGGL((nsf_i8<NS8, I8_G>), dim3(t, t, 1), dim3(512), 0, 0, g);
 }
 static void run_i8(int d, int mode, const I8Args& g) {
@@ -192,8 +192,8 @@ static void check_dim(int d) {
     CK(hipMemset(d_st, 0, sizeof(NsState))); CK(hipMemset(d_s32, 0, sizeof(Ns32State))); CK(hipMemset(d_hdr, 0, sizeof(FastHdr)));
     PrepArgs pa; memset(&pa, 0, sizeof(pa));
     pa.acc[0] = d_acc[0]; pa.acc[1] = d_acc[1]; pa.d = d; pa.ddof = 1; pa.gen = gen; pa.mus = d_mus; pa.covs = d_covs; pa.dig[0] = d_dig[0]; pa.dig[1] = d_dig[1];
-    pa.st = d_st; pa.hdr = d_hdr;
-    hipLaunchKernelGGL(nsf_prepare, dim3((unsigned)(dd / 2048), 2), dim3(128), 0, 0, pa);
+    pa.st = d_st; pa.hdr = d_hdr; pa.mean_dtype = -1;
+    hipLaunchKernelGGL(nsf_prepare, dim3((unsigned)(dd / 2048 + 1), 2), dim3(512), 0, 0, pa);
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
     FastHdr hdr = d2h(d_hdr, 1)[0];
     auto covs = d2h(d_covs, 2 * dd); auto mus = d2h(d_mus, 2 * d);
@@ -219,15 +219,20 @@ static void check_dim(int d) {
         snprintf(buf, sizeof(buf), "K1 set %d: scale (power of two)", s); report(buf, std::fabs(hdr.s[s] - scale_ref[s]), 0.0);
         snprintf(buf, sizeof(buf), "K1 set %d: trace", s); report(buf, std::fabs(hdr.tr[s] - tr_ref[s]) / tr_ref[s], 1e-13);
     }
+    {
+        NsState st0 = d2h(d_st, 1)[0];
+        double mt = 0.0; for (int i = 0; i < d; ++i) { const double q = mus[i] - mus[d + i]; mt += q * q; }
+        report("K1: mean term (spare workgroup)", std::fabs(st0.mean_term - mt) / mt, 1e-13);
+    }
     report("K1: no flags raised", (double)(hdr.bad[0] | hdr.bad[1]) + (hdr.flag_gen[0] == gen) + (hdr.flag_gen[1] == gen), 0.0);
     {   // a NaN off the diagonal must raise the element flag (caller-given matrices, second set)
         std::vector<double> cz = cov_ref[1]; cz[(size_t)3 * d + 4] = std::nan("");
         double* d_cz = dmalloc<double>(dd); h2d(d_cz, cz);
         FastHdr* d_h2 = dmalloc<FastHdr>(1); CK(hipMemset(d_h2, 0, sizeof(FastHdr)));
-        PrepArgs pb = pa; pb.acc[0] = nullptr; pb.acc[1] = nullptr; pb.cov_in[0] = d_covs; pb.cov_in[1] = d_cz; pb.hdr = d_h2; pb.gen = gen + 1;
+        PrepArgs pb = pa; pb.acc[0] = nullptr; pb.acc[1] = nullptr; pb.cov_in[0] = d_covs; pb.cov_in[1] = d_cz; pb.mu_in[0] = d_mus; pb.mu_in[1] = d_mus + d; pb.hdr = d_h2; pb.gen = gen + 1;
         pb.dig[0] = reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd)); pb.dig[1] = reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd));
         NsState* d_st2 = dmalloc<NsState>(1); pb.st = d_st2;
-        hipLaunchKernelGGL(nsf_prepare, dim3((unsigned)(dd / 2048), 2), dim3(128), 0, 0, pb);
+        hipLaunchKernelGGL(nsf_prepare, dim3((unsigned)(dd / 2048 + 1), 2), dim3(512), 0, 0, pb);
         CK(hipGetLastError()); CK(hipDeviceSynchronize());
         FastHdr h2 = d2h(d_h2, 1)[0];
         report("K1: NaN off the diagonal raises the element flag of its set only", (h2.flag_gen[1] == gen + 1 && h2.flag_gen[0] != gen + 1 && !h2.bad[0] && !h2.bad[1]) ? 0.0 : 1.0, 0.0);
@@ -240,7 +245,7 @@ static void check_dim(int d) {
     double* d_stats = dmalloc<double>((size_t)(kTileStats + 2) * nb * nb);
     I8Args ia; memset(&ia, 0, sizeof(ia));
     ia.Adig = d_dig[0]; ia.Bdig = d_dig[1]; ia.d = d; ia.gen = gen; ia.hdr = d_hdr; ia.stats = d_stats; ia.A64 = d_A64; ia.P = P;
-    ia.st = d_st; ia.mu1 = d_mus; ia.mu2 = d_mus + d; ia.mean_dtype = -1;
+    ia.st = d_st;
     run_i8(d, I8_A, ia);
     auto A64 = d2h(d_A64, dd);
     auto statsA = d2h(d_stats, (size_t)kTileStats * nb * nb);
@@ -267,9 +272,6 @@ static void check_dim(int d) {
         report("K2: per-tile sum a^2", e0, 1e-12);
         report("K2: per-tile trace share", e1, 1e-13);
         report("K2: per-tile largest row / column sum of |a|", e2, 1e-5);
-        NsState st = d2h(d_st, 1)[0];
-        double mt = 0.0; for (int i = 0; i < d; ++i) { const double q = mus[i] - mus[d + i]; mt += q * q; }
-        report("K2: mean term (spare workgroup)", std::fabs(st.mean_term - mt) / mt, 1e-13);
     }
 
     // ---------------- K3: iteration 0.  A well-conditioned stand-in for the product (I + noise, uneven diagonal) is written into
