@@ -349,8 +349,8 @@ def main():
     comm_stream = torch.cuda.Stream(device=device) if distributed else None
 
     class Lane:
-        def __init__(self, k):
-            own = args.lane_streams and n_lanes > 1
+        def __init__(self, k, own=None):
+            own = (args.lane_streams and n_lanes > 1) if own is None else own
             self.stream = torch.cuda.Stream(device=device) if own else torch.cuda.current_stream(device)
             self.shared = fdist.SharedStats(DIM, SETS, local_rank)
             self.ma, self.mb = self.shared.moments
@@ -382,11 +382,12 @@ def main():
             job, self.job = self.job, None
             return job.result()
 
-    lanes = [Lane(k) for k in range(n_lanes)]
+    lanes = all_lanes = [Lane(k) for k in range(n_lanes)]
     plen = lanes[0].ma.packed_len
     ma, mb = lanes[0].ma, lanes[0].mb
 
-    def run_steps(count, marks=None, rotate=True):
+    def run_steps(count, marks=None, rotate=True, lanes=None):
+        lanes = all_lanes if lanes is None else lanes
         """`count` steps, at most n_lanes of them in flight; every one of them is collected before this returns.  Order of the
         enqueues: feed(i), score(i-1), so the device sees  moments(i) | Frechet(i-1) | moments(i+1) | Frechet(i) ...  and the
         host collects score(i - n_lanes) before it reuses that lane -- with three lanes two more steps are queued behind the
@@ -454,6 +455,17 @@ def main():
         return time.perf_counter() - t0
     repeat_s = [block(True) for _ in range(5)] if args.steps > 0 else []
     same_pair_s = [block(False) for _ in range(3)] if args.steps > 0 else []
+    # ... and K steps with ONE STREAM PER SCORE in flight: the latency-bound square-root chain of one score then overlaps the moments
+    # kernel of the next (more scores/s; per-kernel durations include the contention, which is why the headline keeps one stream)
+    per_stream_s = []
+    if args.steps > 0 and n_lanes > 1 and not args.lane_streams:
+        lanes_s = [Lane(k, own=True) for k in range(n_lanes)]
+        run_steps(min(args.steps, 6), None, True, lanes_s)
+        for _ in range(3):
+            fence(); t0 = time.perf_counter(); run_steps(args.steps, None, True, lanes_s); fence()
+            per_stream_s.append(time.perf_counter() - t0)
+        for ln in lanes_s:
+            ln.shared.close()
 
     # ONE launch of the tile kernel covers both sets (recorded on the first handle of lane 0: steps 0, n_lanes, 2 n_lanes ...)
     timed_launches = -(-args.steps // n_lanes)
@@ -502,15 +514,30 @@ def main():
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:       # noqa: BLE001
             traffic = None
-    # Frechet chain: 2 fp64 products (C1 C2, Y Y) + the fp32 iterations (iteration 0 needs one product, every later one
-    # three) when the mixed route ran; 3 fp64 products per iteration (+ C1 C2) on the all-fp64 route
+    # Frechet chain, by route (diag["route"]): 2 = eight launches: split-float16 products (3 MFMA terms each: iteration 0 needs one
+    # product, every later iteration three) + two exact products through digit planes on the int8 MFMA (30 and 26 digit pairs);
+    # 1 = round 2's chain (float32 products on the f32 MFMA + two float64 products); 0 = the all-float64 iteration
     it = int(diag["iters"])
-    if diag["converged"] == 3:
+    route = int(diag.get("route", 0)) if diag["converged"] == 3 else 0
+    d3 = 2.0 * DIM ** 3
+    if route == 2:
+        n_split = 1 + 3 * max(it - 2, 0)
+        work = {"f16_mfma_flops": 3 * n_split * d3, "i8_mfma_ops": (30 + 26) * d3}
+        gemms = {"split_f16_products": n_split, "exact_i8_products": 2, "launches": 2 + 1 + 2 * max(it - 2, 0) + 1}
+        ideal_ms = (work["f16_mfma_flops"] / (MFMA_F16_PEAK_TFLOPS * 1e12) + work["i8_mfma_ops"] / (2 * MFMA_F16_PEAK_TFLOPS * 1e12)) * 1e3
+        peak_note = "time the issued MFMA work needs at the dense peaks (f16 2.5 PFLOP/s, int8 5 POP/s: MI355X_MICROARCH.md) / measured time"
+    elif route == 1:
         gemms = {"f32": 1 + 3 * max(it - 2, 0), "f64": 2}
+        work = {"f32_mfma_flops": gemms["f32"] * d3, "f64_mfma_flops": 2 * d3}
+        ideal_ms = (work["f32_mfma_flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12) + work["f64_mfma_flops"] / 78.6e12) * 1e3
+        peak_note = "f32-input MFMA 157.3 TFLOP/s, f64 MFMA 78.6 TFLOP/s (datasheet)"
     else:
-        gemms = {"f32": 0, "f64": 1 + 1 + 3 * max(it - 1, 0)}
+        gemms = {"f64": 1 + 1 + 3 * max(it - 1, 0)}
+        work = {"f64_mfma_flops": gemms["f64"] * d3}
+        ideal_ms = work["f64_mfma_flops"] / 78.6e12 * 1e3
+        peak_note = "f64 MFMA 78.6 TFLOP/s (datasheet)"
     fr_ms = float(np.median(bf))
-    fr_flops = (gemms["f32"] + gemms["f64"]) * 2.0 * DIM ** 3
+    fr_flops = float(sum(work.values()))
     out = {
         "metric": "FAD scores/sec + cov-GEMM TFLOP/s (% MFMA peak), N=100k D=512",
         "value": n_gpus * args.steps / elapsed,
@@ -536,6 +563,10 @@ def main():
                                 "min": min(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None,
                                 "max": max(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None, "blocks": len(repeat_s),
                                 "note": "the same K steps repeated outside the timed region (rank 0's clock)"},
+        "value_stream_per_score": {"median": float(np.median([n_gpus * args.steps / t for t in per_stream_s])) if per_stream_s else None,
+                                   "blocks": len(per_stream_s),
+                                   "note": "the same K steps with one HIP stream per score in flight (--lane-streams): chains and moments "
+                                           "kernels of consecutive scores overlap"},
         "value_same_pair": {"median": float(np.median([n_gpus * args.steps / t for t in same_pair_s])) if same_pair_s else None,
                             "blocks": len(same_pair_s),
                             "note": "K steps that re-feed ONE pair (204.8 MB: Infinity-Cache resident) -- the loop rounds 1-2 timed"},
@@ -559,12 +590,12 @@ def main():
                      "algorithmic_bytes_per_launch": SETS * N_ROWS * DIM * 2,
                      "hbm_GBps_algorithmic": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
                      "hbm_frac_of_8TBps": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "roofline_frechet": {"kernels": "finalize + gemm_f64 (C1 C2, Y Y) + gemm_f32 x%d + 5 small kernels" % gemms["f32"],
-                             "bound": "launch-chain latency (dependent D^3 products of 0.27 GFLOP each)",
-                             "gemms": gemms, "flops": fr_flops, "ms": fr_ms, "achieved": fr_flops / (fr_ms * 1e-3) / 1e12,
-                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fr_flops / (fr_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                             "peak_source": "f32-input MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md); the two fp64 products run on "
-                                            "v_mfma_f64_16x16x4 (measured ceiling 45-47 TFLOP/s, scripts/probes/mfma_rate.hip)"},
+        "roofline_frechet": {"route": {2: "eight launches: split-float16 Newton-Schulz + exact int8-MFMA products (csrc/ns_fast.h)",
+                                       1: "float32 Newton-Schulz on the f32 MFMA + float64 correction", 0: "all-float64 iteration"}[route],
+                             "bound": "launch chain: ~4.2 us per dependent launch before it does anything, then the CU's vector-memory "
+                                      "path (128-192 KB of operands per 32 x 32 tile); the matrix pipes are idle most of the time",
+                             "gemms": gemms, "work": work, "ms": fr_ms, "achieved": fr_flops / (fr_ms * 1e-3) / 1e12, "unit": "T(FL)OP/s issued",
+                             "ideal_ms_at_mfma_peaks": ideal_ms, "frac": ideal_ms / fr_ms, "peak_source": peak_note},
     }
     if extra:
         out["extra"] = extra

@@ -904,7 +904,7 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
             const double tr_sqrt = sqrt(r.c) * r.tr_scaled;
             if (out_fad) *out_fad = r.mean_term + r.tr1 + r.tr2 - 2.0 * tr_sqrt;
             if (diag) {
-                diag->iters = r.iters + 1; diag->converged = 3; diag->used_eps = 0; diag->reserved = 0;
+                diag->iters = r.iters + 1; diag->converged = 3; diag->used_eps = 0; diag->route = ws.job.fast ? 2 : 1;
                 diag->residual = r.res; diag->scale = r.c; diag->mean_term = r.mean_term; diag->tr1 = r.tr1; diag->tr2 = r.tr2;
                 diag->tr_sqrt = tr_sqrt;
             }
@@ -943,7 +943,7 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
     if (out_fad) *out_fad = hs->mean_term + tr1 + tr2 - 2.0 * tr_sqrt;
     if (diag) {
         diag->iters = hs->final_iter + 1; diag->converged = hs->conv; diag->used_eps = used_eps ? 1 : 0;
-        diag->reserved = 0; diag->residual = hs->res_last; diag->scale = hs->c;
+        diag->route = 0; diag->residual = hs->res_last; diag->scale = hs->c;
         diag->mean_term = hs->mean_term; diag->tr1 = tr1; diag->tr2 = tr2; diag->tr_sqrt = tr_sqrt;
     }
     if (hs->conv == 0)

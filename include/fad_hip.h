@@ -149,8 +149,10 @@ int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_r
  *   ||mu1-mu2||^2 + tr C1 + tr C2 - 2 tr sqrt(C1 C2)
  * tr sqrt(C1 C2) = sum_i sqrt(lambda_i(C1 C2)) -- the value the reference returns through
  * scipy.linalg.eig (fad.py:91-92) -- is computed with a coupled Newton-Schulz iteration on MFMA tiles: for
- * well-conditioned products (and d a multiple of 64) the iterations run in float32 and one float64 correction
- * restores float64 accuracy; otherwise (or when max_iter / tol are given) everything runs in float64.
+ * well-conditioned products (and d a multiple of 64) the iterations run in low precision (float32 on the f32 MFMA; for
+ * d = 256 / 512 / 768 / 1024 split float16 on the f16 MFMA with the two products that need it formed EXACTLY through
+ * base-128 digit planes on the int8 MFMA) and one float64-accurate correction restores float64 accuracy; otherwise (or
+ * when max_iter / tol are given) everything runs in float64.
  * eps: added to both diagonals for a retry when the first attempt diverges (fad.py:94-99).
  * max_iter <= 0 -> default (64); tol <= 0 -> default.
  */
@@ -159,7 +161,8 @@ typedef struct fad_diag {
     int32_t converged;      /* 1: residual < tol, 2: trace stagnated / divergence guard (rank-deficient or near-singular
                                product), 3: float32 iterations + float64 correction accepted, 0: max_iter */
     int32_t used_eps;       /* 1 if the eps-regularised retry produced the result                */
-    int32_t reserved;
+    int32_t route;          /* with converged == 3: 1 = float32 iterations on the f32 MFMA, 2 = split-float16 iterations + exact
+                               int8-MFMA products (d = 256 / 512 / 768 / 1024); 0 otherwise (all-float64 iteration)        */
     double residual;        /* ||I - Z Y||_F at the last iteration                               */
     double scale;           /* c with Y0 = C1 C2 / c                                             */
     double mean_term;       /* ||mu1 - mu2||^2 in float64                                        */

@@ -124,7 +124,7 @@ static double scale_from_stats(const std::vector<double>& rec, int d) {
         inf_b = std::fmax(inf_b, a); one_b = std::fmax(one_b, b);
     }
     double u = std::sqrt(fro2); if (inf_b < u) u = inf_b; if (one_b < u) u = one_b;
-    double c = u / 2.5; const double wm = fro2 / tr; if (wm > c && wm <= u) c = wm;
+    double c = u / 2.9; const double wm = fro2 / tr; if (wm > c && wm <= u) c = wm;
     return c;
 }
 
