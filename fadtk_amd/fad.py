@@ -300,24 +300,30 @@ class FrechetAudioDistance:
         code = {np.dtype(np.float16): hip.K.FAD_F16, np.dtype(np.float32): hip.K.FAD_F32}.get(embeds.dtype)
         mean_dtype = -1 if code is None else (hip.K.FAD_MEAN_SECOND_ONLY | code)
         budget = 2 << 30                             # bytes of gathered frames alive at once
-        values = []
+        # Resamples of fewer than 16 rows per column have (nearly) rank-deficient covariances: the distance then moves with the
+        # SQUARE ROOT of a perturbation of the moments, and the library sums such inputs exactly in float64 -- but it picks the
+        # kernel per launch, by the launch's largest set.  So short and long resamples never share a launch.
+        order = [k for k in range(len(picks)) if picks[k].size < 16 * d] + [k for k in range(len(picks)) if picks[k].size >= 16 * d]
+        n_short = sum(1 for idx in picks if idx.size < 16 * d)
+        values = [None] * len(picks)
         with torch.cuda.device(dev):
             base = hip.Moments(d, self.device_index).import_(packed)
             accs = [hip.Moments(d, self.device_index) for _ in range(8)]
             try:
-                k = 0
-                while k < len(picks):
+                pos = 0
+                while pos < len(order):
+                    stop = n_short if pos < n_short else len(order)
                     group, nbytes = [], 0
-                    while k < len(picks) and len(group) < 8 and (not group or nbytes + picks[k].size * d * rows.element_size() <= budget):
-                        group.append(picks[k]); nbytes += picks[k].size * d * rows.element_size(); k += 1
-                    gathered = [rows.index_select(0, torch.from_numpy(idx).to(dev)) for idx in group]
+                    while pos < stop and len(group) < 8 and (not group or nbytes + picks[order[pos]].size * d * rows.element_size() <= budget):
+                        group.append(order[pos]); nbytes += picks[order[pos]].size * d * rows.element_size(); pos += 1
+                    gathered = [rows.index_select(0, torch.from_numpy(picks[k]).to(dev)) for k in group]
                     for a in accs[:len(group)]:
                         a.reset()
                     hip.Moments.update_multi(accs[:len(group)], gathered)
                     jobs = [hip.FrechetJob(base, a, mean_dtype=mean_dtype) for a in accs[:len(group)]]
-                    for job in jobs:
+                    for k, job in zip(group, jobs):
                         fad, _ = job.result()
-                        values.append(np.float64(fad))
+                        values[k] = np.float64(fad)
             finally:
                 base.close()
                 for a in accs:
