@@ -425,6 +425,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if os.environ.get("FAD_BENCH_PREWARM") == "1":       # diagnosis only: a block of K untimed steps in front of the warm-up
+        run_steps(args.steps)
     run_steps(max(args.warmup, 0))
     # The tile kernel is timed by HIP events the library records around it on the launch stream -- on ONE lane (every
     # n_lanes-th step of the timed region) and without the third event behind the reduce: a timed event record between two
@@ -457,13 +459,17 @@ def main():
     same_pair_s = [block(False) for _ in range(3)] if args.steps > 0 else []
     # ... and K steps with ONE STREAM PER SCORE in flight: the latency-bound square-root chain of one score then overlaps the moments
     # kernel of the next (more scores/s; per-kernel durations include the contention, which is why the headline keeps one stream)
-    per_stream_s = []
+    per_stream_s, per_stream_kernel_ms = [], None
     if args.steps > 0 and n_lanes > 1 and not args.lane_streams:
         lanes_s = [Lane(k, own=True) for k in range(n_lanes)]
         run_steps(min(args.steps, 6), None, True, lanes_s)
-        for _ in range(3):
+        for rep in range(3):
+            if rep == 2:
+                lanes_s[0].ma.set_timing(2)          # what the overlap does to the tile kernel itself (last block)
             fence(); t0 = time.perf_counter(); run_steps(args.steps, None, True, lanes_s); fence()
             per_stream_s.append(time.perf_counter() - t0)
+        per_stream_kernel_ms = lanes_s[0].ma.last_timing()[0]
+        lanes_s[0].ma.set_timing(False)
         for ln in lanes_s:
             ln.shared.close()
 
@@ -564,7 +570,7 @@ def main():
                                 "max": max(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None, "blocks": len(repeat_s),
                                 "note": "the same K steps repeated outside the timed region (rank 0's clock)"},
         "value_stream_per_score": {"median": float(np.median([n_gpus * args.steps / t for t in per_stream_s])) if per_stream_s else None,
-                                   "blocks": len(per_stream_s),
+                                   "blocks": len(per_stream_s), "tile_kernel_ms": per_stream_kernel_ms,
                                    "note": "the same K steps with one HIP stream per score in flight (--lane-streams): chains and moments "
                                            "kernels of consecutive scores overlap"},
         "value_same_pair": {"median": float(np.median([n_gpus * args.steps / t for t in same_pair_s])) if same_pair_s else None,

@@ -368,34 +368,46 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     const uint4* Ad = alt ? g.Adig_alt : g.Adig;
     const uint4* Bd = alt ? g.Bdig_alt : g.Bdig;
 
-    i32x4 a[2][kDigits], b[2][kDigits];
+    // Operand pieces are requested most significant digit first, A and B alternating, and the MFMAs follow in the order the
+    // pieces land: as soon as digit m of both operands is there, every pair with min(p, q) = m can go (the compiler places the
+    // counted waits) -- the matrix pipe starts after two pieces instead of twelve.  D <= 512: all pieces of the wave's k-steps are
+    // requested up front; above, the next k-step is requested while the current one is multiplied.
+    constexpr int NBUF = (NS8 <= 2) ? NS8 : 2;
+    i32x4 a[NBUF][kDigits], b[NBUF][kDigits];
     auto fetch = [&](int buf, int s) {
         const i32x4* pa = reinterpret_cast<const i32x4*>(Ad + dg_idx(ty, wave * NS8 + s, 0, lane, d));
         const i32x4* pb = reinterpret_cast<const i32x4*>(Bd + dg_idx(tx, wave * NS8 + s, 0, lane, d));
 #pragma unroll
-        for (int p = 0; p < kDigits; ++p) { a[buf][p] = pa[64 * p]; b[buf][p] = pb[64 * p]; }
+        for (int m = kDigits - 1; m >= 0; --m) { a[buf][m] = pa[64 * m]; b[buf][m] = pb[64 * m]; }
     };
     i32x16 acc[kGroups];
 #pragma unroll
     for (int u = 0; u < kGroups; ++u)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[u][q] = 0;
-    fetch(0, 0);
+    auto mma = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < NS8; ++s) {
-        if (s + 1 < NS8) fetch((s + 1) & 1, s + 1);
-        // pairs (p, q), p + q = u >= kUmin; the j-th pair of every u in turn, so that consecutive MFMAs use different accumulators
+        for (int m = kDigits - 1; m >= 0; --m) {
 #pragma unroll
-        for (int j = 0; j < kDigits; ++j)
+            for (int q = kDigits - 1; q >= m; --q)
+                if (m + q >= kUmin) acc[m + q - kUmin] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[buf][m], b[buf][q], acc[m + q - kUmin], 0, 0, 0);
 #pragma unroll
-            for (int u = kUmin; u <= 2 * (kDigits - 1); ++u) {
-                const int p_lo = (u > kDigits - 1) ? u - (kDigits - 1) : 0;
-                const int n_u = (u <= kDigits - 1) ? u + 1 : 2 * (kDigits - 1) - u + 1;
-                if (j < n_u) {
-                    const int p = p_lo + j, q = u - p;
-                    acc[u - kUmin] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s & 1][p], b[s & 1][q], acc[u - kUmin], 0, 0, 0);
-                }
-            }
+            for (int p = kDigits - 1; p > m; --p)
+                if (p + m >= kUmin) acc[p + m - kUmin] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[buf][p], b[buf][m], acc[p + m - kUmin], 0, 0, 0);
+        }
+    };
+    if constexpr (NS8 <= 2) {
+#pragma unroll
+        for (int s = 0; s < NS8; ++s) fetch(s, s);
+#pragma unroll
+        for (int s = 0; s < NS8; ++s) mma(s);
+    } else {
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < NS8; ++s) {
+            if (s + 1 < NS8) fetch((s + 1) & 1, s + 1);
+            mma(s & 1);
+        }
     }
     // this wave's share of the tile in float64: sum_u acc_u 2^(7 u - 80)
     double gp[16];
