@@ -825,6 +825,14 @@ int fad_moments_set_timing(fad_moments_t* h, int enabled) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
     h->timing = (enabled == 2) ? 2 : (enabled != 0 ? 1 : 0);
     h->ev_count = 0;
+    if (h->timing && !h->ev) {
+        // the ring of events is created HERE, not by the first timed update: 768 hipEventCreate calls took ~0.35 ms out of
+        // bench.py's timed region (round 3: the timed block read 8-10 % below the same block repeated without them)
+        DeviceGuard g(h->device);
+        h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3];
+        if (!h->ev) return set_error(FAD_ERR_ALLOC, "out of host memory");
+        for (int i = 0; i < fad_moments::kRing * 3; ++i) FAD_HIP_TRY(hipEventCreate(&h->ev[i]));
+    }
     return FAD_OK;
 }
 
