@@ -231,6 +231,39 @@ def extra_c5_frames(torch, hip, device):
             "note": "per song: frames times sqrt(Sigma_b) (one root per call), covariance of the [1500 x 768] result, a 768^3 Newton-Schulz on that symmetric matrix (batched over the songs, mirrored tiles skipped)"}
 
 
+def extra_c4_songs(torch, hip, device):
+    """Config-4 shape per song (Encodec: D = 128, 30 s at 75 frames/s): 2000 songs of [2250 x 128] float16 frames against one baseline,
+    one batched call (five timed, median); every song is a full 128 x 128 problem.  CPU baseline = 16 of the songs through the oracle."""
+    from oracle import fad_oracle as O
+    nsongs, frames, d4 = 2000, 2250, 128
+    g4 = torch.Generator(device=device); g4.manual_seed(44)
+    scale = 0.6 + 0.8 * torch.rand((d4,), generator=g4, device=device)
+    songs = (torch.randn((nsongs * frames, d4), generator=g4, device=device) * scale).to(torch.float16)
+    base = torch.randn((50000, d4), generator=g4, device=device, dtype=torch.float64) * scale.double() * 1.03 + 0.02
+    mu4 = base.mean(0).cpu().numpy(); cov4 = torch.cov(base.T).cpu().numpy()
+    offs = np.arange(0, nsongs * frames + 1, frames)
+    hip.frechet_batched(mu4, cov4, songs, offs)
+    ms = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sc, stt = hip.frechet_batched(mu4, cov4, songs, offs)
+        torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
+    dt = float(np.median(ms)) * 1e-3
+    n_cpu = 16
+    sample = songs[: n_cpu * frames].cpu().numpy()
+    t0 = time.perf_counter()
+    want = [O.individual_scores(mu4, cov4, [sample[i * frames:(i + 1) * frames]], run_sqrtm=True)[0] for i in range(n_cpu)]
+    dt_cpu = time.perf_counter() - t0
+    want = np.array([np.nan if w is None else float(w) for w in want])
+    rel = float(np.nanmax(np.abs(sc[:n_cpu] - want) / np.abs(want)))
+    return {"songs": nsongs, "dim": d4, "frames_per_song": frames, "ms": dt * 1e3, "ms_spread": spread(ms), "songs_per_s": nsongs / dt,
+            "ok": int((stt == 0).sum()), "max_rel_err_vs_oracle_sample": rel,
+            "GBps_frames": songs.numel() * 2 / dt / 1e9,
+            "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": "BLAS threads as numpy finds them", "kind": "port",
+                             "sample": f"{n_cpu} of the same songs through the oracle (np.cov + eig + sqrtm per song), one after the other",
+                             "seconds": dt_cpu}}
+
+
 def extra_score_inf(fadtk_amd, a_host, b_host):
     """FAD-inf at config-3 size (fad.py:304-351): 25 resampled sizes of the [100000 x 512] float16 eval set against the
     baseline's statistics.  Batched device route (frames in HBM, eight resamples per moments launch, square-root chains in
@@ -494,7 +527,8 @@ def main():
     if rank == 0 and not distributed and not args.no_extras:
         for name, fn in (("c4_moments", lambda: extra_c4(torch, hip, device, local_rank)),
                          ("per_song_config5_shape", lambda: extra_c5(torch, hip, device)),
-                         ("per_song_config5_encoder_frames", lambda: extra_c5_frames(torch, hip, device))):
+                         ("per_song_config5_encoder_frames", lambda: extra_c5_frames(torch, hip, device)),
+                         ("per_song_config4_shape", lambda: extra_c4_songs(torch, hip, device))):
             try:
                 extra[name] = fn()
             except Exception as e:      # noqa: BLE001  side measurements must never break the bench line

@@ -271,7 +271,9 @@ struct Workspace : NsWorkspace {
     void* song_pin = nullptr; size_t song_pin_cap = 0;      // ... and its pinned staging: offsets going up, scores coming down
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats)
     DevBuf fast;                                    // the eight-launch chain (ns_fast.h): header, digit planes, split planes
-    int fast_gen = 0;                               // per-score token of that chain (FastHdr::flag_gen)
+    int fast_gen = 0;                               // per-call token of that chain (MatHdr::flag_gen)
+    DevBuf fast_songs;                              // ... its batched form for songs: baseline digits + one block per song
+    void* fast_songs_pin = nullptr; size_t fast_songs_pin_cap = 0;      // ... and what its correction kernel leaves for the host
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
     bool busy = false;
     struct Job {
@@ -287,6 +289,8 @@ struct Workspace : NsWorkspace {
     struct Pool* pool = nullptr;
     void release_all() {
         release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release(); base_root.release(); fast.release();
+        fast_songs.release();
+        if (fast_songs_pin) { (void)hipHostFree(fast_songs_pin); fast_songs_pin = nullptr; fast_songs_pin_cap = 0; }
         if (done_ev) { (void)hipEventDestroy(done_ev); done_ev = nullptr; }
         if (song_pin) { (void)hipHostFree(song_pin); song_pin = nullptr; song_pin_cap = 0; }
     }
@@ -616,7 +620,7 @@ static bool fast_eligible(Workspace& ws, int d, int max_iter, double tol) {
 }
 
 struct FastBufs {
-    nsf::FastHdr* hdr;
+    nsf::MatHdr* hdr;                               // [2]
     uint4* digC[2];
     nsf::SplitMat P, Y[2], Z[2], T;
     uint4 *digY[2], *digYt[2];
@@ -636,7 +640,7 @@ static FastBufs fast_bufs(Workspace& ws, int d) {
     const size_t dd = (size_t)d * d;
     char* p = static_cast<char*>(ws.fast.p);
     FastBufs f;
-    f.hdr = reinterpret_cast<nsf::FastHdr*>(p); p += 256;
+    f.hdr = reinterpret_cast<nsf::MatHdr*>(p); p += 256;
     for (int i = 0; i < 2; ++i) { f.digC[i] = reinterpret_cast<uint4*>(p); p += 6 * dd; }
     nsf::SplitMat* mats[6] = {&f.P, &f.Y[0], &f.Y[1], &f.Z[0], &f.Z[1], &f.T};
     for (nsf::SplitMat* m : mats) {
@@ -673,37 +677,38 @@ static int fast_prepare(Workspace& ws, int d, int ddof, const double* acc1, cons
     a.mus = mus; a.covs = covs;
     a.dig[0] = f.digC[0]; a.dig[1] = f.digC[1];
     a.st = static_cast<NsState*>(ws.small.p);
-    a.hdr = f.hdr;
+    a.hdr[0] = f.hdr; a.hdr[1] = f.hdr + 1;
     hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)((int64_t)d * d / 2048 + 1), 2), dim3(512), 0, st, a);
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
 }
 
-template <int NS> static void fast_launch_split(int mode, unsigned t, const nsf::SplitArgs& g, hipStream_t st) {
-    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_FIRST>), dim3(t, t, 1), dim3(512), 0, st, g);
-    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_T>), dim3(t, t, 1), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_U>), dim3(t, t, 3), dim3(512), 0, st, g);
+template <int NS> static void fast_launch_split(int mode, unsigned t, unsigned B, const nsf::SplitArgs& g, hipStream_t st) {
+    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_FIRST>), dim3(t, t, B), dim3(512), 0, st, g);
+    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_T>), dim3(t, t, B), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_U>), dim3(t, t, 3 * B), dim3(512), 0, st, g);
 }
-static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st) {
+static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st, unsigned B = 1) {
     const unsigned t = (unsigned)(d / 32);
     switch (d) {
-        case 256: fast_launch_split<2>(mode, t, g, st); break;
-        case 512: fast_launch_split<4>(mode, t, g, st); break;
-        case 768: fast_launch_split<6>(mode, t, g, st); break;
-        default: fast_launch_split<8>(mode, t, g, st); break;
+        case 128: fast_launch_split<1>(mode, t, B, g, st); break;
+        case 256: fast_launch_split<2>(mode, t, B, g, st); break;
+        case 512: fast_launch_split<4>(mode, t, B, g, st); break;
+        case 768: fast_launch_split<6>(mode, t, B, g, st); break;
+        default: fast_launch_split<8>(mode, t, B, g, st); break;
     }
 }
-template <int NS8> static void fast_launch_i8(int mode, unsigned t, const nsf::I8Args& g, hipStream_t st) {
-    if (mode == nsf::I8_A) hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_A>), dim3(t, t, 1), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_G>), dim3(t, t, 1), dim3(512), 0, st, g);
+template <int NS8> static void fast_launch_i8(int mode, unsigned t, unsigned B, const nsf::I8Args& g, hipStream_t st) {
+    if (mode == nsf::I8_A) hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_A>), dim3(t, t, B), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_G>), dim3(t, t, B), dim3(512), 0, st, g);
 }
-static void fast_i8(int d, int mode, const nsf::I8Args& g, hipStream_t st) {
+static void fast_i8(int d, int mode, const nsf::I8Args& g, hipStream_t st, unsigned B = 1) {
     const unsigned t = (unsigned)(d / 32);
     switch (d) {
-        case 256: fast_launch_i8<1>(mode, t, g, st); break;
-        case 512: fast_launch_i8<2>(mode, t, g, st); break;
-        case 768: fast_launch_i8<3>(mode, t, g, st); break;
-        default: fast_launch_i8<4>(mode, t, g, st); break;
+        case 128: case 256: fast_launch_i8<1>(mode, t, B, g, st); break;       // (d = 128: four k-steps, half the waves idle)
+        case 512: fast_launch_i8<2>(mode, t, B, g, st); break;
+        case 768: fast_launch_i8<3>(mode, t, B, g, st); break;
+        default: fast_launch_i8<4>(mode, t, B, g, st); break;
     }
 }
 
@@ -718,12 +723,12 @@ static int fast_enqueue(Workspace& ws, int upto) {
     for (int& k = ws.job.k; k < upto; ++k) {
         nsf::SplitArgs g;
         memset(&g, 0, sizeof(g));
-        g.d = d; g.gen = ws.job.gen; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
+        g.d = d; g.gen = ws.job.gen; g.hA = f.hdr; g.hB = f.hdr + 1; g.st = m.dstate; g.s32 = m.s32;
         if (k == 0) {
             // A = C1 C2 (exact) + its statistics + the mean term, then iteration 0: Y1 = Y0 T0, Z1 = T0
             nsf::I8Args a;
             memset(&a, 0, sizeof(a));
-            a.Adig = f.digC[0]; a.Bdig = f.digC[1]; a.d = d; a.gen = ws.job.gen; a.hdr = f.hdr; a.stats = m.tilestats;
+            a.Adig = f.digC[0]; a.Bdig = f.digC[1]; a.d = d; a.gen = ws.job.gen; a.hA = f.hdr; a.hB = f.hdr + 1; a.stats = m.tilestats;
             a.A64 = m.A; a.P = f.P; a.st = m.dstate;
             fast_i8(d, nsf::I8_A, a, stream);
             g.A[0] = f.P; g.B[0] = f.P; g.C[0] = f.Y[1]; g.C[1] = f.Z[1]; g.Cdig[0] = f.digY[1]; g.Cdig_t[0] = f.digYt[1];
@@ -738,7 +743,7 @@ static int fast_enqueue(Workspace& ws, int upto) {
         fast_split(d, nsf::SP_T, g, stream);
         // Y <- Y T, Z <- T Z + the check of iteration k as an extra workgroup
         memset(&g, 0, sizeof(g));
-        g.d = d; g.gen = ws.job.gen; g.hdr = f.hdr; g.st = m.dstate; g.s32 = m.s32;
+        g.d = d; g.gen = ws.job.gen; g.hA = f.hdr; g.hB = f.hdr + 1; g.st = m.dstate; g.s32 = m.s32;
         g.A[0] = f.Y[cur]; g.B[0] = f.T; g.C[0] = f.Y[cur ^ 1];
         g.A[1] = f.T; g.B[1] = f.Z[cur]; g.C[1] = f.Z[cur ^ 1];
         g.Cdig[0] = f.digY[cur ^ 1]; g.Cdig_t[0] = f.digYt[cur ^ 1];
@@ -751,7 +756,7 @@ static int fast_enqueue(Workspace& ws, int upto) {
     nsf::I8Args a;
     memset(&a, 0, sizeof(a));
     a.Adig = f.digY[0]; a.Bdig = f.digYt[0]; a.Adig_alt = f.digY[1]; a.Bdig_alt = f.digYt[1]; a.sel = &m.s32->final_iter;
-    a.d = d; a.gen = ws.job.gen; a.hdr = f.hdr; a.skip = &m.s32->skip_corr; a.stats = f.host_stats; a.st = m.dstate; a.A64in = m.A;
+    a.d = d; a.gen = ws.job.gen; a.hA = f.hdr; a.hB = f.hdr + 1; a.skip = &m.s32->skip_corr; a.stats = f.host_stats; a.st = m.dstate; a.A64in = m.A;
     a.Y[0] = f.Y[0]; a.Y[1] = f.Y[1]; a.Z[0] = f.Z[0]; a.Z[1] = f.Z[1];
     a.s32 = m.s32; a.host_words = f.host_words; a.host_vals = f.host_vals;
     f.host_words[12] = 0;                          // (the kernel stamps the snapshot with this score's token)
@@ -763,13 +768,10 @@ static int fast_enqueue(Workspace& ws, int upto) {
 }
 
 // The closing decision, on the host (the enqueued chain has been waited for): reduce the correction's per-tile partials, bound the
-// neglected terms, accept / reject -- what ns32_finish does on the device for the float32 chain, minus a launch.  Fills *m.hres.
-static int fast_decide(Workspace& ws) {
-    const int d = ws.job.d, nb = d / 32;
-    MixedBufs m = mixed_bufs(ws, d);
-    FastBufs f = fast_bufs(ws, d);
-    const int* hw = f.host_words; const double* hv = f.host_vals; const double* hsx = f.host_stats;
-    if (hw[12] != ws.job.gen) return set_error(FAD_ERR_HIP, "the correction kernel of the fast Frechet chain left no result");
+// neglected terms, accept / reject -- what ns32_finish does on the device for the float32 chain, minus a launch.
+// hw / hv / hsx: what nsf_i8<G> left for ONE problem.  -> status 1 accepted, 2 rejected, 4 a predicted final iterate was rejected
+// (the iteration may go on from it), 0 not finished yet.
+static void fast_decide_one(const int* hw, const double* hv, const double* hsx, int nb, MixedResult* out) {
     MixedResult o;
     memset(&o, 0, sizeof(o));
     const bool bad = hw[0] != 0;
@@ -806,15 +808,165 @@ static int fast_decide(Workspace& ws) {
         const double fad = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs;
         const bool accept = finite && (est <= 1e-9 * std::fabs(trs) || 2.0 * std::sqrt(o.c) * est <= 1e-6 * std::fabs(fad));
         o.status = accept ? 1 : 2;
-        if (!accept && finite && !strict && hw[8] == fi - 1 && fi + 1 < kMaxLow) {
-            // the iterate was taken as final on a PREDICTED residual and the correction cannot absorb it: nothing is lost --
-            // (Y_f, Z_f) are intact, the iteration goes on from there and only the float32 floor ends it now
-            o.status = 4;
-            hipLaunchKernelGGL(nsf::nsf_rearm, dim3(1), dim3(64), 0, ws.job.stream, m.s32);
-            FAD_HIP_TRY(hipGetLastError());
-        }
+        if (!accept && finite && !strict && hw[8] == fi - 1 && fi + 1 < kMaxLow) o.status = 4;
     }
-    *m.hres = o;
+    *out = o;
+}
+
+static int fast_decide(Workspace& ws) {
+    const int d = ws.job.d, nb = d / 32;
+    MixedBufs m = mixed_bufs(ws, d);
+    FastBufs f = fast_bufs(ws, d);
+    if (f.host_words[12] != ws.job.gen) return set_error(FAD_ERR_HIP, "the correction kernel of the fast Frechet chain left no result");
+    fast_decide_one(f.host_words, f.host_vals, f.host_stats, nb, m.hres);
+    if (m.hres->status == 4) {
+        // the iterate was taken as final on a PREDICTED residual and the correction cannot absorb it: nothing is lost --
+        // (Y_f, Z_f) are intact, the iteration goes on from there and only the float32 floor ends it now
+        hipLaunchKernelGGL(nsf::nsf_rearm, dim3(1), dim3(64), 0, ws.job.stream, m.s32);
+        FAD_HIP_TRY(hipGetLastError());
+    }
+    return FAD_OK;
+}
+
+// ==========================================================================================
+// The same chain for a BATCH of songs against one baseline (fad_frechet_batched_vs_baseline, songs with at least D + 1 frames:
+// every song is a full D x D problem): tr sqrt(Sigma_b Sigma_s) for B songs in eight launches of B times the workgroups.
+// Replaces the per-song scipy.linalg.sqrtm / eig of fadtk/fad.py:373-378 for those songs; songs whose product the chain does not
+// accept (spread spectra, non-finite input) are handed back to the float64 routes.  D in {128, 256, 512, 768, 1024}.
+// ==========================================================================================
+static bool fast_song_dim(int d) { return d == 128 || d == 256 || d == 512 || d == 768 || d == 1024; }
+
+struct SongBlock {                               // byte offsets inside one song's device block, and its size
+    size_t hdr, st, s32, partials, stats, A64, P, Y[2], Z[2], T, digS, digY[2], digYt[2], stride;
+};
+static SongBlock song_block(int d) {
+    const size_t dd = (size_t)d * d, nb = (size_t)d / 32;
+    SongBlock b; size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    b.hdr = take(sizeof(nsf::MatHdr)); b.st = take(sizeof(NsState)); b.s32 = take(sizeof(Ns32State));
+    b.partials = take(nb * nb * sizeof(double)); b.stats = take(nsf::kTileStats * nb * nb * sizeof(double));
+    b.A64 = take(8 * dd); b.P = take(8 * dd);
+    b.Y[0] = take(8 * dd); b.Y[1] = take(8 * dd); b.Z[0] = take(8 * dd); b.Z[1] = take(8 * dd); b.T = take(8 * dd);
+    b.digS = take(6 * dd);
+    b.digY[0] = take(6 * dd); b.digYt[0] = take(6 * dd); b.digY[1] = take(6 * dd); b.digYt[1] = take(6 * dd);
+    b.stride = o;
+    return b;
+}
+static size_t song_host_stride(int d) {
+    const size_t nb = (size_t)d / 32;
+    return ((nsf::kHostVals + (nsf::kTileStats + 2) * nb * nb) * sizeof(double) + nsf::kHostWords * sizeof(int) + 63) & ~(size_t)63;
+}
+static int64_t fast_songs_capacity(int d, size_t budget_bytes) {
+    const int64_t n = (int64_t)(budget_bytes / song_block(d).stride);
+    return n < 1 ? 1 : (n > 16384 ? 16384 : n);
+}
+
+// covs: B covariances [d x d] float64 on the device; -> tr_sqrt[b] and ok[b] (1: accepted, 0: hand the song to the float64 routes)
+static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipStream_t st, Workspace& ws,
+                      std::vector<double>& tr_sqrt, std::vector<char>& ok) {
+    const size_t dd = (size_t)d * d;
+    const int nb = d / 32;
+    const SongBlock L = song_block(d);
+    const size_t hs = song_host_stride(d);
+    FAD_TRY(ws.fast_songs.reserve(512 + 6 * dd + (size_t)B * L.stride));
+    if (!ws.fast_songs_pin || ws.fast_songs_pin_cap < (size_t)B * hs) {
+        if (ws.fast_songs_pin) (void)hipHostFree(ws.fast_songs_pin);
+        ws.fast_songs_pin = nullptr; ws.fast_songs_pin_cap = 0;
+        FAD_HIP_TRY(hipHostMalloc(&ws.fast_songs_pin, (size_t)B * hs + 4096, hipHostMallocDefault));
+        ws.fast_songs_pin_cap = (size_t)B * hs + 4096;
+    }
+    char* base = static_cast<char*>(ws.fast_songs.p);
+    nsf::MatHdr* hdr_b = reinterpret_cast<nsf::MatHdr*>(base);
+    uint4* dig_b = reinterpret_cast<uint4*>(base + 512);
+    char* blk = base + 512 + ((6 * dd + 255) & ~(size_t)255);
+    char* hpin = static_cast<char*>(ws.fast_songs_pin);
+    double* h_vals = reinterpret_cast<double*>(hpin);
+    double* h_stats = h_vals + nsf::kHostVals;
+    int* h_words = reinterpret_cast<int*>(h_stats + (size_t)(nsf::kTileStats + 2) * nb * nb);
+    auto at = [&](size_t off) { return blk + off; };
+    auto mat = [&](size_t off) { nsf::SplitMat m; m.a = reinterpret_cast<uint4*>(at(off)); m.at = reinterpret_cast<uint4*>(at(off + 4 * dd)); return m; };
+    const int gen = ++ws.fast_gen;
+    if (ws.fast_gen > (1 << 30)) ws.fast_gen = 1;
+    // fresh headers carry no stale token
+    FAD_HIP_TRY(hipMemsetAsync(hdr_b, 0, sizeof(nsf::MatHdr), st));
+    FAD_HIP_TRY(hipMemset2DAsync(at(L.hdr), L.stride, 0, sizeof(nsf::MatHdr), (size_t)B, st));
+
+    nsf::PrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.cov_in[0] = dcov_b; pa.cov_in[1] = covs; pa.d = d; pa.ddof = 1; pa.gen = gen; pa.mean_dtype = -1;
+    pa.dig[0] = dig_b; pa.dig[1] = reinterpret_cast<uint4*>(at(L.digS));
+    pa.st = reinterpret_cast<NsState*>(at(L.st)); pa.hdr[0] = hdr_b; pa.hdr[1] = reinterpret_cast<nsf::MatHdr*>(at(L.hdr));
+    pa.batch = 1; pa.pstride = (int64_t)L.stride;
+    hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)(dd / 2048), (unsigned)(1 + B)), dim3(512), 0, st, pa);
+
+    NsState* st0 = reinterpret_cast<NsState*>(at(L.st));
+    Ns32State* s32_0 = reinterpret_cast<Ns32State*>(at(L.s32));
+    double* partials = reinterpret_cast<double*>(at(L.partials));
+    double* stats = reinterpret_cast<double*>(at(L.stats));
+    double* A64 = reinterpret_cast<double*>(at(L.A64));
+    const nsf::SplitMat P = mat(L.P), Y[2] = {mat(L.Y[0]), mat(L.Y[1])}, Z[2] = {mat(L.Z[0]), mat(L.Z[1])}, T = mat(L.T);
+    uint4* digY[2] = {reinterpret_cast<uint4*>(at(L.digY[0])), reinterpret_cast<uint4*>(at(L.digY[1]))};
+    uint4* digYt[2] = {reinterpret_cast<uint4*>(at(L.digYt[0])), reinterpret_cast<uint4*>(at(L.digYt[1]))};
+    auto split_args = [&]() {
+        nsf::SplitArgs g;
+        memset(&g, 0, sizeof(g));
+        g.d = d; g.gen = gen; g.hA = hdr_b; g.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); g.pstride = (int64_t)L.stride;
+        g.st = st0; g.s32 = s32_0;
+        return g;
+    };
+    {
+        nsf::I8Args a;
+        memset(&a, 0, sizeof(a));
+        a.Adig = dig_b; a.Bdig = reinterpret_cast<uint4*>(at(L.digS)); a.d = d; a.gen = gen; a.hA = hdr_b;
+        a.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); a.pstride = (int64_t)L.stride; a.stats = stats; a.A64 = A64; a.P = P; a.st = st0;
+        fast_i8(d, nsf::I8_A, a, st, (unsigned)B);
+        nsf::SplitArgs g = split_args();
+        g.A[0] = P; g.B[0] = P; g.C[0] = Y[1]; g.C[1] = Z[1]; g.Cdig[0] = digY[1]; g.Cdig_t[0] = digYt[1]; g.A64 = A64; g.statsA = stats;
+        fast_split(d, nsf::SP_FIRST, g, st, (unsigned)B);
+    }
+    tr_sqrt.assign((size_t)B, 0.0); ok.assign((size_t)B, 0);
+    std::vector<char> settled((size_t)B, 0);
+    int k = 1, upto = 5;
+    for (;;) {
+        for (; k < upto; ++k) {
+            const int cur = k & 1;
+            nsf::SplitArgs g = split_args();
+            g.A[0] = Z[cur]; g.B[0] = Y[cur]; g.C[0] = T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f;
+            g.partials = partials; g.skip = &s32_0->done;
+            fast_split(d, nsf::SP_T, g, st, (unsigned)B);
+            g = split_args();
+            g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1];
+            g.Cdig[0] = digY[cur ^ 1]; g.Cdig_t[0] = digYt[cur ^ 1];
+            g.skip = &s32_0->upd_skip[k & 1];
+            g.k = k; g.max_low = kMaxLow; g.nslots = nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
+            fast_split(d, nsf::SP_U, g, st, (unsigned)B);
+        }
+        nsf::I8Args a;
+        memset(&a, 0, sizeof(a));
+        a.Adig = digY[0]; a.Bdig = digYt[0]; a.Adig_alt = digY[1]; a.Bdig_alt = digYt[1]; a.sel = &s32_0->final_iter;
+        a.d = d; a.gen = gen; a.hA = hdr_b; a.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); a.pstride = (int64_t)L.stride; a.hstride = (int64_t)hs;
+        a.skip = &s32_0->skip_corr; a.stats = h_stats; a.st = st0; a.A64in = A64;
+        a.Y[0] = Y[0]; a.Y[1] = Y[1]; a.Z[0] = Z[0]; a.Z[1] = Z[1]; a.s32 = s32_0; a.host_words = h_words; a.host_vals = h_vals;
+        for (int64_t b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + b * hs)[12] = 0;
+        fast_i8(d, nsf::I8_G, a, st, (unsigned)B);
+        FAD_HIP_TRY(hipGetLastError());
+        FAD_HIP_TRY(hipStreamSynchronize(st));
+        bool pending = false;
+        for (int64_t b = 0; b < B; ++b) {
+            if (settled[b]) continue;
+            const int* hw = reinterpret_cast<const int*>(reinterpret_cast<const char*>(h_words) + b * hs);
+            const double* hv = reinterpret_cast<const double*>(reinterpret_cast<const char*>(h_vals) + b * hs);
+            const double* hx = reinterpret_cast<const double*>(reinterpret_cast<const char*>(h_stats) + b * hs);
+            if (hw[12] != gen) return set_error(FAD_ERR_HIP, "the correction kernel of the batched fast chain left no result for song %lld", (long long)b);
+            MixedResult r;
+            fast_decide_one(hw, hv, hx, nb, &r);
+            if (r.status == 0 && k < kMaxLow) { pending = true; continue; }      // not finished yet: more iterations for this song
+            settled[b] = 1;
+            if (r.status == 1) { ok[b] = 1; tr_sqrt[b] = std::sqrt(r.c) * r.tr_scaled; }
+        }
+        if (!pending) break;
+        upto = (k + 2 < kMaxLow) ? k + 2 : kMaxLow;
+    }
     return FAD_OK;
 }
 
@@ -1807,6 +1959,36 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             }
             g0 = g1;
         }
+    }
+
+    // ---- songs of at least D + 1 frames, D in {128, 256, 512, 768, 1024}: the eight-launch chain, batched over the songs (fast_songs);
+    // whatever it does not accept falls through to the float64 routes below.  FAD_SONG_FAST=0 switches it off.
+    // (read per call -- a batched call is milliseconds; 2 = strict: an error when the chain accepts NO song of the call, for tests)
+    const char* fs_env = getenv("FAD_SONG_FAST");
+    const int fastsongs_on = fs_env ? atoi(fs_env) : 1;
+    if (fastsongs_on && fast_song_dim(d) && !general.empty() && tr_b == tr_b) {
+        ws.pool = &thread_pool(device);
+        std::vector<int64_t> rest;
+        const int64_t sub = std::min<int64_t>(fast_songs_capacity(d, (size_t)3 << 30), (int64_t)general.size());
+        FAD_TRY(ws.songmat.reserve((size_t)sub * dd * sizeof(double)));
+        double* covs = static_cast<double*>(ws.songmat.p);
+        const int nt64 = (int)cdiv(d, 64);
+        std::vector<double> trs; std::vector<char> okv;
+        for (size_t g0 = 0; g0 < general.size(); g0 += (size_t)sub) {
+            const int64_t B = (int64_t)std::min<size_t>((size_t)sub, general.size() - g0);
+            FAD_HIP_TRY(hipMemcpyAsync(ids_dev, general.data() + g0, B * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((song_cov_mfma<TIn>), dim3((unsigned)(nt64 * (nt64 + 1) / 2), 1, (unsigned)B), dim3(256), 0, st, drows,
+                               ld, d, nt64, d_off, ids_dev, mean_exact, covs);
+            FAD_TRY(fast_songs(d, B, dcov_b, covs, st, ws, trs, okv));       // (synchronises: `general` may be read again)
+            for (int64_t b = 0; b < B; ++b) {
+                const int64_t sg = general[g0 + b];
+                if (okv[b]) out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * trs[b];
+                else rest.push_back(sg);
+            }
+        }
+        if (fastsongs_on == 2 && rest.size() == general.size())
+            return set_error(FAD_ERR_INVALID, "FAD_SONG_FAST=2: the batched fast chain accepted none of %zu songs", general.size());
+        general.swap(rest);
     }
 
     // ---- songs of D + 1 .. 8 D frames (D >= 64): the symmetric form of the D x D problem.  With B = sqrt(Sigma_b) (ONE

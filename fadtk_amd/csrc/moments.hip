@@ -50,6 +50,7 @@ struct fad_moments {
     unsigned update_seq = 0;
     int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0, read at creation)
     bool force_generic = false;            // FAD_MOMENTS_FORCE_GENERIC=1 (read at creation): always the fp64 kernel
+    int load_policy = 0;                   // FAD_MOMENTS_LOAD_POLICY=nt (read at creation): 1 = non-temporal LDS-DMA loads in the hot loop
     bool fresh = false;                    // reset since the last update: the next reduce stores instead of adding
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
     // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
@@ -85,7 +86,8 @@ typedef void (*tile_kernel_t)(TileLaunch);
 static tile_kernel_t tr_kernel_shift(bool fast) {          // second pass of the shift guard (float16 rows only)
     return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false, true>;
 }
-static tile_kernel_t tr_kernel(int dtype, bool fast) {       // multi-tile: 4 stages of 16 KiB; single tile: 8 stages of 8 KiB
+static tile_kernel_t tr_kernel(int dtype, bool fast, int policy = 0) {       // multi-tile: 4 stages of 16 KiB; single tile: 8 stages of 8 KiB
+    if (dtype == FAD_F16 && fast && policy == 1) return &moments_tile_h16_tr<FAD_F16, H_NST, true, false, 1>;
     if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false>;
     return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, 2 * H_NST, false>;
 }
@@ -100,9 +102,12 @@ static int ensure_kernel_attrs(int device) {
         for (bool fast : {false, true}) {
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
-            if (dt == FAD_F16)
+            if (dt == FAD_F16) {
                 FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel_shift(fast)),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
+                if (fast) FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, true, 1)),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
+            }
         }
     }
     done[device] = true;
@@ -146,7 +151,7 @@ static int timing_events(fad_moments* h, hipEvent_t** ev) {
     *ev = nullptr;
     if (!h->timing) return FAD_OK;
     if (!h->ev) {
-        h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3];
+        h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3]();
         if (!h->ev) return set_error(FAD_ERR_ALLOC, "out of host memory");
         for (int i = 0; i < fad_moments::kRing * 3; ++i) FAD_HIP_TRY(hipEventCreate(&h->ev[i]));
     }
@@ -257,7 +262,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         }
         L.total = item;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
+        hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1, h0->load_policy), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
 
         // shift guard: exact fp64 redo of every flagged set, one gated launch for all of them
@@ -467,6 +472,8 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     h->guard = !(gs && gs[0] == '0');
     const char* fg = getenv("FAD_MOMENTS_FORCE_GENERIC");
     h->force_generic = fg && fg[0] == '1';
+    const char* lp = getenv("FAD_MOMENTS_LOAD_POLICY");
+    h->load_policy = (lp && lp[0] == 'n') ? 1 : 0;
     *out = h;
     return FAD_OK;
 }
@@ -481,7 +488,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release();
     if (h->tab_host) (void)hipHostFree(h->tab_host);
     if (h->tab_ev) (void)hipEventDestroy(h->tab_ev);
-    if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
+    if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
     delete h;
     return FAD_OK;
 }
@@ -829,7 +836,7 @@ int fad_moments_set_timing(fad_moments_t* h, int enabled) {
         // the ring of events is created HERE, not by the first timed update: 768 hipEventCreate calls took ~0.35 ms out of
         // bench.py's timed region (round 3: the timed block read 8-10 % below the same block repeated without them)
         DeviceGuard g(h->device);
-        h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3];
+        h->ev = new (std::nothrow) hipEvent_t[fad_moments::kRing * 3]();
         if (!h->ev) return set_error(FAD_ERR_ALLOC, "out of host memory");
         for (int i = 0; i < fad_moments::kRing * 3; ++i) FAD_HIP_TRY(hipEventCreate(&h->ev[i]));
     }

@@ -141,21 +141,30 @@ __device__ __forceinline__ void tile_of_block(int& ty, int& tx) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Per-score header (device): what K1 finds out about the two covariances.  `gen` is the caller's per-score token: a flag word
-// that EQUALS it was raised during this score (no reset pass between scores).
-struct FastHdr {
-    double s[2];        // power-of-two scales: |s_i Sigma_i| <= 1
-    double tr[2];       // tr Sigma_i (caller's units)
-    int bad[2];         // covariance i has a non-finite / non-positive diagonal or its set has < 2 rows
-    int flag_gen[2];    // == gen: some element of covariance i is not finite or does not fit the fixed-point grid
+// Per-matrix header (device): what K1 finds out about one covariance.  `gen` is the caller's per-call token: a flag word that
+// EQUALS it was raised during this call (no reset pass between calls).
+struct MatHdr {
+    double s;           // power-of-two scale: |s Sigma| <= 1
+    double tr;          // tr Sigma (caller's units)
+    int bad;            // non-finite / non-positive diagonal, or its set has < 2 rows
+    int flag_gen;       // == gen: some element is not finite or does not fit the fixed-point grid
+    int pad[2];
 };
-__device__ __forceinline__ bool hdr_bad(const FastHdr* h, int gen) {
-    return (h->bad[0] | h->bad[1]) != 0 || h->flag_gen[0] == gen || h->flag_gen[1] == gen;
+__device__ __forceinline__ bool hdr_bad(const MatHdr* a, const MatHdr* b, int gen) {
+    return (a->bad | b->bad) != 0 || a->flag_gen == gen || b->flag_gen == gen;
 }
-__device__ __forceinline__ double hdr_inv_s12(const FastHdr* h) { return 1.0 / (h->s[0] * h->s[1]); }      // powers of two: exact
+__device__ __forceinline__ double hdr_inv_s12(const MatHdr* a, const MatHdr* b) { return 1.0 / (a->s * b->s); }      // powers of two: exact
+
+// BATCHES (per-song scores against one baseline, frechet.hip: fast_songs): problem b = blockIdx.z / (z-slices of the kernel); every
+// per-problem buffer of problem b lives `pstride` bytes behind problem 0's (host-side buffers: `hstride`); the baseline's digit
+// planes and header (the A side of A = Sigma_b Sigma_s) are shared.  A single pair is a batch of one with pstride = 0.
+template <class T> __device__ __forceinline__ T* adv(T* p, int64_t bytes) {
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes);
+}
 
 // One matrix in split-float16 form: fragment-major planes of X (as an A operand) and of X^T (as a B operand), d * d / 4 pieces each.
 struct SplitMat { uint4* a; uint4* at; };
+__device__ __forceinline__ SplitMat adv(const SplitMat& m, int64_t bytes) { return SplitMat{adv(m.a, bytes), adv(m.at, bytes)}; }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // K1: means, mean term, traces, scales and digit planes of both covariances from the packed moments (or the caller's matrices).
@@ -169,15 +178,20 @@ struct PrepArgs {
     double* mus;                     // [2][d]          (written only with acc)
     double* covs;                    // [2][d * d]      (written only with acc: what the float64 route reads if it has to take over)
     uint4* dig[2];                   // digit planes of s_1 Sigma_1 (A operand) and of (s_2 Sigma_2)^T (B operand)
-    NsState* st; FastHdr* hdr;
+    NsState* st; MatHdr* hdr[2];
+    // batch (per-song scores): blockIdx.y = 0 is the baseline (cov_in[0], dig[0], hdr[0]); blockIdx.y = 1 + b is song b:
+    // cov_in[1] + b d^2, and dig[1], hdr[1], st advanced by b * pstride bytes.  No means, no mean term, no spare workgroup.
+    int batch; int64_t pstride;
 };
 
 __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     __shared__ double red[8 * 2];
     __shared__ double mu_lds[2 * 1024];
     __shared__ float gaps[1024];
-    const int set = blockIdx.y, tid = threadIdx.x, d = a.d;
-    if (blockIdx.x == gridDim.x - 1) {
+    const int tid = threadIdx.x, d = a.d;
+    const int set = a.batch ? (blockIdx.y ? 1 : 0) : (int)blockIdx.y;
+    const int64_t po = a.batch && blockIdx.y ? (int64_t)(blockIdx.y - 1) * a.pstride : 0;      // byte offset of this song's buffers
+    if (!a.batch && blockIdx.x == gridDim.x - 1) {
         // the spare workgroup: means of both sets -> global (with acc) and LDS, then the mean term -> state
         if (set != 0 || tid >= 256) return;
         for (int q = 0; q < 2; ++q) {
@@ -196,7 +210,9 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     const double* acc = a.acc[set];
     const double n = acc ? acc[0] : 2.0;
     const double* sum = acc ? acc + 1 : nullptr;
-    const double* M = acc ? acc + 1 + d : a.cov_in[set];
+    const double* M = acc ? acc + 1 + d : a.cov_in[set] + ((a.batch && blockIdx.y) ? (int64_t)(blockIdx.y - 1) * d * d : 0);
+    MatHdr* hdr = adv(a.hdr[set], po);
+    NsState* st = adv(a.st, po);
     const double inv_n = 1.0 / n, inv_nd = 1.0 / (n - (double)a.ddof);
     // this thread's dword: quarter qd of the piece of lane (r, g), k-step ks, row block rb -- consecutive threads write
     // consecutive dwords of consecutive pieces
@@ -231,11 +247,12 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     if (!bad) (void)frexp(mx, &ex);                      // mx = m 2^ex, m in [0.5, 1)
     const double s = bad ? 1.0 : ldexp(1.0, -ex);
     if (blockIdx.x == 0 && tid == 0) {
-        a.hdr->s[set] = s; a.hdr->tr[set] = tr; a.hdr->bad[set] = bad ? 1 : 0;
-        a.st->too_few[set] = few ? 1 : 0;
-        if (set == 0) {                                  // the per-call reset of the iteration state (finalize_for_frechet did this)
-            a.st->done = 0; a.st->finished = 0; a.st->nonfinite = 0; a.st->conv = 0; a.st->final_iter = -1;
-            a.st->upd_skip[0] = 0; a.st->upd_skip[1] = 0;
+        hdr->s = s; hdr->tr = tr; hdr->bad = bad ? 1 : 0;
+        if (!a.batch) st->too_few[set] = few ? 1 : 0;
+        if (a.batch ? set == 1 : set == 0) {             // the per-call reset of the iteration state (finalize_for_frechet did this)
+            st->done = 0; st->finished = 0; st->nonfinite = 0; st->conv = 0; st->final_iter = -1;
+            st->upd_skip[0] = 0; st->upd_skip[1] = 0;
+            if (a.batch) { st->too_few[0] = 0; st->too_few[1] = 0; st->mean_term = 0.0; }
         }
     }
     // (Sigma_2 is used as its own transpose: the moments give a bit-for-bit symmetric matrix; for caller-given matrices the
@@ -258,8 +275,8 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
 #pragma unroll
         for (int p = 0; p < kDigits; ++p) w[p] |= ((uint32_t)dg[p] & 0xffu) << (8 * q);
     }
-    if (off_grid) a.hdr->flag_gen[set] = a.gen;          // (every raiser writes the same value)
-    uint4* out = a.dig[set];
+    if (off_grid) hdr->flag_gen = a.gen;                 // (every raiser writes the same value)
+    uint4* out = adv(a.dig[set], po);
 #pragma unroll
     for (int p = 0; p < kDigits; ++p) reinterpret_cast<uint32_t*>(out + dg_idx(rb, ks, p, 32 * g + r, d))[qd] = w[p];
 }
@@ -321,7 +338,8 @@ struct I8Args {
     const uint4* Adig; const uint4* Bdig;        // A operand rows / B operand COLUMNS (= rows of B^T), digit planes
     const uint4* Adig_alt; const uint4* Bdig_alt; const int* sel;      // I8_G: used instead when *sel is odd (ping-pong iterates)
     int d, gen;
-    const FastHdr* hdr;
+    const MatHdr* hA; const MatHdr* hB;          // headers of the two covariances (hA: the shared baseline in a batch)
+    int64_t pstride, hstride;                    // bytes between consecutive problems of a batch: device buffers / host buffers
     const int* skip;                             // *skip != 0: nothing to do
     double* stats;                               // I8_A: [nb * nb][4] (device);  I8_G: [nb * nb][4] then [nb * nb][2] (PINNED HOST memory)
     // I8_A
@@ -343,13 +361,16 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     constexpr int kUmin = (MODE == I8_A) ? kUminA : kUminG;
     constexpr int kGroups = 2 * (kDigits - 1) - kUmin + 1;
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
-    const bool bad = hdr_bad(g.hdr, g.gen);
-    const bool skipped = bad || (g.skip && *g.skip != 0);
+    const int64_t po = (int64_t)blockIdx.z * g.pstride, ho = (int64_t)blockIdx.z * g.hstride;      // this problem's buffers
+    const MatHdr* hB = adv(g.hB, po);
+    NsState* const st_p = adv(g.st, po);
+    const bool bad = hdr_bad(g.hA, hB, g.gen);
+    const bool skipped = bad || (g.skip && *adv(g.skip, po) != 0);
     if constexpr (MODE == I8_G) {
         // whatever happens, the host finds the state of the iteration next to the partials
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-            const NsState* st = g.st; const Ns32State* s = g.s32;
-            int* hw = g.host_words; double* hv = g.host_vals;
+            const NsState* st = st_p; const Ns32State* s = adv(g.s32, po);
+            int* hw = adv(g.host_words, ho); double* hv = adv(g.host_vals, ho);
             hw[0] = bad ? 1 : 0; hw[1] = st->done; hw[2] = st->nonfinite; hw[3] = st->too_few[0]; hw[4] = st->too_few[1];
             hw[5] = s->ok; hw[6] = s->failed; hw[7] = s->final_iter; hw[8] = s->decided_at; hw[9] = s->strict; hw[10] = s->finished;
             hw[11] = skipped ? 1 : 0;
@@ -364,9 +385,11 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 5, r = lane & 31;
     const int row0 = ty * 32, col0 = tx * 32;
-    const bool alt = (MODE == I8_G) && g.sel && (*g.sel & 1);
-    const uint4* Ad = alt ? g.Adig_alt : g.Adig;
-    const uint4* Bd = alt ? g.Bdig_alt : g.Bdig;
+    const bool alt = (MODE == I8_G) && g.sel && (*adv(g.sel, po) & 1);
+    // (A = Sigma_b Sigma_s: the A operand is the batch's shared baseline; G = Y Y: both operands are the problem's own)
+    const uint4* Ad = (MODE == I8_A) ? g.Adig : adv(alt ? g.Adig_alt : g.Adig, po);
+    const uint4* Bd = adv(alt ? g.Bdig_alt : g.Bdig, po);
+    const bool idle = wave * NS8 >= (d >> 5);            // d = 128: four k-steps, waves 4..7 contribute zeros
 
     // Operand pieces are requested most significant digit first, A and B alternating, and the MFMAs follow in the order the
     // pieces land: as soon as digit m of both operands is there, every pair with min(p, q) = m can go (the compiler places the
@@ -396,7 +419,9 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
                 if (p + m >= kUmin) acc[p + m - kUmin] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[buf][p], b[buf][m], acc[p + m - kUmin], 0, 0, 0);
         }
     };
-    if constexpr (NS8 <= 2) {
+    if (idle) {
+        // nothing to multiply: this wave's share of the tile is zero
+    } else if constexpr (NS8 <= 2) {
 #pragma unroll
         for (int s = 0; s < NS8; ++s) fetch(s, s);
 #pragma unroll
@@ -436,25 +461,26 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     }
     const int nb = gridDim.x;
     const int gr = row0 + rr, gc = col0 + 2 * cp;
-    double* scal = g.stats + (size_t)kTileStats * (ty * nb + tx);
+    double* const stats = adv(g.stats, (MODE == I8_A) ? po : ho);
+    double* scal = stats + (size_t)kTileStats * (ty * nb + tx);
     double m = 0.0, v3[3] = {0.0, 0.0, 0.0};
     if constexpr (MODE == I8_A) {
         // A in the caller's units (float64), the split planes of its normalised image P = s1 s2 A, the tile's statistics
-        const double inv = hdr_inv_s12(g.hdr);
-        *reinterpret_cast<double2*>(g.A64 + (int64_t)gr * d + gc) = make_double2(G2[0] * inv, G2[1] * inv);
+        const double inv = hdr_inv_s12(g.hA, hB);
+        *reinterpret_cast<double2*>(adv(g.A64, po) + (int64_t)gr * d + gc) = make_double2(G2[0] * inv, G2[1] * inv);
         fin[rr * 33 + 2 * cp] = (float)G2[0]; fin[rr * 33 + 2 * cp + 1] = (float)G2[1];
         v3[0] = G2[0] * G2[0] + G2[1] * G2[1];
         v3[1] = (gr == gc ? G2[0] : 0.0) + (gr == gc + 1 ? G2[1] : 0.0);
         __syncthreads();
-        store_tile(fin, g.P, nullptr, nullptr, ty, tx, d, tid);
+        store_tile(fin, adv(g.P, po), nullptr, nullptr, ty, tx, d, tid);
         if (tid < 32) { for (int c = 0; c < 32; ++c) m += fabsf(fin[tid * 33 + c]); }                  // row sum of |a|
         else if (tid < 64) { for (int q = 0; q < 32; ++q) m += fabsf(fin[q * 33 + tid - 32]); }        // column sum
     } else {
         // R = A/c - G for this tile; Z enters through its mirror tile: Z^T[gr][gc] = Z[gc][gr] pairs with R[gr][gc] in tr(Z R)
-        const SplitMat& Zm = g.Z[alt ? 1 : 0];
-        const SplitMat& Ym = g.Y[alt ? 1 : 0];
-        const double inv_c = 1.0 / g.st->c;
-        const double2 a2 = *reinterpret_cast<const double2*>(g.A64in + (int64_t)gr * d + gc);
+        const SplitMat Zm = adv(g.Z[alt ? 1 : 0], po);
+        const SplitMat Ym = adv(g.Y[alt ? 1 : 0], po);
+        const double inv_c = 1.0 / st_p->c;
+        const double2 a2 = *reinterpret_cast<const double2*>(adv(g.A64in, po) + (int64_t)gr * d + gc);
         int half;
         const size_t zi0 = fa_elem(gr, gc, 0, d, half);               // Z^T in the A layout: row gr, k = gc (even); gc + 1 sits in the same piece
         const f16x2 zh = *reinterpret_cast<const f16x2*>(reinterpret_cast<const _Float16*>(Zm.at + zi0) + half);
@@ -483,7 +509,7 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
         } else {
             scal[0] = v3[0]; scal[1] = v3[1]; scal[2] = v3[2]; scal[3] = 0.0;
             // this tile holds |Z| of rows col0.. (row block tx) x columns row0.. (column block ty)
-            double* zmax = g.stats + (size_t)kTileStats * nb * nb + 2 * (size_t)(ty * nb + tx);
+            double* zmax = stats + (size_t)kTileStats * nb * nb + 2 * (size_t)(ty * nb + tx);
             zmax[0] = mrow; zmax[1] = mcol;
         }
     }
@@ -495,7 +521,8 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
 enum { SP_FIRST = 0, SP_T = 1, SP_U = 2 };
 struct SplitArgs {
     int d, gen;
-    const FastHdr* hdr;
+    const MatHdr* hA; const MatHdr* hB;  // headers of the two covariances (hA: the shared baseline in a batch)
+    int64_t pstride;                     // bytes between consecutive problems of a batch (everything below but hA is per problem)
     const int* skip;
     SplitMat A[2], B[2], C[2];           // per product of the launch: A operand, B operand (its ^T planes are read), output
     uint4* Cdig[2]; uint4* Cdig_t[2];    // digit planes of C[0] and of C[0]^T (SP_FIRST, SP_U)
@@ -512,15 +539,17 @@ struct SplitArgs {
 
 // Decision of iteration k from r_k = ||I - Z_k Y_k||_F = 2 ||T_k - I||_F (one workgroup; the rules are those of round 2's
 // float32 leg, gemm_f32.hip: ns32_check).
-__device__ __forceinline__ void nsf_check(const SplitArgs& g, double* red) {
-    Ns32State* st = g.s32;
+__device__ __forceinline__ void nsf_check(const SplitArgs& g, int64_t po, double* red) {
+    Ns32State* st = adv(g.s32, po);
+    const NsState* st64 = adv(g.st, po);
+    const double* chk_partials = adv(g.chk_partials, po);
     const int k = g.k;
-    if (st->finished || g.st->done) {
-        if (threadIdx.x == 0) { st->upd_skip[(k + 1) & 1] = 1; if (g.st->done && !st->finished) { st->finished = 1; st->failed = 1; st->done = 1; } }
+    if (st->finished || st64->done) {
+        if (threadIdx.x == 0) { st->upd_skip[(k + 1) & 1] = 1; if (st64->done && !st->finished) { st->finished = 1; st->failed = 1; st->done = 1; } }
         return;
     }
     double s[1] = {0.0};
-    for (int i = threadIdx.x; i < g.nslots; i += 512) s[0] += g.chk_partials[i];
+    for (int i = threadIdx.x; i < g.nslots; i += 512) s[0] += chk_partials[i];
     wg8_sum<1>(s, red);
     if (threadIdx.x != 0) return;
     const double res = 2.0 * sqrt(s[0]);
@@ -548,14 +577,18 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     __shared__ float fin2[32 * 33];
     __shared__ double red[8 * 4];
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
+    constexpr int ZPER = (MODE == SP_U) ? 3 : 1;         // z-slices per problem
+    const int64_t po = (int64_t)(blockIdx.z / ZPER) * g.pstride;
+    const int zs = (int)(blockIdx.z % ZPER);
     if constexpr (MODE == SP_U) {
-        if (blockIdx.z == 2) {
-            if (blockIdx.x == 0 && blockIdx.y == 0) nsf_check(g, red);
+        if (zs == 2) {
+            if (blockIdx.x == 0 && blockIdx.y == 0) nsf_check(g, po, red);
             return;
         }
     }
-    if (hdr_bad(g.hdr, g.gen)) return;
-    const int zi = (MODE == SP_U) ? (int)blockIdx.z : 0;
+    const MatHdr* hB = adv(g.hB, po);
+    if (hdr_bad(g.hA, hB, g.gen)) return;
+    const int zi = (MODE == SP_U) ? zs : 0;
     int ty, tx; tile_of_block(ty, tx);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 5, r = lane & 31;
@@ -565,8 +598,8 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     // eight XCDs, the first touch of a panel is an L2 miss, and one exposed latency is all this kernel should pay
     f16x8 ah[NS], al[NS], bh[NS], bl[NS];
     {
-        const SplitMat& Am = g.A[zi];
-        const SplitMat& Bm = g.B[zi];
+        const SplitMat Am = adv(g.A[zi], po);
+        const SplitMat Bm = adv(g.B[zi], po);
         const f16x8* pa = reinterpret_cast<const f16x8*>(Am.a + fa_idx(ty, wave * NS, 0, lane, d));
         const f16x8* pb = reinterpret_cast<const f16x8*>(Bm.at + fa_idx(tx, wave * NS, 0, lane, d));
 #pragma unroll
@@ -576,11 +609,11 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     double inv_c = 0.0, inv_cn = 0.0;
     double2 a2 = make_double2(0.0, 0.0);
     if constexpr (MODE == SP_FIRST) {
-        a2 = *reinterpret_cast<const double2*>(g.A64 + (int64_t)(row0 + rr) * d + col0 + 2 * cp);    // this thread's elements of A
+        a2 = *reinterpret_cast<const double2*>(adv(g.A64, po) + (int64_t)(row0 + rr) * d + col0 + 2 * cp);    // this thread's elements of A
         // ---- the scale (what ns_prepare did in a launch of its own): every workgroup, identically, from K2's tile statistics.
         // One record per thread goes through LDS (a per-thread loop over a row of records is a chain of dependent cache misses).
         const int nb = gridDim.x;
-        const double* scal = g.statsA;
+        const double* scal = adv(g.statsA, po);
         double* tmax = reinterpret_cast<double*>(part);              // [2][nb * nb]: largest row / column sum of |a| per tile
         double v2[2] = {0.0, 0.0};
         for (int k = tid; k < nb * nb; k += 512) {
@@ -607,15 +640,16 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         double c = u / 2.9;
         const double wmean = (trA > 0.0) ? fro2 / trA : 0.0;      // where the bulk of a flat spectrum sits (||A||_F^2 stands in for tr A^2)
         if (wmean > c && wmean <= u) c = wmean;
-        const double mean_term = g.st->mean_term, tr1 = g.hdr->tr[0], tr2 = g.hdr->tr[1];
+        NsState* const st_p = adv(g.st, po);
+        const double mean_term = st_p->mean_term, tr1 = g.hA->tr, tr2 = hB->tr;
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
         // the float32-class iteration only serves spectra that are flat within a few hundred: participation ratio (tr A)^2 / ||A||_F^2 >= d/4
         // ... and whose bulk is not far below the largest covariance entries: A lives on a fixed-point grid of 2^-41 relative to those
         const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-            NsState* st = g.st; Ns32State* s32 = g.s32;
-            st->c = zero ? 1.0 : c * hdr_inv_s12(g.hdr);     // in the caller's units: A / st->c = (s1 s2 A) / c
+            NsState* st = st_p; Ns32State* s32 = adv(g.s32, po);
+            st->c = zero ? 1.0 : c * hdr_inv_s12(g.hA, hB);     // in the caller's units: A / st->c = (s1 s2 A) / c
             st->tr1 = tr1; st->tr2 = tr2;
             st->res_last = 0.0; st->tr_last = 0.0; st->res_min = 1e300; st->tr_safe = 0.0; st->has_safe = 0;
             st->final_iter = zero ? 0 : -1; st->conv = zero ? 1 : 0;
@@ -627,9 +661,9 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         }
         if (bad || zero || hopeless) return;
         inv_cn = 1.0 / c;                                // for the normalised product P P
-        inv_c = inv_cn / hdr_inv_s12(g.hdr);             // for A in the caller's units: 1 / st->c
+        inv_c = inv_cn / hdr_inv_s12(g.hA, hB);          // for A in the caller's units: 1 / st->c
     } else {
-        if (g.skip && *g.skip != 0) return;
+        if (g.skip && *adv(g.skip, po) != 0) return;
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -668,12 +702,12 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     }
     __syncthreads();
     const bool with_digits = (MODE == SP_FIRST) || (MODE == SP_U && zi == 0);
-    store_tile(fin, g.C[zi], with_digits ? g.Cdig[0] : nullptr, with_digits ? g.Cdig_t[0] : nullptr, ty, tx, d, tid);
-    if constexpr (MODE == SP_FIRST) store_tile(fin2, g.C[1], nullptr, nullptr, ty, tx, d, tid);       // Z1 = T0
+    store_tile(fin, adv(g.C[zi], po), with_digits ? adv(g.Cdig[0], po) : nullptr, with_digits ? adv(g.Cdig_t[0], po) : nullptr, ty, tx, d, tid);
+    if constexpr (MODE == SP_FIRST) store_tile(fin2, adv(g.C[1], po), nullptr, nullptr, ty, tx, d, tid);       // Z1 = T0
     if constexpr (MODE == SP_T) {
         double s1[1] = {ss};
         wg8_sum<1>(s1, red);
-        if (tid == 0) g.partials[ty * gridDim.x + tx] = s1[0];
+        if (tid == 0) adv(g.partials, po)[ty * gridDim.x + tx] = s1[0];
     }
 }
 

@@ -188,14 +188,15 @@ static void check_dim(int d) {
     double* d_acc[2]; for (int s = 0; s < 2; ++s) { d_acc[s] = dmalloc<double>(2 + d + dd); h2d(d_acc[s], acc[s]); }
     double* d_mus = dmalloc<double>(2 * d); double* d_covs = dmalloc<double>(2 * dd);
     uint4* d_dig[2] = {reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd)), reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd))};
-    NsState* d_st = dmalloc<NsState>(1); Ns32State* d_s32 = dmalloc<Ns32State>(1); FastHdr* d_hdr = dmalloc<FastHdr>(1);
-    CK(hipMemset(d_st, 0, sizeof(NsState))); CK(hipMemset(d_s32, 0, sizeof(Ns32State))); CK(hipMemset(d_hdr, 0, sizeof(FastHdr)));
+    NsState* d_st = dmalloc<NsState>(1); Ns32State* d_s32 = dmalloc<Ns32State>(1); MatHdr* d_hdr = dmalloc<MatHdr>(2);
+    CK(hipMemset(d_st, 0, sizeof(NsState))); CK(hipMemset(d_s32, 0, sizeof(Ns32State))); CK(hipMemset(d_hdr, 0, 2 * sizeof(MatHdr)));
     PrepArgs pa; memset(&pa, 0, sizeof(pa));
     pa.acc[0] = d_acc[0]; pa.acc[1] = d_acc[1]; pa.d = d; pa.ddof = 1; pa.gen = gen; pa.mus = d_mus; pa.covs = d_covs; pa.dig[0] = d_dig[0]; pa.dig[1] = d_dig[1];
-    pa.st = d_st; pa.hdr = d_hdr; pa.mean_dtype = -1;
+    pa.st = d_st; pa.hdr[0] = d_hdr; pa.hdr[1] = d_hdr + 1; pa.mean_dtype = -1;
     hipLaunchKernelGGL(nsf_prepare, dim3((unsigned)(dd / 2048 + 1), 2), dim3(512), 0, 0, pa);
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
-    FastHdr hdr = d2h(d_hdr, 1)[0];
+    auto hdrs = d2h(d_hdr, 2);
+    struct { double s[2], tr[2]; int bad[2], flag_gen[2]; } hdr = {{hdrs[0].s, hdrs[1].s}, {hdrs[0].tr, hdrs[1].tr}, {hdrs[0].bad, hdrs[1].bad}, {hdrs[0].flag_gen, hdrs[1].flag_gen}};
     auto covs = d2h(d_covs, 2 * dd); auto mus = d2h(d_mus, 2 * d);
     std::vector<int8_t> dig[2] = {d2h(reinterpret_cast<const int8_t*>(d_dig[0]), 6 * dd), d2h(reinterpret_cast<const int8_t*>(d_dig[1]), 6 * dd)};
     std::vector<double> Cn[2];                                              // the normalised matrices the digit planes represent
@@ -228,13 +229,14 @@ static void check_dim(int d) {
     {   // a NaN off the diagonal must raise the element flag (caller-given matrices, second set)
         std::vector<double> cz = cov_ref[1]; cz[(size_t)3 * d + 4] = std::nan("");
         double* d_cz = dmalloc<double>(dd); h2d(d_cz, cz);
-        FastHdr* d_h2 = dmalloc<FastHdr>(1); CK(hipMemset(d_h2, 0, sizeof(FastHdr)));
-        PrepArgs pb = pa; pb.acc[0] = nullptr; pb.acc[1] = nullptr; pb.cov_in[0] = d_covs; pb.cov_in[1] = d_cz; pb.mu_in[0] = d_mus; pb.mu_in[1] = d_mus + d; pb.hdr = d_h2; pb.gen = gen + 1;
+        MatHdr* d_h2 = dmalloc<MatHdr>(2); CK(hipMemset(d_h2, 0, 2 * sizeof(MatHdr)));
+        PrepArgs pb = pa; pb.acc[0] = nullptr; pb.acc[1] = nullptr; pb.cov_in[0] = d_covs; pb.cov_in[1] = d_cz; pb.mu_in[0] = d_mus; pb.mu_in[1] = d_mus + d; pb.hdr[0] = d_h2; pb.hdr[1] = d_h2 + 1; pb.gen = gen + 1;
         pb.dig[0] = reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd)); pb.dig[1] = reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd));
         NsState* d_st2 = dmalloc<NsState>(1); pb.st = d_st2;
         hipLaunchKernelGGL(nsf_prepare, dim3((unsigned)(dd / 2048 + 1), 2), dim3(512), 0, 0, pb);
         CK(hipGetLastError()); CK(hipDeviceSynchronize());
-        FastHdr h2 = d2h(d_h2, 1)[0];
+        auto h2v = d2h(d_h2, 2);
+        struct { double s[2]; int bad[2], flag_gen[2]; } h2 = {{h2v[0].s, h2v[1].s}, {h2v[0].bad, h2v[1].bad}, {h2v[0].flag_gen, h2v[1].flag_gen}};
         report("K1: NaN off the diagonal raises the element flag of its set only", (h2.flag_gen[1] == gen + 1 && h2.flag_gen[0] != gen + 1 && !h2.bad[0] && !h2.bad[1]) ? 0.0 : 1.0, 0.0);
         report("K1: caller-given matrices get the same scale", std::fabs(h2.s[0] - scale_ref[0]), 0.0);
     }
@@ -244,7 +246,7 @@ static void check_dim(int d) {
     SplitMat P = alloc_split(d);
     double* d_stats = dmalloc<double>((size_t)(kTileStats + 2) * nb * nb);
     I8Args ia; memset(&ia, 0, sizeof(ia));
-    ia.Adig = d_dig[0]; ia.Bdig = d_dig[1]; ia.d = d; ia.gen = gen; ia.hdr = d_hdr; ia.stats = d_stats; ia.A64 = d_A64; ia.P = P;
+    ia.Adig = d_dig[0]; ia.Bdig = d_dig[1]; ia.d = d; ia.gen = gen; ia.hA = d_hdr; ia.hB = d_hdr + 1; ia.stats = d_stats; ia.A64 = d_A64; ia.P = P;
     ia.st = d_st;
     run_i8(d, I8_A, ia);
     auto A64 = d2h(d_A64, dd);
@@ -290,7 +292,7 @@ static void check_dim(int d) {
     uint4* d_digYt[2] = {reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd)), reinterpret_cast<uint4*>(dmalloc<int8_t>(6 * dd))};
     double* d_part = dmalloc<double>((size_t)nb * nb);
     SplitArgs g; memset(&g, 0, sizeof(g));
-    g.d = d; g.gen = gen; g.hdr = d_hdr; g.st = d_st; g.s32 = d_s32;
+    g.d = d; g.gen = gen; g.hA = d_hdr; g.hB = d_hdr + 1; g.st = d_st; g.s32 = d_s32;
     g.A[0] = P; g.B[0] = P; g.C[0] = Y[1]; g.C[1] = Z[1]; g.Cdig[0] = d_digY[1]; g.Cdig_t[0] = d_digYt[1]; g.A64 = d_A64; g.statsA = d_stats;
     run_split(d, SP_FIRST, g);
     NsState st = d2h(d_st, 1)[0]; Ns32State s32 = d2h(d_s32, 1)[0];
@@ -326,7 +328,7 @@ static void check_dim(int d) {
     // ---------------- K4: T = 1.5 I - 0.5 Z Y with residual partials (operands: what K3 left)
     HostSplit hy = fetch_split(Y[1], d), hz = fetch_split(Z[1], d);
     memset(&g, 0, sizeof(g));
-    g.d = d; g.gen = gen; g.hdr = d_hdr; g.st = d_st; g.s32 = d_s32;
+    g.d = d; g.gen = gen; g.hA = d_hdr; g.hB = d_hdr + 1; g.st = d_st; g.s32 = d_s32;
     g.A[0] = Z[1]; g.B[0] = Y[1]; g.C[0] = T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f; g.partials = d_part; g.skip = &d_s32->done;
     run_split(d, SP_T, g);
     HostSplit ht = fetch_split(T, d);
@@ -349,7 +351,7 @@ static void check_dim(int d) {
 
     // ---------------- K5: Y <- Y T, Z <- T Z, check of iteration 1, digits of the new Y
     memset(&g, 0, sizeof(g));
-    g.d = d; g.gen = gen; g.hdr = d_hdr; g.st = d_st; g.s32 = d_s32;
+    g.d = d; g.gen = gen; g.hA = d_hdr; g.hB = d_hdr + 1; g.st = d_st; g.s32 = d_s32;
     g.A[0] = Y[1]; g.B[0] = T; g.C[0] = Y[0]; g.A[1] = T; g.B[1] = Z[1]; g.C[1] = Z[0];
     g.Cdig[0] = d_digY[0]; g.Cdig_t[0] = d_digYt[0]; g.skip = &d_s32->upd_skip[1];
     g.k = 1; g.max_low = 14; g.nslots = nb * nb; g.chk_partials = d_part; g.thr_pred = 2.5e-3 * d / 512.0;
@@ -382,7 +384,7 @@ static void check_dim(int d) {
         int* d_words = dmalloc<int>(kHostWords); double* d_vals = dmalloc<double>(kHostVals);
         I8Args ig; memset(&ig, 0, sizeof(ig));
         ig.Adig = d_digY[0]; ig.Bdig = d_digYt[0]; ig.Adig_alt = d_digY[1]; ig.Bdig_alt = d_digYt[1]; ig.sel = &d_s32->final_iter;
-        ig.d = d; ig.gen = gen; ig.hdr = d_hdr; ig.skip = &d_s32->skip_corr; ig.stats = d_stats; ig.st = d_st; ig.A64in = d_A64;
+        ig.d = d; ig.gen = gen; ig.hA = d_hdr; ig.hB = d_hdr + 1; ig.skip = &d_s32->skip_corr; ig.stats = d_stats; ig.st = d_st; ig.A64in = d_A64;
         ig.Y[0] = Y[0]; ig.Y[1] = Y[1]; ig.Z[0] = Z[0]; ig.Z[1] = Z[1]; ig.s32 = d_s32; ig.host_words = d_words; ig.host_vals = d_vals;
         run_i8(d, I8_G, ig);
         auto sg = d2h(d_stats, (size_t)(kTileStats + 2) * nb * nb);

@@ -1099,3 +1099,32 @@ def test_score_inf_points_on_device_match_the_sequential_route(F, d, dtype):
         mu_e, cov_e = O.embd_statistics(rows[idx])
         ref = O.frechet_distance(mu_b, cov_b, mu_e, cov_e, run_sqrtm=False)
         assert abs(v - ref) <= FAD_BAR / 10 * abs(ref)
+
+
+@pytest.mark.parametrize("d,frames", [(128, [129, 300, 2250, 140, 777]), (256, [257, 600, 300, 1500]), (768, [1500, 900])])
+def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
+    """Songs with at least D + 1 frames, D in {128, 256, 512, 768, 1024}: the eight-launch chain of the single pair, batched over
+    the songs (frechet.hip: fast_songs) -- exact int8-MFMA products, split-float16 Newton-Schulz, one correction, decided per song
+    on the host.  Against the oracle (fad.py:373-378) and against the float64 routes (FAD_SONG_FAST=0); a song without any spread
+    and a song whose spectrum the chain does not accept ride along and must come back through the float64 routes."""
+    from fadtk_amd import hip
+    rng = np.random.default_rng(d)
+    mu_b, cov_b = R.baseline_stats(700 + d, 6 * d, d)
+    sg = [(rng.standard_normal((n, d)) * (0.7 + 0.6 * rng.random(d)) + 0.1 * rng.standard_normal(d)).astype(np.float16) for n in frames]
+    flat = np.tile(sg[0][:1], (d + 5, 1))                                       # all frames equal: Sigma_s = 0
+    steep = (rng.standard_normal((2 * d, d)) * np.arange(1, d + 1) ** -1.5).astype(np.float16)      # decaying spectrum: not for this chain
+    sg = sg + [flat, steep]
+    rows = np.concatenate(sg)
+    offs = np.concatenate([[0], np.cumsum([s.shape[0] for s in sg])])
+    monkeypatch.setenv("FAD_SONG_FAST", "2")                                  # strict: an error if the chain accepts no song at all
+    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+    assert (status == 0).all(), status
+    want = O.individual_scores(mu_b, cov_b, sg, run_sqrtm=False)
+    np.testing.assert_allclose(scores, want, rtol=2e-6)
+    monkeypatch.setenv("FAD_SONG_FAST", "0")                                  # the float64 routes on the same call
+    scores64, status64 = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+    assert (status64 == 0).all()
+    np.testing.assert_allclose(scores, scores64, rtol=2e-6)
+    with pytest.raises(RuntimeError):                                         # only songs the chain cannot take: strict mode must say so
+        monkeypatch.setenv("FAD_SONG_FAST", "2")
+        hip.frechet_batched(mu_b, cov_b, np.concatenate([flat, steep]), [0, flat.shape[0], flat.shape[0] + steep.shape[0]], mean_mode=1)
