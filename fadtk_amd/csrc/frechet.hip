@@ -28,10 +28,12 @@
 #include "ns32.h"
 #include "ns_mean.h"
 #include "ns_fast.h"
+#include "ns_fast_big.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <vector>
 
 struct fad_moments;
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ st
 }
 
 constexpr int kMaxLow = 14;
+constexpr int kSymMaxIter = 16;   // symmetric per-song route: iterates beyond this mean a spread the route's sqrt(Sigma_b) cannot carry
 
 // When may the check of iteration k declare Y_{k+1} final from the bound b = 3/4 r_k^2 + 1/4 r_k^3 on its residual?
 // The fp64 correction leaves an error of about (||Z||^3/8 + ||Z||/2) b^2 (ns32_finish: est, with ||R|| <~ b), which has
@@ -698,6 +701,19 @@ static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st,
         default: fast_launch_split<8>(mode, t, B, g, st); break;
     }
 }
+// the batched form of SP_T / SP_U on 128 x 128 tiles (ns_fast_big.h); 64 KiB + of dynamic LDS: the attribute is set once per device
+static int fast_split_big(int d, int mode, const nsf::SplitArgs& g, hipStream_t st, unsigned B, int device) {
+    static std::atomic<unsigned> ready{0};
+    if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
+        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
+        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
+        ready.fetch_or(1u << device, std::memory_order_release);
+    }
+    const unsigned t = (unsigned)(d / 128);
+    if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(t, t, B), dim3(256), nsf::kBigLds, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U>), dim3(t, t, 3 * B), dim3(256), nsf::kBigLds, st, g);
+    return FAD_OK;
+}
 template <int NS8> static void fast_launch_i8(int mode, unsigned t, unsigned B, const nsf::I8Args& g, hipStream_t st) {
     if (mode == nsf::I8_A) hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_A>), dim3(t, t, B), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((nsf::nsf_i8<NS8, nsf::I8_G>), dim3(t, t, B), dim3(512), 0, st, g);
@@ -802,11 +818,12 @@ static void fast_decide_one(const int* hw, const double* hv, const double* hsx, 
         const double est = zn * zn * zn * rn * rn / 8.0 + zn * res * rn / 2.0;
         const bool finite = std::isfinite(trs) && std::isfinite(est);
         o.tr_scaled = trs; o.res = res; o.est = est;
-        // accepted when the bound on the neglected terms is below 1e-9 of the trace, or moves the DISTANCE by less than 1e-6 of
-        // itself (100x inside the 1e-4 bar; the bound overestimates the true error 10..10^4 times, most for spread spectra where
-        // ||Z|| is large: scripts/ns_emulate_split.py)
+        // accepted when the bound on the neglected terms is below 1e-9 of the trace, or moves the DISTANCE by less than 1e-5 of
+        // itself (10x inside the 1e-4 bar AS A BOUND: it overestimates the true error 10..10^5 times, most for spread spectra
+        // where the norm bound of Z is 3-4x its 2-norm and enters cubed -- a song of 2 D frames, condition 400: bound 2e-8 of the
+        // trace, true error 2e-13, scripts/ns_emulate_split.py)
         const double fad = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs;
-        const bool accept = finite && (est <= 1e-9 * std::fabs(trs) || 2.0 * std::sqrt(o.c) * est <= 1e-6 * std::fabs(fad));
+        const bool accept = finite && (est <= 1e-9 * std::fabs(trs) || 2.0 * std::sqrt(o.c) * est <= 1e-5 * std::fabs(fad));
         o.status = accept ? 1 : 2;
         if (!accept && finite && !strict && hw[8] == fi - 1 && fi + 1 < kMaxLow) o.status = 4;
     }
@@ -863,7 +880,8 @@ static int64_t fast_songs_capacity(int d, size_t budget_bytes) {
 
 // covs: B covariances [d x d] float64 on the device; -> tr_sqrt[b] and ok[b] (1: accepted, 0: hand the song to the float64 routes)
 static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipStream_t st, Workspace& ws,
-                      std::vector<double>& tr_sqrt, std::vector<char>& ok) {
+                      std::vector<double>& tr_sqrt, std::vector<char>& ok, int device) {
+    static const bool big = [] { const char* e = getenv("FAD_SONG_BIG"); return !(e && e[0] == '0'); }();      // 0: the single-problem kernels, batched
     const size_t dd = (size_t)d * d;
     const int nb = d / 32;
     const SongBlock L = song_block(d);
@@ -926,20 +944,26 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
     }
     tr_sqrt.assign((size_t)B, 0.0); ok.assign((size_t)B, 0);
     std::vector<char> settled((size_t)B, 0);
-    int k = 1, upto = 5;
+    // iterations 1..8 blind (a song of 2 D .. 20 D frames needs 7-11: its product has a condition number of a few hundred), then the
+    // correction for the songs whose check finished them; if any is still iterating, the rest of the budget in one go (every song
+    // stops itself: the launches of a finished song exit at once)
+    static const bool trace = [] { const char* e = getenv("FAD_FAST_TRACE"); return e && e[0] == '1'; }();
+    int k = 1, upto = 9;
     for (;;) {
         for (; k < upto; ++k) {
             const int cur = k & 1;
             nsf::SplitArgs g = split_args();
             g.A[0] = Z[cur]; g.B[0] = Y[cur]; g.C[0] = T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f;
             g.partials = partials; g.skip = &s32_0->done;
-            fast_split(d, nsf::SP_T, g, st, (unsigned)B);
+            if (big) FAD_TRY(fast_split_big(d, nsf::SP_T, g, st, (unsigned)B, device));
+            else fast_split(d, nsf::SP_T, g, st, (unsigned)B);
             g = split_args();
             g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1];
             g.Cdig[0] = digY[cur ^ 1]; g.Cdig_t[0] = digYt[cur ^ 1];
             g.skip = &s32_0->upd_skip[k & 1];
-            g.k = k; g.max_low = kMaxLow; g.nslots = nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
-            fast_split(d, nsf::SP_U, g, st, (unsigned)B);
+            g.k = k; g.max_low = kMaxLow; g.nslots = big ? (d / 128) * (d / 128) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
+            if (big) FAD_TRY(fast_split_big(d, nsf::SP_U, g, st, (unsigned)B, device));
+            else fast_split(d, nsf::SP_U, g, st, (unsigned)B);
         }
         nsf::I8Args a;
         memset(&a, 0, sizeof(a));
@@ -963,9 +987,12 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
             if (r.status == 0 && k < kMaxLow) { pending = true; continue; }      // not finished yet: more iterations for this song
             settled[b] = 1;
             if (r.status == 1) { ok[b] = 1; tr_sqrt[b] = std::sqrt(r.c) * r.tr_scaled; }
+            if (trace)
+                fprintf(stderr, "[fad fast songs] song %lld: status %d iters %d decided_at %d res %.3e est %.3e tr %.6e c %.3e (words bad %d done %d ok %d failed %d skipped %d)\n",
+                        (long long)b, r.status, r.iters, r.decided_at, r.res, r.est, r.tr_scaled, r.c, hw[0], hw[1], hw[5], hw[6], hw[11]);
         }
         if (!pending) break;
-        upto = (k + 2 < kMaxLow) ? k + 2 : kMaxLow;
+        upto = kMaxLow;
     }
     return FAD_OK;
 }
@@ -1979,7 +2006,7 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             FAD_HIP_TRY(hipMemcpyAsync(ids_dev, general.data() + g0, B * sizeof(int64_t), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((song_cov_mfma<TIn>), dim3((unsigned)(nt64 * (nt64 + 1) / 2), 1, (unsigned)B), dim3(256), 0, st, drows,
                                ld, d, nt64, d_off, ids_dev, mean_exact, covs);
-            FAD_TRY(fast_songs(d, B, dcov_b, covs, st, ws, trs, okv));       // (synchronises: `general` may be read again)
+            FAD_TRY(fast_songs(d, B, dcov_b, covs, st, ws, trs, okv, device));       // (synchronises: `general` may be read again)
             for (int64_t b = 0; b < B; ++b) {
                 const int64_t sg = general[g0 + b];
                 if (okv[b]) out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * trs[b];
@@ -2062,10 +2089,16 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
                 FAD_TRY(run_ns(pb, 0, 0.0, device, st, ws, &hs));                          // (synchronises: the index vectors may go)
                 for (int64_t b = 0; b < B; ++b) {
                     const int64_t sg = sym_songs[g0 + b];
-                    if (hs[b].nonfinite || !(tr_b == tr_b)) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
+                    if (!(tr_b == tr_b)) { out_status[sg] = FAD_ERR_NOT_FINITE; out_scores[sg] = __builtin_nan(""); continue; }
+                    // This route sees the song through sqrt(Sigma_b), which Newton-Schulz delivers to ~1e-10, and an eigenvalue of the
+                    // transformed covariance moves with that error divided by its own square root: only songs whose iteration shows
+                    // a moderate spread keep the result (a start value (1.5)^-13 below 1 is lambda_min / c ~ 3e-5); the others --
+                    // and whatever did not converge or overflowed here -- go on to the product route below, which forms
+                    // Sigma_b Sigma_s itself.  (Round 3: a k^-3 spectrum at D = 768 came back 4e-5 off with status 0, at D = 1024
+                    // as NaN; tests/test_gpu_parity.py: test_songs_full_rank_route_on_the_matrix_pipes.)
+                    if (hs[b].nonfinite || hs[b].conv == 0 || hs[b].final_iter < 0 || hs[b].final_iter > kSymMaxIter) { rest.push_back(sg); continue; }
                     const double tr_sqrt = sqrt(hs[b].c) * hs[b].tr_last;
                     out_scores[sg] = h_scal[2 * sg] + tr_b + h_scal[2 * sg + 1] - 2.0 * tr_sqrt;
-                    if (hs[b].conv == 0) out_status[sg] = FAD_ERR_NOT_CONVERGED;
                 }
                 g0 = g1;
             }

@@ -50,7 +50,6 @@ struct fad_moments {
     unsigned update_seq = 0;
     int guard = 1;                         // 0 disables the guard (FAD_MOMENTS_SHIFT_GUARD=0, read at creation)
     bool force_generic = false;            // FAD_MOMENTS_FORCE_GENERIC=1 (read at creation): always the fp64 kernel
-    int load_policy = 0;                   // FAD_MOMENTS_LOAD_POLICY=nt (read at creation): 1 = non-temporal LDS-DMA loads in the hot loop
     bool fresh = false;                    // reset since the last update: the next reduce stores instead of adding
     // opt-in HIP-event timing: a ring of (before tile kernel, after tile kernel, after reduce) triplets,
     // recorded on the caller's stream and only read back by fad_moments_last_timing (no sync in update)
@@ -86,8 +85,7 @@ typedef void (*tile_kernel_t)(TileLaunch);
 static tile_kernel_t tr_kernel_shift(bool fast) {          // second pass of the shift guard (float16 rows only)
     return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false, true>;
 }
-static tile_kernel_t tr_kernel(int dtype, bool fast, int policy = 0) {       // multi-tile: 4 stages of 16 KiB; single tile: 8 stages of 8 KiB
-    if (dtype == FAD_F16 && fast && policy == 1) return &moments_tile_h16_tr<FAD_F16, H_NST, true, false, 1>;
+static tile_kernel_t tr_kernel(int dtype, bool fast) {       // multi-tile: 4 stages of 16 KiB; single tile: 8 stages of 8 KiB
     if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false>;
     return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, 2 * H_NST, false>;
 }
@@ -102,12 +100,9 @@ static int ensure_kernel_attrs(int device) {
         for (bool fast : {false, true}) {
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
-            if (dt == FAD_F16) {
+            if (dt == FAD_F16)
                 FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel_shift(fast)),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
-                if (fast) FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, true, 1)),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
-            }
         }
     }
     done[device] = true;
@@ -262,7 +257,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
         }
         L.total = item;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1, h0->load_policy), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
+        hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
 
         // shift guard: exact fp64 redo of every flagged set, one gated launch for all of them
@@ -472,8 +467,6 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     h->guard = !(gs && gs[0] == '0');
     const char* fg = getenv("FAD_MOMENTS_FORCE_GENERIC");
     h->force_generic = fg && fg[0] == '1';
-    const char* lp = getenv("FAD_MOMENTS_LOAD_POLICY");
-    h->load_policy = (lp && lp[0] == 'n') ? 1 : 0;
     *out = h;
     return FAD_OK;
 }

@@ -164,7 +164,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int outstanding
 // of every column, tripped or not.  moments_reduce restores the raw moments in float64: sum x_i x_j = S'_ij + c_i s'_j +
 // s'_i c_j + n c_i c_j with s' the column sums of x - c.  Two passes of this kernel + a few loads per split in the reduce
 // instead of the float64 kernel over the whole block: ~10x faster when the guard fires (scripts/probe_guard.py).
-template <int KIND, int NST, bool DIAG, bool FAST, bool SHIFT = false, int POL = 0>
+template <int KIND, int NST, bool DIAG, bool FAST, bool SHIFT = false>
 __device__ __forceinline__ void tile_h16_tr_body(
     const uint16_t* __restrict__ E, int64_t k_begin0, int64_t k_end0, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
@@ -244,12 +244,8 @@ __device__ __forceinline__ void tile_h16_tr_body(
             const uint64_t ub = ((uint64_t)hi << 32) | lo;
             const uint32_t dst = smem_lds + (uint32_t)(((kb % NST) * STAGE + 256 * h + 64 * wave + (side_b ? H_KB * 16 : 0)) * 16);
             const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst);
-            // POL = 1: the non-temporal hint on the stream of frames (FAD_MOMENTS_LOAD_POLICY=nt, measured in round 3 with inputs that
-            // really come from HBM: three pairs rotated, 614 MB)
-            if constexpr (POL == 1)
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
-            else
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
+            // (the non-temporal hint `nt` on this load, measured in round 3 on the bench's rotated inputs: 889 instead of 1270 GB/s)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
         }
     };
     int nfast = 0;                                 // stages [0, nfast) of the current run may be loaded the fast way
@@ -496,7 +492,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     }
 }
 
-template <int KIND, int NST, bool FAST, bool SHIFT = false, int POL = 0>
+template <int KIND, int NST, bool FAST, bool SHIFT = false>
 __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
     const int w = xcd_contiguous(blockIdx.x, L.total);
@@ -510,11 +506,11 @@ __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
     float* partials = static_cast<float*>(s.partials);
     // (the second pass neither re-examines the columns nor rewrites the shifts: no flag, but the shifts to read)
     if (ta == tb)
-        tile_h16_tr_body<KIND, NST, true, FAST, SHIFT, POL>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, true, FAST, SHIFT>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
                                                        partials, s.colpart, smem_dyn, SHIFT ? nullptr : s.flag, s.runs, run_lo, run_hi,
                                                        s.cvec);
     else if constexpr (FAST)
-        tile_h16_tr_body<KIND, NST, false, FAST, SHIFT, POL>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+        tile_h16_tr_body<KIND, NST, false, FAST, SHIFT>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
                                                         partials, s.colpart, smem_dyn, nullptr, s.runs, run_lo, run_hi, s.cvec);
 }
 

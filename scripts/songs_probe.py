@@ -21,7 +21,7 @@ if what in ("c5", "c4"):
         sc, st = hip.frechet_batched(mu, cov, songs, offs)
         torch.cuda.synchronize(); print(what, "call", i, "%.3f ms" % ((time.perf_counter() - t0) * 1e3), "ok", int((st == 0).sum()))
 else:
-    sys.path.insert(0, "tests")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
     from oracle import fad_oracle as O
     import recipes as R
     for d, frames in ((768, [1500, 900]), (512, [1100]), (1024, [2100])):

@@ -1101,7 +1101,8 @@ def test_score_inf_points_on_device_match_the_sequential_route(F, d, dtype):
         assert abs(v - ref) <= FAD_BAR / 10 * abs(ref)
 
 
-@pytest.mark.parametrize("d,frames", [(128, [129, 300, 2250, 140, 777]), (256, [257, 600, 300, 1500]), (768, [1500, 900])])
+@pytest.mark.parametrize("d,frames", [(128, [129, 300, 2250, 140, 777]), (256, [257, 600, 300, 1500]), (512, [1100, 513]), (768, [1500, 900]),
+                                      (1024, [2100])])
 def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     """Songs with at least D + 1 frames, D in {128, 256, 512, 768, 1024}: the eight-launch chain of the single pair, batched over
     the songs (frechet.hip: fast_songs) -- exact int8-MFMA products, split-float16 Newton-Schulz, one correction, decided per song
