@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <atomic>
+#include <type_traits>
 #include <vector>
 
 struct fad_moments;
@@ -274,6 +275,7 @@ struct Workspace : NsWorkspace {
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats)
     DevBuf fast;                                    // the eight-launch chain (ns_fast.h): header, digit planes, split planes
     int fast_gen = 0;                               // per-call token of that chain (MatHdr::flag_gen)
+    DevBuf songcov;                                 // ... scratch of the float16 per-song covariances (partial tiles, column sums, shifts)
     DevBuf fast_songs;                              // ... its batched form for songs: baseline digits + one block per song
     void* fast_songs_pin = nullptr; size_t fast_songs_pin_cap = 0;      // ... and what its correction kernel leaves for the host
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
@@ -291,7 +293,7 @@ struct Workspace : NsWorkspace {
     struct Pool* pool = nullptr;
     void release_all() {
         release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release(); base_root.release(); fast.release();
-        fast_songs.release();
+        fast_songs.release(); songcov.release();
         if (fast_songs_pin) { (void)hipHostFree(fast_songs_pin); fast_songs_pin = nullptr; fast_songs_pin_cap = 0; }
         if (done_ev) { (void)hipEventDestroy(done_ev); done_ev = nullptr; }
         if (song_pin) { (void)hipHostFree(song_pin); song_pin = nullptr; song_pin_cap = 0; }
@@ -702,16 +704,17 @@ static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st,
     }
 }
 // the batched form of SP_T / SP_U on 128 x 128 tiles (ns_fast_big.h); 64 KiB + of dynamic LDS: the attribute is set once per device
-static int fast_split_big(int d, int mode, const nsf::SplitArgs& g, hipStream_t st, unsigned B, int device) {
+static int fast_split_big(int d, int mode, nsf::SplitArgs g, hipStream_t st, unsigned B, int device) {
     static std::atomic<unsigned> ready{0};
     if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
         FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
         FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
         ready.fetch_or(1u << device, std::memory_order_release);
     }
-    const unsigned t = (unsigned)(d / 128);
-    if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(t, t, B), dim3(256), nsf::kBigLds, st, g);
-    else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U>), dim3(t, t, 3 * B), dim3(256), nsf::kBigLds, st, g);
+    const unsigned t = (unsigned)(d / 128), Bp = (B + 7u) & ~7u;
+    g.nprob = (int)B; g.nprob_pad = (int)Bp;
+    if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(t * t * Bp), dim3(256), nsf::kBigLds, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U>), dim3(2 * t * t * Bp + B), dim3(256), nsf::kBigLds, st, g);
     return FAD_OK;
 }
 template <int NS8> static void fast_launch_i8(int mode, unsigned t, unsigned B, const nsf::I8Args& g, hipStream_t st) {
@@ -881,7 +884,11 @@ static int64_t fast_songs_capacity(int d, size_t budget_bytes) {
 // covs: B covariances [d x d] float64 on the device; -> tr_sqrt[b] and ok[b] (1: accepted, 0: hand the song to the float64 routes)
 static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipStream_t st, Workspace& ws,
                       std::vector<double>& tr_sqrt, std::vector<char>& ok, int device) {
-    static const bool big = [] { const char* e = getenv("FAD_SONG_BIG"); return !(e && e[0] == '0'); }();      // 0: the single-problem kernels, batched
+    // FAD_SONG_BIG = smallest batch that iterates on the 128 x 128 tiles of ns_fast_big.h (default 8: a handful of songs fills the chip
+    // only on 32 x 32 tiles; 0 = never; read per call -- tests force either kernel family on the same songs)
+    const char* big_env = getenv("FAD_SONG_BIG");
+    const long big_min = big_env ? atol(big_env) : 8;
+    const bool big = big_min > 0 && B >= big_min;
     const size_t dd = (size_t)d * d;
     const int nb = d / 32;
     const SongBlock L = song_block(d);
@@ -2004,8 +2011,17 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         for (size_t g0 = 0; g0 < general.size(); g0 += (size_t)sub) {
             const int64_t B = (int64_t)std::min<size_t>((size_t)sub, general.size() - g0);
             FAD_HIP_TRY(hipMemcpyAsync(ids_dev, general.data() + g0, B * sizeof(int64_t), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL((song_cov_mfma<TIn>), dim3((unsigned)(nt64 * (nt64 + 1) / 2), 1, (unsigned)B), dim3(256), 0, st, drows,
-                               ld, d, nt64, d_off, ids_dev, mean_exact, covs);
+            // float16 frames: the covariances on the float16 matrix pipe, shifted by the song's mean (moments_kernels.h: song_cov_*;
+            // FAD_SONG_COV16=0: the float64 MFMA kernel, as for every other dtype)
+            static const bool cov16_on = [] { const char* e = getenv("FAD_SONG_COV16"); return !(e && e[0] == '0'); }();
+            if (std::is_same<TIn, r_f16>::value && cov16_on && song_cov_f16_ok(drows, ld, d)) {
+                int64_t max_frames = 0;
+                for (int64_t b = 0; b < B; ++b) { const int64_t sg = general[g0 + b]; max_frames = std::max(max_frames, h_off[sg + 1] - h_off[sg]); }
+                FAD_TRY(song_cov_f16_launch(drows, ld, d, d_off, ids_dev, B, max_frames, mean_exact, covs, ws.songcov, device, st));
+            } else {
+                hipLaunchKernelGGL((song_cov_mfma<TIn>), dim3((unsigned)(nt64 * (nt64 + 1) / 2), 1, (unsigned)B), dim3(256), 0, st, drows,
+                                   ld, d, nt64, d_off, ids_dev, mean_exact, covs);
+            }
             FAD_TRY(fast_songs(d, B, dcov_b, covs, st, ws, trs, okv, device));       // (synchronises: `general` may be read again)
             for (int64_t b = 0; b < B; ++b) {
                 const int64_t sg = general[g0 + b];

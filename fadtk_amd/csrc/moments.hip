@@ -871,3 +871,46 @@ int moments_settle(const fad_moments* h, hipStream_t st) { return settle(h, st);
 int moments_device(const fad_moments* h) { return h->device; }
 int moments_dim(const fad_moments* h) { return h->d; }
 }
+
+// ==========================================================================================
+// Covariances of B songs of float16 frames on the tile kernels (moments_kernels.h: song_cov_*); for frechet.hip's batched per-song
+// chain.  rows: 16-byte aligned, ld and d multiples of 8; mean_exact [song][d] and offsets on the device; cov_out [B][d * d].
+// ==========================================================================================
+namespace fad {
+bool song_cov_f16_ok(const void* rows, int64_t ld, int d) {
+    return d % 8 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15u) == 0 && ld < ((int64_t)1 << 26);
+}
+int song_cov_f16_launch(const void* rows, int64_t ld, int d, const int64_t* d_offsets, const int64_t* d_song_ids, int64_t B,
+                        int64_t max_frames, const double* d_mean_exact, double* d_cov_out, DevBuf& scratch, int device, hipStream_t st) {
+    if (B <= 0) return FAD_OK;
+    {
+        static std::mutex mu;
+        static bool done[64] = {false};
+        std::lock_guard<std::mutex> lk(mu);
+        if (device < 0 || device >= 64) return set_error(FAD_ERR_INVALID, "device %d out of range", device);
+        if (!done[device]) {
+            FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&song_cov_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
+            FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&song_cov_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
+            done[device] = true;
+        }
+    }
+    SongCovLaunch L;
+    L.rows = static_cast<const uint16_t*>(rows); L.ld = ld; L.d = d;
+    L.nt = (d + H_BT - 1) / H_BT; L.T = L.nt * (L.nt + 1) / 2;
+    int64_t S = (max_frames + 4095) / 4096;
+    L.S = (int)(S < 1 ? 1 : (S > 64 ? 64 : S));
+    L.offsets = d_offsets; L.song_ids = d_song_ids; L.mean_exact = d_mean_exact; L.cov_out = d_cov_out;
+    const size_t dpad = (size_t)L.nt * H_BT, runs = (size_t)B * L.S;
+    const size_t b_part = (runs * L.T * H_TS * sizeof(float) + 255) & ~(size_t)255, b_col = (runs * dpad * sizeof(double) + 255) & ~(size_t)255;
+    FAD_TRY(scratch.reserve(b_part + b_col + runs * dpad * sizeof(uint16_t) + 256));
+    char* base = static_cast<char*>(scratch.p);
+    L.partials = reinterpret_cast<float*>(base); L.colpart = reinterpret_cast<double*>(base + b_part);
+    L.cvec = reinterpret_cast<uint16_t*>(base + b_part + b_col);
+    hipLaunchKernelGGL(song_cov_shift, dim3((unsigned)B), dim3(256), 0, st, L);
+    if (L.T > 1) hipLaunchKernelGGL(song_cov_tile<true>, dim3((unsigned)L.T, (unsigned)L.S, (unsigned)B), dim3(256), kTrLds, st, L);
+    else hipLaunchKernelGGL(song_cov_tile<false>, dim3(1, (unsigned)L.S, (unsigned)B), dim3(256), kTrLds, st, L);
+    hipLaunchKernelGGL(song_cov_finish, dim3((unsigned)(L.T * 16), (unsigned)B), dim3(256), 0, st, L);
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+}  // namespace fad

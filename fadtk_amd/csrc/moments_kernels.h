@@ -1022,4 +1022,97 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(
     cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-song covariances on the float16 tile body (frechet.hip: the batched per-song chain, songs of at least D + 1 float16 frames).
+// Round 2 formed them on the float64 MFMA (song_cov_mfma, frechet.hip): 3.0 ms of a 10.5 ms call for 2000 songs of [2250 x 128],
+// 1.0 of 8.5 ms for 32 songs of [1500 x 768] (profiles/r03j_*).  Here a song is what a split is to moments_tile_h16_tr, in its
+// SHIFTED form: every column is shifted by c = float16(mean) (the exact mean is known: the statistics kernel ran), the rows enter
+// the MFMAs as the error-free pair x - c = x' + e, the products are exact in float32 and what is summed is centred -- float32-sum
+// accuracy relative to the variances (~1e-7), which moves tr sqrt(Sigma_b Sigma_s) by ~1e-8 of itself; tr Sigma_s and the mean term
+// of the score stay the exact float64 sums of the statistics kernel.  Songs longer than 4096 frames are cut into S runs, each with
+// its own float32 partial tile; song_cov_finish sums the runs in float64 and writes
+//     Sigma = (S' - s' s'^T / n) / (n - 1),    S' = sum (x - c)(x - c)^T,  s' = sum (x - c)      (both triangles).
+struct SongCovLaunch {
+    const uint16_t* rows; int64_t ld; int d, nt, T, S;
+    const int64_t* offsets; const int64_t* song_ids;       // slot -> song (nullptr: slot == song)
+    const double* mean_exact;                              // [song][d]
+    uint16_t* cvec;                                        // [slot * S + run][nt * H_BT]
+    float* partials;                                       // [(slot * S + run) * T + tile][H_TS]
+    double* colpart;                                       // [slot * S + run][nt * H_BT]
+    double* cov_out;                                       // [slot][d * d]
+};
+
+__global__ __launch_bounds__(256) void song_cov_shift(SongCovLaunch L) {
+    const int64_t slot = blockIdx.x, s = L.song_ids ? L.song_ids[slot] : slot;
+    const int dpad = L.nt * H_BT;
+    for (int col = threadIdx.x; col < dpad; col += 256) {
+        uint16_t bits = 0;
+        if (col < L.d) {
+            const double m = L.mean_exact[s * L.d + col];
+            const _Float16 ch = ((m == m) && fabs(m) < 65000.0) ? (_Float16)(float)m : (_Float16)0.0f;
+            __builtin_memcpy(&bits, &ch, 2);
+        }
+        for (int run = 0; run < L.S; ++run) L.cvec[(slot * L.S + run) * dpad + col] = bits;
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void song_cov_tile(SongCovLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];
+    const int tile = blockIdx.x, run = blockIdx.y;
+    const int64_t slot = blockIdx.z, s = L.song_ids ? L.song_ids[slot] : slot;
+    const int64_t r0 = L.offsets[s], r1 = L.offsets[s + 1];
+    const int64_t per = (((r1 - r0 + L.S - 1) / L.S) + H_KB - 1) / H_KB * H_KB;     // whole stages: only a song's last run ends ragged
+    const int64_t k_begin = (r0 + run * per < r1) ? r0 + run * per : r1;
+    const int64_t k_end = (k_begin + per < r1) ? k_begin + per : r1;
+    const int split = (int)(slot * L.S + run);
+    int ta, tb; tile_coords(tile, L.nt, ta, tb);
+    if (ta == tb)
+        tile_h16_tr_body<FAD_F16, FAST ? H_NST : 2 * H_NST, true, FAST, true>(L.rows, k_begin, k_end, L.ld, L.d, L.nt, L.T, split, tile, ta * H_BT,
+                                                                              tb * H_BT, L.partials, L.colpart, smem_dyn, nullptr, nullptr, 0, 0, L.cvec);
+    else if constexpr (FAST)
+        tile_h16_tr_body<FAD_F16, H_NST, false, FAST, true>(L.rows, k_begin, k_end, L.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                            L.partials, L.colpart, smem_dyn, nullptr, nullptr, 0, 0, L.cvec);
+}
+
+// grid (T * 16, songs): a thread owns one float4 of a partial tile = rows ga .. ga + 3 of column gb (the fragment-major layout of
+// tile_h16_tr_body); on a diagonal tile only the blocks on and above the diagonal hold sums ("mirror": the block (rows 0..63,
+// columns 64..127) is the sum of two half-sums), the rest follows by symmetry
+__global__ __launch_bounds__(256) void song_cov_finish(SongCovLaunch L) {
+    const int64_t slot = blockIdx.y, s = L.song_ids ? L.song_ids[slot] : slot;
+    const int tile = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
+    int ta, tb; tile_coords(tile, L.nt, ta, tb);
+    const int fa = e >> 10, fb = (e >> 8) & 3, q = (e >> 6) & 3, el = e & 63;
+    const bool diag = ta == tb;
+    if (diag && fa > fb) return;
+    const int nsrc = (diag && fa < 2 && fb >= 2) ? 2 : 1;
+    const int dpad = L.nt * H_BT;
+    const int ga = ta * H_BT + 32 * fa + 8 * q + 4 * (el >> 5), gb = tb * H_BT + 32 * fb + (el & 31);
+    double s4[4] = {0.0, 0.0, 0.0, 0.0}, sa[4] = {0.0, 0.0, 0.0, 0.0}, sb = 0.0;
+    for (int run = 0; run < L.S; ++run) {
+        const int64_t sp = slot * L.S + run;
+        const float* p = L.partials + (sp * L.T + tile) * H_TS + e * 4;
+        for (int h = 0; h < nsrc; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(p + h * (6 * 256 * 4));
+            s4[0] += (double)v.x; s4[1] += (double)v.y; s4[2] += (double)v.z; s4[3] += (double)v.w;
+        }
+        const double* cp = L.colpart + sp * dpad;
+        sb += cp[gb];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sa[k] += cp[ga + k];
+    }
+    const double n = (double)(L.offsets[s + 1] - L.offsets[s]);
+    const double inv_n = 1.0 / n, inv = 1.0 / (n - 1.0);
+    double* out = L.cov_out + slot * (int64_t)L.d * L.d;
+    if (gb >= L.d) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = ga + k;
+        if (i >= L.d) continue;
+        const double v = (s4[k] - (sa[k] * sb) * inv_n) * inv;
+        out[(int64_t)i * L.d + gb] = v;
+        out[(int64_t)gb * L.d + i] = v;
+    }
+}
+
 }  // namespace fad

@@ -541,6 +541,7 @@ struct SplitArgs {
     NsState* st; Ns32State* s32;
     // SP_U: the check of iteration k rides on the launch (blockIdx.z == 2)
     int k, max_low, nslots;
+    int nprob, nprob_pad;                // ns_fast_big.h: problems of the batch, and that rounded up to a multiple of 8
     double thr_pred;
     const double* chk_partials;
 };

@@ -31,20 +31,29 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
     double* red = reinterpret_cast<double*>(ring + kBigStages * kBigStage);
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
-    constexpr int ZPER = (MODE == SP_U) ? 3 : 1;
-    const int64_t po = (int64_t)(blockIdx.z / ZPER) * g.pstride;
-    const int zs = (int)(blockIdx.z % ZPER);
+    // ---- which (song, product, tile): a 1-D grid.  Workgroup L runs on XCD L % 8 and is that XCD's (L / 8)-th: the XCD takes songs
+    // xcd, xcd + 8, ... one after the other, product by product, tile by tile -- the t^2 tiles of a product run side by side on ONE
+    // XCD and walk the k range in step, so its L2 fetches every operand strip once for the 2 t tiles that read it.  (With z = song the
+    // tiles of a song were dealt round the eight XCDs and every L2 fetched everything: 885 MB per T launch at D = 768 x 32 songs through
+    // the fabric, 4.9 TB/s, a quarter of the matrix rate -- profiles/r03i_c5_kernel_stats.csv.)  The songs are padded to a multiple of
+    // eight (g.nprob_pad); after the product workgroups come the check workgroups of SP_U, one per song.
+    constexpr int ZP = (MODE == SP_U) ? 2 : 1;
+    const int t = d >> 7, tt = t * t;
+    const int L = blockIdx.x;
+    const int nprod = tt * ZP * g.nprob_pad;
     if constexpr (MODE == SP_U) {
-        if (zs == 2) {
-            if (blockIdx.x == 0 && blockIdx.y == 0) nsf_check<256>(g, po, red);
-            return;
-        }
+        if (L >= nprod) { nsf_check<256>(g, (int64_t)(L - nprod) * g.pstride, red); return; }
     }
+    const int xcd = L & 7, idx = L >> 3;
+    const int unit = idx / tt, tile = idx - unit * tt;
+    const int song = 8 * (unit / ZP) + xcd;
+    if (song >= g.nprob) return;
+    const int zi = unit % ZP;
+    const int TY = tile / t, TX = tile - TY * t;
+    const int64_t po = (int64_t)song * g.pstride;
     const MatHdr* hB = adv(g.hB, po);
     if (hdr_bad(g.hA, hB, g.gen)) return;
     if (g.skip && *adv(g.skip, po) != 0) return;
-    const int zi = (MODE == SP_U) ? zs : 0;
-    int TY, TX; tile_of_block(TY, TX);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int nks = d >> 4;
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
     if constexpr (MODE == SP_T) {
         double s1[1] = {ss};
         wg8_sum<1, 4>(s1, red);
-        if (tid == 0) adv(g.partials, po)[TY * gridDim.x + TX] = s1[0];
+        if (tid == 0) adv(g.partials, po)[tile] = s1[0];
     }
 }
 

@@ -1101,7 +1101,7 @@ def test_score_inf_points_on_device_match_the_sequential_route(F, d, dtype):
         assert abs(v - ref) <= FAD_BAR / 10 * abs(ref)
 
 
-@pytest.mark.parametrize("d,frames", [(128, [129, 300, 2250, 140, 777]), (256, [257, 600, 300, 1500]), (512, [1100, 513]), (768, [1500, 900]),
+@pytest.mark.parametrize("d,frames", [(128, [129, 300, 2250, 140, 777, 500, 200, 350, 9000]), (256, [257, 600, 300, 1500]), (512, [1100, 513]), (768, [1500, 900]),
                                       (1024, [2100])])
 def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     """Songs with at least D + 1 frames, D in {128, 256, 512, 768, 1024}: the eight-launch chain of the single pair, batched over
@@ -1118,10 +1118,13 @@ def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     rows = np.concatenate(sg)
     offs = np.concatenate([[0], np.cumsum([s.shape[0] for s in sg])])
     monkeypatch.setenv("FAD_SONG_FAST", "2")                                  # strict: an error if the chain accepts no song at all
-    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
-    assert (status == 0).all(), status
     want = O.individual_scores(mu_b, cov_b, sg, run_sqrtm=False)
-    np.testing.assert_allclose(scores, want, rtol=2e-6)
+    for big_min in ("1", "0"):                                                # iteration on 128 x 128 tiles (ns_fast_big.h) / on 32 x 32 tiles
+        monkeypatch.setenv("FAD_SONG_BIG", big_min)
+        scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+        assert (status == 0).all(), (big_min, status)
+        np.testing.assert_allclose(scores, want, rtol=2e-6, err_msg=f"FAD_SONG_BIG={big_min}")
+    monkeypatch.delenv("FAD_SONG_BIG")
     monkeypatch.setenv("FAD_SONG_FAST", "0")                                  # the float64 routes on the same call
     scores64, status64 = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
     assert (status64 == 0).all()
