@@ -29,6 +29,7 @@
 #include "ns_mean.h"
 #include "ns_fast.h"
 #include "ns_fast_big.h"
+#include "ns_fast_res.h"
 
 #include <algorithm>
 #include <cmath>
@@ -889,6 +890,9 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
     const char* big_env = getenv("FAD_SONG_BIG");
     const long big_min = big_env ? atol(big_env) : 8;
     const bool big = big_min > 0 && B >= big_min;
+    // FAD_SONG_RES=0: D = 128 iterates through the batched kernels like the other dimensions (tests compare)
+    const char* res_env = getenv("FAD_SONG_RES");
+    const bool resident = d == 128 && !(res_env && res_env[0] == '0');
     const size_t dd = (size_t)d * d;
     const int nb = d / 32;
     const SongBlock L = song_block(d);
@@ -945,9 +949,24 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
         a.Adig = dig_b; a.Bdig = reinterpret_cast<uint4*>(at(L.digS)); a.d = d; a.gen = gen; a.hA = hdr_b;
         a.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); a.pstride = (int64_t)L.stride; a.stats = stats; a.A64 = A64; a.P = P; a.st = st0;
         fast_i8(d, nsf::I8_A, a, st, (unsigned)B);
-        nsf::SplitArgs g = split_args();
-        g.A[0] = P; g.B[0] = P; g.C[0] = Y[1]; g.C[1] = Z[1]; g.Cdig[0] = digY[1]; g.Cdig_t[0] = digYt[1]; g.A64 = A64; g.statsA = stats;
-        fast_split(d, nsf::SP_FIRST, g, st, (unsigned)B);
+        if (resident) {
+            // D = 128: the whole iteration of a song in one workgroup (ns_fast_res.h)
+            static std::atomic<unsigned> ready{0};
+            if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_res128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kResLds));
+                ready.fetch_or(1u << device, std::memory_order_release);
+            }
+            nsf::ResArgs r;
+            memset(&r, 0, sizeof(r));
+            r.gen = gen; r.max_low = kMaxLow; r.thr_pred = pred_threshold(ws.pool, d); r.hA = hdr_b; r.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr));
+            r.pstride = (int64_t)L.stride; r.A64 = A64; r.statsA = stats; r.st = st0; r.s32 = s32_0;
+            r.Y[0] = Y[0]; r.Y[1] = Y[1]; r.Z[0] = Z[0]; r.Z[1] = Z[1];
+            hipLaunchKernelGGL(nsf::nsf_res128, dim3((unsigned)B), dim3(256), nsf::kResLds, st, r);
+        } else {
+            nsf::SplitArgs g = split_args();
+            g.A[0] = P; g.B[0] = P; g.C[0] = Y[1]; g.C[1] = Z[1]; g.A64 = A64; g.statsA = stats;      // (no digit planes: nsf_digitize, below)
+            fast_split(d, nsf::SP_FIRST, g, st, (unsigned)B);
+        }
     }
     tr_sqrt.assign((size_t)B, 0.0); ok.assign((size_t)B, 0);
     std::vector<char> settled((size_t)B, 0);
@@ -955,7 +974,7 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
     // correction for the songs whose check finished them; if any is still iterating, the rest of the budget in one go (every song
     // stops itself: the launches of a finished song exit at once)
     static const bool trace = [] { const char* e = getenv("FAD_FAST_TRACE"); return e && e[0] == '1'; }();
-    int k = 1, upto = 9;
+    int k = 1, upto = resident ? 1 : 9;                 // (resident: nothing left to launch but the correction)
     for (;;) {
         for (; k < upto; ++k) {
             const int cur = k & 1;
@@ -966,11 +985,17 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
             else fast_split(d, nsf::SP_T, g, st, (unsigned)B);
             g = split_args();
             g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1];
-            g.Cdig[0] = digY[cur ^ 1]; g.Cdig_t[0] = digYt[cur ^ 1];
             g.skip = &s32_0->upd_skip[k & 1];
             g.k = k; g.max_low = kMaxLow; g.nslots = big ? (d / 128) * (d / 128) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
             if (big) FAD_TRY(fast_split_big(d, nsf::SP_U, g, st, (unsigned)B, device));
             else fast_split(d, nsf::SP_U, g, st, (unsigned)B);
+        }
+        {
+            nsf::DigArgs dg;
+            memset(&dg, 0, sizeof(dg));
+            dg.d = d; dg.gen = gen; dg.hA = hdr_b; dg.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); dg.pstride = (int64_t)L.stride; dg.s32 = s32_0;
+            dg.Y[0] = Y[0]; dg.Y[1] = Y[1]; dg.dig[0] = digY[0]; dg.dig[1] = digY[1]; dg.dig_t[0] = digYt[0]; dg.dig_t[1] = digYt[1];
+            hipLaunchKernelGGL(nsf::nsf_digitize, dim3((unsigned)((dd / 16 + 255) / 256), 2, (unsigned)B), dim3(256), 0, st, dg);
         }
         nsf::I8Args a;
         memset(&a, 0, sizeof(a));
@@ -991,7 +1016,7 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
             if (hw[12] != gen) return set_error(FAD_ERR_HIP, "the correction kernel of the batched fast chain left no result for song %lld", (long long)b);
             MixedResult r;
             fast_decide_one(hw, hv, hx, nb, &r);
-            if (r.status == 0 && k < kMaxLow) { pending = true; continue; }      // not finished yet: more iterations for this song
+            if (r.status == 0 && k < kMaxLow && !resident) { pending = true; continue; }      // not finished yet: more iterations for this song
             settled[b] = 1;
             if (r.status == 1) { ok[b] = 1; tr_sqrt[b] = std::sqrt(r.c) * r.tr_scaled; }
             if (trace)

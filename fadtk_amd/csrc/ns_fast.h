@@ -712,7 +712,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         }
     }
     __syncthreads();
-    const bool with_digits = (MODE == SP_FIRST) || (MODE == SP_U && zi == 0);
+    const bool with_digits = ((MODE == SP_FIRST) || (MODE == SP_U && zi == 0)) && g.Cdig[0] != nullptr;     // (batches digitise the final Y only)
     store_tile(fin, adv(g.C[zi], po), with_digits ? adv(g.Cdig[0], po) : nullptr, with_digits ? adv(g.Cdig_t[0], po) : nullptr, ty, tx, d, tid);
     if constexpr (MODE == SP_FIRST) store_tile(fin2, adv(g.C[1], po), nullptr, nullptr, ty, tx, d, tid);       // Z1 = T0
     if constexpr (MODE == SP_T) {
@@ -720,6 +720,48 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         wg8_sum<1>(s1, red);
         if (tid == 0) adv(g.partials, po)[ty * gridDim.x + tx] = s1[0];
     }
+}
+
+// Batches: the digit planes of the FINAL iterate only (the single-problem chain writes them for every new Y, because its K8 must follow
+// K7 without a launch in between; in a batch that was half of the update kernel's epilogue, ten times per song).
+// grid (d * d / 16 / 256, 2, problems): a thread forms one 16-byte digit piece of every plane, y = 0: of Y, y = 1: of Y^T.
+struct DigArgs {
+    int d, gen;
+    const MatHdr* hA; const MatHdr* hB; int64_t pstride;
+    const Ns32State* s32;
+    SplitMat Y[2]; uint4* dig[2]; uint4* dig_t[2];
+};
+__global__ __launch_bounds__(256) void nsf_digitize(DigArgs g) {
+    const int64_t po = (int64_t)blockIdx.z * g.pstride;
+    if (hdr_bad(g.hA, adv(g.hB, po), g.gen)) return;
+    const Ns32State* s = adv(g.s32, po);
+    if (s->skip_corr) return;
+    const int d = g.d, par = s->final_iter & 1;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (d * d) >> 4) return;
+    const SplitMat Ym = adv(g.Y[par], po);
+    const uint4* src = blockIdx.y ? Ym.at : Ym.a;
+    uint4* dst = adv(blockIdx.y ? g.dig_t[par] : g.dig[par], po);
+    const int lane = t & 63, ksrb = t >> 6, ks = ksrb % (d >> 5), rb = ksrb / (d >> 5);
+    const int m = lane & 31, g2 = lane >> 5;
+    uint32_t w[kDigits][4];
+#pragma unroll
+    for (int p = 0; p < kDigits; ++p) { w[p][0] = 0u; w[p][1] = 0u; w[p][2] = 0u; w[p][3] = 0u; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint4 uh = src[fa_idx(rb, 2 * ks + g2, 0, 32 * h + m, d)], ul = src[fa_idx(rb, 2 * ks + g2, 1, 32 * h + m, d)];
+        f16x8 hi, lo; __builtin_memcpy(&hi, &uh, 16); __builtin_memcpy(&lo, &ul, 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int dg[kDigits];
+            digits_of<float>(used16(hi[j], lo[j]), dg);
+            const int byte = 8 * h + j;
+#pragma unroll
+            for (int p = 0; p < kDigits; ++p) w[p][byte >> 2] |= ((uint32_t)dg[p] & 0xffu) << (8 * (byte & 3));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < kDigits; ++p) dst[dg_idx(rb, ks, p, lane, d)] = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
 }
 
 // re-arm the low-precision iteration after the host rejected a PREDICTED final iterate (rare): it goes on from that iterate

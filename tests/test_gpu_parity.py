@@ -1119,12 +1119,18 @@ def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     offs = np.concatenate([[0], np.cumsum([s.shape[0] for s in sg])])
     monkeypatch.setenv("FAD_SONG_FAST", "2")                                  # strict: an error if the chain accepts no song at all
     want = O.individual_scores(mu_b, cov_b, sg, run_sqrtm=False)
-    for big_min in ("1", "0"):                                                # iteration on 128 x 128 tiles (ns_fast_big.h) / on 32 x 32 tiles
+    # iteration on 128 x 128 tiles (ns_fast_big.h) / on 32 x 32 tiles; D = 128 first through its resident kernel (ns_fast_res.h)
+    variants = ([("8", "1")] if d == 128 else []) + [("1", "0"), ("0", "0")]
+    for big_min, res in variants:
         monkeypatch.setenv("FAD_SONG_BIG", big_min)
-        scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
-        assert (status == 0).all(), (big_min, status)
-        np.testing.assert_allclose(scores, want, rtol=2e-6, err_msg=f"FAD_SONG_BIG={big_min}")
-    monkeypatch.delenv("FAD_SONG_BIG")
+        monkeypatch.setenv("FAD_SONG_RES", res)
+        scores_v, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+        assert (status == 0).all(), (big_min, res, status)
+        np.testing.assert_allclose(scores_v, want, rtol=2e-6, err_msg=f"FAD_SONG_BIG={big_min} FAD_SONG_RES={res}")
+    monkeypatch.delenv("FAD_SONG_BIG"); monkeypatch.delenv("FAD_SONG_RES")
+    scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)          # the defaults
+    assert (status == 0).all(), status
+    np.testing.assert_allclose(scores, want, rtol=2e-6)
     monkeypatch.setenv("FAD_SONG_FAST", "0")                                  # the float64 routes on the same call
     scores64, status64 = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
     assert (status64 == 0).all()
