@@ -228,7 +228,9 @@ def extra_c5_frames(torch, hip, device):
             "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": "BLAS threads as numpy finds them", "kind": "port",
                              "sample": f"{n_cpu} of the same songs through the oracle (np.cov + eig + sqrtm per song, fad.py:373-378), "
                                        "one after the other", "seconds": dt_cpu},
-            "note": "per song: frames times sqrt(Sigma_b) (one root per call), covariance of the [1500 x 768] result, a 768^3 Newton-Schulz on that symmetric matrix (batched over the songs, mirrored tiles skipped)"}
+            "note": "per call: one-pass float64 statistics, covariances on the float16 tile kernel (shifted by the song's mean), A = Sigma_b Sigma_s "
+                    "exact on the int8 MFMA, split-float16 Newton-Schulz on 128 x 128 tiles (one XCD per song, 8-12 iterations), digits of "
+                    "the final Y, exact correction, decision per song on the host; a song the chain does not accept goes to the float64 routes"}
 
 
 def extra_c4_songs(torch, hip, device):
@@ -259,6 +261,8 @@ def extra_c4_songs(torch, hip, device):
     return {"songs": nsongs, "dim": d4, "frames_per_song": frames, "ms": dt * 1e3, "ms_spread": spread(ms), "songs_per_s": nsongs / dt,
             "ok": int((stt == 0).sum()), "max_rel_err_vs_oracle_sample": rel,
             "GBps_frames": songs.numel() * 2 / dt / 1e9,
+            "note": "as per_song_config5_encoder_frames, but D = 128: the whole Newton-Schulz iteration of a song runs in ONE workgroup, iterates in "
+                    "LDS and registers (ns_fast_res.h)",
             "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": "BLAS threads as numpy finds them", "kind": "port",
                              "sample": f"{n_cpu} of the same songs through the oracle (np.cov + eig + sqrtm per song), one after the other",
                              "seconds": dt_cpu}}

@@ -1260,6 +1260,70 @@ __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ r
     }
 }
 
+// float16 frames, 16-byte aligned rows (D a multiple of 8): ONE pass, eight columns (one 16-byte load) per thread and row, the
+// workgroup's other threads on other rows.  Sums of x - x0 and of (x - x0)^2 in float64, x0 = the song's first frame (the
+// differences and their squares are exact in float64; sum q - s^2 / n loses a factor (1 + (mean - x0)^2 / var) of 1e-16).  One
+// workgroup per song writes the mean, the mean term and tr Sigma_s.  The two-pass kernel above read the frames twice, two bytes per
+// lane: 1.14 ms for 2000 songs of [2250 x 128] = 1.0 TB/s (profiles/r03m_c4_kernel_stats.csv).
+__global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict__ rows, int64_t ld, int d,
+                                                      const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
+                                                      int mean_mode, double* __restrict__ mean_exact,
+                                                      double* __restrict__ out /*[S][chunks][2]: scal itself when there is one chunk*/) {
+    // grid (songs, chunks of 128 columns): 16 column groups of 8 side by side, 16 row lanes
+    __shared__ double sm[16 * 16 * 8 * 2];               // [row lane][group][column][sum | sum of squares]
+    __shared__ double red[4];
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = offsets[s], r1 = offsets[s + 1], n = r1 - r0;
+    const int gl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int grp = blockIdx.y * 16 + gl;
+    const bool live = grp * 8 < d;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    double sx[8], sq[8];
+    float x0[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sx[q] = 0.0; sq[q] = 0.0; x0[q] = 0.f; }
+    if (live && n > 0) {
+        const uint4 u0 = *reinterpret_cast<const uint4*>(rows + r0 * ld + grp * 8);
+        h8 h; __builtin_memcpy(&h, &u0, 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x0[q] = (float)h[q];
+        for (int64_t r = r0 + rl; r < r1; r += 16) {
+            const uint4 u = *reinterpret_cast<const uint4*>(rows + r * ld + grp * 8);
+            h8 x; __builtin_memcpy(&x, &u, 16);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double e = (double)((float)x[q] - x0[q]);       // exact: two float16 values
+                sx[q] += e; sq[q] = __builtin_fma(e, e, sq[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sm[((rl * 16 + gl) * 8 + q) * 2] = sx[q]; sm[((rl * 16 + gl) * 8 + q) * 2 + 1] = sq[q]; }
+    __syncthreads();
+    double mt = 0.0, ts = 0.0;
+    if (threadIdx.x < 128) {                             // one thread per column of the chunk
+        const int cl = threadIdx.x, a = blockIdx.y * 128 + cl;
+        if (a < d) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) { s1 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2]; s2 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2 + 1]; }
+            const double first = (n > 0) ? ld_f64<r_f16>(reinterpret_cast<const r_f16*>(rows), r0 * ld + a) : 0.0;
+            const double m = (n > 0) ? first + s1 / (double)n : 0.0;
+            const double mr = mean_mode ? round_like_input<r_f16>(m) : m;
+            if (mean_exact) mean_exact[s * d + a] = m;
+            const double df = mu_b[a] - mr;
+            mt = df * df;
+            ts = (n > 0) ? s2 - (s1 * s1) / (double)n : 0.0;
+        }
+    }
+    mt = block_sum(mt, red);
+    ts = block_sum(ts, red);
+    if (threadIdx.x == 0) {
+        double* o = out + 2 * (s * gridDim.y + blockIdx.y);
+        o[0] = mt; o[1] = (n > 1) ? ts / (double)(n - 1) : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void song_scal_sum(const double* __restrict__ part, int chunks, int64_t n_songs,
                                                      double* __restrict__ scal /*[S][2]*/) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (song, which scalar)
@@ -1841,7 +1905,15 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
     std::vector<double> h_scal;
     double tr_b = 0.0;
     if (others) {                       // (two-frame songs get their scalars from pair_stats_diff)
-        if ((h_off[n_songs] - h_off[0]) / n_songs >= 64) {
+        static const bool stats16_on = [] { const char* e = getenv("FAD_SONG_STATS16"); return !(e && e[0] == '0'); }();
+        if (std::is_same<TIn, r_f16>::value && stats16_on && (h_off[n_songs] - h_off[0]) / n_songs >= 64 && song_cov_f16_ok(drows, ld, d)) {
+            const int chunks = (int)cdiv(d, 128);
+            double* part = scal;
+            if (chunks > 1) { FAD_TRY(ws.rows2.reserve((size_t)2 * n_songs * chunks * sizeof(double))); part = static_cast<double*>(ws.rows2.p); }
+            hipLaunchKernelGGL(song_stats_f16, dim3((unsigned)n_songs, (unsigned)chunks), dim3(256), 0, st,
+                               reinterpret_cast<const uint16_t*>(drows), ld, d, d_off, dmu_b, mean_mode, mean_exact, part);
+            if (chunks > 1) hipLaunchKernelGGL(song_scal_sum, dim3((unsigned)cdiv(2 * n_songs, 256)), dim3(256), 0, st, part, chunks, n_songs, scal);
+        } else if ((h_off[n_songs] - h_off[0]) / n_songs >= 64) {
             const int chunks = (int)cdiv(d, 64);
             FAD_TRY(ws.rows2.reserve((size_t)2 * n_songs * chunks * sizeof(double)));
             double* part = static_cast<double*>(ws.rows2.p);

@@ -67,11 +67,14 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
     const int blk_global0 = 4 * (side ? TX : TY) + blk0;
     const uint32_t voff = (uint32_t)lane * 16u;
     const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)ring;
+    // (all tiles of a product walk k from 0 in step -- letting tile (TY, TX) start (TY t + TX) s k-steps in, s = 1 .. 13, so that they do
+    //  not ask for the same pieces at the same moment, measured 1-14 % SLOWER: the six tiles that share a strip want it together)
     auto issue = [&](int ks) {
+        const int kk = ks;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int blk = q >> 1, plane = q & 1;
-            const uint64_t sb = (uint64_t)(src_mat + fa_idx(blk_global0 + blk, ks, plane, 0, d));
+            const uint64_t sb = (uint64_t)(src_mat + fa_idx(blk_global0 + blk, kk, plane, 0, d));
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
             const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
             const uint64_t ub = ((uint64_t)hi << 32) | lo;
