@@ -62,7 +62,8 @@ struct DevBuf {
 // moments.hip: covariances of B songs of float16 frames on the moments tile kernels (for frechet.hip's batched per-song chain)
 bool song_cov_f16_ok(const void* rows, int64_t ld, int d);
 int song_cov_f16_launch(const void* rows, int64_t ld, int d, const int64_t* d_offsets, const int64_t* d_song_ids, int64_t B,
-                        int64_t max_frames, const double* d_mean_exact, double* d_cov_out, DevBuf& scratch, int device, hipStream_t st);
+                        int64_t max_frames, const double* d_mean_exact, const double* d_var_exact, double* d_cov_out, DevBuf& scratch,
+                        int device, hipStream_t st);
 
 // Scratch buffers of the handle-less entry points: one set per (host thread, device), so callers in a thread pool
 // (fad.py:229, 387 use tmap) never share scratch memory, and the memory goes back to the device when the thread ends.

@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ r
 // lane: 1.14 ms for 2000 songs of [2250 x 128] = 1.0 TB/s (profiles/r03m_c4_kernel_stats.csv).
 __global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict__ rows, int64_t ld, int d,
                                                       const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
-                                                      int mean_mode, double* __restrict__ mean_exact,
+                                                      int mean_mode, double* __restrict__ mean_exact, double* __restrict__ var_exact,
                                                       double* __restrict__ out /*[S][chunks][2]: scal itself when there is one chunk*/) {
     // grid (songs, chunks of 128 columns): 16 column groups of 8 side by side, 16 row lanes
     __shared__ double sm[16 * 16 * 8 * 2];               // [row lane][group][column][sum | sum of squares]
@@ -1314,6 +1314,7 @@ __global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict
             const double df = mu_b[a] - mr;
             mt = df * df;
             ts = (n > 0) ? s2 - (s1 * s1) / (double)n : 0.0;
+            if (var_exact) var_exact[s * d + a] = (n > 1) ? ts / (double)(n - 1) : 0.0;      // the diagonal of Sigma_s, exact
         }
     }
     mt = block_sum(mt, red);
@@ -1895,12 +1896,13 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
 
     // ---- per-song scalars and means
     // songbuf: scal [S*2] | score [S] | tr_b [1] | ids (int64) [S] | mean_exact [S*d] (only when a song has more than two frames)
-    FAD_TRY(ws.songbuf.reserve(((size_t)n_songs * 4 + 2 + (others ? (size_t)n_songs * d : 0)) * sizeof(double) + 64));
+    FAD_TRY(ws.songbuf.reserve(((size_t)n_songs * 4 + 2 + (others ? (size_t)2 * n_songs * d : 0)) * sizeof(double) + 64));
     double* scal = static_cast<double*>(ws.songbuf.p);
     double* score_dev = scal + 2 * (size_t)n_songs;
     double* trb_dev = score_dev + n_songs;
     int64_t* ids_dev = reinterpret_cast<int64_t*>(trb_dev + 1);
     double* mean_exact = others ? reinterpret_cast<double*>(ids_dev + n_songs) : nullptr;
+    double* var_exact = nullptr;                         // [S * d] the exact variances: only the one-pass float16 statistics kernel leaves them
     hipLaunchKernelGGL(diag_trace, dim3(1), dim3(256), 0, st, dcov_b, d, trb_dev);
     std::vector<double> h_scal;
     double tr_b = 0.0;
@@ -1911,7 +1913,9 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             double* part = scal;
             if (chunks > 1) { FAD_TRY(ws.rows2.reserve((size_t)2 * n_songs * chunks * sizeof(double))); part = static_cast<double*>(ws.rows2.p); }
             hipLaunchKernelGGL(song_stats_f16, dim3((unsigned)n_songs, (unsigned)chunks), dim3(256), 0, st,
-                               reinterpret_cast<const uint16_t*>(drows), ld, d, d_off, dmu_b, mean_mode, mean_exact, part);
+                               reinterpret_cast<const uint16_t*>(drows), ld, d, d_off, dmu_b, mean_mode, mean_exact,
+                               mean_exact + (size_t)n_songs * d, part);
+            var_exact = mean_exact + (size_t)n_songs * d;
             if (chunks > 1) hipLaunchKernelGGL(song_scal_sum, dim3((unsigned)cdiv(2 * n_songs, 256)), dim3(256), 0, st, part, chunks, n_songs, scal);
         } else if ((h_off[n_songs] - h_off[0]) / n_songs >= 64) {
             const int chunks = (int)cdiv(d, 64);
@@ -2111,10 +2115,10 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             // float16 frames: the covariances on the float16 matrix pipe, shifted by the song's mean (moments_kernels.h: song_cov_*;
             // FAD_SONG_COV16=0: the float64 MFMA kernel, as for every other dtype)
             static const bool cov16_on = [] { const char* e = getenv("FAD_SONG_COV16"); return !(e && e[0] == '0'); }();
-            if (std::is_same<TIn, r_f16>::value && cov16_on && song_cov_f16_ok(drows, ld, d)) {
+            if (std::is_same<TIn, r_f16>::value && cov16_on && var_exact && song_cov_f16_ok(drows, ld, d)) {      // (only with the exact diagonal)
                 int64_t max_frames = 0;
                 for (int64_t b = 0; b < B; ++b) { const int64_t sg = general[g0 + b]; max_frames = std::max(max_frames, h_off[sg + 1] - h_off[sg]); }
-                FAD_TRY(song_cov_f16_launch(drows, ld, d, d_off, ids_dev, B, max_frames, mean_exact, covs, ws.songcov, device, st));
+                FAD_TRY(song_cov_f16_launch(drows, ld, d, d_off, ids_dev, B, max_frames, mean_exact, var_exact, covs, ws.songcov, device, st));
             } else {
                 hipLaunchKernelGGL((song_cov_mfma<TIn>), dim3((unsigned)(nt64 * (nt64 + 1) / 2), 1, (unsigned)B), dim3(256), 0, st, drows,
                                    ld, d, nt64, d_off, ids_dev, mean_exact, covs);

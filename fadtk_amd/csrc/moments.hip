@@ -881,7 +881,8 @@ bool song_cov_f16_ok(const void* rows, int64_t ld, int d) {
     return d % 8 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15u) == 0 && ld < ((int64_t)1 << 26);
 }
 int song_cov_f16_launch(const void* rows, int64_t ld, int d, const int64_t* d_offsets, const int64_t* d_song_ids, int64_t B,
-                        int64_t max_frames, const double* d_mean_exact, double* d_cov_out, DevBuf& scratch, int device, hipStream_t st) {
+                        int64_t max_frames, const double* d_mean_exact, const double* d_var_exact, double* d_cov_out, DevBuf& scratch,
+                        int device, hipStream_t st) {
     if (B <= 0) return FAD_OK;
     {
         static std::mutex mu;
@@ -899,7 +900,7 @@ int song_cov_f16_launch(const void* rows, int64_t ld, int d, const int64_t* d_of
     L.nt = (d + H_BT - 1) / H_BT; L.T = L.nt * (L.nt + 1) / 2;
     int64_t S = (max_frames + 4095) / 4096;
     L.S = (int)(S < 1 ? 1 : (S > 64 ? 64 : S));
-    L.offsets = d_offsets; L.song_ids = d_song_ids; L.mean_exact = d_mean_exact; L.cov_out = d_cov_out;
+    L.offsets = d_offsets; L.song_ids = d_song_ids; L.mean_exact = d_mean_exact; L.var_exact = d_var_exact; L.cov_out = d_cov_out;
     const size_t dpad = (size_t)L.nt * H_BT, runs = (size_t)B * L.S;
     const size_t b_part = (runs * L.T * H_TS * sizeof(float) + 255) & ~(size_t)255, b_col = (runs * dpad * sizeof(double) + 255) & ~(size_t)255;
     FAD_TRY(scratch.reserve(b_part + b_col + runs * dpad * sizeof(uint16_t) + 256));

@@ -1036,6 +1036,7 @@ struct SongCovLaunch {
     const uint16_t* rows; int64_t ld; int d, nt, T, S;
     const int64_t* offsets; const int64_t* song_ids;       // slot -> song (nullptr: slot == song)
     const double* mean_exact;                              // [song][d]
+    const double* var_exact;                               // [song][d] exact variances (float64 one-pass sums), or nullptr
     uint16_t* cvec;                                        // [slot * S + run][nt * H_BT]
     float* partials;                                       // [(slot * S + run) * T + tile][H_TS]
     double* colpart;                                       // [slot * S + run][nt * H_BT]
@@ -1109,7 +1110,12 @@ __global__ __launch_bounds__(256) void song_cov_finish(SongCovLaunch L) {
     for (int k = 0; k < 4; ++k) {
         const int i = ga + k;
         if (i >= L.d) continue;
-        const double v = (s4[k] - (sa[k] * sb) * inv_n) * inv;
+        double v = (s4[k] - (sa[k] * sb) * inv_n) * inv;
+        // the diagonal from the statistics kernel's float64 sums: a variance is a sum of POSITIVE terms, the float32 partial sum
+        // drifts by ~4e-7 of it (140 accumulations for 2250 frames), and with Sigma_s close to Sigma_b the score moves by half
+        // the sum of those drifts (d tr sqrt(Sigma_b Sigma_s) = 1/2 tr dSigma_s there) -- 1.1e-5 of a small score, measured; the
+        // off-diagonal sums hover around zero and carry ~1e-8
+        if (i == gb && L.var_exact) v = L.var_exact[s * L.d + i];
         out[(int64_t)i * L.d + gb] = v;
         out[(int64_t)gb * L.d + i] = v;
     }

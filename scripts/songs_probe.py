@@ -20,6 +20,26 @@ if what in ("c5", "c4"):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sc, st = hip.frechet_batched(mu, cov, songs, offs)
         torch.cuda.synchronize(); print(what, "call", i, "%.3f ms" % ((time.perf_counter() - t0) * 1e3), "ok", int((st == 0).sum()))
+elif what in ("acc4", "acc5"):
+    # accuracy of the batched call on bench.py's per-song extras (a few songs against the oracle), under whatever FAD_SONG_* is set
+    from oracle import fad_oracle as O
+    nsongs, frames, d = (24, 2250, 128) if what == "acc4" else (6, 1500, 768)
+    g = torch.Generator(device=dev); g.manual_seed(44 if what == "acc4" else 55)
+    if what == "acc4":
+        scale = 0.6 + 0.8 * torch.rand((d,), generator=g, device=dev)
+        songs = (torch.randn((nsongs * frames, d), generator=g, device=dev) * scale).to(torch.float16)
+        base = torch.randn((50000, d), generator=g, device=dev, dtype=torch.float64) * scale.double() * 1.03 + 0.02
+    else:
+        scale = 0.5 + torch.rand((d,), generator=g, device=dev)
+        songs = (torch.randn((nsongs * frames, d), generator=g, device=dev) * scale).to(torch.float16)
+        base = torch.randn((20000, d), generator=g, device=dev, dtype=torch.float64) * scale.double() * 1.05 + 0.01
+    mu, cov = base.mean(0).cpu().numpy(), torch.cov(base.T).cpu().numpy()
+    offs = np.arange(0, nsongs * frames + 1, frames)
+    sc, st = hip.frechet_batched(mu, cov, songs, offs)
+    host = songs.cpu().numpy()
+    want = np.array(O.individual_scores(mu, cov, [host[i * frames:(i + 1) * frames] for i in range(nsongs)], run_sqrtm=False), dtype=np.float64)
+    rel = np.abs(sc - want) / np.abs(want)
+    print(what, {k: v for k, v in os.environ.items() if k.startswith("FAD_SONG")}, "max rel %.3e  median %.3e  (scores %.4f .. %.4f)" % (rel.max(), np.median(rel), want.min(), want.max()))
 else:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
     from oracle import fad_oracle as O
