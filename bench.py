@@ -132,11 +132,28 @@ def extra_c4(torch, hip, device, local_rank):
     stats.frames.set_timing(False)
     mu, cov = stats.finish()
     stats.close()
+    # the same 16384 files as ONE update (9.4 GB resident): what the ~0.17 ms of small kernels and launch gaps per update cost the pass above
+    one_ms = None
+    try:
+        x4 = x.repeat(groups, 1)
+        sizes4 = np.full(groups * files_per_group, rows_per_file, dtype=np.int64)
+        st4 = OnlineStats(d, local_rank, compat=True)
+        st4.add_group(x4, sizes4)
+        torch.cuda.synchronize()
+        t4 = []
+        for _ in range(3):
+            t0 = time.perf_counter(); st4.add_group(x4, sizes4); torch.cuda.synchronize(); t4.append((time.perf_counter() - t0) * 1e3)
+        one_ms = float(np.median(t4))
+        st4.close()
+        del x4
+    except Exception:       # noqa: BLE001  (memory on a shared box ...)
+        one_ms = None
     nbytes = groups * x.numel() * 2
     return {"files": groups * files_per_group, "frames_per_file": rows_per_file, "dim": d, "files_per_update": files_per_group,
             "ms": dt * 1e3, "ms_spread": spread(ms), "frames_per_s": groups * x.shape[0] / dt, "GBps_algorithmic": nbytes / dt / 1e9,
             "frac_of_8TBps": nbytes / dt / 1e9 / HBM_PEAK_GBS, "includes": "tile kernel + reduce + per-file sums + per-file mean terms",
             "tile_kernel_ms_per_update": k_ms, "tile_kernel_frac_of_8TBps": x.numel() * 2 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "one_update_of_all_files": ({"ms": one_ms, "frac_of_8TBps": nbytes / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if one_ms else None),
             "cov_trace_per_dim": float(np.trace(cov)) / d}
 
 
@@ -339,12 +356,14 @@ def main():
                     help="scores in flight: consecutive steps alternate over this many pairs of accumulators (each with its own "
                          "Frechet job); the moments of step i and the Frechet chain of step i-1 are enqueued before the score of "
                          "step i-N is collected (3 or more keep the device busy); 1 = every step waits for its score")
-    ap.add_argument("--lane-streams", action="store_true",
-                    help="one HIP stream per score in flight instead of one stream for all of them")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="all scores in flight on ONE stream (rounds 1-3a: no two kernels ever overlap) instead of one HIP stream per "
+                         "score in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (used under rocprofv3 "
                                                              "so that the kernel statistics hold the config-3 launches only)")
     args = ap.parse_args()
+    args.lane_streams = not args.single_stream
 
     # Library banners (RCCL prints its version block to stdout) must not mix with the ONE JSON line: everything
     # written to fd 1 goes to stderr until the result is printed.
@@ -376,11 +395,13 @@ def main():
     a, b = pairs[0]
     # both handles of a score keep their statistics in ONE device buffer: the exchange of the path -- the sum of the ranks'
     # sufficient statistics -- is a single in-place all-reduce over it (the product's --gpus path uses the same class).
-    # One such buffer per score in flight ("lane").  By default the lanes share ONE stream: the host enqueues steps ahead of
-    # the score it collects (run_steps), so the device never waits for the host between steps, and the kernels of different
-    # steps never overlap (the HIP-event duration of the tile kernel stays a clean single-kernel measurement).  --lane-streams
-    # gives every lane its own stream: more scores/s (the latency-bound Frechet chain of one step overlaps the tile kernel
-    # of the next), at the price of per-kernel durations that include the contention.
+    # One such buffer per score in flight ("lane"), and one HIP stream per lane: the host enqueues steps ahead of the score it
+    # collects (run_steps), so the device never waits for the host between steps, and the latency-bound square-root chain of one
+    # score (eight dependent launches, the matrix pipes idle most of the time) runs UNDER the moments kernel of the next -- 6787
+    # instead of 5618 scores/s (profiles/r03r_streams.txt).  The price is in the per-kernel numbers: the tile kernel shares the
+    # CUs with another score's chain and its HIP-event duration grows from 0.083 to 0.104 ms -- `roofline` reports that (it is
+    # what the timed region ran) and `roofline.alone` the duration on a stream of its own (--single-stream times that loop).
+    # (Tried and dropped: moments on a high-priority stream, chains on a low-priority one -- 5511 scores/s.)
     n_lanes = max(1, min(int(args.inflight), 8))
 
     comm_stream = torch.cuda.Stream(device=device) if distributed else None
@@ -494,11 +515,11 @@ def main():
         return time.perf_counter() - t0
     repeat_s = [block(True) for _ in range(5)] if args.steps > 0 else []
     same_pair_s = [block(False) for _ in range(3)] if args.steps > 0 else []
-    # ... and K steps with ONE STREAM PER SCORE in flight: the latency-bound square-root chain of one score then overlaps the moments
-    # kernel of the next (more scores/s; per-kernel durations include the contention, which is why the headline keeps one stream)
+    # ... and K steps in the other stream layout: by default that is ONE stream for all scores in flight -- no two kernels overlap, the
+    # tile kernel's duration there is the kernel alone
     per_stream_s, per_stream_kernel_ms = [], None
-    if args.steps > 0 and n_lanes > 1 and not args.lane_streams:
-        lanes_s = [Lane(k, own=True) for k in range(n_lanes)]
+    if args.steps > 0 and n_lanes > 1:                      # the OTHER stream layout (one stream for all lanes / one per lane)
+        lanes_s = [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
         run_steps(min(args.steps, 6), None, True, lanes_s)
         for rep in range(3):
             if rep == 2:
@@ -607,10 +628,11 @@ def main():
                                 "min": min(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None,
                                 "max": max(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None, "blocks": len(repeat_s),
                                 "note": "the same K steps repeated outside the timed region (rank 0's clock)"},
-        "value_stream_per_score": {"median": float(np.median([n_gpus * args.steps / t for t in per_stream_s])) if per_stream_s else None,
-                                   "blocks": len(per_stream_s), "tile_kernel_ms": per_stream_kernel_ms,
-                                   "note": "the same K steps with one HIP stream per score in flight (--lane-streams): chains and moments "
-                                           "kernels of consecutive scores overlap"},
+        ("value_single_stream" if args.lane_streams else "value_stream_per_score"): {
+            "median": float(np.median([n_gpus * args.steps / t for t in per_stream_s])) if per_stream_s else None,
+            "blocks": len(per_stream_s), "tile_kernel_ms": per_stream_kernel_ms,
+            "note": ("the same K steps with all scores in flight on ONE stream (--single-stream): no two kernels overlap" if args.lane_streams
+                     else "the same K steps with one HIP stream per score in flight: chains and moments kernels of consecutive scores overlap")},
         "value_same_pair": {"median": float(np.median([n_gpus * args.steps / t for t in same_pair_s])) if same_pair_s else None,
                             "blocks": len(same_pair_s),
                             "note": "K steps that re-feed ONE pair (204.8 MB: Infinity-Cache resident) -- the loop rounds 1-2 timed"},
@@ -633,7 +655,15 @@ def main():
                                        "fp16 peak; `frac` = algorithmic 2 N D^2 per set over the same time",
                      "algorithmic_bytes_per_launch": SETS * N_ROWS * DIM * 2,
                      "hbm_GBps_algorithmic": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
-                     "hbm_frac_of_8TBps": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "hbm_frac_of_8TBps": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "contended": bool(args.lane_streams and n_lanes > 1),
+                     "contended_note": "the timed loop runs one stream per score in flight: this kernel shares the CUs with the square-root "
+                                       "chain of the previous score, and kernel_ms / achieved / frac above include that; `alone` = the "
+                                       "same launches with all scores on one stream (no two kernels overlap), side block of this run",
+                     "alone": ({"kernel_ms": per_stream_kernel_ms, "achieved": flops / (per_stream_kernel_ms * 1e-3) / 1e12,
+                                "frac": flops / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                "mfma_util": issued / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}
+                               if (args.lane_streams and per_stream_kernel_ms) else None)},
         "roofline_frechet": {"route": {2: "eight launches: split-float16 Newton-Schulz + exact int8-MFMA products (csrc/ns_fast.h)",
                                        1: "float32 Newton-Schulz on the f32 MFMA + float64 correction", 0: "all-float64 iteration"}[route],
                              "bound": "launch chain: ~4.2 us per dependent launch before it does anything, then the CU's vector-memory "
