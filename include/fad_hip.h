@@ -132,18 +132,6 @@ int fad_moments_allreduce(fad_moments_t* h, void* rccl_comm, void* stream);
 int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* cov, int64_t* n,
                          int on_device, void* stream);
 
-/* Opt-in HIP-event timing (bench.py's roofline): while enabled every update records events around
- * its tile kernel on the caller's stream (no synchronisation); last_timing() returns the AVERAGE
- * duration in ms of the tile kernel and of the reduce kernels over the updates recorded since the
- * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA, 1 = generic fp64).
- * A fad_moments_update_multi call is ONE update recorded on hs[0]: its tile-kernel time covers all sets.
- * enabled = 2 records the two events around the tile kernel only (ms_reduce comes back 0): an event record between two
- * kernels costs the stream a few microseconds, and the one behind the reduce sits in front of whatever the caller
- * enqueues next. */
-int fad_moments_set_timing(fad_moments_t* h, int enabled);
-int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_reduce_kernel,
-                            int* kernel_variant);
-
 /* ------------------------------------------------------------------ Frechet distance
  * Replaces calc_frechet_distance (fadtk/fad.py:51-120):
  *   ||mu1-mu2||^2 + tr C1 + tr C2 - 2 tr sqrt(C1 C2)
@@ -191,7 +179,7 @@ int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, i
  * end() waits for it and delivers the same result (and the same errors) as fad_frechet_from_moments -- topping the
  * iteration up or falling back to the float64 iteration when the device says so.  A caller that begins score k+1 before it
  * ends score k never leaves the device waiting between scores (bench.py: +10 % scores/s on ONE stream); with one stream
- * per score the chains and moments passes of consecutive scores overlap as well (another +20-25 %).
+ * per score the chains and moments passes of consecutive scores overlap as well (another +20 %: bench.py's timed layout).
  * The handles may be reset / fed again ON `stream` as soon as begin() has returned (their statistics were copied out in
  * stream order); on another stream only after end().  A job must be ended (or cancelled) by the host thread that began it:
  * the slots are thread-local, 8 per thread and device.  cancel() gives the slot back without a result. */
@@ -210,6 +198,13 @@ int fad_frechet_cancel(fad_frechet_job_t* job);
  * np.mean does for float16 (model_loader.py:47-48 + fad.py:48).
  * on_device = 1: rows, mu_b and cov_b are DEVICE pointers (a caller scoring many batches against one baseline uploads it
  * once); offsets, out_scores and out_status are host pointers either way.  cov_b is read as (cov_b + cov_b^T)/2.
+ * Routes, chosen per song by its frame count n (the result does not depend on the route beyond ~1e-8 of a score):
+ *   n = 2: closed form; n - 1 < D: the Gram form on the n - 1 non-zero eigenvalues; n >= D + 1 and D in {128, 256, 512, 768,
+ *   1024}: the low-precision chain of the single pair, batched over the songs (exact int8-MFMA products, split-float16
+ *   Newton-Schulz, one float64-accurate correction, accepted per song on a bound of what the correction neglects), with
+ *   float16 frames also the covariances on the float16 matrix pipe; whatever that chain does not accept -- and every other D --
+ *   the float64 Newton-Schulz routes.  Environment switches (tests, diagnosis): FAD_SONG_FAST=0 (float64 routes only),
+ *   FAD_SONG_BIG=<smallest batch on 128 x 128 tiles>, FAD_SONG_RES=0, FAD_SONG_COV16=0, FAD_SONG_STATS16=0, FAD_FAST_TRACE=1.
  */
 int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const double* cov_b,
                                     const void* rows, int64_t n_rows, int64_t ld, int dtype,
@@ -256,6 +251,23 @@ int fad_logmel_htsat(const float* wav, const int64_t* offsets, int64_t n_clips, 
 int64_t fad_resample_num_samples(int64_t n, int orig_sr, int new_sr);
 int fad_resample_kaiser(const float* wav, int64_t n, int orig_sr, int new_sr, int quantize_pcm16, float* out,
                         int64_t out_capacity, int on_device, int device, void* stream);
+
+/* ------------------------------------------------------------------ diagnostics (NOT part of the drop-in surface)
+ * Nothing in fadtk corresponds to these two calls and no binding of the reference needs them: they exist for bench.py's
+ * roofline object (HIP events around the tile kernel on the stream it is launched on) and for the GPU tests that check
+ * which kernel variant ran.
+ *
+ * Opt-in HIP-event timing (bench.py's roofline): while enabled every update records events around
+ * its tile kernel on the caller's stream (no synchronisation); last_timing() returns the AVERAGE
+ * duration in ms of the tile kernel and of the reduce kernels over the updates recorded since the
+ * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA, 1 = generic fp64).
+ * A fad_moments_update_multi call is ONE update recorded on hs[0]: its tile-kernel time covers all sets.
+ * enabled = 2 records the two events around the tile kernel only (ms_reduce comes back 0): an event record between two
+ * kernels costs the stream a few microseconds, and the one behind the reduce sits in front of whatever the caller
+ * enqueues next. */
+int fad_moments_set_timing(fad_moments_t* h, int enabled);
+int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_reduce_kernel,
+                            int* kernel_variant);
 
 #ifdef __cplusplus
 }
