@@ -618,7 +618,7 @@ static int mixed_enqueue(Workspace& ws, int upto) {
 // D in {256, 512, 768, 1024}; FAD_FRECHET_FAST=0 keeps round 2's float32 chain (the two are compared in the tests).
 // ==========================================================================================
 static bool mixed_eligible(Workspace& ws, int d, int max_iter, double tol);
-static bool fast_dim(int d) { return d == 256 || d == 512 || d == 768 || d == 1024; }
+static bool fast_dim(int d) { return d == 256 || d == 384 || d == 512 || d == 768 || d == 1024; }
 static bool fast_eligible(Workspace& ws, int d, int max_iter, double tol) {
     Pool* p = ws.pool;
     if (p && p->fast < 0) { const char* e = getenv("FAD_FRECHET_FAST"); p->fast = (e && e[0] == '0') ? 0 : 1; }
@@ -699,6 +699,7 @@ static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st,
     switch (d) {
         case 128: fast_launch_split<1>(mode, t, B, g, st); break;
         case 256: fast_launch_split<2>(mode, t, B, g, st); break;
+        case 384: fast_launch_split<3>(mode, t, B, g, st); break;
         case 512: fast_launch_split<4>(mode, t, B, g, st); break;
         case 768: fast_launch_split<6>(mode, t, B, g, st); break;
         default: fast_launch_split<8>(mode, t, B, g, st); break;
@@ -726,7 +727,7 @@ static void fast_i8(int d, int mode, const nsf::I8Args& g, hipStream_t st, unsig
     const unsigned t = (unsigned)(d / 32);
     switch (d) {
         case 128: case 256: fast_launch_i8<1>(mode, t, B, g, st); break;       // (d = 128: four k-steps, half the waves idle)
-        case 512: fast_launch_i8<2>(mode, t, B, g, st); break;
+        case 384: case 512: fast_launch_i8<2>(mode, t, B, g, st); break;                  // (d = 384: twelve k-steps, waves 6, 7 idle)
         case 768: fast_launch_i8<3>(mode, t, B, g, st); break;
         default: fast_launch_i8<4>(mode, t, B, g, st); break;
     }
@@ -853,9 +854,9 @@ static int fast_decide(Workspace& ws) {
 // The same chain for a BATCH of songs against one baseline (fad_frechet_batched_vs_baseline, songs with at least D + 1 frames:
 // every song is a full D x D problem): tr sqrt(Sigma_b Sigma_s) for B songs in eight launches of B times the workgroups.
 // Replaces the per-song scipy.linalg.sqrtm / eig of fadtk/fad.py:373-378 for those songs; songs whose product the chain does not
-// accept (spread spectra, non-finite input) are handed back to the float64 routes.  D in {128, 256, 512, 768, 1024}.
+// accept (spread spectra, non-finite input) are handed back to the float64 routes.  D in {128, 256, 384, 512, 768, 1024}.
 // ==========================================================================================
-static bool fast_song_dim(int d) { return d == 128 || d == 256 || d == 512 || d == 768 || d == 1024; }
+static bool fast_song_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024; }
 
 struct SongBlock {                               // byte offsets inside one song's device block, and its size
     size_t hdr, st, s32, partials, stats, A64, P, Y[2], Z[2], T, digS, digY[2], digYt[2], stride;
@@ -2096,7 +2097,7 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         }
     }
 
-    // ---- songs of at least D + 1 frames, D in {128, 256, 512, 768, 1024}: the eight-launch chain, batched over the songs (fast_songs);
+    // ---- songs of at least D + 1 frames, D in {128, 256, 384, 512, 768, 1024}: the eight-launch chain, batched over the songs (fast_songs);
     // whatever it does not accept falls through to the float64 routes below.  FAD_SONG_FAST=0 switches it off.
     // (read per call -- a batched call is milliseconds; 2 = strict: an error when the chain accepts NO song of the call, for tests)
     const char* fs_env = getenv("FAD_SONG_FAST");

@@ -363,7 +363,11 @@ struct I8Args {
 
 template <int NS8, int MODE>
 __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
-    __shared__ __attribute__((aligned(16))) double part[8 * 32 * 33];
+    // LDS: 21 KB.  (Round 3's first version kept all eight waves' partial tiles side by side: 72 KB -- and a workgroup of this
+    // chain could not share a CU with TWO workgroups of the moments tile kernel (2 x 64 KB of the 160): with one HIP stream per
+    // score in flight every launch of the chain took one of that kernel's two slots on every CU.  Now the partial tiles meet in a
+    // tree through two slots.)
+    __shared__ __attribute__((aligned(16))) double part[2 * 32 * 33];
     __shared__ float fin[32 * 33];
     __shared__ double red[8 * 4];
     constexpr int kUmin = (MODE == I8_A) ? kUminA : kUminG;
@@ -452,20 +456,38 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) gp[q] = __builtin_fma((double)acc[u][q], wgt, gp[q]);
     }
+    // the eight shares meet in a tree: waves 6, 7 hand theirs to 4, 5; those to 2, 3; those to 0, 1; whose two sums are added below
+    {
+        auto put = [&](int slot) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-        part[wave * (32 * 33) + rr * 33 + r] = gp[reg];
+            for (int reg = 0; reg < 16; ++reg) part[slot * (32 * 33) + ((reg & 3) + 8 * (reg >> 2) + 4 * kg) * 33 + r] = gp[reg];
+        };
+        auto add = [&](int slot) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gp[reg] += part[slot * (32 * 33) + ((reg & 3) + 8 * (reg >> 2) + 4 * kg) * 33 + r];
+        };
+        if (wave >= 6) put(wave - 6);
+        __syncthreads();
+        if (wave == 4 || wave == 5) add(wave - 4);
+        __syncthreads();
+        if (wave == 4 || wave == 5) put(wave - 4);
+        __syncthreads();
+        if (wave == 2 || wave == 3) add(wave - 2);
+        __syncthreads();
+        if (wave == 2 || wave == 3) put(wave - 2);
+        __syncthreads();
+        if (wave < 2) add(wave);
+        __syncthreads();
+        if (wave < 2) put(wave);
+        __syncthreads();
     }
-    __syncthreads();
     // thread -> elements (rr, 2 cp), (rr, 2 cp + 1)
     const int rr = tid >> 4, cp = tid & 15;
     double G2[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int o = rr * 33 + 2 * cp + q;
-        G2[q] = ((part[o] + part[(32 * 33) + o]) + (part[2 * (32 * 33) + o] + part[3 * (32 * 33) + o])) +
-                ((part[4 * (32 * 33) + o] + part[5 * (32 * 33) + o]) + (part[6 * (32 * 33) + o] + part[7 * (32 * 33) + o]));
+        G2[q] = part[o] + part[(32 * 33) + o];
     }
     const int nb = gridDim.x;
     const int gr = row0 + rr, gc = col0 + 2 * cp;
@@ -583,7 +605,7 @@ template <int NT = 512> __device__ __forceinline__ void nsf_check(const SplitArg
 
 template <int NS, int MODE>
 __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
-    __shared__ __attribute__((aligned(16))) float part[8 * 32 * 33];
+    __shared__ __attribute__((aligned(16))) float part[4 * 32 * 33];      // (four slots: waves 4..7 hand their partial tiles to waves 0..3; see nsf_i8)
     __shared__ float fin[32 * 33];
     __shared__ float fin2[32 * 33];
     __shared__ double red[8 * 4];
@@ -685,10 +707,14 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], acc1, 0, 0, 0);
     }
+    if (wave >= 4) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int q = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-        part[wave * (32 * 33) + q * 33 + r] = acc0[reg] + acc1[reg] * kLoInv;
+        for (int reg = 0; reg < 16; ++reg) part[(wave - 4) * (32 * 33) + ((reg & 3) + 8 * (reg >> 2) + 4 * kg) * 33 + r] = acc0[reg] + acc1[reg] * kLoInv;
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) part[wave * (32 * 33) + ((reg & 3) + 8 * (reg >> 2) + 4 * kg) * 33 + r] += acc0[reg] + acc1[reg] * kLoInv;
     }
     __syncthreads();
     const float alpha = (MODE == SP_T) ? g.alpha : 1.f, beta = (MODE == SP_T) ? g.beta_eye : 0.f;
@@ -696,8 +722,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int o = rr * 33 + 2 * cp + q;
-        const float sum = ((part[o] + part[(32 * 33) + o]) + (part[2 * (32 * 33) + o] + part[3 * (32 * 33) + o])) +
-                          ((part[4 * (32 * 33) + o] + part[5 * (32 * 33) + o]) + (part[6 * (32 * 33) + o] + part[7 * (32 * 33) + o]));
+        const float sum = (part[o] + part[(32 * 33) + o]) + (part[2 * (32 * 33) + o] + part[3 * (32 * 33) + o]);
         const bool dg = (row0 + rr) == (col0 + 2 * cp + q);
         if constexpr (MODE == SP_FIRST) {
             // Y0 = A/c; the product is P P = (c Y0)^2 in normalised units: Y1 = Y0 T0 = 1.5 Y0 - 0.5 Y0^2, Z1 = T0 = 1.5 I - 0.5 Y0

@@ -8,8 +8,13 @@ from fadtk_amd import hip
 
 dev = torch.device("cuda", 0)
 what = sys.argv[1]
-if what in ("c5", "c4"):
-    nsongs, frames, d = (32, 1500, 768) if what == "c5" else (2000, 2250, 128)
+if what in ("c5", "c4", "gen"):
+    # gen <d> <frames> <songs> [calls]: any shape
+    if what == "gen":
+        d, frames, nsongs = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        sys.argv = sys.argv[:2] + sys.argv[5:]
+    else:
+        nsongs, frames, d = (32, 1500, 768) if what == "c5" else (2000, 2250, 128)
     g = torch.Generator(device=dev); g.manual_seed(55)
     scale = 0.5 + torch.rand((d,), generator=g, device=dev)
     songs = (torch.randn((nsongs * frames, d), generator=g, device=dev) * scale).to(torch.float16)

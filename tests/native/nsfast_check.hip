@@ -135,7 +135,7 @@ template <int NS> static void launch_split(int mode, unsigned t, const SplitArgs
 }
 static void run_split(int d, int mode, const SplitArgs& g) {
     const unsigned t = d / 32;
-    switch (d) { case 256: launch_split<2>(mode, t, g); break; case 512: launch_split<4>(mode, t, g); break;
+    switch (d) { case 256: launch_split<2>(mode, t, g); break; case 384: launch_split<3>(mode, t, g); break; case 512: launch_split<4>(mode, t, g); break;
                  case 768: launch_split<6>(mode, t, g); break; default: launch_split<8>(mode, t, g); }
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
 }
@@ -145,7 +145,7 @@ template <int NS8> static void launch_i8(int mode, unsigned t, const I8Args& g) 
 }
 static void run_i8(int d, int mode, const I8Args& g) {
     const unsigned t = d / 32;
-    switch (d) { case 256: launch_i8<1>(mode, t, g); break; case 512: launch_i8<2>(mode, t, g); break;
+    switch (d) { case 256: launch_i8<1>(mode, t, g); break; case 384: case 512: launch_i8<2>(mode, t, g); break;
                  case 768: launch_i8<3>(mode, t, g); break; default: launch_i8<4>(mode, t, g); }
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
 }

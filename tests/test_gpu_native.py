@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 EXE = Path(__file__).resolve().parent / "native" / "nsfast_check"
 
 
-@pytest.mark.parametrize("dims", [["512"], ["256", "768"], ["1024"]])
+@pytest.mark.parametrize("dims", [["512"], ["256", "768"], ["1024", "384"]])
 def test_ns_fast_kernels_against_host_arithmetic(dims):
     if not EXE.exists():
         from fadtk_amd.build import build_native_tests

@@ -1006,7 +1006,7 @@ def test_moments_bind_keeps_statistics_in_callers_buffer(F):
         np.testing.assert_allclose(buf[:plen].cpu().numpy(), want, rtol=0, atol=1e-6 * np.abs(want).max())
 
 
-@pytest.mark.parametrize("d,n", [(256, 3000), (512, 6000), (768, 9000), (1024, 12000)])
+@pytest.mark.parametrize("d,n", [(256, 3000), (384, 4500), (512, 6000), (768, 9000), (1024, 12000)])
 def test_frechet_nine_launch_chain_matches_float32_chain_and_oracle(F, monkeypatch, d, n):
     """Round 3: for D in {256, 512, 768, 1024} the square root runs as nine launches -- exact products on the int8 MFMA, iteration
     on split-float16 operands (csrc/ns_fast.h).  From packed moments (the bench's route, float16 frames, the reference's float16
@@ -1101,7 +1101,7 @@ def test_score_inf_points_on_device_match_the_sequential_route(F, d, dtype):
         assert abs(v - ref) <= FAD_BAR / 10 * abs(ref)
 
 
-@pytest.mark.parametrize("d,frames", [(128, [129, 300, 2250, 140, 777, 500, 200, 350, 9000]), (256, [257, 600, 300, 1500]), (512, [1100, 513]), (768, [1500, 900]),
+@pytest.mark.parametrize("d,frames", [(128, [129, 300, 2250, 140, 777, 500, 200, 350, 9000]), (256, [257, 600, 300, 1500]), (384, [900, 500]), (512, [1100, 513]), (768, [1500, 900]),
                                       (1024, [2100])])
 def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     """Songs with at least D + 1 frames, D in {128, 256, 512, 768, 1024}: the eight-launch chain of the single pair, batched over
