@@ -894,6 +894,7 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
     // FAD_SONG_RES=0: D = 128 iterates through the batched kernels like the other dimensions (tests compare)
     const char* res_env = getenv("FAD_SONG_RES");
     const bool resident = d == 128 && !(res_env && res_env[0] == '0');
+    const bool res_full = resident && !(res_env && res_env[0] == '1');      // 1: only the iteration resident; default: the exact products too
     const size_t dd = (size_t)d * d;
     const int nb = d / 32;
     const SongBlock L = song_block(d);
@@ -949,12 +950,13 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
         memset(&a, 0, sizeof(a));
         a.Adig = dig_b; a.Bdig = reinterpret_cast<uint4*>(at(L.digS)); a.d = d; a.gen = gen; a.hA = hdr_b;
         a.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); a.pstride = (int64_t)L.stride; a.stats = stats; a.A64 = A64; a.P = P; a.st = st0;
-        fast_i8(d, nsf::I8_A, a, st, (unsigned)B);
+        if (!res_full) fast_i8(d, nsf::I8_A, a, st, (unsigned)B);
         if (resident) {
             // D = 128: the whole iteration of a song in one workgroup (ns_fast_res.h)
             static std::atomic<unsigned> ready{0};
             if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
-                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_res128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kResLds));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_res128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kResLds));
+                FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_res128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kResLdsFull));
                 ready.fetch_or(1u << device, std::memory_order_release);
             }
             nsf::ResArgs r;
@@ -962,7 +964,15 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
             r.gen = gen; r.max_low = kMaxLow; r.thr_pred = pred_threshold(ws.pool, d); r.hA = hdr_b; r.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr));
             r.pstride = (int64_t)L.stride; r.A64 = A64; r.statsA = stats; r.st = st0; r.s32 = s32_0;
             r.Y[0] = Y[0]; r.Y[1] = Y[1]; r.Z[0] = Z[0]; r.Z[1] = Z[1];
-            hipLaunchKernelGGL(nsf::nsf_res128, dim3((unsigned)B), dim3(256), nsf::kResLds, st, r);
+            if (res_full) {
+                // ... and the two exact products with it: A = Sigma_b Sigma_s in front, the correction behind; the host record is this kernel's
+                r.Adig = dig_b; r.Bdig = reinterpret_cast<uint4*>(at(L.digS)); r.hstride = (int64_t)hs;
+                r.stats = h_stats; r.host_words = h_words; r.host_vals = h_vals;
+                for (int64_t b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + b * hs)[12] = 0;
+                hipLaunchKernelGGL(nsf::nsf_res128<true>, dim3((unsigned)B), dim3(256), nsf::kResLdsFull, st, r);
+            } else {
+                hipLaunchKernelGGL(nsf::nsf_res128<false>, dim3((unsigned)B), dim3(256), nsf::kResLds, st, r);
+            }
         } else {
             nsf::SplitArgs g = split_args();
             g.A[0] = P; g.B[0] = P; g.C[0] = Y[1]; g.C[1] = Z[1]; g.A64 = A64; g.statsA = stats;      // (no digit planes: nsf_digitize, below)
@@ -991,21 +1001,23 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
             if (big) FAD_TRY(fast_split_big(d, nsf::SP_U, g, st, (unsigned)B, device));
             else fast_split(d, nsf::SP_U, g, st, (unsigned)B);
         }
-        {
+        if (!res_full) {
             nsf::DigArgs dg;
             memset(&dg, 0, sizeof(dg));
             dg.d = d; dg.gen = gen; dg.hA = hdr_b; dg.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); dg.pstride = (int64_t)L.stride; dg.s32 = s32_0;
             dg.Y[0] = Y[0]; dg.Y[1] = Y[1]; dg.dig[0] = digY[0]; dg.dig[1] = digY[1]; dg.dig_t[0] = digYt[0]; dg.dig_t[1] = digYt[1];
             hipLaunchKernelGGL(nsf::nsf_digitize, dim3((unsigned)((dd / 16 + 255) / 256), 2, (unsigned)B), dim3(256), 0, st, dg);
         }
-        nsf::I8Args a;
-        memset(&a, 0, sizeof(a));
-        a.Adig = digY[0]; a.Bdig = digYt[0]; a.Adig_alt = digY[1]; a.Bdig_alt = digYt[1]; a.sel = &s32_0->final_iter;
-        a.d = d; a.gen = gen; a.hA = hdr_b; a.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); a.pstride = (int64_t)L.stride; a.hstride = (int64_t)hs;
-        a.skip = &s32_0->skip_corr; a.stats = h_stats; a.st = st0; a.A64in = A64;
-        a.Y[0] = Y[0]; a.Y[1] = Y[1]; a.Z[0] = Z[0]; a.Z[1] = Z[1]; a.s32 = s32_0; a.host_words = h_words; a.host_vals = h_vals;
-        for (int64_t b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + b * hs)[12] = 0;
-        fast_i8(d, nsf::I8_G, a, st, (unsigned)B);
+        if (!res_full) {
+            nsf::I8Args a;
+            memset(&a, 0, sizeof(a));
+            a.Adig = digY[0]; a.Bdig = digYt[0]; a.Adig_alt = digY[1]; a.Bdig_alt = digYt[1]; a.sel = &s32_0->final_iter;
+            a.d = d; a.gen = gen; a.hA = hdr_b; a.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); a.pstride = (int64_t)L.stride; a.hstride = (int64_t)hs;
+            a.skip = &s32_0->skip_corr; a.stats = h_stats; a.st = st0; a.A64in = A64;
+            a.Y[0] = Y[0]; a.Y[1] = Y[1]; a.Z[0] = Z[0]; a.Z[1] = Z[1]; a.s32 = s32_0; a.host_words = h_words; a.host_vals = h_vals;
+            for (int64_t b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + b * hs)[12] = 0;
+            fast_i8(d, nsf::I8_G, a, st, (unsigned)B);
+        }
         FAD_HIP_TRY(hipGetLastError());
         FAD_HIP_TRY(hipStreamSynchronize(st));
         bool pending = false;

@@ -114,7 +114,7 @@ template <int N, int NW = 8> __device__ __forceinline__ void wg8_sum(double (&v)
         v[q] = t;
     }
 }
-__device__ __forceinline__ double wg8_max(double v, double* red) {
+template <int NW = 8> __device__ __forceinline__ double wg8_max(double v, double* red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
     __syncthreads();
@@ -122,7 +122,7 @@ __device__ __forceinline__ double wg8_max(double v, double* red) {
     __syncthreads();
     double t = red[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) t = fmax(t, red[w]);
+    for (int w = 1; w < NW; ++w) t = fmax(t, red[w]);
     return t;
 }
 

@@ -1120,7 +1120,8 @@ def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     monkeypatch.setenv("FAD_SONG_FAST", "2")                                  # strict: an error if the chain accepts no song at all
     want = O.individual_scores(mu_b, cov_b, sg, run_sqrtm=False)
     # iteration on 128 x 128 tiles (ns_fast_big.h) / on 32 x 32 tiles; D = 128 first through its resident kernel (ns_fast_res.h)
-    variants = ([("8", "1")] if d == 128 else []) + [("1", "0"), ("0", "0")]
+    # (FAD_SONG_RES: 2 / unset = products and iteration in one workgroup per song, 1 = the iteration only, 0 = the batched kernels)
+    variants = ([("8", "2"), ("8", "1")] if d == 128 else []) + [("1", "0"), ("0", "0")]
     for big_min, res in variants:
         monkeypatch.setenv("FAD_SONG_BIG", big_min)
         monkeypatch.setenv("FAD_SONG_RES", res)
