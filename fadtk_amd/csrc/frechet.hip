@@ -711,12 +711,26 @@ static int fast_split_big(int d, int mode, nsf::SplitArgs g, hipStream_t st, uns
     if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
         FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
         FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
+        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_FIRST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
         ready.fetch_or(1u << device, std::memory_order_release);
     }
     const unsigned t = (unsigned)(d / 128), Bp = (B + 7u) & ~7u;
     g.nprob = (int)B; g.nprob_pad = (int)Bp;
-    if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(t * t * Bp), dim3(256), nsf::kBigLds, st, g);
+    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_FIRST>), dim3(t * t * Bp), dim3(256), nsf::kBigLds, st, g);
+    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(t * t * Bp), dim3(256), nsf::kBigLds, st, g);
     else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U>), dim3(2 * t * t * Bp + B), dim3(256), nsf::kBigLds, st, g);
+    return FAD_OK;
+}
+static int fast_i8_big(int d, int mode, const nsf::I8Args& g, hipStream_t st, unsigned B, int device) {
+    static std::atomic<unsigned> ready{0};
+    if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
+        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_i8_big<nsf::I8_A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kI8BigLds));
+        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_i8_big<nsf::I8_G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kI8BigLds));
+        ready.fetch_or(1u << device, std::memory_order_release);
+    }
+    const unsigned tiles = (unsigned)((d / 128) * (d / 64)), Bp = (B + 7u) & ~7u;
+    if (mode == nsf::I8_A) hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_A>), dim3(tiles * Bp), dim3(512), nsf::kI8BigLds, st, g, (int)B, (int)Bp);
+    else hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_G>), dim3(tiles * Bp), dim3(512), nsf::kI8BigLds, st, g, (int)B, (int)Bp);
     return FAD_OK;
 }
 template <int NS8> static void fast_launch_i8(int mode, unsigned t, unsigned B, const nsf::I8Args& g, hipStream_t st) {
@@ -950,7 +964,9 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
         memset(&a, 0, sizeof(a));
         a.Adig = dig_b; a.Bdig = reinterpret_cast<uint4*>(at(L.digS)); a.d = d; a.gen = gen; a.hA = hdr_b;
         a.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); a.pstride = (int64_t)L.stride; a.stats = stats; a.A64 = A64; a.P = P; a.st = st0;
-        if (!res_full) fast_i8(d, nsf::I8_A, a, st, (unsigned)B);
+        if (res_full) { /* nsf_res128<FULL> forms the product itself */ }
+        else if (big && d >= 256) FAD_TRY(fast_i8_big(d, nsf::I8_A, a, st, (unsigned)B, device));
+        else fast_i8(d, nsf::I8_A, a, st, (unsigned)B);
         if (resident) {
             // D = 128: the whole iteration of a song in one workgroup (ns_fast_res.h)
             static std::atomic<unsigned> ready{0};
@@ -976,7 +992,8 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
         } else {
             nsf::SplitArgs g = split_args();
             g.A[0] = P; g.B[0] = P; g.C[0] = Y[1]; g.C[1] = Z[1]; g.A64 = A64; g.statsA = stats;      // (no digit planes: nsf_digitize, below)
-            fast_split(d, nsf::SP_FIRST, g, st, (unsigned)B);
+            if (big && d >= 256) FAD_TRY(fast_split_big(d, nsf::SP_FIRST, g, st, (unsigned)B, device));
+            else fast_split(d, nsf::SP_FIRST, g, st, (unsigned)B);
         }
     }
     tr_sqrt.assign((size_t)B, 0.0); ok.assign((size_t)B, 0);
@@ -1016,7 +1033,8 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
             a.skip = &s32_0->skip_corr; a.stats = h_stats; a.st = st0; a.A64in = A64;
             a.Y[0] = Y[0]; a.Y[1] = Y[1]; a.Z[0] = Z[0]; a.Z[1] = Z[1]; a.s32 = s32_0; a.host_words = h_words; a.host_vals = h_vals;
             for (int64_t b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + b * hs)[12] = 0;
-            fast_i8(d, nsf::I8_G, a, st, (unsigned)B);
+            if (big && d >= 256) FAD_TRY(fast_i8_big(d, nsf::I8_G, a, st, (unsigned)B, device));
+            else fast_i8(d, nsf::I8_G, a, st, (unsigned)B);
         }
         FAD_HIP_TRY(hipGetLastError());
         FAD_HIP_TRY(hipStreamSynchronize(st));

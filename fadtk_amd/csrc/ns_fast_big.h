@@ -27,7 +27,7 @@ constexpr size_t kBigLds = (size_t)kBigStages * kBigStage * 16 + 256;   // + the
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
-    static_assert(MODE == SP_T || MODE == SP_U, "iteration products only");
+    static_assert(MODE == SP_T || MODE == SP_U || MODE == SP_FIRST, "SP_FIRST: iteration 0 (scale from nsf_i8<A>'s statistics, Y1, Z1)");
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
     double* red = reinterpret_cast<double*>(ring + kBigStages * kBigStage);
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
@@ -53,7 +53,59 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
     const int64_t po = (int64_t)song * g.pstride;
     const MatHdr* hB = adv(g.hB, po);
     if (hdr_bad(g.hA, hB, g.gen)) return;
-    if (g.skip && *adv(g.skip, po) != 0) return;
+    double inv_c = 0.0, inv_cn = 0.0;
+    if constexpr (MODE == SP_FIRST) {
+        // ---- the scale, as nsf_split<FIRST> derives it (every workgroup, identically, from nsf_i8<A>'s 32 x 32 tile statistics);
+        // the ring is not in use yet: it holds the per-tile maxima meanwhile
+        const int nb = d >> 5;
+        const double* scal = adv(g.statsA, po);
+        double* tmax = reinterpret_cast<double*>(ring);              // [2][nb * nb]
+        double v2[2] = {0.0, 0.0};
+        for (int k = tid; k < nb * nb; k += 256) {
+            const double2 r0 = *reinterpret_cast<const double2*>(scal + kTileStats * k), r1 = *reinterpret_cast<const double2*>(scal + kTileStats * k + 2);
+            v2[0] += r0.x; v2[1] += r0.y;
+            tmax[k] = (r1.x == r1.x) ? r1.x : 1e300; tmax[nb * nb + k] = (r1.y == r1.y) ? r1.y : 1e300;
+        }
+        __syncthreads();
+        double bnd = 0.0;
+        if (tid < 2 * nb) {
+            const int line = tid % nb; const bool col = tid >= nb;
+            for (int q = 0; q < nb; ++q) bnd += col ? tmax[nb * nb + q * nb + line] : tmax[line * nb + q];
+        }
+        const double inf_b = wg8_max<4>((tid < nb) ? bnd : 0.0, red);
+        const double one_b = wg8_max<4>((tid >= nb && tid < 2 * nb) ? bnd : 0.0, red);
+        wg8_sum<2, 4>(v2, red);
+        const double fro2 = v2[0], trA = v2[1];
+        double u = sqrt(fro2);
+        if (inf_b < u) u = inf_b;
+        if (one_b < u) u = one_b;
+        double c = u / 2.9;
+        const double wmean = (trA > 0.0) ? fro2 / trA : 0.0;
+        if (wmean > c && wmean <= u) c = wmean;
+        NsState* const st_p = adv(g.st, po);
+        const double mean_term = st_p->mean_term, tr1 = g.hA->tr, tr2 = hB->tr;
+        const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
+        const bool zero = !bad && !(c > 0.0);
+        const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
+        if (tile == 0 && tid == 0) {
+            NsState* st = st_p; Ns32State* s32 = adv(g.s32, po);
+            st->c = zero ? 1.0 : c * hdr_inv_s12(g.hA, hB);
+            st->tr1 = tr1; st->tr2 = tr2;
+            st->res_last = 0.0; st->tr_last = 0.0; st->res_min = 1e300; st->tr_safe = 0.0; st->has_safe = 0;
+            st->final_iter = zero ? 0 : -1; st->conv = zero ? 1 : 0;
+            st->nonfinite = bad ? 1 : 0; st->done = (bad || zero) ? 1 : 0; st->finished = (bad || zero) ? 1 : 0;
+            s32->done = 0; s32->finished = 0; s32->ok = 0; s32->final_iter = -1; s32->failed = 0;
+            s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = 0;
+            s32->res[0] = 1e300;
+            if (bad || zero || hopeless) { s32->done = 1; s32->finished = 1; s32->failed = 1; s32->upd_skip[0] = 1; s32->upd_skip[1] = 1; }
+        }
+        if (bad || zero || hopeless) return;
+        inv_cn = 1.0 / c;
+        inv_c = inv_cn / hdr_inv_s12(g.hA, hB);
+        __syncthreads();                                             // the maxima have been read: the ring may fill
+    } else {
+        if (g.skip && *adv(g.skip, po) != 0) return;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int nks = d >> 4;
@@ -131,6 +183,31 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int by = 4 * TY + 2 * wr + i, bx = 4 * TX + 2 * wc + j;
+            if constexpr (MODE == SP_FIRST) {
+                // Y0 = A/c; the product is P P = (c Y0)^2 in normalised units: Y1 = Y0 T0 = 1.5 Y0 - 0.5 Y0^2, Z1 = T0 = 1.5 I - 0.5 Y0
+                const double* A64 = adv(g.A64, po) + (int64_t)(32 * by + 4 * kg) * d + 32 * bx + r;
+                float z1[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int q = (reg & 3) + 8 * (reg >> 2);
+                    const float y0 = (float)(A64[(int64_t)q * d] * inv_c);
+                    const float y2 = (float)((double)(acc0[i][j][reg] + acc1[i][j][reg] * kLoInv) * (inv_cn * inv_cn));
+                    fin[(q + 4 * kg) * 33 + r] = 1.5f * y0 - 0.5f * y2;
+                    z1[reg] = ((by == bx && q + 4 * kg == r) ? 1.5f : 0.f) - 0.5f * y0;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) store_tile_planes(fin, Cm, by, bx, d, pass * 64 + lane);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) fin[((reg & 3) + 8 * (reg >> 2) + 4 * kg) * 33 + r] = z1[reg];
+                __builtin_amdgcn_wave_barrier();
+                const SplitMat Zm1 = adv(g.C[1], po);
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) store_tile_planes(fin, Zm1, by, bx, d, pass * 64 + lane);
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int q = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
@@ -153,6 +230,178 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
         wg8_sum<1, 4>(s1, red);
         if (tid == 0) adv(g.partials, po)[tile] = s1[0];
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The two exact products (nsf_i8<A>, nsf_i8<G>) for a batch, D >= 256: workgroup tile 128 x 64, eight waves, each wave ONE 32 x 32
+// block over the whole k range -- no k-split, no partial tiles to sum -- digit pieces staged through LDS by LDS-DMA (per k-step of
+// 32: four row blocks and two column blocks x six digit planes = 36 pieces of 1 KiB, two stages), one XCD per song.  On 32 x 32
+// workgroup tiles a batch of 32 songs of D = 768 pulled 295 KB of digit planes per tile through the L2s (5.4 GB per launch,
+// 0.76 / 0.95 ms: profiles/r03o_c5_kernel_stats.csv); here a block costs 28 KB.
+constexpr int kI8BigStage = 36 * 64;                               // uint4 per stage
+constexpr size_t kI8BigLds = (size_t)2 * kI8BigStage * 16 + 256;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob_pad) {
+    extern __shared__ __attribute__((aligned(16))) uint4 ring[];
+    double* red = reinterpret_cast<double*>(ring + 2 * kI8BigStage);
+    constexpr int kUmin = (MODE == I8_A) ? kUminA : kUminG;
+    constexpr int kGroups = 2 * (kDigits - 1) - kUmin + 1;
+    const int d = g.d, tid = threadIdx.x, lane = tid & 63;
+    const int tr_ = d >> 7, tc_ = d >> 6, tt = tr_ * tc_;           // tiles per song: rows of 128, columns of 64
+    const int L = blockIdx.x;
+    const int xcd = L & 7, idx = L >> 3;
+    const int unit = idx / tt, tile = idx - unit * tt;
+    const int song = 8 * unit + xcd;
+    if (song >= nprob) return;
+    (void)nprob_pad;
+    const int TY = tile / tc_, TX = tile - TY * tc_;
+    const int64_t po = (int64_t)song * g.pstride, ho = (int64_t)song * g.hstride;
+    const MatHdr* hB = adv(g.hB, po);
+    NsState* const st_p = adv(g.st, po);
+    const bool bad = hdr_bad(g.hA, hB, g.gen);
+    const bool skipped = bad || (g.skip && *adv(g.skip, po) != 0);
+    if constexpr (MODE == I8_G) {
+        if (tile == 0 && tid == 0) {                                 // whatever happens, the host finds the state next to the partials
+            const NsState* st = st_p; const Ns32State* s = adv(g.s32, po);
+            int* hw = adv(g.host_words, ho); double* hv = adv(g.host_vals, ho);
+            hw[0] = bad ? 1 : 0; hw[1] = st->done; hw[2] = st->nonfinite; hw[3] = st->too_few[0]; hw[4] = st->too_few[1];
+            hw[5] = s->ok; hw[6] = s->failed; hw[7] = s->final_iter; hw[8] = s->decided_at; hw[9] = s->strict; hw[10] = s->finished;
+            hw[11] = skipped ? 1 : 0;
+            hv[0] = st->c; hv[1] = st->tr1; hv[2] = st->tr2; hv[3] = st->mean_term;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hv[4 + q] = s->res[q];
+            hw[12] = g.gen;
+        }
+    }
+    if (skipped) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool alt = (MODE == I8_G) && g.sel && (*adv(g.sel, po) & 1);
+    const uint4* Ad = (MODE == I8_A) ? g.Adig : adv(alt ? g.Adig_alt : g.Adig, po);
+    const uint4* Bd = adv(alt ? g.Bdig_alt : g.Bdig, po);
+    const int nks = d >> 5;
+
+    // piece q of a stage: q < 24: A side, row block q / 6, digit q % 6; else B side, column block (q - 24) / 6.  Wave w moves pieces
+    // w, w + 8, ... (waves 0..3: five, the others four)
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)ring;
+    auto issue = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = wave + 8 * i;
+            if (q < 36) {
+                const bool bs = q >= 24;
+                const int blk = bs ? (q - 24) / 6 : q / 6, p = bs ? (q - 24) % 6 : q % 6;
+                const uint64_t sb = (uint64_t)((bs ? Bd : Ad) + dg_idx((bs ? 2 * TX : 4 * TY) + blk, ks, p, 0, d));
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
+                const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+                const uint64_t ub = ((uint64_t)hi << 32) | lo;
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(((ks & 1) * kI8BigStage + q * 64) * 16));
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
+            }
+        }
+    };
+    i32x16 acc[kGroups];
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[u][q] = 0;
+    issue(0);
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // stage ks is there for every wave; the other stage is free
+        if (ks + 1 < nks) issue(ks + 1);
+        const i32x4* st = reinterpret_cast<const i32x4*>(ring + (ks & 1) * kI8BigStage) + lane;
+        i32x4 a[kDigits], b[kDigits];
+#pragma unroll
+        for (int p = 0; p < kDigits; ++p) { a[p] = st[(wr * 6 + p) * 64]; b[p] = st[(24 + wc * 6 + p) * 64]; }
+#pragma unroll
+        for (int p = kDigits - 1; p >= 0; --p)
+#pragma unroll
+            for (int q = kDigits - 1; q >= 0; --q)
+                if (p + q >= kUmin) acc[p + q - kUmin] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[q], acc[p + q - kUmin], 0, 0, 0);
+    }
+    __syncthreads();                                               // the ring is scratch now: one [32][33] float area per wave
+    double gp[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gp[q] = 0.0;
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+        const double wgt = __builtin_ldexp(1.0, 7 * (u + kUmin) - 80);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gp[q] = __builtin_fma((double)acc[u][q], wgt, gp[q]);
+    }
+    float* fin = reinterpret_cast<float*>(ring) + wave * (32 * 33 + 32);
+    const int kg = lane >> 5, n = lane & 31;
+    const int by = 4 * TY + wr, bx = 2 * TX + wc, nb = d >> 5;
+    const int row0 = 32 * by, col0 = 32 * bx;
+    double* const stats = adv(g.stats, (MODE == I8_A) ? po : ho);
+    double* scal = stats + (size_t)kTileStats * (by * nb + bx);
+    double v3[3] = {0.0, 0.0, 0.0};
+    if constexpr (MODE == I8_A) {
+        const double inv = hdr_inv_s12(g.hA, hB);
+        double* A64 = adv(g.A64, po) + (int64_t)(row0 + 4 * kg) * d + col0 + n;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int q = (reg & 3) + 8 * (reg >> 2);
+            A64[(int64_t)q * d] = gp[reg] * inv;
+            fin[(q + 4 * kg) * 33 + n] = (float)gp[reg];
+            v3[0] += gp[reg] * gp[reg];
+            if (by == bx && q + 4 * kg == n) v3[1] += gp[reg];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const SplitMat Pm = adv(g.P, po);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) store_tile_planes(fin, Pm, by, bx, d, pass * 64 + lane);
+    } else {
+        const SplitMat Zm = adv(g.Z[alt ? 1 : 0], po);
+        const SplitMat Ym = adv(g.Y[alt ? 1 : 0], po);
+        const double inv_c = 1.0 / st_p->c;
+        const double* A64 = adv(g.A64in, po) + (int64_t)(row0 + 4 * kg) * d + col0 + n;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int q = (reg & 3) + 8 * (reg >> 2), gr = row0 + q + 4 * kg, gc = col0 + n;
+            const double R = A64[(int64_t)q * d] * inv_c - gp[reg];
+            int half;
+            const size_t zi = fa_elem(gr, gc, 0, d, half);         // Z^T[gr][gc] = Z[gc][gr] pairs with R[gr][gc] in tr(Z R)
+            const double z = (double)used16(reinterpret_cast<const _Float16*>(Zm.at + zi)[half], reinterpret_cast<const _Float16*>(Zm.at + zi + 64)[half]);
+            v3[0] += z * R; v3[1] += R * R;
+            if (by == bx && gr == gc) {
+                int hy;
+                const size_t yi = fa_elem(gr, gr, 0, d, hy);
+                v3[2] += (double)used16(reinterpret_cast<const _Float16*>(Ym.a + yi)[hy], reinterpret_cast<const _Float16*>(Ym.a + yi + 64)[hy]);
+            }
+            fin[(q + 4 * kg) * 33 + n] = fabsf((float)z);           // |Z[col0 + c][row0 + r]| at (r, c)
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // largest row / column sum inside the block (nsf_i8's rule: lanes 0..31 one kind, 32..63 the other)
+    double m = 0.0;
+    if constexpr (MODE == I8_A) {
+        if (lane < 32) { for (int c = 0; c < 32; ++c) m += fabsf(fin[lane * 33 + c]); }
+        else { for (int q = 0; q < 32; ++q) m += fabsf(fin[q * 33 + lane - 32]); }
+    } else {
+        if (lane < 32) { for (int q = 0; q < 32; ++q) m += fin[q * 33 + lane]; }
+        else { for (int c = 0; c < 32; ++c) m += fin[(lane - 32) * 33 + c]; }
+    }
+    double mrow = (lane < 32) ? m : 0.0, mcol = (lane >= 32) ? m : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mrow = fmax(mrow, __shfl_xor(mrow, off)); mcol = fmax(mcol, __shfl_xor(mcol, off));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v3[q] += __shfl_xor(v3[q], off);
+    }
+    if (lane == 0) {
+        if constexpr (MODE == I8_A) {
+            scal[0] = v3[0]; scal[1] = v3[1]; scal[2] = mrow; scal[3] = mcol;
+        } else {
+            scal[0] = v3[0]; scal[1] = v3[1]; scal[2] = v3[2]; scal[3] = 0.0;
+            double* zmax = stats + (size_t)kTileStats * nb * nb + 2 * (size_t)(by * nb + bx);
+            zmax[0] = mrow; zmax[1] = mcol;
+        }
+    }
+    (void)red;
 }
 
 }  // namespace nsf
