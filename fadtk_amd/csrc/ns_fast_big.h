@@ -9,9 +9,9 @@
 // 128 x 128 tile and walks the whole k range: per k-step of 16 it needs 16 operand pieces of 1 KiB (four row blocks of A and four
 // column blocks of B, hi and lo plane) -- which the fragment-major layout stores exactly as the MFMA reads them, so one
 // global_load_lds_dwordx4 per piece moves it into LDS verbatim (no swizzle, no transpose read: the 64 lanes' 16-byte operands back to
-// back) and one ds_read_b128 per lane brings it to the MFMA.  A ring of four stages of one k-step; 12 MFMAs (2 x 2 blocks x hi hi,
+// back) and one ds_read_b128 per lane brings it to the MFMA.  A ring of three stages of one k-step; 12 MFMAs (2 x 2 blocks x hi hi,
 // hi lo, lo hi) against 8 ds_read_b128 and 4 LDS-DMA instructions per wave and k-step; operand traffic per tile is a quarter of
-// the small-tile kernels'.  64 KiB of LDS: two workgroups per CU.
+// the small-tile kernels'.  48 KiB of LDS: three workgroups per CU.
 //
 // The epilogue is ns_fast.h's, a 32 x 32 block at a time: each wave parks a block of its 64 x 64 result in its own (now free) part
 // of the ring and runs the store_tile tasks over it in a few passes.
@@ -21,12 +21,18 @@
 namespace fad {
 namespace nsf {
 
-constexpr int kBigStages = 4;
+// Ring depth (stages of one k-step = 16 KiB) and with it the workgroups per CU.  Measured at 32 songs x [1500 x 768], T / U launch:
+// 4 stages x 2 workgroups 164 / 283 us, 8 stages x 1 workgroup 175 / 318 us, 3 stages x 3 workgroups 142 / 243 us: what hides the
+// operand latency here is another workgroup's epilogue and loop, not a deeper ring.
+#ifndef FAD_BIG_STAGES
+#define FAD_BIG_STAGES 3
+#endif
+constexpr int kBigStages = FAD_BIG_STAGES;
 constexpr int kBigStage = 1024;                                   // uint4 per stage: A pieces [4 rb][2 planes][64 lanes], then B pieces
 constexpr size_t kBigLds = (size_t)kBigStages * kBigStage * 16 + 256;   // + the reduction scratch
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
+__global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <= 4) ? 2 : 1)) void nsf_big(SplitArgs g) {
     static_assert(MODE == SP_T || MODE == SP_U || MODE == SP_FIRST, "SP_FIRST: iteration 0 (scale from nsf_i8<A>'s statistics, Y1, Z1)");
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
     double* red = reinterpret_cast<double*>(ring + kBigStages * kBigStage);
@@ -147,9 +153,15 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
     for (int ks = 0; ks < nks; ++ks) {
         // stage ks must have landed; up to two younger stages stay in flight (the count has to be an immediate)
         const int ahead = (nks - 1 - ks < kBigStages - 2) ? (nks - 1 - ks) : (kBigStages - 2);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        switch (ahead) {
+            case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();                          // stage ks is in LDS for every wave; the slot of stage ks - 1 is free
         if (ks + kBigStages - 1 < nks) issue(ks + kBigStages - 1);
         const f16x8* st = reinterpret_cast<const f16x8*>(ring + (ks % kBigStages) * kBigStage) + lane;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void nsf_big(SplitArgs g) {
     __syncthreads();                                           // every wave has left the ring: it is scratch now
 
     // ---- epilogue, per wave: its four 32 x 32 blocks one after the other through a [32][33] float area of its own
-    float* fin = reinterpret_cast<float*>(ring + wave * kBigStage);
+    float* fin = reinterpret_cast<float*>(ring) + wave * (32 * 33 + 32);
     const int kg = lane >> 5, r = lane & 31;
     const float alpha = (MODE == SP_T) ? g.alpha : 1.f, beta = (MODE == SP_T) ? g.beta_eye : 0.f;
     const SplitMat Cm = adv(g.C[zi], po);
