@@ -118,3 +118,41 @@ def test_fuzz_frechet_against_oracle(F=None):
         assert abs(got - want) <= 1e-4 * abs(want) + 1e-10 * terms, what
         worst = max(worst, err if full_rank else 0.0)
     assert worst < 1e-10
+
+
+def test_fuzz_per_song_scores_fast_chain_against_float64_routes_and_oracle(monkeypatch):
+    """The batched per-song call on songs of at least D + 1 float16 frames, D in {128, 256, 384}: the low-precision chain (default)
+    against the float64 routes (FAD_SONG_FAST=0) on the same call and against the oracle (fad.py:373-378) -- with overall scales
+    from 1e-2 to 30, columns whose mean is far above their spread (the shift of the float16 covariances), a few columns carrying
+    most of the variance, songs barely above D frames and long ones, and batches on either side of the big-tile threshold."""
+    from fadtk_amd import hip
+    rng = np.random.default_rng(23)
+    for case in range(10):
+        d = int(rng.choice([128, 256, 384]))
+        nsongs = int(rng.choice([3, 9, 17]))
+        scale = float(rng.choice([1e-2, 1.0, 30.0]))
+        col = (0.5 + rng.random(d)) * scale
+        if case % 3 == 0:
+            col[: d // 16] *= 6.0                                       # a few dominant columns
+        mean = np.where(rng.random(d) < 0.15, 8.0, 0.1) * col * rng.standard_normal(d)     # |mean| >> std on ~15 % of the columns
+        base = rng.standard_normal((6 * d, d)) * col * 1.1 + mean
+        mu_b, cov_b = base.mean(0), np.cov(base, rowvar=False)
+        frames = [int(rng.choice([d + 1, d + 7, 2 * d, 5 * d, 4100 if d == 128 else 3 * d])) for _ in range(nsongs)]
+        songs = [(rng.standard_normal((n, d)) * col * (0.8 + 0.4 * rng.random()) + mean * (1.0 + 0.05 * rng.standard_normal())).astype(np.float16)
+                 for n in frames]
+        rows = np.concatenate(songs)
+        offs = np.concatenate([[0], np.cumsum(frames)])
+        want = np.array(O.individual_scores(mu_b, cov_b, songs, run_sqrtm=False), dtype=np.float64)
+        monkeypatch.delenv("FAD_SONG_FAST", raising=False)
+        fast, st_fast = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+        monkeypatch.setenv("FAD_SONG_FAST", "0")
+        f64, st_f64 = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
+        what = f"case {case}: d={d} songs={nsongs} scale={scale} frames={frames}"
+        assert (st_fast == 0).all() and (st_f64 == 0).all(), what
+        # a song of D + 1 frames has a (numerically) singular covariance: the reference's eig is good to ~sqrt(eps) there
+        tol = np.where(np.array(frames) < d + 16, 2e-5, 2e-6)
+        rel_o = np.abs(fast - want) / np.abs(want)
+        rel_f = np.abs(fast - f64) / np.abs(f64)
+        print(f"{what} max rel vs oracle {rel_o.max():.2e} vs float64 routes {rel_f.max():.2e}")
+        assert (rel_o <= tol).all(), (what, rel_o)
+        assert (rel_f <= tol).all(), (what, rel_f)
