@@ -1,5 +1,7 @@
 // The square-root chain of ONE Frechet score in eight launches (gfx950): replaces scipy.linalg.sqrtm / eig of fadtk/fad.py:88-92 for
-// well-conditioned pairs of dimension 256 / 512 / 768 / 1024 (frechet.hip: fast_begin; everything else keeps the routes there).
+// well-conditioned pairs of dimension 256 / 384 / 512 / 768 / 1024 (frechet.hip: fast_begin; everything else keeps the routes there).
+// Batches of problems (per-song scores) run the same arithmetic through ns_fast_big.h (D >= 256: 128 x 128 tiles staged through LDS) and
+// ns_fast_res.h (D = 128: a song resident in one workgroup); this file's kernels serve ONE problem, or a handful.
 //
 //   tr sqrt(A), A = C1 C2:   Newton-Schulz  Y0 = A/c, Z0 = I;  T = (3I - ZY)/2;  Y <- Y T;  Z <- T Z   on LOW-precision operands,
 //   then ONE float64-accurate correction   tr sqrt(A/c) = tr Y + 1/2 tr(Z (A/c - Y Y)) + O(err^2)     (SURVEY.md H1).
