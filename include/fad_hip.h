@@ -199,7 +199,7 @@ int fad_frechet_cancel(fad_frechet_job_t* job);
  * on_device = 1: rows, mu_b and cov_b are DEVICE pointers (a caller scoring many batches against one baseline uploads it
  * once); offsets, out_scores and out_status are host pointers either way.  cov_b is read as (cov_b + cov_b^T)/2.
  * Routes, chosen per song by its frame count n (the result does not depend on the route beyond ~1e-8 of a score):
- *   n = 2: closed form; n - 1 < D: the Gram form on the n - 1 non-zero eigenvalues; n >= D + 1 and D in {128, 256, 512, 768,
+ *   n = 2: closed form; n - 1 < D: the Gram form on the n - 1 non-zero eigenvalues; n >= D + 1 and D in {128, 256, 384, 512, 768,
  *   1024}: the low-precision chain of the single pair, batched over the songs (exact int8-MFMA products, split-float16
  *   Newton-Schulz, one float64-accurate correction, accepted per song on a bound of what the correction neglects), with
  *   float16 frames also the covariances on the float16 matrix pipe; whatever that chain does not accept -- and every other D --
