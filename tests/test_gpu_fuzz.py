@@ -138,7 +138,9 @@ def test_fuzz_per_song_scores_fast_chain_against_float64_routes_and_oracle(monke
         base = rng.standard_normal((6 * d, d)) * col * 1.1 + mean
         mu_b, cov_b = base.mean(0), np.cov(base, rowvar=False)
         frames = [int(rng.choice([d + 1, d + 7, 2 * d, 5 * d, 4100 if d == 128 else 3 * d])) for _ in range(nsongs)]
-        songs = [(rng.standard_normal((n, d)) * col * (0.8 + 0.4 * rng.random()) + mean * (1.0 + 0.05 * rng.standard_normal())).astype(np.float16)
+        # (every fifth case in float32: those frames keep the float64-MFMA covariances and the two-pass statistics in front of the chain)
+        dt = np.float32 if case % 5 == 4 else np.float16
+        songs = [(rng.standard_normal((n, d)) * col * (0.8 + 0.4 * rng.random()) + mean * (1.0 + 0.05 * rng.standard_normal())).astype(dt)
                  for n in frames]
         rows = np.concatenate(songs)
         offs = np.concatenate([[0], np.cumsum(frames)])
@@ -147,12 +149,14 @@ def test_fuzz_per_song_scores_fast_chain_against_float64_routes_and_oracle(monke
         fast, st_fast = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
         monkeypatch.setenv("FAD_SONG_FAST", "0")
         f64, st_f64 = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
-        what = f"case {case}: d={d} songs={nsongs} scale={scale} frames={frames}"
+        what = f"case {case}: d={d} songs={nsongs} scale={scale} dtype={np.dtype(dt).name} frames={frames}"
         assert (st_fast == 0).all() and (st_f64 == 0).all(), what
         # a song of D + 1 frames has a (numerically) singular covariance: the reference's eig is good to ~sqrt(eps) there
         tol = np.where(np.array(frames) < d + 16, 2e-5, 2e-6)
         rel_o = np.abs(fast - want) / np.abs(want)
         rel_f = np.abs(fast - f64) / np.abs(f64)
         print(f"{what} max rel vs oracle {rel_o.max():.2e} vs float64 routes {rel_f.max():.2e}")
-        assert (rel_o <= tol).all(), (what, rel_o)
+        # float32 frames: the reference's np.mean accumulates them in float32 (pairwise), ~1e-7 off the rounded exact mean this library
+        # forms -- 1e-5 of a small score, inside the 1e-4 bar (fadtk itself stores float16 embeddings: model_loader.py:47-48)
+        assert (rel_o <= (tol if dt == np.float16 else 5e-5)).all(), (what, rel_o)
         assert (rel_f <= tol).all(), (what, rel_f)
