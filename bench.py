@@ -347,6 +347,13 @@ def extra_host(fadtk_amd, a_host, b_host, fad_ref):
                     "h2d_GBps_per_set divides the set's bytes by the WHOLE calc_embd_statistics call"}
 
 
+def torchrun_command(gpus, argv):
+    """`python bench.py --gpus N ...` from a plain shell: the command that starts the N ranks (one per GPU, RCCL), exactly as
+    fadtk_amd/cli.py:_relaunch does for the product's --gpus (reference: the spawn pool of fadtk/fad_batch.py:43-48)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", os.environ.get("MASTER_PORT", "29541"), str(Path(__file__).resolve()), *argv]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,8 +369,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (used under rocprofv3 "
                                                              "so that the kernel statistics hold the config-3 launches only)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warm-up + the timed loop and nothing else (no repeat / same-pair / other-layout / breakdown blocks, no extras, "
+                         "no CPU baseline): the command every rocprofv3 pass under profiles/ runs, so that its kernel statistics hold the "
+                         "timed layout's launches only")
+    ap.add_argument("--chain-cus", type=int, default=0,
+                    help="experiment (profiles/r04*_streams.txt): confine the square-root chains to this many CUs per XCD (CU-masked "
+                         "streams) and the moments kernels to the others; 0 = no masks")
     args = ap.parse_args()
     args.lane_streams = not args.single_stream
+    if args.timed_only:
+        args.no_extras = True; args.no_cpu_baseline = True
+    if (args.gpus > 1 or os.environ.get("FAD_BENCH_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # started from a plain shell: launch the ranks ourselves (the driver's N > 1 command goes through torch.distributed.run and
+        # arrives here with WORLD_SIZE set)
+        import subprocess
+        cmd = torchrun_command(max(args.gpus, 1), sys.argv[1:])
+        if os.environ.get("FAD_BENCH_PRINT_LAUNCH") == "1":      # tests: show the command instead of running it
+            print(json.dumps(cmd))
+            return
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
     # Library banners (RCCL prints its version block to stdout) must not mix with the ONE JSON line: everything
     # written to fd 1 goes to stderr until the result is printed.
@@ -372,6 +397,8 @@ def main():
     os.dup2(2, 1)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts: dmabuf IPC only
+    if args.chain_cus > 0:                                               # before any handle is created (the knob is read there)
+        os.environ["FAD_MOMENTS_CUS"] = str(8 * (32 - args.chain_cus))
     import torch
     import torch.distributed as dist
     from fadtk_amd import dist as fdist, hip
@@ -380,7 +407,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus {args.gpus}` (it starts the "
+                         f"ranks itself) or under torch.distributed.run with --nproc-per-node {args.gpus}")
     # FAD_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, packed all-reduce) even with one rank,
     # so that it can be exercised on a single-GPU box
     distributed = world > 1 or os.environ.get("FAD_BENCH_FORCE_DIST") == "1"
@@ -406,10 +434,17 @@ def main():
 
     comm_stream = torch.cuda.Stream(device=device) if distributed else None
 
+    masked = args.chain_cus > 0 and args.lane_streams and n_lanes > 1
+
     class Lane:
         def __init__(self, k, own=None):
             own = (args.lane_streams and n_lanes > 1) if own is None else own
             self.stream = torch.cuda.Stream(device=device) if own else torch.cuda.current_stream(device)
+            self.cstream = self.stream                                   # where the square-root chain goes
+            if masked and own:
+                # --chain-cus C: moments on CUs [C, 32) of every XCD, chains on CUs [0, C) (FAD_MOMENTS_CUS tells the planner)
+                self.stream = hip.cu_masked_stream(range(args.chain_cus, 32), local_rank)
+                self.cstream = hip.cu_masked_stream(range(0, args.chain_cus), local_rank)
             self.shared = fdist.SharedStats(DIM, SETS, local_rank)
             self.ma, self.mb = self.shared.moments
             self.job = None
@@ -431,9 +466,14 @@ def main():
 
         def score(self):
             """Phase 2: [wait for the exchange,] enqueue the whole Frechet chain; nothing is waited for on the host."""
-            with torch.cuda.stream(self.stream):
+            if self.cstream is not self.stream and not distributed:
+                with torch.cuda.stream(self.stream):
+                    self.fed.record()
+            with torch.cuda.stream(self.cstream):
                 if distributed:
                     torch.cuda.current_stream().wait_event(self.reduced)
+                elif self.cstream is not self.stream:
+                    torch.cuda.current_stream().wait_event(self.fed)
                 self.job = hip.FrechetJob(self.ma, self.mb, mean_dtype=FAD_F16)
 
         def collect(self):
@@ -513,12 +553,13 @@ def main():
         run_steps(args.steps, None, rotate)
         fence()
         return time.perf_counter() - t0
-    repeat_s = [block(True) for _ in range(5)] if args.steps > 0 else []
-    same_pair_s = [block(False) for _ in range(3)] if args.steps > 0 else []
+    side = args.steps > 0 and not args.timed_only
+    repeat_s = [block(True) for _ in range(5)] if side else []
+    same_pair_s = [block(False) for _ in range(3)] if side else []
     # ... and K steps in the other stream layout: by default that is ONE stream for all scores in flight -- no two kernels overlap, the
     # tile kernel's duration there is the kernel alone
     per_stream_s, per_stream_kernel_ms = [], None
-    if args.steps > 0 and n_lanes > 1:                      # the OTHER stream layout (one stream for all lanes / one per lane)
+    if side and n_lanes > 1:                                # the OTHER stream layout (one stream for all lanes / one per lane)
         lanes_s = [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
         run_steps(min(args.steps, 6), None, True, lanes_s)
         for rep in range(3):
@@ -537,15 +578,18 @@ def main():
     # ---- untimed breakdown (torch events on the same stream: stream 0 is torch's current stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     bm, bf = [], []
-    ma.set_timing(True)
-    for _ in range(7):
+    fad0, diag0, reduce_ms = fad, diag, None
+    if not args.timed_only:
+        ma.set_timing(True)
+    for _ in range(0 if args.timed_only else 7):
         ma.reset(); mb.reset()
         ev[0].record(); hip.Moments.update_multi([ma, mb], [a, b]); ev[1].record()
         fad0, diag0 = hip.frechet_from_moments(ma, mb, mean_dtype=FAD_F16); ev[2].record()       # pair 0 = the golden G7 pair
         torch.cuda.synchronize()
         bm.append(ev[0].elapsed_time(ev[1])); bf.append(ev[1].elapsed_time(ev[2]))
-    _, reduce_ms, _ = ma.last_timing()
-    ma.set_timing(False)
+    if not args.timed_only:
+        _, reduce_ms, _ = ma.last_timing()
+        ma.set_timing(False)
 
     # ---- untimed side measurements (rank 0, single GPU)
     extra = {}
@@ -569,8 +613,12 @@ def main():
     flops = SETS * 2.0 * N_ROWS * DIM * DIM                # algorithmic, per launch
     achieved = flops / (kernel_ms * 1e-3) / 1e12
     nt = -(-DIM // 128)
-    # issued: upper-triangular 128 x 128 tiles, 32 MFMAs per 32-row stage off the diagonal, 20 on it
+    # issued: upper-triangular 128 x 128 tiles, 32 MFMAs per 32-row stage off the diagonal, 20 on it; the 256-column-slab kernel
+    # issues the 32 x 32 blocks on and above the diagonal (136 of 256 at D = 512: the same count)
     issued = SETS * 2.0 * N_ROWS * 128 * 128 * (nt * (nt - 1) // 2 + nt * 20.0 / 32.0)
+    if variant == 2:
+        nb = -(-DIM // 32)
+        issued = SETS * 2.0 * N_ROWS * 32 * 32 * (nb * (nb + 1) // 2)
     traffic, traffic_src = None, None
     tpath = ROOT / "profiles" / "moments_traffic.json"     # separate rocprofv3 --pmc passes of this same command
     if tpath.exists():
@@ -601,8 +649,11 @@ def main():
         work = {"f64_mfma_flops": gemms["f64"] * d3}
         ideal_ms = work["f64_mfma_flops"] / 78.6e12 * 1e3
         peak_note = "f64 MFMA 78.6 TFLOP/s (datasheet)"
-    fr_ms = float(np.median(bf))
+    fr_ms = float(np.median(bf)) if bf else None
     fr_flops = float(sum(work.values()))
+    kernel_name = {0: "moments_tile_h16_tr<f16> (128 x 128 tiles)", 1: "moments_tile_f64", 2: "moments_tile256<f16> (256-column slabs)"}.get(variant, str(variant))
+    dtype_fr = {2: "split-f16 MFMA iterations (f32 accumulate) + exact int8-MFMA products (int32 accumulate) + f64 correction",
+                1: "f32 MFMA iterations + f64 correction", 0: "f64 MFMA iterations"}[route]
     out = {
         "metric": "FAD scores/sec + cov-GEMM TFLOP/s (% MFMA peak), N=100k D=512",
         "value": n_gpus * args.steps / elapsed,
@@ -610,7 +661,7 @@ def main():
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 in, f32 MFMA accumulate (moments); f32 MFMA iterations + f64 correction (Frechet)", "data": "synthetic",
+        "dtype": f"f16 in, f16 MFMA with f32 accumulate over <= 8192-row runs, f64 across runs (moments); {dtype_fr} (Frechet)", "data": "synthetic",
         "config": {"workload": "C3: CLAP-sized embeddings N=100000 D=512 fp16 per set per GPU, "
                                "moments of both sets + Newton-Schulz Frechet, inputs resident in HBM "
                                f"({N_PAIRS} distinct pairs rotated: every step reads its frames from HBM, not from the Infinity Cache)",
@@ -618,7 +669,8 @@ def main():
                    "sharding": "rows sharded over ranks; ONE in-place all-reduce over the buffer holding both sets' packed "
                                f"(n, sum x, sum xxT) fp64 [2 x {plen} doubles]" if distributed else "single GPU, no collective",
                    "collective_backend": coll_backend, "collective_ranks": coll_ranks},
-        "fad": fad0, "fad_pair": "pair 0 (seeds 10 / 11: the golden G7 pair) on this rank's rows", "fad_last_timed_step": fad,
+        "fad": fad0, "fad_pair": ("pair 0 (seeds 10 / 11: the golden G7 pair) on this rank's rows" if not args.timed_only else "last timed step"),
+        "fad_last_timed_step": fad, "timed_only": bool(args.timed_only), "chain_cus_per_xcd": int(args.chain_cus),
         "newton_schulz_iters": diag["iters"], "ns_converged": diag["converged"],
         "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,
         "input_rotation": {"pairs": N_PAIRS, "bytes": N_PAIRS * SETS * N_ROWS * DIM * 2,
@@ -639,9 +691,9 @@ def main():
         "scores_in_flight": n_lanes, "lane_streams": bool(args.lane_streams and n_lanes > 1),
         "step_ms_spread": {"min": float(step_ms.min()), "p10": float(np.percentile(step_ms, 10)), "median": float(np.median(step_ms)),
                            "p90": float(np.percentile(step_ms, 90)), "max": float(step_ms.max())},
-        "breakdown_ms": {"moments_both_sets": float(np.median(bm)), "frechet": fr_ms,
+        "breakdown_ms": {"moments_both_sets": float(np.median(bm)) if bm else None, "frechet": fr_ms,
                          "moments_reduce_kernels": reduce_ms},
-        "roofline": {"kernel": "moments_tile_h16_tr<f16>" if variant == 0 else "moments_tile_f64",
+        "roofline": {"kernel": kernel_name,
                      "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_source": traffic_src or "not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
@@ -651,8 +703,9 @@ def main():
                      "issued_flops_per_launch": issued, "frac_issued": issued / (kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                      # utilisation of the matrix pipe comes from ISSUED flops; `frac` above credits the symmetry
                      "mfma_util": issued / (kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                     "mfma_util_note": "issued MFMA flops (upper-triangular tiles, 20 of 32 MFMAs on a diagonal tile) / kernel time / dense "
-                                       "fp16 peak; `frac` = algorithmic 2 N D^2 per set over the same time",
+                     "mfma_util_note": "issued MFMA flops (the 32 x 32 blocks on and above the diagonal; on 128 x 128 tiles: upper-triangular "
+                                       "tiles, 20 of 32 MFMAs on a diagonal tile) / kernel time / dense fp16 peak; `frac` = algorithmic "
+                                       "2 N D^2 per set over the same time",
                      "algorithmic_bytes_per_launch": SETS * N_ROWS * DIM * 2,
                      "hbm_GBps_algorithmic": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
                      "hbm_frac_of_8TBps": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -668,8 +721,9 @@ def main():
                                        1: "float32 Newton-Schulz on the f32 MFMA + float64 correction", 0: "all-float64 iteration"}[route],
                              "bound": "launch chain: ~4.2 us per dependent launch before it does anything, then the CU's vector-memory "
                                       "path (128-192 KB of operands per 32 x 32 tile); the matrix pipes are idle most of the time",
-                             "gemms": gemms, "work": work, "ms": fr_ms, "achieved": fr_flops / (fr_ms * 1e-3) / 1e12, "unit": "T(FL)OP/s issued",
-                             "ideal_ms_at_mfma_peaks": ideal_ms, "frac": ideal_ms / fr_ms, "peak_source": peak_note},
+                             "gemms": gemms, "work": work, "ms": fr_ms, "achieved": (fr_flops / (fr_ms * 1e-3) / 1e12) if fr_ms else None,
+                             "unit": "T(FL)OP/s issued",
+                             "ideal_ms_at_mfma_peaks": ideal_ms, "frac": (ideal_ms / fr_ms) if fr_ms else None, "peak_source": peak_note},
     }
     if extra:
         out["extra"] = extra

@@ -73,6 +73,8 @@ SIGNATURES = {
     "fad_moments_finalize": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(_I64), C.c_int, _P]),
     "fad_moments_set_timing": (C.c_int, [_P, C.c_int]),
     "fad_moments_last_timing": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "fad_stream_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(_P)]),
+    "fad_stream_destroy": (C.c_int, [C.c_int, _P]),
     "fad_frechet": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, _P,
                               C.POINTER(C.c_double), C.POINTER(FadDiag)]),
     "fad_frechet_from_moments": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, _P,

@@ -72,6 +72,23 @@ int fad_device_count(void) {
 
 const char* fad_last_error(void) { return fad::err_buf(); }
 
+int fad_stream_create_cu_mask(int device, const uint32_t* mask, int words, void** stream) {
+    if (!mask || words < 1 || !stream) return fad::set_error(FAD_ERR_INVALID, "NULL argument");
+    FAD_TRY(fad::check_device(device));
+    fad::DeviceGuard g(device);
+    hipStream_t st = nullptr;
+    FAD_HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+    *stream = st;
+    return FAD_OK;
+}
+
+int fad_stream_destroy(int device, void* stream) {
+    if (!stream) return FAD_OK;
+    fad::DeviceGuard g(device);
+    FAD_HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return FAD_OK;
+}
+
 const char* fad_device_arch(int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count || device >= fad::kMaxDev) return "";

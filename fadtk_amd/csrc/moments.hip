@@ -27,7 +27,9 @@
 //   colpart      [split][nt*BT] fp64
 #include "fad_common.h"
 #include "moments_kernels.h"
+#include "moments_tile256.h"
 #include <dlfcn.h>
+#include <vector>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -44,6 +46,9 @@ struct fad_moments {
     fad::DevBuf partials64, colpart64;     // exact fp64 redo of a block flagged by the shift guard
     fad::DevBuf cvec;                      // float16 rows: per-split column shifts for the guard's second pass
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
+    fad::DevBuf blocktab;                  // 256-column-slab kernel: where every 32 x 32 block's partial sums sit (tile256_roles.h)
+    int blocktab_nsb = 0;
+    int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
     void* tab_host = nullptr; size_t tab_host_cap = 0;     // pinned staging of the segment tables of update_segmented
     hipEvent_t tab_ev = nullptr;           // recorded behind the upload of tab_host: the next call waits before rewriting it
     int* shift_flag = nullptr;             // device int[2], ping-pong between updates
@@ -57,7 +62,7 @@ struct fad_moments {
     int timing = 0;                        // 0 off, 1 all three events, 2 tile kernel only (no event behind the reduce)
     hipEvent_t* ev = nullptr;              // [kRing][3]
     int ev_count = 0;                      // entries recorded since the last query
-    int last_variant = -1;                 // 0: h16 MFMA tile kernel, 1: generic fp64 kernel
+    int last_variant = -1;                 // 0: h16 MFMA 128 x 128 tile kernel, 1: generic fp64 kernel, 2: h16 MFMA 256-column-slab kernel
     int last_sets = 1;                     // frame matrices the last timed launch covered
     int n_cu = 256;
 };
@@ -96,6 +101,10 @@ static int ensure_kernel_attrs(int device) {
     std::lock_guard<std::mutex> lk(mu);
     if (device < 0 || device >= 64) return set_error(FAD_ERR_INVALID, "device %d out of range", device);
     if (done[device]) return FAD_OK;
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
     for (int dt : {FAD_F16, FAD_BF16}) {
         for (bool fast : {false, true}) {
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
@@ -119,8 +128,8 @@ static int ensure_kernel_attrs(int device) {
 // (it behaves like truncation): measured -3.5e-7 relative at 32768 rows per run, ~1e-8 per 1000 rows, so runs are
 // capped at 8192 rows and long inputs simply use more splits than resident slots.
 static void plan_splits(int count, const int64_t* n, int d, int bt, int kb, int n_cu, int wg_per_cu, int64_t min_rows,
-                        int64_t max_rows, SplitPlan* out) {
-    const int nt = (int)cdiv(d, bt), T = nt * (nt + 1) / 2;
+                        int64_t max_rows, SplitPlan* out, int items_per_split = 0) {
+    const int nt = (int)cdiv(d, bt), T = items_per_split > 0 ? items_per_split : nt * (nt + 1) / 2;
     const int64_t slots = (int64_t)n_cu * wg_per_cu;
     int64_t total = 0, longest = 1;
     for (int i = 0; i < count; ++i) { total += n[i]; if (n[i] > longest) longest = n[i]; }
@@ -192,6 +201,104 @@ static int stage_tables(fad_moments* h, size_t bytes, char** host) {
     return FAD_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// D >= 512, float16 rows: the 256-column-slab kernel (moments_tile256.h).  Same three launches as the 128 x 128 path -- tile
+// kernel, gated second pass of the shift guard, reduce -- with ONE workgroup per CU and work items of 64-72 blocks.
+// ------------------------------------------------------------------------------------------
+static int block_table(fad_moments* h, int nsb, hipStream_t st) {
+    if (h->blocktab_nsb == nsb) return FAD_OK;
+    // host copies live for the life of the process: the upload below reads them asynchronously
+    static std::mutex mu;
+    static std::vector<t256::BlockSrc>* cache[t256::MAX_SB + 1] = {nullptr};
+    const std::vector<t256::BlockSrc>* tab = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!cache[nsb]) {
+            auto* v = new (std::nothrow) std::vector<t256::BlockSrc>((size_t)t256::n_blocks(t256::NFR * nsb));
+            if (!v) return set_error(FAD_ERR_ALLOC, "out of host memory");
+            if (!t256::build_block_table(nsb, v->data())) { delete v; return set_error(FAD_ERR_INVALID, "block table of %d superblocks is inconsistent", nsb); }
+            cache[nsb] = v;
+        }
+        tab = cache[nsb];
+    }
+    const size_t bytes = tab->size() * sizeof(t256::BlockSrc);
+    FAD_TRY(h->blocktab.reserve(bytes));
+    FAD_HIP_TRY(hipMemcpyAsync(h->blocktab.p, tab->data(), bytes, hipMemcpyHostToDevice, st));
+    h->blocktab_nsb = nsb;
+    return FAD_OK;
+}
+
+static bool tile256_eligible(const fad_moments* h0, int count, const int64_t* n, int dtype, bool aligned, bool seg) {
+    const int d = h0->d;
+    if (!h0->tile256 || !aligned || seg || dtype != FAD_F16 || h0->force_generic) return false;
+    if (d < 2 * t256::SB || d > t256::MAX_SB * t256::SB) return false;
+    for (int i = 0; i < count; ++i) if (n[i] < 16 * (int64_t)d) return false;      // (what the guard's second pass asks for as well)
+    return true;
+}
+
+static int update_tile256(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n, const int64_t* ld,
+                          hipStream_t st, hipEvent_t* ev) {
+    fad_moments* h0 = hs[0];
+    const int d = h0->d, nsb = (int)cdiv(d, t256::SB), dpad = nsb * t256::SB;
+    FAD_TRY(ensure_kernel_attrs(h0->device));
+    T256Launch L;
+    memset(&L, 0, sizeof(L));
+    L.nsets = count; L.d = d; L.nsb = nsb;
+    L.NT = t256::item_types(nsb, L.type, L.sa, L.sb);
+    const bool has_z = (nsb & 1) != 0;
+    SplitPlan plan[kMaxSets];
+    plan_splits(count, n, d, t256::SB, has_z ? 2 * T2_KB : T2_KB, h0->n_cu, 1, 256, 8192, plan, L.NT);
+    FAD_TRY(block_table(h0, nsb, st));
+    R256Launch R;
+    memset(&R, 0, sizeof(R));
+    R.table = static_cast<const t256::BlockSrc*>(h0->blocktab.p);
+    R.d = d; R.nsb = nsb; R.NT = L.NT; R.nblk = t256::n_blocks(t256::NFR * nsb);
+    R.z_sb = has_z ? (uint8_t)(nsb - 1) : (uint8_t)255;
+    int item = 0, max_s = 0;
+    bool any_guard = false;
+    for (int i = 0; i < count; ++i) {
+        fad_moments* h = hs[i];
+        const SplitPlan& p = plan[i];
+        FAD_TRY(h->partials.reserve((size_t)p.S * L.NT * t256::ITEM_STRIDE * sizeof(float)));
+        FAD_TRY(h->colpart.reserve((size_t)p.S * 2 * dpad * sizeof(double)));
+        T256Set& s = L.set[i];
+        s.E = rows[i]; s.n = n[i]; s.ld = ld[i]; s.rows_per_split = p.rows_per_split; s.S = p.S; s.item0 = item;
+        s.partials = static_cast<float*>(h->partials.p); s.colpart = static_cast<double*>(h->colpart.p);
+        s.flag = nullptr; s.cvec = nullptr;
+        R256Job& j = R.job[i];
+        if (h->guard) {
+            FAD_TRY(h->cvec.reserve((size_t)p.S * dpad * sizeof(uint16_t)));
+            s.cvec = static_cast<uint16_t*>(h->cvec.p);
+            s.flag = h->shift_flag + (h->update_seq & 1u);
+            j.clear_flag = h->shift_flag + ((h->update_seq + 1u) & 1u);
+            h->update_seq++;
+            j.gate = s.flag; j.cvec = s.cvec;
+            any_guard = true;
+        }
+        j.partials = s.partials; j.colpart = s.colpart;
+        j.acc = h->acc; j.n_add = (double)n[i]; j.overwrite = h->fresh ? 1 : 0;
+        j.S = p.S; j.rows_per_split = p.rows_per_split; j.n_rows = n[i];
+        if (p.S > max_s) max_s = p.S;
+        item += p.S * L.NT;
+        h->last_variant = 2;
+    }
+    L.total = item;
+    if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), kT256Lds, st, L);
+    if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
+    if (any_guard)       // second pass of the shift guard: same geometry, gated per set; rewrites the flagged sets' partials and column sums
+        hipLaunchKernelGGL((moments_tile256<FAD_F16, true>), dim3((unsigned)L.total), dim3(512), kT256Lds, st, L);
+    R.sl = (max_s > 32) ? 16 : (max_s > 8) ? 4 : 1;
+    const int G = 256 / R.sl;
+    const int blocks = (int)cdiv((int64_t)R.nblk * 256, G) + (int)cdiv(d, 256);
+    hipLaunchKernelGGL(moments_reduce256, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, R);
+    if (ev && h0->timing == 1) FAD_HIP_TRY(hipEventRecord(ev[2], st));
+    FAD_HIP_TRY(hipGetLastError());
+    for (int i = 0; i < count; ++i) hs[i]->fresh = false;
+    return FAD_OK;
+}
+
 // One pass over `count` frame matrices (DEVICE pointers), all of the handles' dimension, dtype and device:
 // tile kernel (one launch for all sets) -> gated fp64 redo (one launch) -> reduce (one launch).
 // `seg` (count == 1, fp16/bf16 aligned input only): segment-aligned splits; colpart then has one row per run.
@@ -213,6 +320,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
     hipEvent_t* ev = nullptr;
     FAD_TRY(timing_events(h0, &ev));
     h0->last_sets = count;
+    if (use_h16 && tile256_eligible(h0, count, n, dtype, aligned, seg != nullptr)) return update_tile256(count, hs, rows, n, ld, st, ev);
     SplitPlan plan[kMaxSets];
     ReduceLaunch R;
     memset(&R, 0, sizeof(R));
@@ -467,6 +575,10 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     h->guard = !(gs && gs[0] == '0');
     const char* fg = getenv("FAD_MOMENTS_FORCE_GENERIC");
     h->force_generic = fg && fg[0] == '1';
+    const char* t2 = getenv("FAD_MOMENTS_TILE256");
+    h->tile256 = !(t2 && t2[0] == '0');
+    const char* nc = getenv("FAD_MOMENTS_CUS");        // plan for fewer CUs than the device has (a CU-masked stream)
+    if (nc && atoi(nc) >= 8 && atoi(nc) < h->n_cu) h->n_cu = atoi(nc);
     *out = h;
     return FAD_OK;
 }
@@ -476,7 +588,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     DeviceGuard g(h->device);
     if (h->acc && h->owns_acc) (void)hipFree(h->acc);
     if (h->shift_flag) (void)hipFree(h->shift_flag);
-    h->partials64.release(); h->colpart64.release(); h->cvec.release(); h->presum.release(); h->presum_col.release();
+    h->partials64.release(); h->colpart64.release(); h->cvec.release(); h->presum.release(); h->presum_col.release(); h->blocktab.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
     h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release();
     if (h->tab_host) (void)hipHostFree(h->tab_host);

@@ -211,6 +211,23 @@ class Moments:
         return float(a.value), float(b.value), int(v.value)
 
 
+def cu_masked_stream(cus_per_xcd, device: int = 0, xcds: int = 8, cus_in_xcd: int = 32):
+    """A torch stream confined to CUs `cus_per_xcd` = range(lo, hi) of every XCD (diagnostics: bench.py --chain-cus).  Mask bit
+    i = CU i of the runtime's numbering, XCD-interleaved: CU c of XCD x is bit c * xcds + x."""
+    import torch
+    lib = K.load_library()
+    K.require_gpu(device)
+    words = (xcds * cus_in_xcd + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for c in cus_per_xcd:
+        for x in range(xcds):
+            bit = c * xcds + x
+            mask[bit // 32] |= (1 << (bit % 32))
+    ptr = C.c_void_p()
+    K.check(lib.fad_stream_create_cu_mask(int(device), mask, words, C.byref(ptr)), "fad_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", device))
+
+
 def frechet(mu1, cov1, mu2, cov2, eps: float = 1e-6, max_iter: int = 0, tol: float = 0.0, device: int = 0):
     """``fad_frechet`` on host float64 arrays -> (fad, diag dict).  Shapes are checked by the caller."""
     lib = K.load_library()

@@ -260,7 +260,8 @@ int fad_resample_kaiser(const float* wav, int64_t n, int orig_sr, int new_sr, in
  * Opt-in HIP-event timing (bench.py's roofline): while enabled every update records events around
  * its tile kernel on the caller's stream (no synchronisation); last_timing() returns the AVERAGE
  * duration in ms of the tile kernel and of the reduce kernels over the updates recorded since the
- * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA, 1 = generic fp64).
+ * last query (at most 256), and which tile kernel ran (0 = fp16/bf16 MFMA on 128 x 128 tiles, 1 = generic fp64,
+ * 2 = fp16 MFMA on 256-column slabs, D >= 512).
  * A fad_moments_update_multi call is ONE update recorded on hs[0]: its tile-kernel time covers all sets.
  * enabled = 2 records the two events around the tile kernel only (ms_reduce comes back 0): an event record between two
  * kernels costs the stream a few microseconds, and the one behind the reduce sits in front of whatever the caller
@@ -268,6 +269,13 @@ int fad_resample_kaiser(const float* wav, int64_t n, int orig_sr, int new_sr, in
 int fad_moments_set_timing(fad_moments_t* h, int enabled);
 int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_reduce_kernel,
                             int* kernel_variant);
+
+/* A HIP stream confined to a subset of the device's CUs (hipExtStreamCreateWithCUMask; `mask` = `words` x 32 bits, bit i = CU i in
+ * the runtime's numbering, which on this 8-XCD part walks the XCDs first: bit i -> XCD i % 8).  bench.py's --chain-cus layout
+ * experiment puts the square-root chains and the moments kernels on disjoint CU sets with it; nothing in the library uses it.
+ * The stream is the caller's (destroy with fad_stream_destroy); `*stream` is a hipStream_t. */
+int fad_stream_create_cu_mask(int device, const uint32_t* mask, int words, void** stream);
+int fad_stream_destroy(int device, void* stream);
 
 #ifdef __cplusplus
 }

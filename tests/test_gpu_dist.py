@@ -157,6 +157,24 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert abs(out["fad"] - want) <= 1e-9 * abs(want)
 
 
+def test_bench_starts_its_own_ranks_when_world_size_is_unset():
+    """`python bench.py --gpus N` from a plain shell re-launches itself under torch.distributed.run (here N = 1,
+    forced onto the multi-rank path): one JSON line from rank 0 with the collective's backend and rank count."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR")}
+    env.update(FAD_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--timed-only"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and out["timed_only"] is True
+    assert out["config"]["collective_backend"] == "nccl" and out["config"]["collective_ranks"] == 1
+    assert out["roofline"]["frac"] > 0
+
+
 def test_fused_stats_cli_under_torchrun_with_rccl(tmp_path):
     """`fadtk <model> <base> <eval> <csv> --fused-stats` relaunched the way `--gpus N` relaunches it (torch.distributed.run),
     with a ONE-rank RCCL group (FAD_DIST_FORCE=1): embed_and_accumulate's shared buffer goes through the nccl all_reduce, rank 0

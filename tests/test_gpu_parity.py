@@ -110,6 +110,73 @@ def test_moments_mfma_and_generic_kernels_agree(F, monkeypatch):
     assert p_mfma[0] == 5000 and p_gen[0] == 5000
 
 
+@pytest.mark.parametrize("n,d", [(8200, 512), (20011, 512), (12300, 768), (16500, 1024), (10250, 640), (20500, 1280)])
+def test_moments_tile256_kernel_matches_float64(F, monkeypatch, n, d):
+    """D >= 512, float16, at least 16 rows per column: the 256-column-slab kernel (moments_tile256.h) -- P/Q pairs (512, 1024),
+    a leftover Z triangle (768, 1280), a ragged last superblock (640) -- against exact float64 raw moments, and against the
+    128 x 128 kernel (FAD_MOMENTS_TILE256=0) on the same rows."""
+    from fadtk_amd.hip import Moments
+    x = structured_rows(n + d, n, d, np.float16)
+    x64 = x.astype(np.float64)
+    exact, sums = x64.T @ x64, x64.sum(0)
+    got = {}
+    for knob, want_variant in (("1", 2), ("0", 0)):
+        monkeypatch.setenv("FAD_MOMENTS_TILE256", knob)
+        with Moments(d) as m:
+            m.set_timing(True)
+            m.update(x[: n // 2]); m.update(x[n // 2:])            # two updates accumulate (halves below 16 d rows: the float64 kernel)
+            variant = m.last_timing()[2]
+            p = m.export()
+        if n // 2 >= 16 * d:
+            assert variant == want_variant
+        got[knob] = p
+    monkeypatch.setenv("FAD_MOMENTS_TILE256", "1")
+    with Moments(d) as m:                                    # the whole matrix in one update: always eligible here
+        m.set_timing(True); m.update(x)
+        assert m.last_timing()[2] == 2
+        p = m.export()
+    M = p[1 + d:].reshape(d, d)
+    assert p[0] == n
+    np.testing.assert_allclose(M, exact, rtol=0, atol=1e-6 * np.abs(exact).max())
+    np.testing.assert_array_equal(M, M.T)
+    np.testing.assert_allclose(p[1:1 + d], sums, rtol=1e-7, atol=1e-5)
+    for knob in got:
+        np.testing.assert_allclose(got[knob][1 + d:].reshape(d, d), exact, rtol=0, atol=1e-6 * np.abs(exact).max(), err_msg=knob)
+    mu, cov = F.calc_embd_statistics(x)
+    mu_o, cov_o = O.embd_statistics(x)
+    np.testing.assert_allclose(cov, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+
+
+def test_moments_tile256_two_sets_one_launch_and_guard_second_pass(F):
+    """update_multi on the 256-column-slab kernel: one benign set and one whose outlier columns trip the shift guard (second
+    pass over x - c, un-shifted in the reduce), D = 768 so that a Z item carries its two column-sum rows through the un-shift."""
+    from fadtk_amd.hip import Moments
+    rng = np.random.default_rng(123)
+    n, d = 13000, 768
+    a = structured_rows(1, n, d, np.float16)
+    b = rng.standard_normal((n + 700, d))
+    b[:, 5:70] = 30.0 + 0.04 * b[:, 5:70]           # mean / std ~ 750 in superblock 0 ...
+    b[:, 600:640] = -20.0 + 0.03 * b[:, 600:640]    # ... and in the Z superblock
+    b[:, 300] = 2.5
+    b = b.astype(np.float16)
+    with Moments(d) as ma, Moments(d) as mb:
+        ma.set_timing(True)
+        Moments.update_multi([ma, mb], [a, b])
+        assert ma.last_timing()[2] == 2
+        _, cov_a, na = ma.finalize()
+        _, cov_b, nb = mb.finalize()
+    assert na == n and nb == n + 700
+    _, cov_ao = O.embd_statistics(a)
+    _, cov_bo = O.embd_statistics(b)
+    np.testing.assert_allclose(cov_a, cov_ao, rtol=0, atol=2e-6 * np.abs(cov_ao).max())
+    assert np.abs(cov_b - cov_bo).max() <= 1e-6 * np.abs(cov_bo).max()
+    blk = np.ix_(range(5, 70), range(5, 70))
+    assert np.abs(cov_b[blk] - cov_bo[blk]).max() < 1e-6 * np.abs(cov_bo[blk]).max()      # accuracy relative to the VARIANCES
+    blk = np.ix_(range(600, 640), range(600, 640))
+    assert np.abs(cov_b[blk] - cov_bo[blk]).max() < 1e-6 * np.abs(cov_bo[blk]).max()
+    assert abs(cov_b[300, 300]) < 1e-12
+
+
 def test_moments_shift_guard_large_mean_small_std(F, monkeypatch):
     """|mean| >> std: the covariance is a tiny difference of huge raw moments.  The guard must notice; float16 rows then get a
     second pass over x - c (c = the column's mean on the float16 grid, exact by Sterbenz) and the raw moments are restored in

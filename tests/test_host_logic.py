@@ -125,3 +125,38 @@ def test_wav2vec2_family_loader_layer_and_truncation(monkeypatch):
     e_long, e_cut = m.get_embedding(x), m.get_embedding(x[:16000])
     assert e_long.dtype == np.float16 and e_long.shape == (49, 768)
     assert np.array_equal(e_long, e_cut)                                # 3 s were truncated to the same 1 s
+
+
+def test_bench_gpus_n_builds_the_torchrun_command_itself():
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE) must start the ranks itself -- here only
+    the command is printed (FAD_BENCH_PRINT_LAUNCH=1): torch.distributed.run, one process per GPU, loopback rendezvous, the
+    original flags passed through.  Under torchrun (WORLD_SIZE set) the same flags must NOT relaunch."""
+    import json
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FAD_BENCH_PRINT_LAUNCH"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout.strip().split("\n")[-1])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(str(ROOT / "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "5", "--warmup", "1"]
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert bench.torchrun_command(8, ["--gpus", "8"])[4] == "--nproc-per-node=8"
+
+
+def test_tile256_role_tables_cover_the_upper_triangle(tmp_path):
+    """fadtk_amd/csrc/tile256_roles.h (shared by the 256-column-slab moments kernel, its planner and its reduce): every 32 x 32
+    block on or above the diagonal is owned by exactly one wave of one work item (two on a Z item's triangle), for 1..8 superblocks,
+    with the same matrix-pipe load on every SIMD.  Plain C++, checked with g++ (no GPU)."""
+    exe = tmp_path / "tile256_cover"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-o", str(exe), str(ROOT / "tests" / "native_cpu" / "tile256_cover.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "nsb=2: 2 item types, 136 blocks per split, 136 output blocks ok" in r.stdout
+    assert "nsb=3: 5 item types" in r.stdout and "nsb=8: 32 item types" in r.stdout
