@@ -373,6 +373,13 @@ def main():
                     help="warm-up + the timed loop and nothing else (no repeat / same-pair / other-layout / breakdown blocks, no extras, "
                          "no CPU baseline): the command every rocprofv3 pass under profiles/ runs, so that its kernel statistics hold the "
                          "timed layout's launches only")
+    ap.add_argument("--group", type=int, default=0,
+                    help="grouped schedule: the moments of G consecutive steps back to back on ONE stream, then their G square-root chains "
+                         "side by side on G streams (two groups in flight: 2 G scores); 0 = the lane schedule (one stream per score)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="batched chains (the default schedule): the moments of B consecutive steps, then ONE square-root chain for the B "
+                         "scores (fad_frechet_from_moments_multi_begin: nine launches carry all B); three such batches in flight, one stream "
+                         "each; 0 = the lane schedule of round 3 (one stream and one chain per score, --inflight of them)")
     ap.add_argument("--chain-cus", type=int, default=0,
                     help="experiment (profiles/r04*_streams.txt): confine the square-root chains to this many CUs per XCD (CU-masked "
                          "streams) and the moments kernels to the others; 0 = no masks")
@@ -437,10 +444,13 @@ def main():
     masked = args.chain_cus > 0 and args.lane_streams and n_lanes > 1
 
     class Lane:
-        def __init__(self, k, own=None):
+        def __init__(self, k, own=None, mstream=None):
             own = (args.lane_streams and n_lanes > 1) if own is None else own
             self.stream = torch.cuda.Stream(device=device) if own else torch.cuda.current_stream(device)
             self.cstream = self.stream                                   # where the square-root chain goes
+            if mstream is not None:                                      # grouped schedule: shared moments stream, own chain stream
+                self.cstream, self.stream = self.stream, mstream
+            self.group_ev = None
             if masked and own:
                 # --chain-cus C: moments on CUs [C, 32) of every XCD, chains on CUs [0, C) (FAD_MOMENTS_CUS tells the planner)
                 self.stream = hip.cu_masked_stream(range(args.chain_cus, 32), local_rank)
@@ -466,13 +476,15 @@ def main():
 
         def score(self):
             """Phase 2: [wait for the exchange,] enqueue the whole Frechet chain; nothing is waited for on the host."""
-            if self.cstream is not self.stream and not distributed:
+            if self.cstream is not self.stream and not distributed and self.group_ev is None:
                 with torch.cuda.stream(self.stream):
                     self.fed.record()
             with torch.cuda.stream(self.cstream):
+                if self.group_ev is not None:
+                    torch.cuda.current_stream().wait_event(self.group_ev)
                 if distributed:
                     torch.cuda.current_stream().wait_event(self.reduced)
-                elif self.cstream is not self.stream:
+                elif self.cstream is not self.stream and self.group_ev is None:
                     torch.cuda.current_stream().wait_event(self.fed)
                 self.job = hip.FrechetJob(self.ma, self.mb, mean_dtype=FAD_F16)
 
@@ -480,21 +492,34 @@ def main():
             job, self.job = self.job, None
             return job.result()
 
-    lanes = all_lanes = [Lane(k) for k in range(n_lanes)]
+    G = max(0, min(int(args.group), 4))
+    if G:
+        NGRP = 3 if 3 * G <= 8 else 2                                     # groups in flight (8 score slots per thread)
+        n_lanes = NGRP * G
+        mstream = torch.cuda.Stream(device=device)
+        lanes = all_lanes = [Lane(k, own=True, mstream=mstream) for k in range(n_lanes)]
+    else:
+        lanes = all_lanes = [Lane(k) for k in range(n_lanes)]
     plen = lanes[0].ma.packed_len
     ma, mb = lanes[0].ma, lanes[0].mb
 
-    def run_steps(count, marks=None, rotate=True, lanes=None):
+    host_s = [0.0, 0.0, 0.0]            # host seconds spent enqueueing moments / enqueueing chains / waiting for + collecting scores
+
+    def run_steps_lanes(count, marks=None, rotate=True, lanes=None):
         lanes = all_lanes if lanes is None else lanes
+        n_lanes = len(lanes)
         """`count` steps, at most n_lanes of them in flight; every one of them is collected before this returns.  Order of the
         enqueues: feed(i), score(i-1), so the device sees  moments(i) | Frechet(i-1) | moments(i+1) | Frechet(i) ...  and the
         host collects score(i - n_lanes) before it reuses that lane -- with three lanes two more steps are queued behind the
         one it waits for, so the device never runs dry."""
         out, fed = None, None
+        pc = time.perf_counter
 
         def collect(lane):
             nonlocal out
+            t = pc()
             out = lane.collect()
+            host_s[2] += pc() - t
             if marks is not None:
                 marks.append(time.perf_counter())
 
@@ -502,13 +527,17 @@ def main():
             lane = lanes[i % n_lanes]
             if lane.job is not None:
                 collect(lane)
+            t = pc()
             lane.feed(pairs[i % N_PAIRS] if rotate else pairs[0])       # consecutive steps stream DIFFERENT frames from HBM
+            host_s[0] += pc() - t
+            t = pc()
             if n_lanes == 1:
                 lane.score()
             else:
                 if fed is not None:
                     fed.score()
                 fed = lane
+            host_s[1] += pc() - t
         if fed is not None:
             fed.score()
         for k in range(n_lanes):                                         # drain, oldest first
@@ -516,6 +545,101 @@ def main():
             if lane.job is not None:
                 collect(lane)
         return out
+
+    def run_steps_grouped(count, marks=None, rotate=True, lanes=None):
+        """Grouped schedule (--group G): moments of G steps on the shared moments stream, one event behind the last of them, then the G
+        chains on their own streams -- latency-bound launches of G different scores side by side instead of under a tile kernel that
+        leaves them no room on a CU.  Two groups are in flight; a group's scores are collected before its lanes are fed again."""
+        lanes = all_lanes if lanes is None else lanes
+        out = None
+        pc = time.perf_counter
+        i = 0
+        g = 0
+        while i < count:
+            grp = lanes[(g % NGRP) * G:(g % NGRP) * G + G]
+            m = min(G, count - i)
+            for lane in grp[:m]:
+                if lane.job is not None:
+                    t = pc(); out = lane.collect(); host_s[2] += pc() - t
+                    if marks is not None:
+                        marks.append(pc())
+            t = pc()
+            for k, lane in enumerate(grp[:m]):
+                lane.feed(pairs[(i + k) % N_PAIRS] if rotate else pairs[0])
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(grp[0].stream):
+                ev.record()
+            host_s[0] += pc() - t
+            t = pc()
+            for lane in grp[:m]:
+                lane.group_ev = ev
+                lane.score()
+            host_s[1] += pc() - t
+            i += m; g += 1
+        for gg in range(g, g + NGRP):                                    # drain, oldest group first
+            for lane in lanes[(gg % NGRP) * G:(gg % NGRP) * G + G]:
+                if lane.job is not None:
+                    t = pc(); out = lane.collect(); host_s[2] += pc() - t
+                    if marks is not None:
+                        marks.append(pc())
+        return out
+
+    run_steps = run_steps_lanes
+    if G:
+        run_steps = run_steps_grouped
+
+    BATCH = 0 if G else max(0, min(int(args.batch), 8))
+    if BATCH:
+        NB_FLY = 3
+        bstreams = [torch.cuda.Stream(device=device) for _ in range(NB_FLY)]
+        blanes = [[Lane(k, own=False) for k in range(BATCH)] for _ in range(NB_FLY)]
+        for q in range(NB_FLY):
+            for ln in blanes[q]:
+                ln.stream = ln.cstream = bstreams[q]
+        bjobs = [None] * NB_FLY
+
+        def run_steps_batched(count, marks=None, rotate=True, lanes=None):
+            """Batched schedule (--batch B): per batch, the moments of B steps and then ONE chain for their B scores on the batch's
+            stream; NB_FLY batches in flight.  Every score is collected inside the call."""
+            out = None
+            pc = time.perf_counter
+
+            def collect(q):
+                nonlocal out
+                t = pc()
+                res = bjobs[q][0].result()
+                host_s[2] += pc() - t
+                out = res[-1]
+                if marks is not None:
+                    now = pc()
+                    marks.extend([now] * bjobs[q][1])
+                bjobs[q] = None
+
+            i, b = 0, 0
+            while i < count:
+                q = b % NB_FLY
+                if bjobs[q] is not None:
+                    collect(q)
+                m = min(BATCH, count - i)
+                t = pc()
+                for k in range(m):
+                    blanes[q][k].feed(pairs[(i + k) % N_PAIRS] if rotate else pairs[0])
+                host_s[0] += pc() - t
+                t = pc()
+                with torch.cuda.stream(bstreams[q]):
+                    if distributed:
+                        for k in range(m):
+                            torch.cuda.current_stream().wait_event(blanes[q][k].reduced)
+                    bjobs[q] = (hip.FrechetMultiJob([(blanes[q][k].ma, blanes[q][k].mb) for k in range(m)], mean_dtype=FAD_F16), m)
+                host_s[1] += pc() - t
+                i += m; b += 1
+            for qq in range(b, b + NB_FLY):
+                if bjobs[qq % NB_FLY] is not None:
+                    collect(qq % NB_FLY)
+            return out
+
+        run_steps = run_steps_batched
+        lanes = blanes[0]
 
     def fence():
         torch.cuda.synchronize()
@@ -525,6 +649,10 @@ def main():
 
     if os.environ.get("FAD_BENCH_PREWARM") == "1":       # diagnosis only: a block of K untimed steps in front of the warm-up
         run_steps(args.steps)
+    if BATCH:
+        # set-up, not warm-up: every one of the three job slots allocates its batch workspace (8 x 28 MB) on first use, and a warm-up of
+        # W < 3 B steps would leave that to the timed region (measured: 0.77 instead of 0.12 ms per step at W = 3).  One full round here.
+        run_steps(3 * BATCH)
     run_steps(max(args.warmup, 0))
     # The tile kernel is timed by HIP events the library records around it on the launch stream -- on ONE lane (every
     # n_lanes-th step of the timed region) and without the third event behind the reduce: a timed event record between two
@@ -533,7 +661,9 @@ def main():
     lanes[0].ma.set_timing(2)
     fence()
     marks = [time.perf_counter()]
+    host_s[:] = [0.0, 0.0, 0.0]
     fad, diag = run_steps(args.steps, marks)                             # every score is delivered inside the timed region
+    host_timed = list(host_s)
     fence()
     elapsed = time.perf_counter() - marks[0]
     if distributed:
@@ -559,21 +689,29 @@ def main():
     # ... and K steps in the other stream layout: by default that is ONE stream for all scores in flight -- no two kernels overlap, the
     # tile kernel's duration there is the kernel alone
     per_stream_s, per_stream_kernel_ms = [], None
-    if side and n_lanes > 1:                                # the OTHER stream layout (one stream for all lanes / one per lane)
-        lanes_s = [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
-        run_steps(min(args.steps, 6), None, True, lanes_s)
+    if side and n_lanes > 1 and not G:                      # the OTHER stream layout (one stream for all lanes / one per lane)
+        lanes_s = all_lanes if BATCH else [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
+        if BATCH:                                            # (batched schedule: the other layout = round 3's lanes on ONE stream)
+            for ln in lanes_s:
+                ln.stream = ln.cstream = torch.cuda.current_stream(device)
+        run_steps_lanes(min(args.steps, 6), None, True, lanes_s)
         for rep in range(3):
             if rep == 2:
                 lanes_s[0].ma.set_timing(2)          # what the overlap does to the tile kernel itself (last block)
-            fence(); t0 = time.perf_counter(); run_steps(args.steps, None, True, lanes_s); fence()
+            fence(); t0 = time.perf_counter(); run_steps_lanes(args.steps, None, True, lanes_s); fence()
             per_stream_s.append(time.perf_counter() - t0)
         per_stream_kernel_ms = lanes_s[0].ma.last_timing()[0]
         lanes_s[0].ma.set_timing(False)
-        for ln in lanes_s:
-            ln.shared.close()
+        if not BATCH:
+            for ln in lanes_s:
+                ln.shared.close()
 
     # ONE launch of the tile kernel covers both sets (recorded on the first handle of lane 0: steps 0, n_lanes, 2 n_lanes ...)
     timed_launches = -(-args.steps // n_lanes)
+    if BATCH:
+        timed_launches = sum(1 for i in range(args.steps) if (i % BATCH == 0 and (i // BATCH) % 3 == 0))
+    if G:
+        timed_launches = sum(1 for i in range(args.steps) if (i % G == 0 and (i // G) % NGRP == 0))
 
     # ---- untimed breakdown (torch events on the same stream: stream 0 is torch's current stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -670,7 +808,7 @@ def main():
                                f"(n, sum x, sum xxT) fp64 [2 x {plen} doubles]" if distributed else "single GPU, no collective",
                    "collective_backend": coll_backend, "collective_ranks": coll_ranks},
         "fad": fad0, "fad_pair": ("pair 0 (seeds 10 / 11: the golden G7 pair) on this rank's rows" if not args.timed_only else "last timed step"),
-        "fad_last_timed_step": fad, "timed_only": bool(args.timed_only), "chain_cus_per_xcd": int(args.chain_cus),
+        "fad_last_timed_step": fad, "timed_only": bool(args.timed_only), "chain_cus_per_xcd": int(args.chain_cus), "group": G, "batched_chains": BATCH,
         "newton_schulz_iters": diag["iters"], "ns_converged": diag["converged"],
         "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,
         "input_rotation": {"pairs": N_PAIRS, "bytes": N_PAIRS * SETS * N_ROWS * DIM * 2,
@@ -688,7 +826,13 @@ def main():
         "value_same_pair": {"median": float(np.median([n_gpus * args.steps / t for t in same_pair_s])) if same_pair_s else None,
                             "blocks": len(same_pair_s),
                             "note": "K steps that re-feed ONE pair (204.8 MB: Infinity-Cache resident) -- the loop rounds 1-2 timed"},
-        "scores_in_flight": n_lanes, "lane_streams": bool(args.lane_streams and n_lanes > 1),
+        "host_ms_per_step": {"enqueue_moments": 1e3 * host_timed[0] / max(args.steps, 1), "enqueue_chain": 1e3 * host_timed[1] / max(args.steps, 1),
+                             "wait_and_collect": 1e3 * host_timed[2] / max(args.steps, 1),
+                             "note": "host wall-clock inside the timed loop: what the Python loop spends enqueueing (the device is never waited "
+                                     "for there) and in FrechetJob.result (which waits for the oldest score in flight)"},
+        "scores_in_flight": (3 * BATCH if BATCH else n_lanes), "lane_streams": bool(args.lane_streams and n_lanes > 1),
+        "schedule": (f"batched: moments of {BATCH} steps, then ONE square-root chain for their {BATCH} scores (fad_frechet_from_moments_multi_begin), "
+                     "3 batches in flight on 3 streams" if BATCH else (f"grouped ({G})" if G else f"lanes: one chain per score, {n_lanes} in flight")),
         "step_ms_spread": {"min": float(step_ms.min()), "p10": float(np.percentile(step_ms, 10)), "median": float(np.median(step_ms)),
                            "p90": float(np.percentile(step_ms, 90)), "max": float(step_ms.max())},
         "breakdown_ms": {"moments_both_sets": float(np.median(bm)) if bm else None, "frechet": fr_ms,
@@ -709,7 +853,7 @@ def main():
                      "algorithmic_bytes_per_launch": SETS * N_ROWS * DIM * 2,
                      "hbm_GBps_algorithmic": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
                      "hbm_frac_of_8TBps": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "contended": bool(args.lane_streams and n_lanes > 1),
+                     "contended": bool(BATCH or (args.lane_streams and n_lanes > 1)),
                      "contended_note": "the timed loop runs one stream per score in flight: this kernel shares the CUs with the square-root "
                                        "chain of the previous score, and kernel_ms / achieved / frac above include that; `alone` = the "
                                        "same launches with all scores on one stream (no two kernels overlap), side block of this run",

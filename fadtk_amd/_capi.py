@@ -82,6 +82,8 @@ SIGNATURES = {
     "fad_frechet_from_moments_begin": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, _P, C.POINTER(_P)]),
     "fad_frechet_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(FadDiag)]),
     "fad_frechet_cancel": (C.c_int, [_P]),
+    "fad_frechet_from_moments_multi_begin": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.c_int, C.c_double, C.c_int, _P, C.POINTER(_P)]),
+    "fad_frechet_multi_end": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(FadDiag)]),
     "fad_frechet_batched_vs_baseline": (C.c_int, [C.c_int, _P, _P, _P, _I64, _I64, C.c_int, C.POINTER(_I64), _I64,
                                                   C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "fad_resample_num_samples": (_I64, [_I64, C.c_int, C.c_int]),

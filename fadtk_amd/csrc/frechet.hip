@@ -279,6 +279,13 @@ struct Workspace : NsWorkspace {
     DevBuf songcov;                                 // ... scratch of the float16 per-song covariances (partial tiles, column sums, shifts)
     DevBuf fast_songs;                              // ... its batched form for songs: baseline digits + one block per song
     void* fast_songs_pin = nullptr; size_t fast_songs_pin_cap = 0;      // ... and what its correction kernel leaves for the host
+    DevBuf fast_pairs;                              // ... and for B independent pairs (fad_frechet_from_moments_multi_begin): one block per pair
+    void* fast_pairs_pin = nullptr; size_t fast_pairs_pin_cap = 0;
+    struct Multi {                                  // an in-flight batch of pairs
+        int count = 0, gen = 0;
+        bool enqueued = false;                      // the batched chain is on the stream (else: end() scores the pairs one by one)
+        const fad_moments_t* h1[8] = {nullptr}; const fad_moments_t* h2[8] = {nullptr};
+    } multi;
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
     bool busy = false;
     struct Job {
@@ -294,7 +301,8 @@ struct Workspace : NsWorkspace {
     struct Pool* pool = nullptr;
     void release_all() {
         release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); mats32.release(); base_root.release(); fast.release();
-        fast_songs.release(); songcov.release();
+        fast_songs.release(); songcov.release(); fast_pairs.release();
+        if (fast_pairs_pin) { (void)hipHostFree(fast_pairs_pin); fast_pairs_pin = nullptr; fast_pairs_pin_cap = 0; }
         if (fast_songs_pin) { (void)hipHostFree(fast_songs_pin); fast_songs_pin = nullptr; fast_songs_pin_cap = 0; }
         if (done_ev) { (void)hipEventDestroy(done_ev); done_ev = nullptr; }
         if (song_pin) { (void)hipHostFree(song_pin); song_pin = nullptr; song_pin_cap = 0; }
@@ -1060,6 +1068,149 @@ static int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs
     return FAD_OK;
 }
 
+
+// ==========================================================================================
+// The chain for B INDEPENDENT PAIRS of packed moments in one sequence of launches (fad_frechet_from_moments_multi_begin): the
+// same eight kernels as a single pair with B times the workgroups -- a launch of this chain costs ~4 us before it does
+// anything and its workgroups are latency-bound, so B scores cost little more than one (bench.py keeps several scores in
+// flight: their chains are enqueued as ONE batch).  Every buffer of pair b lives b * stride bytes behind pair 0's.
+// ==========================================================================================
+struct PairBlock {
+    size_t hdrA, hdrB, st, s32, partials, stats, A64, P, Y[2], Z[2], T, digA, digB, digY[2], digYt[2], mus, covs, stride;
+};
+static PairBlock pair_block(int d) {
+    const size_t dd = (size_t)d * d, nb = (size_t)d / 32;
+    PairBlock b; size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    b.hdrA = take(sizeof(nsf::MatHdr)); b.hdrB = take(sizeof(nsf::MatHdr)); b.st = take(sizeof(NsState)); b.s32 = take(sizeof(Ns32State));
+    b.partials = take(nb * nb * sizeof(double)); b.stats = take(nsf::kTileStats * nb * nb * sizeof(double));
+    b.A64 = take(8 * dd); b.P = take(8 * dd);
+    b.Y[0] = take(8 * dd); b.Y[1] = take(8 * dd); b.Z[0] = take(8 * dd); b.Z[1] = take(8 * dd); b.T = take(8 * dd);
+    b.digA = take(6 * dd); b.digB = take(6 * dd);
+    b.digY[0] = take(6 * dd); b.digYt[0] = take(6 * dd); b.digY[1] = take(6 * dd); b.digYt[1] = take(6 * dd);
+    b.mus = take(2 * (size_t)d * sizeof(double)); b.covs = take(2 * dd * sizeof(double));
+    b.stride = o;
+    return b;
+}
+
+// enqueue: K1 (pairs mode) .. K8 for B pairs; nothing is waited for
+static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const* h1, const fad_moments_t* const* h2, int ddof,
+                         int mean_dtype, hipStream_t st) {
+    const size_t dd = (size_t)d * d;
+    const int nb = d / 32;
+    // FAD_PAIRS_BIG = smallest batch whose products run on the 128 x 128 / 128 x 64 tiles of ns_fast_big.h (their operand traffic per
+    // block is a tenth of the 32 x 32 kernels'; below, too few workgroups to fill the chip); read per call, 0 = never
+    const char* big_env = getenv("FAD_PAIRS_BIG");
+    const long big_min = big_env ? atol(big_env) : 3;
+    const bool big = big_min > 0 && B >= big_min && d >= 256;
+    const int device = ws.job.device;
+    const PairBlock L = pair_block(d);
+    const size_t hs = song_host_stride(d);
+    void* const before = ws.fast_pairs.p;
+    FAD_TRY(ws.fast_pairs.reserve((size_t)(B > 4 ? 8 : 4) * L.stride + 256));      // (room for a full batch at once: no regrowth between calls)
+    if (!ws.fast_pairs_pin || ws.fast_pairs_pin_cap < (size_t)B * hs) {
+        if (ws.fast_pairs_pin) (void)hipHostFree(ws.fast_pairs_pin);
+        ws.fast_pairs_pin = nullptr; ws.fast_pairs_pin_cap = 0;
+        FAD_HIP_TRY(hipHostMalloc(&ws.fast_pairs_pin, (size_t)8 * hs + 4096, hipHostMallocDefault));
+        ws.fast_pairs_pin_cap = (size_t)8 * hs + 4096;
+    }
+    char* blk = static_cast<char*>(ws.fast_pairs.p);
+    char* hpin = static_cast<char*>(ws.fast_pairs_pin);
+    double* h_vals = reinterpret_cast<double*>(hpin);
+    double* h_stats = h_vals + nsf::kHostVals;
+    int* h_words = reinterpret_cast<int*>(h_stats + (size_t)(nsf::kTileStats + 2) * nb * nb);
+    auto at = [&](size_t off) { return blk + off; };
+    auto mat = [&](size_t off) { nsf::SplitMat m; m.a = reinterpret_cast<uint4*>(at(off)); m.at = reinterpret_cast<uint4*>(at(off + 4 * dd)); return m; };
+    const int gen = ++ws.fast_gen;
+    if (ws.fast_gen > (1 << 30)) ws.fast_gen = 1;
+    ws.multi.gen = gen;
+    if (ws.fast_pairs.p != before) {               // fresh headers carry no stale token
+        FAD_HIP_TRY(hipMemset2DAsync(at(L.hdrA), L.stride, 0, sizeof(nsf::MatHdr), (size_t)B, st));
+        FAD_HIP_TRY(hipMemset2DAsync(at(L.hdrB), L.stride, 0, sizeof(nsf::MatHdr), (size_t)B, st));
+    }
+    nsf::MatHdr* hA = reinterpret_cast<nsf::MatHdr*>(at(L.hdrA));
+    nsf::MatHdr* hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdrB));
+    NsState* st0 = reinterpret_cast<NsState*>(at(L.st));
+    Ns32State* s32_0 = reinterpret_cast<Ns32State*>(at(L.s32));
+    double* partials = reinterpret_cast<double*>(at(L.partials));
+    double* stats = reinterpret_cast<double*>(at(L.stats));
+    double* A64 = reinterpret_cast<double*>(at(L.A64));
+    const nsf::SplitMat P = mat(L.P), Y[2] = {mat(L.Y[0]), mat(L.Y[1])}, Z[2] = {mat(L.Z[0]), mat(L.Z[1])}, T = mat(L.T);
+    uint4* digY[2] = {reinterpret_cast<uint4*>(at(L.digY[0])), reinterpret_cast<uint4*>(at(L.digY[1]))};
+    uint4* digYt[2] = {reinterpret_cast<uint4*>(at(L.digYt[0])), reinterpret_cast<uint4*>(at(L.digYt[1]))};
+
+    nsf::PrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    for (int b = 0; b < B; ++b) { pa.accs[2 * b] = moments_packed(h1[b]); pa.accs[2 * b + 1] = moments_packed(h2[b]); }
+    pa.acc[0] = pa.accs[0]; pa.acc[1] = pa.accs[1];
+    pa.d = d; pa.ddof = ddof; pa.gen = gen; pa.mean_dtype = mean_dtype;
+    pa.mus = reinterpret_cast<double*>(at(L.mus)); pa.covs = reinterpret_cast<double*>(at(L.covs));
+    pa.dig[0] = reinterpret_cast<uint4*>(at(L.digA)); pa.dig[1] = reinterpret_cast<uint4*>(at(L.digB));
+    pa.st = st0; pa.hdr[0] = hA; pa.hdr[1] = hB;
+    pa.batch = 2; pa.pstride = (int64_t)L.stride;
+    hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)(dd / 2048 + 1), (unsigned)(2 * B)), dim3(512), 0, st, pa);
+
+    auto split_args = [&]() {
+        nsf::SplitArgs g;
+        memset(&g, 0, sizeof(g));
+        g.d = d; g.gen = gen; g.hA = hA; g.hB = hB; g.pstride = (int64_t)L.stride; g.astride = (int64_t)L.stride;
+        g.st = st0; g.s32 = s32_0;
+        return g;
+    };
+    {
+        nsf::I8Args a;
+        memset(&a, 0, sizeof(a));
+        a.Adig = reinterpret_cast<uint4*>(at(L.digA)); a.Bdig = reinterpret_cast<uint4*>(at(L.digB)); a.d = d; a.gen = gen; a.hA = hA; a.hB = hB;
+        a.pstride = (int64_t)L.stride; a.astride = (int64_t)L.stride; a.stats = stats; a.A64 = A64; a.P = P; a.st = st0;
+        if (big) FAD_TRY(fast_i8_big(d, nsf::I8_A, a, st, (unsigned)B, device));
+        else fast_i8(d, nsf::I8_A, a, st, (unsigned)B);
+        nsf::SplitArgs g = split_args();
+        g.A[0] = P; g.B[0] = P; g.C[0] = Y[1]; g.C[1] = Z[1]; g.A64 = A64; g.statsA = stats;
+        if (big) FAD_TRY(fast_split_big(d, nsf::SP_FIRST, g, st, (unsigned)B, device));      // (digit planes of the final Y only: nsf_digitize below)
+        else { g.Cdig[0] = digY[1]; g.Cdig_t[0] = digYt[1]; fast_split(d, nsf::SP_FIRST, g, st, (unsigned)B); }
+    }
+    int want = ws.pool ? ws.pool->lp_iters : 5;
+    if (want < 2) want = 2;                          // (a pair that is not through after the blind batch goes the single way)
+    if (want > kMaxLow) want = kMaxLow;
+    for (int k = 1; k < want; ++k) {
+        const int cur = k & 1;
+        nsf::SplitArgs g = split_args();
+        g.A[0] = Z[cur]; g.B[0] = Y[cur]; g.C[0] = T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f;
+        g.partials = partials; g.skip = &s32_0->done;
+        if (big) FAD_TRY(fast_split_big(d, nsf::SP_T, g, st, (unsigned)B, device));
+        else fast_split(d, nsf::SP_T, g, st, (unsigned)B);
+        g = split_args();
+        g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1];
+        if (!big) { g.Cdig[0] = digY[cur ^ 1]; g.Cdig_t[0] = digYt[cur ^ 1]; }
+        g.skip = &s32_0->upd_skip[k & 1];
+        g.k = k; g.max_low = kMaxLow; g.nslots = big ? (d / 128) * (d / 128) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
+        if (big) FAD_TRY(fast_split_big(d, nsf::SP_U, g, st, (unsigned)B, device));
+        else fast_split(d, nsf::SP_U, g, st, (unsigned)B);
+    }
+    if (big) {
+        nsf::DigArgs dg;
+        memset(&dg, 0, sizeof(dg));
+        dg.d = d; dg.gen = gen; dg.hA = hA; dg.hB = hB; dg.pstride = (int64_t)L.stride; dg.astride = (int64_t)L.stride; dg.s32 = s32_0;
+        dg.Y[0] = Y[0]; dg.Y[1] = Y[1]; dg.dig[0] = digY[0]; dg.dig[1] = digY[1]; dg.dig_t[0] = digYt[0]; dg.dig_t[1] = digYt[1];
+        hipLaunchKernelGGL(nsf::nsf_digitize, dim3((unsigned)((dd / 16 + 255) / 256), 2, (unsigned)B), dim3(256), 0, st, dg);
+    }
+    {
+        nsf::I8Args a;
+        memset(&a, 0, sizeof(a));
+        a.Adig = digY[0]; a.Bdig = digYt[0]; a.Adig_alt = digY[1]; a.Bdig_alt = digYt[1]; a.sel = &s32_0->final_iter;
+        a.d = d; a.gen = gen; a.hA = hA; a.hB = hB; a.pstride = (int64_t)L.stride; a.astride = (int64_t)L.stride; a.hstride = (int64_t)hs;
+        a.skip = &s32_0->skip_corr; a.stats = h_stats; a.st = st0; a.A64in = A64;
+        a.Y[0] = Y[0]; a.Y[1] = Y[1]; a.Z[0] = Z[0]; a.Z[1] = Z[1]; a.s32 = s32_0; a.host_words = h_words; a.host_vals = h_vals;
+        for (int b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + (size_t)b * hs)[12] = 0;
+        if (big) FAD_TRY(fast_i8_big(d, nsf::I8_G, a, st, (unsigned)B, device));
+        else fast_i8(d, nsf::I8_G, a, st, (unsigned)B);
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    if (!ws.done_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&ws.done_ev, hipEventDisableTiming));
+    FAD_HIP_TRY(hipEventRecord(ws.done_ev, st));
+    return FAD_OK;
+}
+
 // Enqueue the whole low-precision chain of ONE problem on `stream` (nothing is waited for): C1 C2, statistics, scale,
 // iteration 0, the blind batch of iterations, the closing kernels.  The state words must have been cleared.
 static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Workspace& ws) {
@@ -1779,16 +1930,106 @@ int fad_frechet_end(fad_frechet_job_t* job, double* out_fad, fad_diag_t* diag) {
     return frechet_single(j.d, j.cov1, j.cov2, j.mu1, j.mu2, j.eps, 0, 0.0, j.mean_dtype, j.device, j.stream, ws, out_fad, diag, true);
 }
 
+int fad_frechet_from_moments_multi_begin(int count, const fad_moments_t* const* h1, const fad_moments_t* const* h2, int ddof, double eps,
+                                         int mean_dtype, void* stream, fad_frechet_job_t** job) {
+    if (!h1 || !h2 || !job) return set_error(FAD_ERR_INVALID, "NULL argument");
+    *job = nullptr;
+    if (count < 1 || count > 8) return set_error(FAD_ERR_INVALID, "count=%d out of range [1, 8]", count);
+    for (int b = 0; b < count; ++b) if (!h1[b] || !h2[b]) return set_error(FAD_ERR_INVALID, "pair %d: NULL handle", b);
+    const int device = moments_device(h1[0]), d = moments_dim(h1[0]);
+    for (int b = 0; b < count; ++b) {
+        if (moments_dim(h1[b]) != d || moments_dim(h2[b]) != d)
+            return set_error(FAD_ERR_SHAPE, "Training and test covariances have different dimensions (pair %d: %d vs %d, pair 0: %d)", b,
+                             moments_dim(h1[b]), moments_dim(h2[b]), d);
+        if (moments_device(h1[b]) != device || moments_device(h2[b]) != device) return set_error(FAD_ERR_INVALID, "handles live on different devices");
+    }
+    DeviceGuard g(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace* wsp = free_slot(device);
+    if (!wsp) return set_error(FAD_ERR_INVALID, "all %d Frechet slots of this thread are in flight: collect one with fad_frechet_end", Pool::kSlots);
+    Workspace& ws = *wsp;
+    ws.pool = &thread_pool(device);
+    ws.job = Workspace::Job();
+    ws.job.d = d; ws.job.device = device; ws.job.stream = st; ws.job.eps = eps; ws.job.mean_dtype = mean_dtype; ws.job.ddof = ddof;
+    ws.multi = Workspace::Multi();
+    ws.multi.count = count;
+    for (int b = 0; b < count; ++b) { ws.multi.h1[b] = h1[b]; ws.multi.h2[b] = h2[b]; }
+    if (fast_eligible(ws, d, 0, 0.0)) {
+        for (int b = 0; b < count; ++b) { FAD_TRY(moments_settle(h1[b], st)); FAD_TRY(moments_settle(h2[b], st)); }
+        FAD_TRY(pairs_enqueue(ws, d, count, h1, h2, ddof, mean_dtype, st));
+        ws.multi.enqueued = true;
+    }
+    ws.busy = true;
+    *job = reinterpret_cast<fad_frechet_job_t*>(wsp);
+    return FAD_OK;
+}
+
+int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fad_diag_t* diag) {
+    if (!job || !out_fad) return set_error(FAD_ERR_INVALID, "NULL argument");
+    Workspace& ws = *reinterpret_cast<Workspace*>(job);
+    if (!ws.busy) return set_error(FAD_ERR_INVALID, "this job was collected already");
+    if (count != ws.multi.count) return set_error(FAD_ERR_INVALID, "this job holds %d pairs, not %d", ws.multi.count, count);
+    const Workspace::Job j = ws.job;
+    const Workspace::Multi m = ws.multi;
+    DeviceGuard g(j.device);
+    const int d = j.d, nb = d / 32;
+    bool done[8] = {false};
+    int rc = FAD_OK;
+    if (m.enqueued) {
+        const hipError_t e = hipEventSynchronize(ws.done_ev);
+        if (e != hipSuccess) { ws.busy = false; return set_error(FAD_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e)); }
+        const size_t hs = song_host_stride(d);
+        const char* hpin = static_cast<const char*>(ws.fast_pairs_pin);
+        const size_t off_stats = nsf::kHostVals * sizeof(double), off_words = off_stats + (size_t)(nsf::kTileStats + 2) * nb * nb * sizeof(double);
+        int learnt = -1;
+        for (int b = 0; b < count; ++b) {
+            const double* hv = reinterpret_cast<const double*>(hpin + (size_t)b * hs);
+            const double* hx = reinterpret_cast<const double*>(hpin + (size_t)b * hs + off_stats);
+            const int* hw = reinterpret_cast<const int*>(hpin + (size_t)b * hs + off_words);
+            if (hw[12] != m.gen) continue;              // (no record: the single route decides)
+            MixedResult r;
+            fast_decide_one(hw, hv, hx, nb, &r);
+            if (r.too_few0 || r.too_few1) {
+                if (rc == FAD_OK) rc = set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
+                out_fad[b] = NAN; done[b] = true;
+                continue;
+            }
+            if (r.status != 1) continue;
+            const double tr_sqrt = sqrt(r.c) * r.tr_scaled;
+            out_fad[b] = r.mean_term + r.tr1 + r.tr2 - 2.0 * tr_sqrt;
+            if (diag) {
+                fad_diag_t& q = diag[b];
+                memset(&q, 0, sizeof(q));
+                q.iters = r.iters + 1; q.converged = 3; q.used_eps = 0; q.route = 2;
+                q.residual = r.res; q.scale = r.c; q.mean_term = r.mean_term; q.tr1 = r.tr1; q.tr2 = r.tr2; q.tr_sqrt = tr_sqrt;
+            }
+            if (r.decided_at + 1 > learnt) learnt = r.decided_at + 1;
+            done[b] = true;
+        }
+        if (learnt > 0 && ws.pool) ws.pool->lp_iters = learnt;
+    }
+    ws.busy = false;                               // the slot is free again: the single route below takes any free one
+    ws.multi = Workspace::Multi();
+    for (int b = 0; b < count; ++b) {
+        if (done[b]) continue;
+        // not eligible, not finished within the blind batch, or rejected: exactly what the single entry point does for this pair
+        const int r1 = fad_frechet_from_moments(m.h1[b], m.h2[b], j.ddof, j.eps, 0, 0.0, j.mean_dtype, j.stream, &out_fad[b], diag ? &diag[b] : nullptr);
+        if (r1 != FAD_OK && rc == FAD_OK) rc = r1;
+    }
+    return rc;
+}
+
 int fad_frechet_cancel(fad_frechet_job_t* job) {
     if (!job) return set_error(FAD_ERR_INVALID, "NULL argument");
     Workspace& ws = *reinterpret_cast<Workspace*>(job);
     if (!ws.busy) return FAD_OK;
     DeviceGuard g(ws.job.device);
     // the enqueued kernels still write into the slot's buffers: it may only be handed out again once they are through
-    if (ws.job.mixed && ws.done_ev) FAD_HIP_TRY(hipEventSynchronize(ws.done_ev));
+    if ((ws.job.mixed || ws.multi.enqueued) && ws.done_ev) FAD_HIP_TRY(hipEventSynchronize(ws.done_ev));
     else FAD_HIP_TRY(hipStreamSynchronize(ws.job.stream));
     ws.busy = false;
     ws.job = Workspace::Job();
+    ws.multi = Workspace::Multi();
     return FAD_OK;
 }
 

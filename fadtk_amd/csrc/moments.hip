@@ -291,7 +291,7 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
         hipLaunchKernelGGL((moments_tile256<FAD_F16, true>), dim3((unsigned)L.total), dim3(512), kT256Lds, st, L);
     R.sl = (max_s > 32) ? 16 : (max_s > 8) ? 4 : 1;
     const int G = 256 / R.sl;
-    const int blocks = (int)cdiv((int64_t)R.nblk * 256, G) + (int)cdiv(d, 256);
+    const int blocks = (int)cdiv((int64_t)R.nblk * 256, G) + (int)cdiv(d, 64);
     hipLaunchKernelGGL(moments_reduce256, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, R);
     if (ev && h0->timing == 1) FAD_HIP_TRY(hipEventRecord(ev[2], st));
     FAD_HIP_TRY(hipGetLastError());

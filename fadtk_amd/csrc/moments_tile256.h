@@ -23,7 +23,10 @@
 namespace fad {
 
 constexpr int T2_KB = 32;                   // rows per slab and stage
-constexpr int T2_NST = 4;                   // ring depth
+#ifndef T2_NST_VALUE
+#define T2_NST_VALUE 4
+#endif
+constexpr int T2_NST = T2_NST_VALUE;        // ring depth (scripts/probes/tile256_bench.hip builds variants)
 constexpr int T2_SUB = T2_KB * 16;          // uint4 per [32][128] sub-slab
 constexpr int T2_STAGE = 4 * T2_SUB;        // A0 A1 B0 B1: 32 KiB
 constexpr size_t kT256Lds = (size_t)T2_NST * T2_STAGE * sizeof(uint4);      // 128 KiB
@@ -41,6 +44,14 @@ struct T256Launch {
     int nsets, d, nsb, NT, total;
     uint8_t type[t256::MAX_TYPES], sa[t256::MAX_TYPES], sb[t256::MAX_TYPES];
 };
+
+// Workgroup barrier that the instruction scheduler may not move anything across (MFMAs have no memory effects: without the
+// fences hipcc slides them over a bare s_barrier and the load / MFMA halves of the ping-pong loop dissolve).
+__device__ __forceinline__ void t2_phase_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 __device__ __forceinline__ uint4 t2_frag(uint32_t lds_byte) {
     typedef __attribute__((address_space(3))) s16x4* lp_t;
@@ -99,7 +110,6 @@ __device__ __forceinline__ void tile256_wave(
     const T256Launch& L, const T256Set& s, int split, int ti, int type, int sa, int sb, const t256::WaveJob job, uint4* smem) {
     using RD = t256::RoleDef<ROLE>;
     constexpr int NF = RD::NF, NB = RD::NB;
-    constexpr bool TRI = (ROLE == t256::TRI_LO || ROLE == t256::TRI_HI);      // carries the column sums of its four fragments
     static_assert(!SHIFT || KIND == FAD_F16, "the shifted pass is written for float16 rows");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,18 +134,22 @@ __device__ __forceinline__ void tile256_wave(
     const uint32_t smem_lds = (uint32_t)(size_t)(lptr_t)smem;
     const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
     const bool cols_full = (colA + t256::SB <= d) && (colB + t256::SB <= d) && ld < ((int64_t)1 << 26);
-    auto issue_fast = [&](int kb) {
+    auto piece_fast = [&](int kb, int q) {     // piece q (rows 4 q ..) of this wave's share of stage kb: SGPR base + 32-bit lane offset
+#ifdef T2_ABL_NODMA                          // ablation: the ring is filled once and never refilled
+        if (kb >= T2_NST - 1) return;
+#endif
         const uint32_t dst0 = smem_lds + (uint32_t)(((kb % T2_NST) * T2_STAGE + sub * T2_SUB + 256 * (wave & 1)) * 16);
         const uint16_t* src0 = E + (k_begin + (int64_t)kb * rows_per_stage + ld_rowoff) * ld + ld_col0;
+        const uint64_t sbq = (uint64_t)(src0 + (int64_t)(4 * q) * ld);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sbq);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sbq >> 32));
+        const uint64_t ub = ((uint64_t)hi << 32) | lo;
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(64 * q * 16));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
+    };
+    auto issue_fast = [&](int kb) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint64_t sbq = (uint64_t)(src0 + (int64_t)(4 * q) * ld);
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sbq);
-            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sbq >> 32));
-            const uint64_t ub = ((uint64_t)hi << 32) | lo;
-            const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(64 * q * 16));
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
-        }
+        for (int q = 0; q < 4; ++q) piece_fast(kb, q);
     };
     auto issue_slow = [&](int kb) {         // edge stages: per-lane 64-bit addresses, rows / columns out of range read the zero block
         const uint32_t dst0 = smem_lds + (uint32_t)(((kb % T2_NST) * T2_STAGE + sub * T2_SUB + 256 * (wave & 1)) * 16);
@@ -183,69 +197,145 @@ __device__ __forceinline__ void tile256_wave(
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
-    double csum[4] = {0.0, 0.0, 0.0, 0.0};
-    float csq[4] = {0.f, 0.f, 0.f, 0.f};
+    // column sums (and sum x^2 for the guard): every triangle-family wave takes TWO of its fragments -- superblock fragments
+    // 0,1 (TRI_LO), 2,3 (RECT_D), 4,5 (RECT_C), 6,7 (TRI_HI) -- so that no wave carries more than 2 x 2 x 9 VALU ops per stage
+    constexpr bool CSUM = ROLE != t256::XR;
+    constexpr int CS0 = (ROLE == t256::TRI_HI || ROLE == t256::RECT_C) ? 2 : 0;          // F[CS0], F[CS0 + 1]
+    double csum[2] = {0.0, 0.0};
+    float csq[2] = {0.f, 0.f};
 
-    // one stage's arithmetic: all transpose reads of both k-steps, then the MFMAs (the compiler interleaves them by lgkmcnt)
-    auto compute = [&](int kb) {
+    uint4 F0[NF], F1[NF];                    // the fragments of the stage in hand: k-step 0 / 1 (SHIFT: see mma below)
+    // LOAD half of a stage: every transpose read of the stage, then this wave's four LDS-DMA pieces of stage kb + NST - 1
+    auto load_frags = [&](int kb) {
+#ifdef T2_ABL_NOREAD                         // ablation (scripts/probes/tile256_bench.hip): no transpose reads
+        if (kb > 0) return;
+#endif
         const uint32_t base = smem_lds + (uint32_t)((kb % T2_NST) * T2_STAGE * 16);
-        if constexpr (SHIFT) {              // one k-step at a time (x', e and the raw fragment of both k-steps do not fit the registers)
+#pragma unroll
+        for (int i = 0; i < NF; ++i) F0[i] = t2_frag(base + foff[i]);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) F1[i] = t2_frag(base + foff[i] + 4096);
+    };
+    // MFMA half of a stage
+    auto mma = [&](int kb, auto refill) {
+        if constexpr (SHIFT) {
+            if (decltype(refill)::value) issue_fast(kb + T2_NST - 1);              // x - c = x' + e, one k-step at a time (register budget)
             const bool full = kb < nfast;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 X[NF], R[NF];
 #pragma unroll
-                for (int i = 0; i < NF; ++i) X[i] = t2_frag(base + foff[i] + 4096 * ks);
-#pragma unroll
-                for (int i = 0; i < NF; ++i) t2_split2(X[i], cs[i], full ? 8 : rows_left_at(kb, ks, fslab[i]), X[i], R[i]);
+                for (int i = 0; i < NF; ++i) t2_split2(ks ? F1[i] : F0[i], cs[i], full ? 8 : rows_left_at(kb, ks, fslab[i]), X[i], R[i]);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     acc[b] = mfma_h16<KIND>(X[RD::fa[b]], X[RD::fb[b]], acc[b]);
                     acc[b] = mfma_h16<KIND>(X[RD::fa[b]], R[RD::fb[b]], acc[b]);
                     acc[b] = mfma_h16<KIND>(R[RD::fa[b]], X[RD::fb[b]], acc[b]);
                 }
-                if constexpr (TRI) {
+                if constexpr (CSUM) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) csum[i] += (double)sum8<KIND>(X[i]) + (double)sum8<KIND>(R[i]);
+                    for (int i = 0; i < 2; ++i) csum[i] += (double)sum8<KIND>(X[CS0 + i]) + (double)sum8<KIND>(R[CS0 + i]);
                 }
             }
             return;
         }
-        uint4 F0[NF], F1[NF];
+        // hot stages: this wave's four LDS-DMA pieces of stage kb + NST - 1 go BETWEEN the MFMAs (a piece holds the wave ~60
+        // cycles among bare MFMAs, 100-185 among the transpose reads of the load half -- MI355X_MICROARCH.md)
+#ifdef T2_ABL_NOMMA                          // ablation: no MFMAs (the fragments stay live through a cheap VALU use)
 #pragma unroll
-        for (int i = 0; i < NF; ++i) F0[i] = t2_frag(base + foff[i]);
+        for (int i = 0; i < NF; ++i) acc[0][i] += __uint_as_float((F0[i].x ^ F0[i].y ^ F0[i].z ^ F0[i].w ^ F1[i].x ^ F1[i].y ^ F1[i].z ^ F1[i].w) & 0x007fffffu);
+        if (decltype(refill)::value) issue_fast(kb + T2_NST - 1);
+        return;
+#endif
 #pragma unroll
-        for (int i = 0; i < NF; ++i) F1[i] = t2_frag(base + foff[i] + 4096);
+        for (int b = 0; b < NB; ++b) {
+            acc[b] = mfma_h16<KIND>(F0[RD::fa[b]], F0[RD::fb[b]], acc[b]);
+#ifndef T2_OPT_DMA_IN_LOAD
+            if (decltype(refill)::value && (b == 1 || b == 5)) {
+                __builtin_amdgcn_sched_barrier(0); piece_fast(kb + T2_NST - 1, b == 1 ? 0 : 1); __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = mfma_h16<KIND>(F0[RD::fa[b]], F0[RD::fb[b]], acc[b]);
+        for (int b = 0; b < NB; ++b) {
+            acc[b] = mfma_h16<KIND>(F1[RD::fa[b]], F1[RD::fb[b]], acc[b]);
+#ifndef T2_OPT_DMA_IN_LOAD
+            if (decltype(refill)::value && (b == 1 || b == 5)) {
+                __builtin_amdgcn_sched_barrier(0); piece_fast(kb + T2_NST - 1, b == 1 ? 2 : 3); __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        }
+#ifndef T2_OPT_NOCOLSUM
+        if constexpr (CSUM) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = mfma_h16<KIND>(F1[RD::fa[b]], F1[RD::fb[b]], acc[b]);
-        if constexpr (TRI) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                csum[i] += (double)sum8<KIND>(F0[i]) + (double)sum8<KIND>(F1[i]);
-                csq[i] = t2_sumsq8<KIND>(F1[i], t2_sumsq8<KIND>(F0[i], csq[i]));
+            for (int i = 0; i < 2; ++i) {
+                csum[i] += (double)sum8<KIND>(F0[CS0 + i]) + (double)sum8<KIND>(F1[CS0 + i]);
+                csq[i] = t2_sumsq8<KIND>(F1[CS0 + i], t2_sumsq8<KIND>(F0[CS0 + i], csq[i]));
             }
         }
+#endif
     };
+    // this wave's pieces of stage `kb + 1` have landed once at most (stages issued beyond it) x 4 of its loads are outstanding
+    auto wait_next = [&](int kb) {
+        if (kb + 1 >= nkb) return;
+        const int last = (kb + T2_NST - 1 < nkb - 1) ? kb + T2_NST - 1 : nkb - 1;       // youngest stage issued so far
+        wait_vmcnt_upto<4>(last - (kb + 1));
+    };
+    static_assert(T2_NST <= 8, "wait_vmcnt_upto counts at most seven stages");
 
+#ifndef T2_OPT_NO_PINGPONG
+    // ---- PING-PONG.  The two waves of a SIMD are wave w and wave w + 4: the quartets run HALF A STAGE APART, so that while one
+    // wave of every SIMD is in its load half (24 transpose reads + 4 LDS-DMA pieces, each of which holds the wave for 100+
+    // cycles) the other one keeps the matrix pipe busy with its 16-18 MFMAs.  (With both in the same phase -- the first version
+    // -- a stage took ~2600 cycles: DMA issue, reads and 1088 cycles of MFMAs one after the other.)  Half-steps h, a barrier b_h
+    // after each:    quartet 0:  L(0) b0 M(0) b1 L(1) b2 M(1) b3 ...          quartet 1:  --  b0 L(0) b1 M(0) b2 L(1) b3 ...
+    //   * a wave waits for its OWN pieces of stage k + 1 at the end of L(k): both quartets have done so before b_{2k+1}, the
+    //     barrier in front of the first L(k + 1);
+    //   * the slot of stage k - 1 is refilled in L(k): its last readers (quartet 1 in L(k - 1), reads drained by lgkmcnt(0))
+    //     are behind b_{2k-1}.
+    const int quartet = wave >> 2;
     for (int s0 = 0; s0 < T2_NST - 1 && s0 < nkb; ++s0) issue(s0);
-    // hot loop: the stage to refill is a whole one (SGPR-base loads only) and two younger stages stay in flight -- no branches
-    const int hot = nfast - (T2_NST - 1) > 0 ? nfast - (T2_NST - 1) : 0;
+    {
+        wait_vmcnt_upto<4>(((nkb < T2_NST - 1) ? nkb : T2_NST - 1) - 1);               // stages issued beyond stage 0
+    }
+    t2_phase_barrier();
+    if (quartet == 1) t2_phase_barrier();                                     // b0
+    const int hot = nfast - (T2_NST - 1) > 0 ? nfast - (T2_NST - 1) : 0;               // stages whose refill is a whole stage
     int kb = 0;
-    for (; kb < hot; ++kb) {
-        wait_vmcnt<4 * (T2_NST - 2)>();
-        __builtin_amdgcn_s_barrier();               // stage kb is in LDS, stage kb - 1 is free
+    for (; kb < hot; ++kb) {                 // no branches: the refill (SGPR-base pieces) rides in the MFMA half
+        load_frags(kb);
+#ifdef T2_OPT_DMA_IN_LOAD
         issue_fast(kb + T2_NST - 1);
-        compute(kb);
+        wait_vmcnt<4 * (T2_NST - 2)>();
+#else
+        wait_vmcnt<4 * (T2_NST - 3)>();      // in flight at this point: stages kb + 1 .. kb + NST - 2; kb + 1 must have landed
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t2_phase_barrier();
+        mma(kb, std::true_type{});
+        t2_phase_barrier();
     }
     for (; kb < nkb; ++kb) {
+        load_frags(kb);
+        if (kb + T2_NST - 1 < nkb) issue(kb + T2_NST - 1);
+        wait_next(kb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t2_phase_barrier();
+        mma(kb, std::false_type{});
+        if (!(quartet == 1 && kb == nkb - 1)) t2_phase_barrier();
+    }
+#else
+    // (probe only) both quartets in the same phase: wait, barrier, refill, reads, MFMAs
+    for (int s0 = 0; s0 < T2_NST - 1 && s0 < nkb; ++s0) issue(s0);
+    for (int kb = 0; kb < nkb; ++kb) {
         const int ahead = (nkb - 1 - kb < T2_NST - 2) ? (nkb - 1 - kb) : (T2_NST - 2);
         if (ahead >= 2) wait_vmcnt<8>(); else if (ahead == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kb + T2_NST - 1 < nkb) issue(kb + T2_NST - 1);
-        compute(kb);
+        load_frags(kb);
+        mma(kb, std::false_type{});
     }
+#endif
 
     // ---- epilogue: blocks, fragment major -- float4 (q, lane) of block b = registers 4q..4q+3 = rows 8q + 4 (lane >> 5) + 0..3
     // of column lane & 31
@@ -256,8 +346,8 @@ __device__ __forceinline__ void tile256_wave(
         for (int q = 0; q < 4; ++q)
             out[(b * 4 + q) * 64 + lane] = make_float4(acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]);
 
-    if constexpr (TRI) {
-        // column sums of this wave's four fragments over the rows it saw; a Z item's second quartet (slab B) writes the second row
+    if constexpr (CSUM) {
+        // column sums of this wave's two fragments over the rows it saw; a Z item's second quartet (slab B) writes the second row
         const int dpad = L.nsb * t256::SB;
         const int half = (zt && job.slab) ? 1 : 0;
         double* cp = s.colpart + ((int64_t)split * 2 + half) * dpad;
@@ -268,24 +358,25 @@ __device__ __forceinline__ void tile256_wave(
         }
         bool hit = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
+            const int col = fcol[CS0 + i];
             double sx = csum[i];
             sx += __shfl_xor(sx, 32);
-            if (kg == 0) cp[fcol[i]] = sx;
+            if (kg == 0) cp[col] = sx;
             if constexpr (!SHIFT) {
                 if (s.flag) {
                     double s2 = (double)csq[i];
                     s2 += __shfl_xor(s2, 32);
                     const double nr = (double)my_rows;
                     const double mean = sx / nr, var = s2 / nr - mean * mean;
-                    const bool col_in = fcol[i] < d;
+                    const bool col_in = col < d;
                     // the same rule as the 128-kernel; sum x^2 is a float32 sum here (relative error ~1e-6: immaterial against 64 x)
                     hit = hit || (col_in && nr > 0.0 && !(mean * mean <= 64.0 * var) && !(sx == 0.0 && s2 == 0.0));
                     if (s.cvec && kg == 0 && half == 0) {
                         const bool worth = col_in && nr > 0.0 && (mean * mean > var) && (mean == mean) && !isinf(mean) && fabs(mean) < 65000.0;
                         const _Float16 ch = worth ? (_Float16)(float)mean : (_Float16)0.0f;
                         uint16_t bits; __builtin_memcpy(&bits, &ch, 2);
-                        s.cvec[(int64_t)split * dpad + fcol[i]] = bits;
+                        s.cvec[(int64_t)split * dpad + col] = bits;
                     }
                 }
             }
@@ -355,17 +446,32 @@ __global__ __launch_bounds__(256) void moments_reduce256(R256Launch R) {
         return (double)(left < j.rows_per_split ? left : j.rows_per_split);
     };
     if (block >= tile_blocks) {              // trailing blocks: column sums and the row count
-        const int a = (block - tile_blocks) * 256 + threadIdx.x;
-        if (a == 0) j.acc[0] = j.overwrite ? j.n_add : j.acc[0] + j.n_add;
-        if (a >= R.d) return;
-        const bool two = (a / t256::SB) == (int)R.z_sb;
-        double s0 = 0.0, s1 = 0.0;
-        for (int sp = 0; sp < S; ++sp) {
-            s0 += j.colpart[((int64_t)sp * 2) * dpad + a];
-            if (two) s1 += j.colpart[((int64_t)sp * 2 + 1) * dpad + a];
-            if (unshift) s1 += rows_of(sp) * f16_bits_to_f64(j.cvec[(int64_t)sp * dpad + a]);
+        // 64 columns x 4 split lanes per block, eight independent loads per thread and round (a first version walked the S
+        // splits with one dependent load after the other in 2 blocks: 20 of the kernel's 28 us)
+        const int a = (block - tile_blocks) * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
+        if (block == tile_blocks && threadIdx.x == 0) j.acc[0] = j.overwrite ? j.n_add : j.acc[0] + j.n_add;
+        double t = 0.0;
+        if (a < R.d) {
+            const bool two = (a / t256::SB) == (int)R.z_sb;
+            const double* cp = j.colpart + a;
+            int sp = l;
+            for (; sp + 28 < S; sp += 32) {
+                double v[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u] = cp[((int64_t)(sp + 4 * u) * 2) * dpad]; w[u] = two ? cp[((int64_t)(sp + 4 * u) * 2 + 1) * dpad] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t += v[u] + w[u];
+            }
+            for (; sp < S; sp += 4) t += cp[((int64_t)sp * 2) * dpad] + (two ? cp[((int64_t)sp * 2 + 1) * dpad] : 0.0);
+            if (unshift)
+                for (int q = l; q < S; q += 4) t += rows_of(q) * f16_bits_to_f64(j.cvec[(int64_t)q * dpad + a]);
         }
-        j.acc[1 + a] = j.overwrite ? s0 + s1 : j.acc[1 + a] + (s0 + s1);
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (l == 0 && a < R.d) {
+            const double tot = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+            j.acc[1 + a] = j.overwrite ? tot : j.acc[1 + a] + tot;
+        }
         return;
     }
     const int sl = threadIdx.x / G, gl = threadIdx.x % G;
@@ -389,15 +495,18 @@ __global__ __launch_bounds__(256) void moments_reduce256(R256Launch R) {
             const int ti = src.src[h] / t256::SLOTS, slot = src.src[h] - ti * t256::SLOTS;
             const float* p = j.partials + (int64_t)ti * t256::ITEM_STRIDE + (int64_t)slot * t256::BLK + e * 4;
             int sp = sl;
-            for (; sp + 3 * SL < S; sp += 4 * SL) {
-                const float4 v0 = *reinterpret_cast<const float4*>(p + sp * stride);
-                const float4 v1 = *reinterpret_cast<const float4*>(p + (sp + SL) * stride);
-                const float4 v2 = *reinterpret_cast<const float4*>(p + (sp + 2 * SL) * stride);
-                const float4 v3 = *reinterpret_cast<const float4*>(p + (sp + 3 * SL) * stride);
-                s[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-                s[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-                s[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
-                s[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+#ifdef R256_ABL_NOLOAD                       // ablation: no partial tiles read
+            sp = S;
+#endif
+            for (; sp + 7 * SL < S; sp += 8 * SL) {        // eight loads in flight per thread: the reduce is a latency chain otherwise
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (sp + u * SL) * stride);
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    s[0] += (double)v[u].x + (double)v[u + 1].x; s[1] += (double)v[u].y + (double)v[u + 1].y;
+                    s[2] += (double)v[u].z + (double)v[u + 1].z; s[3] += (double)v[u].w + (double)v[u + 1].w;
+                }
             }
             for (; sp < S; sp += SL) {
                 const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
@@ -433,6 +542,10 @@ __global__ __launch_bounds__(256) void moments_reduce256(R256Launch R) {
         }
     }
     if (!live) return;
+#ifdef R256_ABL_NOWRITE                      // ablation: one store per thread instead of the block and its mirror image
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) j.acc[1] = 0.0;
+    return;
+#endif
     double* M = j.acc + 1 + R.d;
     const int d = R.d;
     const int a0 = 32 * bi + 8 * (e >> 6) + 4 * ((e & 63) >> 5), b = 32 * bj + (e & 31);

@@ -181,9 +181,13 @@ struct PrepArgs {
     double* covs;                    // [2][d * d]      (written only with acc: what the float64 route reads if it has to take over)
     uint4* dig[2];                   // digit planes of s_1 Sigma_1 (A operand) and of (s_2 Sigma_2)^T (B operand)
     NsState* st; MatHdr* hdr[2];
-    // batch (per-song scores): blockIdx.y = 0 is the baseline (cov_in[0], dig[0], hdr[0]); blockIdx.y = 1 + b is song b:
+    // batch = 1 (per-song scores): blockIdx.y = 0 is the baseline (cov_in[0], dig[0], hdr[0]); blockIdx.y = 1 + b is song b:
     // cov_in[1] + b d^2, and dig[1], hdr[1], st advanced by b * pstride bytes.  No means, no mean term, no spare workgroup.
+    // batch = 2 (B independent PAIRS from packed moments, frechet.hip: pairs_begin): blockIdx.y = 2 b + set, packed moments
+    // accs[2 b + set]; EVERYTHING (mus, covs, dig, hdr, st) of pair b lives b * pstride bytes behind pair 0's; means, mean term and
+    // the spare workgroup as for a single pair.
     int batch; int64_t pstride;
+    const double* accs[16];
 };
 
 __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
@@ -191,28 +195,31 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     __shared__ double mu_lds[2 * 1024];
     __shared__ float gaps[1024];
     const int tid = threadIdx.x, d = a.d;
-    const int set = a.batch ? (blockIdx.y ? 1 : 0) : (int)blockIdx.y;
-    const int64_t po = a.batch && blockIdx.y ? (int64_t)(blockIdx.y - 1) * a.pstride : 0;      // byte offset of this song's buffers
-    if (!a.batch && blockIdx.x == gridDim.x - 1) {
+    const bool pairs = a.batch == 2, songs = a.batch == 1;
+    const int set = songs ? (blockIdx.y ? 1 : 0) : (pairs ? (int)(blockIdx.y & 1) : (int)blockIdx.y);
+    // byte offset of this problem's buffers
+    const int64_t po = songs ? (blockIdx.y ? (int64_t)(blockIdx.y - 1) * a.pstride : 0) : (pairs ? (int64_t)(blockIdx.y >> 1) * a.pstride : 0);
+    if (!songs && blockIdx.x == gridDim.x - 1) {
         // the spare workgroup: means of both sets -> global (with acc) and LDS, then the mean term -> state
         if (set != 0 || tid >= 256) return;
+        double* mus = adv(a.mus, po);
         for (int q = 0; q < 2; ++q) {
-            const double* acq = a.acc[q];
+            const double* acq = pairs ? a.accs[(blockIdx.y & ~1u) + q] : a.acc[q];
             for (int i = tid; i < d; i += 256) {
                 const double m = acq ? acq[1 + i] / acq[0] : a.mu_in[q][i];       // (sum / n: bit for bit what finalize_for_frechet writes)
                 mu_lds[q * 1024 + i] = m;
-                if (acq) a.mus[(int64_t)q * d + i] = m;
+                if (acq) mus[(int64_t)q * d + i] = m;
             }
         }
         __syncthreads();
         const double mt = mean_term_block(mu_lds, mu_lds + 1024, d, a.mean_dtype, gaps, red);
-        if (tid == 0) a.st->mean_term = mt;
+        if (tid == 0) adv(a.st, po)->mean_term = mt;
         return;
     }
-    const double* acc = a.acc[set];
+    const double* acc = pairs ? a.accs[blockIdx.y] : a.acc[set];
     const double n = acc ? acc[0] : 2.0;
     const double* sum = acc ? acc + 1 : nullptr;
-    const double* M = acc ? acc + 1 + d : a.cov_in[set] + ((a.batch && blockIdx.y) ? (int64_t)(blockIdx.y - 1) * d * d : 0);
+    const double* M = acc ? acc + 1 + d : a.cov_in[set] + ((songs && blockIdx.y) ? (int64_t)(blockIdx.y - 1) * d * d : 0);
     MatHdr* hdr = adv(a.hdr[set], po);
     NsState* st = adv(a.st, po);
     const double inv_n = 1.0 / n, inv_nd = 1.0 / (n - (double)a.ddof);
@@ -250,11 +257,11 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     const double s = bad ? 1.0 : ldexp(1.0, -ex);
     if (blockIdx.x == 0 && tid == 0) {
         hdr->s = s; hdr->tr = tr; hdr->bad = bad ? 1 : 0;
-        if (!a.batch) st->too_few[set] = few ? 1 : 0;
-        if (a.batch ? set == 1 : set == 0) {             // the per-call reset of the iteration state (finalize_for_frechet did this)
+        if (!songs) st->too_few[set] = few ? 1 : 0;
+        if (songs ? set == 1 : set == 0) {               // the per-call reset of the iteration state (finalize_for_frechet did this)
             st->done = 0; st->finished = 0; st->nonfinite = 0; st->conv = 0; st->final_iter = -1;
             st->upd_skip[0] = 0; st->upd_skip[1] = 0;
-            if (a.batch) { st->too_few[0] = 0; st->too_few[1] = 0; st->mean_term = 0.0; }
+            if (songs) { st->too_few[0] = 0; st->too_few[1] = 0; st->mean_term = 0.0; }
         }
     }
     // (Sigma_2 is used as its own transpose: the moments give a bit-for-bit symmetric matrix; for caller-given matrices the
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
 #pragma unroll
     for (int p = 0; p < kDigits; ++p) w[p] = 0u;
     bool off_grid = false;
-    double* cov_out = acc ? a.covs + (int64_t)set * d * d + (int64_t)row * d + k0 : nullptr;
+    double* cov_out = acc ? adv(a.covs, po) + (int64_t)set * d * d + (int64_t)row * d + k0 : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // Sigma[row][k0 + q]: the expression of moments_finalize_kernel up to the reciprocals (symmetric bit for bit)
@@ -348,8 +355,9 @@ struct I8Args {
     const uint4* Adig; const uint4* Bdig;        // A operand rows / B operand COLUMNS (= rows of B^T), digit planes
     const uint4* Adig_alt; const uint4* Bdig_alt; const int* sel;      // I8_G: used instead when *sel is odd (ping-pong iterates)
     int d, gen;
-    const MatHdr* hA; const MatHdr* hB;          // headers of the two covariances (hA: the shared baseline in a batch)
+    const MatHdr* hA; const MatHdr* hB;          // headers of the two covariances (hA: the shared baseline in a batch of songs)
     int64_t pstride, hstride;                    // bytes between consecutive problems of a batch: device buffers / host buffers
+    int64_t astride;                             // ... of the A SIDE (hA; I8_A: Adig): 0 = shared baseline (songs), pstride for a batch of pairs
     const int* skip;                             // *skip != 0: nothing to do
     double* stats;                               // I8_A: [nb * nb][4] (device);  I8_G: [nb * nb][4] then [nb * nb][2] (PINNED HOST memory)
     // I8_A
@@ -377,8 +385,9 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
     const int64_t po = (int64_t)blockIdx.z * g.pstride, ho = (int64_t)blockIdx.z * g.hstride;      // this problem's buffers
     const MatHdr* hB = adv(g.hB, po);
+    const MatHdr* hA = adv(g.hA, (int64_t)blockIdx.z * g.astride);
     NsState* const st_p = adv(g.st, po);
-    const bool bad = hdr_bad(g.hA, hB, g.gen);
+    const bool bad = hdr_bad(hA, hB, g.gen);
     const bool skipped = bad || (g.skip && *adv(g.skip, po) != 0);
     if constexpr (MODE == I8_G) {
         // whatever happens, the host finds the state of the iteration next to the partials
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     const int row0 = ty * 32, col0 = tx * 32;
     const bool alt = (MODE == I8_G) && g.sel && (*adv(g.sel, po) & 1);
     // (A = Sigma_b Sigma_s: the A operand is the batch's shared baseline; G = Y Y: both operands are the problem's own)
-    const uint4* Ad = (MODE == I8_A) ? g.Adig : adv(alt ? g.Adig_alt : g.Adig, po);
+    const uint4* Ad = (MODE == I8_A) ? adv(g.Adig, (int64_t)blockIdx.z * g.astride) : adv(alt ? g.Adig_alt : g.Adig, po);
     const uint4* Bd = adv(alt ? g.Bdig_alt : g.Bdig, po);
     const bool idle = wave * NS8 >= (d >> 5);            // d = 128: four k-steps, waves 4..7 contribute zeros
 
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     double m = 0.0, v3[3] = {0.0, 0.0, 0.0};
     if constexpr (MODE == I8_A) {
         // A in the caller's units (float64), the split planes of its normalised image P = s1 s2 A, the tile's statistics
-        const double inv = hdr_inv_s12(g.hA, hB);
+        const double inv = hdr_inv_s12(hA, hB);
         *reinterpret_cast<double2*>(adv(g.A64, po) + (int64_t)gr * d + gc) = make_double2(G2[0] * inv, G2[1] * inv);
         fin[rr * 33 + 2 * cp] = (float)G2[0]; fin[rr * 33 + 2 * cp + 1] = (float)G2[1];
         v3[0] = G2[0] * G2[0] + G2[1] * G2[1];
@@ -553,8 +562,9 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
 enum { SP_FIRST = 0, SP_T = 1, SP_U = 2 };
 struct SplitArgs {
     int d, gen;
-    const MatHdr* hA; const MatHdr* hB;  // headers of the two covariances (hA: the shared baseline in a batch)
+    const MatHdr* hA; const MatHdr* hB;  // headers of the two covariances (hA: the shared baseline in a batch of songs)
     int64_t pstride;                     // bytes between consecutive problems of a batch (everything below but hA is per problem)
+    int64_t astride;                     // ... of hA: 0 = shared (songs), pstride for a batch of pairs
     const int* skip;
     SplitMat A[2], B[2], C[2];           // per product of the launch: A operand, B operand (its ^T planes are read), output
     uint4* Cdig[2]; uint4* Cdig_t[2];    // digit planes of C[0] and of C[0]^T (SP_FIRST, SP_U)
@@ -622,7 +632,8 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         }
     }
     const MatHdr* hB = adv(g.hB, po);
-    if (hdr_bad(g.hA, hB, g.gen)) return;
+    const MatHdr* hA = adv(g.hA, (int64_t)(blockIdx.z / ZPER) * g.astride);
+    if (hdr_bad(hA, hB, g.gen)) return;
     const int zi = (MODE == SP_U) ? zs : 0;
     int ty, tx; tile_of_block(ty, tx);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -676,7 +687,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         const double wmean = (trA > 0.0) ? fro2 / trA : 0.0;      // where the bulk of a flat spectrum sits (||A||_F^2 stands in for tr A^2)
         if (wmean > c && wmean <= u) c = wmean;
         NsState* const st_p = adv(g.st, po);
-        const double mean_term = st_p->mean_term, tr1 = g.hA->tr, tr2 = hB->tr;
+        const double mean_term = st_p->mean_term, tr1 = hA->tr, tr2 = hB->tr;
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
         // the float32-class iteration only serves spectra that are flat within a few hundred: participation ratio (tr A)^2 / ||A||_F^2 >= d/4
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
             NsState* st = st_p; Ns32State* s32 = adv(g.s32, po);
-            st->c = zero ? 1.0 : c * hdr_inv_s12(g.hA, hB);     // in the caller's units: A / st->c = (s1 s2 A) / c
+            st->c = zero ? 1.0 : c * hdr_inv_s12(hA, hB);     // in the caller's units: A / st->c = (s1 s2 A) / c
             st->tr1 = tr1; st->tr2 = tr2;
             st->res_last = 0.0; st->tr_last = 0.0; st->res_min = 1e300; st->tr_safe = 0.0; st->has_safe = 0;
             st->final_iter = zero ? 0 : -1; st->conv = zero ? 1 : 0;
@@ -696,7 +707,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         }
         if (bad || zero || hopeless) return;
         inv_cn = 1.0 / c;                                // for the normalised product P P
-        inv_c = inv_cn / hdr_inv_s12(g.hA, hB);          // for A in the caller's units: 1 / st->c
+        inv_c = inv_cn / hdr_inv_s12(hA, hB);          // for A in the caller's units: 1 / st->c
     } else {
         if (g.skip && *adv(g.skip, po) != 0) return;
     }
@@ -757,10 +768,11 @@ struct DigArgs {
     const MatHdr* hA; const MatHdr* hB; int64_t pstride;
     const Ns32State* s32;
     SplitMat Y[2]; uint4* dig[2]; uint4* dig_t[2];
+    int64_t astride;                     // bytes between consecutive problems' hA (0 = shared)
 };
 __global__ __launch_bounds__(256) void nsf_digitize(DigArgs g) {
     const int64_t po = (int64_t)blockIdx.z * g.pstride;
-    if (hdr_bad(g.hA, adv(g.hB, po), g.gen)) return;
+    if (hdr_bad(adv(g.hA, (int64_t)blockIdx.z * g.astride), adv(g.hB, po), g.gen)) return;
     const Ns32State* s = adv(g.s32, po);
     if (s->skip_corr) return;
     const int d = g.d, par = s->final_iter & 1;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     const int TY = tile / t, TX = tile - TY * t;
     const int64_t po = (int64_t)song * g.pstride;
     const MatHdr* hB = adv(g.hB, po);
-    if (hdr_bad(g.hA, hB, g.gen)) return;
+    const MatHdr* hA = adv(g.hA, (int64_t)song * g.astride);        // (astride = 0: the songs' shared baseline; pairs: per problem)
+    if (hdr_bad(hA, hB, g.gen)) return;
     double inv_c = 0.0, inv_cn = 0.0;
     if constexpr (MODE == SP_FIRST) {
         // ---- the scale, as nsf_split<FIRST> derives it (every workgroup, identically, from nsf_i8<A>'s 32 x 32 tile statistics);
@@ -89,13 +90,13 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
         const double wmean = (trA > 0.0) ? fro2 / trA : 0.0;
         if (wmean > c && wmean <= u) c = wmean;
         NsState* const st_p = adv(g.st, po);
-        const double mean_term = st_p->mean_term, tr1 = g.hA->tr, tr2 = hB->tr;
+        const double mean_term = st_p->mean_term, tr1 = hA->tr, tr2 = hB->tr;
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
         const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
         if (tile == 0 && tid == 0) {
             NsState* st = st_p; Ns32State* s32 = adv(g.s32, po);
-            st->c = zero ? 1.0 : c * hdr_inv_s12(g.hA, hB);
+            st->c = zero ? 1.0 : c * hdr_inv_s12(hA, hB);
             st->tr1 = tr1; st->tr2 = tr2;
             st->res_last = 0.0; st->tr_last = 0.0; st->res_min = 1e300; st->tr_safe = 0.0; st->has_safe = 0;
             st->final_iter = zero ? 0 : -1; st->conv = zero ? 1 : 0;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
         }
         if (bad || zero || hopeless) return;
         inv_cn = 1.0 / c;
-        inv_c = inv_cn / hdr_inv_s12(g.hA, hB);
+        inv_c = inv_cn / hdr_inv_s12(hA, hB);
         __syncthreads();                                             // the maxima have been read: the ring may fill
     } else {
         if (g.skip && *adv(g.skip, po) != 0) return;
@@ -270,8 +271,9 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
     const int TY = tile / tc_, TX = tile - TY * tc_;
     const int64_t po = (int64_t)song * g.pstride, ho = (int64_t)song * g.hstride;
     const MatHdr* hB = adv(g.hB, po);
+    const MatHdr* hA = adv(g.hA, (int64_t)song * g.astride);
     NsState* const st_p = adv(g.st, po);
-    const bool bad = hdr_bad(g.hA, hB, g.gen);
+    const bool bad = hdr_bad(hA, hB, g.gen);
     const bool skipped = bad || (g.skip && *adv(g.skip, po) != 0);
     if constexpr (MODE == I8_G) {
         if (tile == 0 && tid == 0) {                                 // whatever happens, the host finds the state next to the partials
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const bool alt = (MODE == I8_G) && g.sel && (*adv(g.sel, po) & 1);
-    const uint4* Ad = (MODE == I8_A) ? g.Adig : adv(alt ? g.Adig_alt : g.Adig, po);
+    const uint4* Ad = (MODE == I8_A) ? adv(g.Adig, (int64_t)song * g.astride) : adv(alt ? g.Adig_alt : g.Adig, po);
     const uint4* Bd = adv(alt ? g.Bdig_alt : g.Bdig, po);
     const int nks = d >> 5;
 
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
     double* scal = stats + (size_t)kTileStats * (by * nb + bx);
     double v3[3] = {0.0, 0.0, 0.0};
     if constexpr (MODE == I8_A) {
-        const double inv = hdr_inv_s12(g.hA, hB);
+        const double inv = hdr_inv_s12(hA, hB);
         double* A64 = adv(g.A64, po) + (int64_t)(row0 + 4 * kg) * d + col0 + n;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {

@@ -308,6 +308,51 @@ class FrechetJob:
             pass
 
 
+class FrechetMultiJob:
+    """Up to eight scores in flight as ONE batch (``fad_frechet_from_moments_multi_begin``): pair b = (pairs[b][0], pairs[b][1]);
+    the eight launches of the square-root chain carry all of them.  ``result()`` -> [(fad, diag dict), ...] in order.  Thread
+    rules as FrechetJob."""
+
+    def __init__(self, pairs, ddof: int = 1, eps: float = 1e-6, mean_dtype: int = -1):
+        import threading
+        self._lib = K.load_library()
+        self._owner = threading.get_ident()
+        self._n = len(pairs)
+        if not 1 <= self._n <= 8:
+            raise ValueError("a FrechetMultiJob holds 1..8 pairs")
+        a = (C.c_void_p * self._n)(*[p[0]._h for p in pairs])
+        b = (C.c_void_p * self._n)(*[p[1]._h for p in pairs])
+        job = C.c_void_p()
+        K.check(self._lib.fad_frechet_from_moments_multi_begin(self._n, a, b, int(ddof), float(eps), int(mean_dtype),
+                                                               K.current_stream_ptr(pairs[0][0].device), C.byref(job)),
+                "fad_frechet_from_moments_multi_begin")
+        self._job = job
+
+    def result(self):
+        import threading
+        if self._job is None:
+            raise RuntimeError("this job was collected already")
+        if threading.get_ident() != self._owner:
+            raise RuntimeError("a FrechetMultiJob must be collected by the thread that created it (its slot is thread-local)")
+        out = (C.c_double * self._n)()
+        diag = (K.FadDiag * self._n)()
+        job, self._job = self._job, None
+        K.check(self._lib.fad_frechet_multi_end(job, self._n, out, diag), "fad_frechet_multi_end")
+        return [(float(out[i]), diag[i].as_dict()) for i in range(self._n)]
+
+    def cancel(self):
+        import threading
+        if self._job is not None and threading.get_ident() == self._owner:
+            job, self._job = self._job, None
+            K.check(self._lib.fad_frechet_cancel(job), "fad_frechet_cancel")
+
+    def __del__(self):
+        try:
+            self.cancel()
+        except Exception:         # noqa: BLE001
+            pass
+
+
 def frechet_batched(mu_b, cov_b, rows, offsets: Sequence[int], mean_mode: int = 1, device: int = 0):
     """Per-song FAD against one baseline (``fad_frechet_batched_vs_baseline``).
 

@@ -159,9 +159,10 @@ def test_moments_tile256_two_sets_one_launch_and_guard_second_pass(F):
     b[:, 600:640] = -20.0 + 0.03 * b[:, 600:640]    # ... and in the Z superblock
     b[:, 300] = 2.5
     b = b.astype(np.float16)
+    import torch
     with Moments(d) as ma, Moments(d) as mb:
         ma.set_timing(True)
-        Moments.update_multi([ma, mb], [a, b])
+        Moments.update_multi([ma, mb], [torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()])
         assert ma.last_timing()[2] == 2
         _, cov_a, na = ma.finalize()
         _, cov_b, nb = mb.finalize()
@@ -1206,3 +1207,41 @@ def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     with pytest.raises(RuntimeError):                                         # only songs the chain cannot take: strict mode must say so
         monkeypatch.setenv("FAD_SONG_FAST", "2")
         hip.frechet_batched(mu_b, cov_b, np.concatenate([flat, steep]), [0, flat.shape[0], flat.shape[0] + steep.shape[0]], mean_mode=1)
+
+
+def test_frechet_multi_job_matches_single_scores(F):
+    """fad_frechet_from_moments_multi_begin / _multi_end: B pairs through ONE batched chain give what fad_frechet_from_moments gives
+    pair by pair -- flat pairs (accepted by the batch), a decaying-spectrum pair and a low-rank pair (handed to the single route),
+    and a second batch on the same thread (the learnt iteration count is in use then)."""
+    import torch
+    from fadtk_amd import hip
+    d = 512
+    rng = np.random.default_rng(2024)
+    decay = (np.arange(1, d + 1) ** -0.75)
+    sets = []
+    for k in range(4):
+        a = rng.standard_normal((9000, d)).astype(np.float16)
+        b = ((1.0 + 0.03 * k) * rng.standard_normal((9500, d)) + 0.01 * k).astype(np.float16)
+        sets.append((a, b))
+    sets.append(((rng.standard_normal((9000, d)) * decay).astype(np.float16), (1.1 * rng.standard_normal((9000, d)) * decay).astype(np.float16)))
+    sets.append((rng.standard_normal((9000, d)).astype(np.float16), rng.standard_normal((300, d)).astype(np.float16)))      # fewer rows than dimensions
+    handles = []
+    for a, b in sets:
+        ma, mb = hip.Moments(d), hip.Moments(d)
+        ma.update(torch.from_numpy(a).cuda()); mb.update(torch.from_numpy(b).cuda())
+        handles.append((ma, mb))
+    want = [hip.frechet_from_moments(ma, mb, mean_dtype=0) for ma, mb in handles]
+    for rep in range(2):
+        got = hip.FrechetMultiJob(handles, mean_dtype=0).result()
+        assert len(got) == len(handles)
+        for (f, dg), (fw, dw) in zip(got, want):
+            assert abs(f - fw) <= 2e-9 * abs(fw), (f, fw, dg, dw)
+            assert abs(dg["tr_sqrt"] - dw["tr_sqrt"]) <= 1e-9 * abs(dw["tr_sqrt"])
+        assert [dg["route"] for dg, _ in [(g[1], None) for g in got[:4]]] == [2, 2, 2, 2]           # the flat pairs stayed on the batched chain
+    for (a, b), (f, _) in zip(sets[:2] + sets[4:], got[:2] + got[4:]):                              # ... and against the oracle
+        ref = O.fad_between(a, b)
+        assert abs(f - ref) <= 2e-6 * abs(ref)
+    two = hip.FrechetMultiJob(handles[1:3], mean_dtype=0).result()                                 # a smaller batch out of the same slot
+    assert abs(two[0][0] - want[1][0]) <= 2e-9 * abs(want[1][0]) and abs(two[1][0] - want[2][0]) <= 2e-9 * abs(want[2][0])
+    for ma, mb in handles:
+        ma.close(); mb.close()
