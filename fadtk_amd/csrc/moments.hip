@@ -933,6 +933,18 @@ int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* c
     return FAD_OK;
 }
 
+int fad_moments_trim(fad_moments_t* h, int64_t keep_bytes) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    DeviceGuard g(h->device);
+    if (keep_bytes < 0) keep_bytes = 0;
+    if (h->stage.cap > (size_t)keep_bytes || h->scratch.cap > (size_t)keep_bytes) {
+        FAD_HIP_TRY(hipDeviceSynchronize());       // nothing enqueued may still read what is freed
+        if (h->stage.cap > (size_t)keep_bytes) h->stage.release();
+        if (h->scratch.cap > (size_t)keep_bytes) h->scratch.release();
+    }
+    return FAD_OK;
+}
+
 int fad_moments_set_timing(fad_moments_t* h, int enabled) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
     h->timing = (enabled == 2) ? 2 : (enabled != 0 ? 1 : 0);

@@ -1116,6 +1116,9 @@ __global__ __launch_bounds__(256) void song_cov_finish(SongCovLaunch L) {
         // the sum of those drifts (d tr sqrt(Sigma_b Sigma_s) = 1/2 tr dSigma_s there) -- 1.1e-5 of a small score, measured; the
         // off-diagonal sums hover around zero and carry ~1e-8
         if (i == gb && L.var_exact) v = L.var_exact[s * L.d + i];
+        // in a diagonal 32 x 32 block both (i, gb) and (gb, i) have a thread, and their float32 partials were summed in a
+        // different order: only the upper one writes the pair, so that Sigma_s is symmetric bit for bit and the same on every run
+        if (diag && fa == fb && i > gb) continue;
         out[(int64_t)i * L.d + gb] = v;
         out[(int64_t)gb * L.d + i] = v;
     }

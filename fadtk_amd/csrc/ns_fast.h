@@ -233,8 +233,12 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     // 8-byte loads.)
     double m[4], sk[4], sr = 0.0;
     const double* Mrow = M + (int64_t)row * d + k0;
+    // the B operand is Sigma_2^T: the moments give a bit-for-bit symmetric matrix (read it row-wise), a CALLER's Sigma_2 need
+    // not be (fad_frechet on host arrays): its planes are filled from the transposed read, so that the product is Sigma_1 Sigma_2
+    // on every route (the float64 routes and the reference form sigma1.dot(sigma2), fad.py:88)
+    const bool transposed = !acc && set == 1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) m[q] = Mrow[q];
+    for (int q = 0; q < 4; ++q) m[q] = transposed ? M[(int64_t)(k0 + q) * d + row] : Mrow[q];
     if (acc) {
         sr = sum[row];
 #pragma unroll
@@ -264,8 +268,6 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
             if (songs) { st->too_few[0] = 0; st->too_few[1] = 0; st->mean_term = 0.0; }
         }
     }
-    // (Sigma_2 is used as its own transpose: the moments give a bit-for-bit symmetric matrix; for caller-given matrices the
-    //  product formed is Sigma_1 Sigma_2^T, which differs from Sigma_1 Sigma_2 by the asymmetry of the caller's Sigma_2 only)
     uint32_t w[kDigits];
 #pragma unroll
     for (int p = 0; p < kDigits; ++p) w[p] = 0u;

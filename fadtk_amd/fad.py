@@ -68,6 +68,7 @@ def calc_embd_statistics(embd_lst, device: int = 0):
     acc.reset()
     acc.update(embd_lst)
     mu, cov, _ = acc.finalize(ddof=1)
+    acc.release_inputs()                               # (finalize synchronised: the caller's tensor / a large staging area are not kept)
     try:
         in_dtype = embd_lst.dtype if isinstance(embd_lst, np.ndarray) else \
             np.dtype(str(embd_lst.dtype).replace("torch.", ""))
@@ -258,7 +259,8 @@ class FrechetAudioDistance:
         values = None
         try:                                          # (both routes run on the HIP library; only WHERE the frames live differs)
             values = self._score_inf_points_on_device(mu_base, cov_base, embeds, picks)
-        except ImportError:                           # no torch to hold the frames in HBM: host arrays, one point at a time
+        except (ImportError, RuntimeError) as e:      # no torch to hold the frames in HBM, or not enough of it (torch's OOM is a
+            log.info(f"FAD-inf: device route not available ({type(e).__name__}), scoring point by point")      # RuntimeError): host arrays, one point at a time
             values = None
         if values is None:
             values = self._score_inf_points_sequential(mu_base, cov_base, embeds, picks)
@@ -320,10 +322,13 @@ class FrechetAudioDistance:
                     for a in accs[:len(group)]:
                         a.reset()
                     hip.Moments.update_multi(accs[:len(group)], gathered)
-                    jobs = [hip.FrechetJob(base, a, mean_dtype=mean_dtype) for a in accs[:len(group)]]
-                    for k, job in zip(group, jobs):
-                        fad, _ = job.result()
+                    # the group's distances as ONE batch: the launches of the square-root chain carry all of them
+                    scores = hip.FrechetMultiJob([(base, a) for a in accs[:len(group)]], mean_dtype=mean_dtype).result()
+                    for k, (fad, _) in zip(group, scores):
                         values[k] = np.float64(fad)
+                    for a in accs[:len(group)]:        # (the scores are in: the gathered frames need not outlive this group)
+                        a.release_inputs(staging=False)
+                    del gathered
             finally:
                 base.close()
                 for a in accs:

@@ -63,6 +63,14 @@ class Moments:
     def reset(self):
         K.check(self._lib.fad_moments_reset(self._h, self._stream()), "fad_moments_reset")
 
+    def release_inputs(self, staging: bool = True):
+        """Forget the last device tensor fed (kept alive for the enqueued kernels -- call this only after something synchronised,
+        e.g. finalize() or a collected score) and, with ``staging``, give back a host-input staging area above 64 MiB: a cached
+        handle must not pin the caller's frames or a frame-matrix-sized buffer in HBM between calls."""
+        self._keep = None
+        if staging:
+            K.check(self._lib.fad_moments_trim(self._h, 64 << 20), "fad_moments_trim")
+
     def settle(self):
         """Make a pending reset visible in the packed buffer (the zeroing is deferred until something reads it)."""
         K.check(self._lib.fad_moments_settle(self._h, self._stream()), "fad_moments_settle")
@@ -302,8 +310,14 @@ class FrechetJob:
 
     def __del__(self):            # a job dropped without result(): its slot must not stay taken (8 per thread)
         try:
-            if getattr(self, "_job", None) is not None and self._on_owner_thread():
-                self.cancel()
+            if getattr(self, "_job", None) is not None:
+                if self._on_owner_thread():
+                    self.cancel()
+                else:             # the slot is thread-local: it stays taken until its thread ends -- say so instead of failing later
+                    import warnings
+                    warnings.warn("a FrechetJob was dropped on a thread other than the one that created it: its slot (8 per thread "
+                                  "and device) stays busy until that thread ends; call result() or cancel() on the owner thread",
+                                  ResourceWarning, stacklevel=2)
         except Exception:         # noqa: BLE001  interpreter shutdown, library gone
             pass
 

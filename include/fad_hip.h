@@ -150,7 +150,7 @@ typedef struct fad_diag {
                                product), 3: float32 iterations + float64 correction accepted, 0: max_iter */
     int32_t used_eps;       /* 1 if the eps-regularised retry produced the result                */
     int32_t route;          /* with converged == 3: 1 = float32 iterations on the f32 MFMA, 2 = split-float16 iterations + exact
-                               int8-MFMA products (d = 256 / 512 / 768 / 1024); 0 otherwise (all-float64 iteration)        */
+                               int8-MFMA products (d = 256 / 384 / 512 / 768 / 1024); 0 otherwise (all-float64 iteration)  */
     double residual;        /* ||I - Z Y||_F at the last iteration                               */
     double scale;           /* c with Y0 = C1 C2 / c                                             */
     double mean_term;       /* ||mu1 - mu2||^2 in float64                                        */
@@ -276,6 +276,9 @@ int fad_resample_kaiser(const float* wav, int64_t n, int orig_sr, int new_sr, in
  * enabled = 2 records the two events around the tile kernel only (ms_reduce comes back 0): an event record between two
  * kernels costs the stream a few microseconds, and the one behind the reduce sits in front of whatever the caller
  * enqueues next. */
+/* Give back the handle's host-input staging area (and scratch) when it holds more than `keep_bytes`: a handle cached between calls
+ * (fadtk_amd/fad.py keeps one per thread) otherwise pins up to 1 GiB of HBM for the life of its thread.  Synchronises the device. */
+int fad_moments_trim(fad_moments_t* h, int64_t keep_bytes);
 int fad_moments_set_timing(fad_moments_t* h, int enabled);
 int fad_moments_last_timing(fad_moments_t* h, float* ms_main_kernel, float* ms_reduce_kernel,
                             int* kernel_variant);

@@ -1245,3 +1245,26 @@ def test_frechet_multi_job_matches_single_scores(F):
     assert abs(two[0][0] - want[1][0]) <= 2e-9 * abs(want[1][0]) and abs(two[1][0] - want[2][0]) <= 2e-9 * abs(want[2][0])
     for ma, mb in handles:
         ma.close(); mb.close()
+
+
+def test_frechet_fast_chain_forms_sigma1_sigma2_for_an_asymmetric_caller_matrix(F, monkeypatch):
+    """fad_frechet on host matrices -- a slightly ASYMMETRIC cov2 must give the same value on the eight-launch chain as
+    on the float64 route (both form Sigma_1 Sigma_2, fad.py:88); before, the chain digitised cov2 as its own transpose."""
+    from fadtk_amd import hip
+    d = 512
+    rng = np.random.default_rng(31)
+    a = rng.standard_normal((4 * d, d)); b = 1.05 * rng.standard_normal((4 * d, d))
+    c1 = np.cov(a, rowvar=False); c2 = np.cov(b, rowvar=False)
+    c2 = c2 + 2e-3 * np.triu(rng.standard_normal((d, d)), 1)          # asymmetric perturbation
+    mu = np.zeros(d)
+    f_fast, dg = hip.frechet(mu, c1, mu, c2)
+    monkeypatch.setenv("FAD_FRECHET_MIXED", "0")
+    import threading
+    out = {}
+    t = threading.Thread(target=lambda: out.update(r=hip.frechet(mu, c1, mu, c2)))      # (the knob is read once per thread)
+    t.start(); t.join()
+    f64, dg64 = out["r"]
+    assert dg64["route"] == 0
+    assert abs(f_fast - f64) <= 1e-7 * abs(f64), (f_fast, f64, dg, dg64)
+    f_t, _ = hip.frechet(mu, c1, mu, c2.T.copy())
+    assert abs(f_t - f64) <= 1e-2 * abs(f64)                          # (sanity: the transposed matrix is a different, nearby problem)
