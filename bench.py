@@ -325,6 +325,40 @@ def extra_score_inf(fadtk_amd, a_host, b_host):
             "note": "includes the upload of the [100000 x 512] eval frames (102 MB) once per call and the 25 index vectors"}
 
 
+def extra_decaying(torch, hip, device):
+    """What a pair with a DECAYING spectrum costs (covariances of real embeddings decay; config 3's iid recipe is the flat best case):
+    D = 512, N = 100000 per set, Sigma ~ k^-p for p = 0.5, 1, 2 (both sets share the eigenvectors, scripts/probe_illcond.py), so
+    Sigma_1 Sigma_2 ~ k^-2p.  Per spectrum: route, iterations, blocking fad_frechet_from_moments time (median of 5) and the relative
+    difference to the CPU oracle (eig + sqrtm, fad.py:88-92) on the same float16 frames."""
+    from oracle import fad_oracle as O
+    d, n = 512, N_ROWS
+    out = {}
+    g = torch.Generator(device=device); g.manual_seed(77)
+    q, _ = torch.linalg.qr(torch.randn((d, d), generator=g, device=device, dtype=torch.float64))
+    for p in (0.5, 1.0, 2.0):
+        lam = torch.arange(1, d + 1, device=device, dtype=torch.float64) ** (-p / 2.0)
+        a = ((torch.randn((n, d), generator=g, device=device, dtype=torch.float64) * lam) @ q.T).to(torch.float16)
+        b = ((1.05 * torch.randn((n, d), generator=g, device=device, dtype=torch.float64) * lam) @ q.T + 0.01).to(torch.float16)
+        with hip.Moments(d) as ma, hip.Moments(d) as mb:
+            hip.Moments.update_multi([ma, mb], [a, b])
+            for _ in range(2):
+                fad, diag = hip.frechet_from_moments(ma, mb, mean_dtype=FAD_F16)
+            ms = []
+            for _ in range(5):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                fad, diag = hip.frechet_from_moments(ma, mb, mean_dtype=FAD_F16)
+                ms.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        ref = float(O.fad_between(a.cpu().numpy(), b.cpu().numpy()))
+        out[f"k^-{p:g}"] = {"ms": float(np.median(ms)), "ms_spread": spread(ms), "route": int(diag.get("route", 0)) if diag["converged"] == 3 else 0,
+                            "converged": int(diag["converged"]), "iterations": int(diag["iters"]), "fad": float(fad),
+                            "rel_err_vs_oracle": abs(float(fad) - ref) / abs(ref), "oracle_seconds": time.perf_counter() - t0}
+        del a, b
+    out["note"] = ("covariance spectra k^-p of both sets (product k^-2p); route 2 = eight-launch split-float16 chain, 1 = float32 chain, 0 = float64 "
+                   "Newton-Schulz (scaled steps while the tracked lower bound of the spectrum is below 0.9)")
+    return out
+
+
 def extra_host(fadtk_amd, a_host, b_host, fad_ref):
     """SURVEY 8-d3 'with H2D copy': the same score from PAGEABLE numpy arrays through the reference's own call sequence --
     calc_embd_statistics(A), calc_embd_statistics(B), calc_frechet_distance (fad.py:42-120) -- i.e. 2 x 102.4 MB over PCIe inside
@@ -735,7 +769,8 @@ def main():
         for name, fn in (("c4_moments", lambda: extra_c4(torch, hip, device, local_rank)),
                          ("per_song_config5_shape", lambda: extra_c5(torch, hip, device)),
                          ("per_song_config5_encoder_frames", lambda: extra_c5_frames(torch, hip, device)),
-                         ("per_song_config4_shape", lambda: extra_c4_songs(torch, hip, device))):
+                         ("per_song_config4_shape", lambda: extra_c4_songs(torch, hip, device)),
+                         ("frechet_decaying_c3", lambda: extra_decaying(torch, hip, device))):
             try:
                 extra[name] = fn()
             except Exception as e:      # noqa: BLE001  side measurements must never break the bench line
