@@ -100,6 +100,9 @@ struct GemmType {
     int b_upper = 0;        // B is upper triangular (zeros stored below the diagonal): column tile j stops at k < (j + 1) * tile
     int sym = 0;            // the product is known to be symmetric (commuting symmetric factors): only the tiles on and above the
                             // diagonal are computed, each off-diagonal tile is stored twice (a hint: honoured by the 64 x 64 kernel)
+    // Newton-Schulz T product with a per-problem step scale on the DEVICE: when set, problem b reads m = mu[b * mu_stride] and uses
+    // alpha = -0.5 m^3, beta_eye = 1.5 m, gamma = 1.5 m - 0.5 m^3 instead of the three constants above
+    const double* mu = nullptr; int64_t mu_stride = 0;
 };
 // returns the number of partial slots per problem (>0) or a negative fad_status
 // `check` (optional): one extra workgroup per problem runs ns_check_block (ns_check.h) beside the GEMM tiles.

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
                                                   const double* __restrict__ mu1, int64_t m1,
                                                   const double* __restrict__ mu2, int64_t m2, int mean_dtype,
                                                   NsState* __restrict__ st_all, int mean_given = 0,
-                                                  Ns32State* __restrict__ s32 = nullptr) {
+                                                  Ns32State* __restrict__ s32 = nullptr, int allow_scaled = 1) {
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     NsState* st = st_all + b;
@@ -175,6 +175,42 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
         double c = u / 2.5;
         const double wmean = (trA > 0.0) ? trA2 / trA : 0.0;
         if (wmean > c && wmean <= u) c = wmean;
+        // SCALED STEPS for decaying spectra (round 4).  The participation ratio (tr A)^2 / tr(A^2) = (sum lambda)^2 / sum lambda^2
+        // (exact for a non-normal A as well) says how many eigenvalues matter; below d/4 -- the products the low-precision legs
+        // give up on -- the start is c = u (every eigenvalue x^2 of A/c in (0, 1], which the scaled cubic needs) and the lower
+        // end l_0 of the spectrum of sqrt(A/c) is ESTIMATED from a power-law model: the exponent p with PR(p) = (sum k^-p)^2 /
+        // sum k^-2p (sums by the trapezoid rule), x_min = d^(-p/2), a third of that as l_0.  The schedule stays a valid
+        // Newton-Schulz iteration whatever l_0 is: too small only pushes the top of the spectrum further down before it comes back
+        // (at worst the optimal rate for that l_0), too large leaves the eigenvalues below it to the plain growth.
+        // (not on the symmetric per-song route: it hands a song on by the number of PLAIN iterations it needed -- its proxy for a
+        //  spread that sqrt(Sigma_b) at ~1e-10 cannot carry, kSymMaxIter)
+        const bool scaled = allow_scaled && (trA > 0.0) && (trA2 > 0.0) && (trA * trA < 0.25 * (double)d * trA2) && (u > 0.0);
+        double l = 1.0;
+        if (scaled) {
+            c = u;
+            const double pr = trA * trA / trA2, dn = (double)d;
+            auto S = [&](double p) {
+                if (fabs(p - 1.0) < 1e-9) return 0.5 * (1.0 + 1.0 / dn) + log(dn);
+                return 0.5 * (1.0 + pow(dn, -p)) + (pow(dn, 1.0 - p) - 1.0) / (1.0 - p);
+            };
+            double lo = 0.0, hi = 8.0, p = 4.0;
+            for (int it = 0; it < 40; ++it) {
+                p = 0.5 * (lo + hi);
+                const double s1 = S(p), val = s1 * s1 / S(2.0 * p);
+                if (val > pr) lo = p; else hi = p;
+            }
+            l = pow(dn, -0.5 * p) / 3.0;
+            if (l > 0.5) l = 0.5;
+            if (l < 1e-5) l = 1e-5;
+        }
+        for (int k = 0; k < kMaxIter; ++k) {
+            double m = 1.0;
+            if (scaled && l < 0.9) {
+                m = sqrt(3.0 / (1.0 + l + l * l));
+                l = m * l * (3.0 - m * m * l * l) / 2.0;
+            }
+            st->mu[k] = m;
+        }
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(tr1 == tr1) || !(tr2 == tr2) || isinf(tr1) ||
                          isinf(tr2) || !(mean_term == mean_term) || isinf(mean_term);
         st->c = c; st->tr1 = tr1; st->tr2 = tr2; st->mean_term = mean_term;
@@ -214,14 +250,14 @@ __global__ __launch_bounds__(256) void ns_first(const double* __restrict__ Aall,
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double e2 = 0.0;
     if (g < (int64_t)d * d) {
-        const double inv = 1.0 / st[b].c;
+        const double inv = 1.0 / st[b].c, m = st[b].mu[0], m3 = m * m * m;       // (a scaled first step: T0 = 1.5 mu I - 0.5 mu^3 Y0)
         const int r = (int)(g / d), c = (int)(g - (int64_t)r * d);
         const double y = Aall[(int64_t)b * d * d + g] * inv;
-        const double t = (r == c ? 1.5 : 0.0) - 0.5 * y;
+        const double t = (r == c ? 1.5 * m : 0.0) - 0.5 * m3 * y;
         Y0[b * stride + g] = y;
         T[b * stride + g] = t;
         Z1[b * stride + g] = t;
-        const double e = t - (r == c ? 1.0 : 0.0);
+        const double e = t - (r == c ? 1.5 * m - 0.5 * m3 : 0.0);
         e2 = e * e;
     }
     const double s = block_sum(e2, red);
@@ -405,7 +441,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
         hipLaunchKernelGGL(ns_tilestats, dim3(nb, nb, (unsigned)B), dim3(256), 0, stream, A, d, pb.cov1, pb.s_cov1, pb.cov2,
                            pb.s_cov2, tilestats, dstates);
         hipLaunchKernelGGL(ns_prepare, dim3((unsigned)B), dim3(256), 0, stream, tilestats, d, (int)nb, pb.mu1, pb.s_mu1, pb.mu2,
-                           pb.s_mu2, pb.mean_dtype, dstates);
+                           pb.s_mu2, pb.mean_dtype, dstates, 0, (Ns32State*)nullptr, pb.sym ? 0 : 1);
     }
     // iteration 0 without GEMMs for T and Z (Z0 = I): Y0, T0, Z1 = T0, residual partials
     const int nslots0 = (int)cdiv(dd, 256);
@@ -428,6 +464,7 @@ static int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hip
             int nslots = nslots0;
             if (k > 0) {
                 g[0] = {Z[cur], dd, Y[cur], dd, T, dd, -0.5, 1.5, 1.0, partials, 0, pb.sym};
+                g[0].mu = &dstates[0].mu[k]; g[0].mu_stride = (int64_t)(sizeof(NsState) / sizeof(double));      // the step's scale: on the device
                 nslots = gemm_f64_launch(d, g, 1, B, skip_t, kStateInts, stream, device, pstride);
                 if (nslots < 0) return nslots;
             }

@@ -29,6 +29,7 @@ struct GemmArgs {
     const double* A[2]; const double* B[2]; double* C[2];
     int64_t sa[2], sb[2], sc[2];         // per-batch-index strides (elements); 0 = shared operand
     double alpha[2], beta_eye[2], gamma[2];
+    const double* mu[2]; int64_t mu_stride[2];      // GemmType::mu (device-side step scale of the T product), or nullptr
     double* partials[2];                 // [batch][slots] or nullptr
     const int* skip;                     // skip[batch_index * skip_stride] != 0 -> problem is finished
     int skip_stride;
@@ -121,7 +122,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_f64_kernel(int d, GemmArgs g) {
         if (g.sel && (*g.sel & 1)) { A32 = g.A32_alt; B32 = g.B32_alt; }
     }
     double* C = g.C[zi] + zb * g.sc[zi];
-    const double alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
+    double alpha = g.alpha[zi], beta_eye = g.beta_eye[zi], gamma = g.gamma[zi];
+    if (g.mu[zi]) {                                 // scaled Newton-Schulz step: T = 1.5 m I - 0.5 m^3 Z Y
+        const double m = g.mu[zi][zb * g.mu_stride[zi]];
+        alpha = -0.5 * m * m * m; beta_eye = 1.5 * m; gamma = beta_eye + alpha;
+    }
 
     // ---- tile coordinates (XCD-aware when the tile grid splits evenly into 2 x 4 blocks)
     const int t = gridDim.x;
@@ -451,6 +456,7 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
             g.C[i] = types[i].C + done * types[i].sc;
             g.sa[i] = types[i].sa; g.sb[i] = types[i].sb; g.sc[i] = types[i].sc;
             g.alpha[i] = types[i].alpha; g.beta_eye[i] = types[i].beta_eye; g.gamma[i] = types[i].gamma;
+            g.mu[i] = types[i].mu ? types[i].mu + done * types[i].mu_stride : nullptr; g.mu_stride[i] = types[i].mu_stride;
             g.partials[i] = types[i].partials ? types[i].partials + done * (partial_stride > 0 ? partial_stride : slots) : nullptr;
         }
         g.skip = skip ? skip + done * skip_stride : nullptr;

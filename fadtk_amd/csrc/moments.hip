@@ -47,7 +47,8 @@ struct fad_moments {
     fad::DevBuf cvec;                      // float16 rows: per-split column shifts for the guard's second pass
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
     fad::DevBuf blocktab;                  // 256-column-slab kernel: where every 32 x 32 block's partial sums sit (tile256_roles.h)
-    int blocktab_nsb = 0;
+    int blocktab_nsb = 0, blocktab_plan = -1;
+    int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
     void* tab_host = nullptr; size_t tab_host_cap = 0;     // pinned staging of the segment tables of update_segmented
     hipEvent_t tab_ev = nullptr;           // recorded behind the upload of tab_host: the next call waits before rewriting it
@@ -102,9 +103,9 @@ static int ensure_kernel_attrs(int device) {
     if (device < 0 || device >= 64) return set_error(FAD_ERR_INVALID, "device %d out of range", device);
     if (done[device]) return FAD_OK;
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256LdsCombined));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256LdsCombined));
     for (int dt : {FAD_F16, FAD_BF16}) {
         for (bool fast : {false, true}) {
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
@@ -206,26 +207,26 @@ static int stage_tables(fad_moments* h, size_t bytes, char** host) {
 // D >= 512, float16 rows: the 256-column-slab kernel (moments_tile256.h).  Same three launches as the 128 x 128 path -- tile
 // kernel, gated second pass of the shift guard, reduce -- with ONE workgroup per CU and work items of 64-72 blocks.
 // ------------------------------------------------------------------------------------------
-static int block_table(fad_moments* h, int nsb, hipStream_t st) {
-    if (h->blocktab_nsb == nsb) return FAD_OK;
+static int block_table(fad_moments* h, int nsb, int plan, hipStream_t st) {
+    if (h->blocktab_nsb == nsb && h->blocktab_plan == plan) return FAD_OK;
     // host copies live for the life of the process: the upload below reads them asynchronously
     static std::mutex mu;
-    static std::vector<t256::BlockSrc>* cache[t256::MAX_SB + 1] = {nullptr};
+    static std::vector<t256::BlockSrc>* cache[2][t256::MAX_SB + 1] = {{nullptr}};
     const std::vector<t256::BlockSrc>* tab = nullptr;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!cache[nsb]) {
+        if (!cache[plan][nsb]) {
             auto* v = new (std::nothrow) std::vector<t256::BlockSrc>((size_t)t256::n_blocks(t256::NFR * nsb));
             if (!v) return set_error(FAD_ERR_ALLOC, "out of host memory");
-            if (!t256::build_block_table(nsb, v->data())) { delete v; return set_error(FAD_ERR_INVALID, "block table of %d superblocks is inconsistent", nsb); }
-            cache[nsb] = v;
+            if (!t256::build_block_table(nsb, v->data(), plan)) { delete v; return set_error(FAD_ERR_INVALID, "block table of %d superblocks is inconsistent", nsb); }
+            cache[plan][nsb] = v;
         }
-        tab = cache[nsb];
+        tab = cache[plan][nsb];
     }
     const size_t bytes = tab->size() * sizeof(t256::BlockSrc);
     FAD_TRY(h->blocktab.reserve(bytes));
     FAD_HIP_TRY(hipMemcpyAsync(h->blocktab.p, tab->data(), bytes, hipMemcpyHostToDevice, st));
-    h->blocktab_nsb = nsb;
+    h->blocktab_nsb = nsb; h->blocktab_plan = plan;
     return FAD_OK;
 }
 
@@ -245,16 +246,26 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
     T256Launch L;
     memset(&L, 0, sizeof(L));
     L.nsets = count; L.d = d; L.nsb = nsb;
-    L.NT = t256::item_types(nsb, L.type, L.sa, L.sb);
-    const bool has_z = (nsb & 1) != 0;
+    // Which decomposition: the combined items (plan 1) halve the partial tiles -- 35 instead of 70 MB per launch, written here and
+    // read by the reduce -- at 2.5 instead of 2 slab reads per row; that pays while the partial tiles are a large part of the
+    // launch's traffic, i.e. for D = 512 with few rows per workgroup (config 3: a third).  Larger D keeps plan 0.
+    int64_t rows_total = 0;
+    for (int i = 0; i < count; ++i) rows_total += n[i];
+    int which = h0->tile256_plan;
+    if (which < 0) which = 0;       // (measured, profiles/r04c_plans.txt: at config 3 the 4 us the reduce gains the tile kernel loses; plan 1 is opt-in)
+    (void)rows_total;
+    L.plan = which;
+    L.NT = t256::item_types(nsb, L.type, L.sa, L.sb, which);
+    const bool has_z = which == 1 || (nsb & 1) != 0;
+    const size_t lds_bytes = which == 1 ? kT256LdsCombined : kT256Lds;
     SplitPlan plan[kMaxSets];
     plan_splits(count, n, d, t256::SB, has_z ? 2 * T2_KB : T2_KB, h0->n_cu, 1, 256, 8192, plan, L.NT);
-    FAD_TRY(block_table(h0, nsb, st));
+    FAD_TRY(block_table(h0, nsb, which, st));
     R256Launch R;
     memset(&R, 0, sizeof(R));
     R.table = static_cast<const t256::BlockSrc*>(h0->blocktab.p);
     R.d = d; R.nsb = nsb; R.NT = L.NT; R.nblk = t256::n_blocks(t256::NFR * nsb);
-    R.z_sb = has_z ? (uint8_t)(nsb - 1) : (uint8_t)255;
+    R.two_mask = which == 1 ? ((1u << nsb) - 1u) : ((nsb & 1) ? (1u << (nsb - 1)) : 0u);
     int item = 0, max_s = 0;
     bool any_guard = false;
     for (int i = 0; i < count; ++i) {
@@ -285,10 +296,10 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
     }
     L.total = item;
     if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), kT256Lds, st, L);
+    hipLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
     if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
     if (any_guard)       // second pass of the shift guard: same geometry, gated per set; rewrites the flagged sets' partials and column sums
-        hipLaunchKernelGGL((moments_tile256<FAD_F16, true>), dim3((unsigned)L.total), dim3(512), kT256Lds, st, L);
+        hipLaunchKernelGGL((moments_tile256<FAD_F16, true>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
     R.sl = (max_s > 32) ? 16 : (max_s > 8) ? 4 : 1;
     const int G = 256 / R.sl;
     const int blocks = (int)cdiv((int64_t)R.nblk * 256, G) + (int)cdiv(d, 64);
@@ -577,6 +588,8 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     h->force_generic = fg && fg[0] == '1';
     const char* t2 = getenv("FAD_MOMENTS_TILE256");
     h->tile256 = !(t2 && t2[0] == '0');
+    const char* pl = getenv("FAD_MOMENTS_PLAN");
+    h->tile256_plan = (pl && (pl[0] == '0' || pl[0] == '1')) ? pl[0] - '0' : -1;
     const char* nc = getenv("FAD_MOMENTS_CUS");        // plan for fewer CUs than the device has (a CU-masked stream)
     if (nc && atoi(nc) >= 8 && atoi(nc) < h->n_cu) h->n_cu = atoi(nc);
     *out = h;

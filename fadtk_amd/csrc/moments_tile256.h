@@ -29,7 +29,8 @@ constexpr int T2_KB = 32;                   // rows per slab and stage
 constexpr int T2_NST = T2_NST_VALUE;        // ring depth (scripts/probes/tile256_bench.hip builds variants)
 constexpr int T2_SUB = T2_KB * 16;          // uint4 per [32][128] sub-slab
 constexpr int T2_STAGE = 4 * T2_SUB;        // A0 A1 B0 B1: 32 KiB
-constexpr size_t kT256Lds = (size_t)T2_NST * T2_STAGE * sizeof(uint4);      // 128 KiB
+constexpr size_t kT256Lds = (size_t)T2_NST * T2_STAGE * sizeof(uint4);      // 128 KiB (plan 0)
+constexpr size_t kT256LdsCombined = 144 * 1024;                              // plan 1: three 48 KiB stages of an XZ item = the 36 blocks a ZC quartet hands over
 
 struct T256Set {
     const void* E; int64_t n, ld, rows_per_split;
@@ -43,6 +44,7 @@ struct T256Launch {
     T256Set set[kMaxSets];
     int nsets, d, nsb, NT, total;
     uint8_t type[t256::MAX_TYPES], sa[t256::MAX_TYPES], sb[t256::MAX_TYPES];
+    int plan;                               // 0: P / Q / X / Z items, 1: ZC / XZ (tile256_roles.h)
 };
 
 // Workgroup barrier that the instruction scheduler may not move anything across (MFMAs have no memory effects: without the
@@ -103,61 +105,85 @@ template <int KIND> __device__ __forceinline__ float t2_sumsq8(const uint4& v, f
     return s;
 }
 
-// One wave's share of a work item.  Everything role-dependent is a compile-time constant; `slabsel[i]` (0 = slab A, 1 = slab B)
-// and `fragid[i]` (0..7 within the superblock) say where fragment F[i] comes from.
-template <int KIND, int ROLE, bool SHIFT>
+// One wave's share of a work item.  Everything role-dependent is a compile-time constant.  XZT = the XZ items' stage layout (XR
+// role only): per quartet three 8 KiB sub-slabs -- the 128-column A half, then the 256 B-side columns -- of ITS 32 rows; six
+// sub-slabs = 48 KiB per 64-row stage, ring of three, six LDS-DMA pieces per wave and stage.  Otherwise: four sub-slabs (slab A,
+// slab B) = 32 KiB per stage, ring of T2_NST, four pieces per wave.
+template <int KIND, int ROLE, bool SHIFT, bool XZT>
 __device__ __forceinline__ void tile256_wave(
     const T256Launch& L, const T256Set& s, int split, int ti, int type, int sa, int sb, const t256::WaveJob job, uint4* smem) {
     using RD = t256::RoleDef<ROLE>;
     constexpr int NF = RD::NF, NB = RD::NB;
     static_assert(!SHIFT || KIND == FAD_F16, "the shifted pass is written for float16 rows");
+    static_assert(!XZT || ROLE == t256::XR, "the XZ layout carries XR waves only");
+    constexpr int NSTG = XZT ? 3 : T2_NST;              // ring depth
+    constexpr int NSUB = XZT ? 6 : 4;                   // sub-slabs per stage
+    constexpr int STG = NSUB * T2_SUB;                  // uint4 per stage
+    constexpr int LPS = XZT ? 6 : 4;                    // LDS-DMA pieces per wave and stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quartet = wave >> 2;
     const int li = lane & 31, kg = lane >> 5;
     const uint16_t* __restrict__ E = static_cast<const uint16_t*>(s.E);
     const int64_t ld = s.ld;
     const int d = L.d;
-    const bool zt = type == t256::TYPE_Z;
+    // Z, ZC, XZ: the quartets take alternate 32-row stages (a "stage" of the loop below covers 64 rows)
+    const bool two_rows = type >= t256::TYPE_Z;
+    const bool zlike = type == t256::TYPE_Z || type == t256::TYPE_ZC;
+    const int xh = XZT ? (type - t256::TYPE_XZ0) : 0;                            // XZ: which 128-row half of the tile
     const int64_t k_begin = (int64_t)split * s.rows_per_split;
     const int64_t k_end = (k_begin + s.rows_per_split < s.n) ? k_begin + s.rows_per_split : s.n;
-    const int rows_per_stage = zt ? 2 * T2_KB : T2_KB;                          // Z: slab B = the NEXT 32 rows of slab A's columns
+    const int rows_per_stage = two_rows ? 2 * T2_KB : T2_KB;
     const int nkb = (int)((k_end - k_begin + rows_per_stage - 1) / rows_per_stage);
-    const int colA = t256::SB * sa, colB = t256::SB * (zt ? sa : sb);           // first column behind slab A / slab B
+    const int colA = t256::SB * sa, colB = t256::SB * (zlike ? sa : sb);        // first column behind slab A / slab B
+    const int my_rowoff = two_rows ? T2_KB * quartet : 0;                       // rows of a stage this wave's fragments come from
 
-    // ---- loads: wave w fills rows 16 (w & 1) + 4 q + (lane >> 4), q = 0..3, of sub-slab w >> 1 (0, 1: slab A; 2, 3: slab B)
-    const int sub = wave >> 1;
-    const int ld_col0 = (sub < 2 ? colA : colB) + 128 * (sub & 1);
-    const int ld_rowoff = 16 * (wave & 1) + ((zt && sub >= 2) ? T2_KB : 0);
+    // ---- loads.  Piece p of a wave: (sub-slab, 4-row group) -> LDS uint4 offset inside the stage, source column and row offset
     const int lrow = lane >> 4, lchunk = (lane & 15) ^ (lrow << 2);             // swizzle on the SOURCE side (LDS-DMA writes lane-linear)
-    const bool col_ok = (ld_col0 + lchunk * 8) < d;                             // d % 8 == 0: a chunk is in or out as a whole
     const uint32_t voff = (uint32_t)(((int64_t)lrow * ld + lchunk * 8) * 2);
     const uint32_t smem_lds = (uint32_t)(size_t)(lptr_t)smem;
     const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(&g_zero16);
+    auto piece_geom = [&](int p, int& lds_u4, int& col0, int& rowoff) {
+        if constexpr (XZT) {
+            const int idx = LPS * wave + p;                                     // 0..47: sub-slab idx / 8, row group idx % 8
+            const int ss = idx >> 3, rg = idx & 7, q = ss / 3, kind = ss - 3 * q;
+            lds_u4 = ss * T2_SUB + 64 * rg;
+            col0 = kind == 0 ? colA + 128 * xh : colB + 128 * (kind - 1);
+            rowoff = T2_KB * q + 4 * rg;
+        } else {
+            const int sub = wave >> 1;                                          // 0, 1: slab A; 2, 3: slab B
+            lds_u4 = sub * T2_SUB + 256 * (wave & 1) + 64 * p;
+            col0 = (sub < 2 ? colA : colB) + 128 * (sub & 1);
+            rowoff = 16 * (wave & 1) + 4 * p + ((zlike && sub >= 2) ? T2_KB : 0);
+        }
+    };
     const bool cols_full = (colA + t256::SB <= d) && (colB + t256::SB <= d) && ld < ((int64_t)1 << 26);
-    auto piece_fast = [&](int kb, int q) {     // piece q (rows 4 q ..) of this wave's share of stage kb: SGPR base + 32-bit lane offset
+    auto piece_fast = [&](int kb, int p) {     // SGPR base + 32-bit lane offset
 #ifdef T2_ABL_NODMA                          // ablation: the ring is filled once and never refilled
-        if (kb >= T2_NST - 1) return;
+        if (kb >= NSTG - 1) return;
 #endif
-        const uint32_t dst0 = smem_lds + (uint32_t)(((kb % T2_NST) * T2_STAGE + sub * T2_SUB + 256 * (wave & 1)) * 16);
-        const uint16_t* src0 = E + (k_begin + (int64_t)kb * rows_per_stage + ld_rowoff) * ld + ld_col0;
-        const uint64_t sbq = (uint64_t)(src0 + (int64_t)(4 * q) * ld);
+        int lds_u4, col0, rowoff;
+        piece_geom(p, lds_u4, col0, rowoff);
+        const uint64_t sbq = (uint64_t)(E + (k_begin + (int64_t)kb * rows_per_stage + rowoff) * ld + col0);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sbq);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sbq >> 32));
         const uint64_t ub = ((uint64_t)hi << 32) | lo;
-        const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(64 * q * 16));
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane(smem_lds + (uint32_t)(((kb % NSTG) * STG + lds_u4) * 16));
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
     };
     auto issue_fast = [&](int kb) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) piece_fast(kb, q);
+        for (int p = 0; p < LPS; ++p) piece_fast(kb, p);
     };
     auto issue_slow = [&](int kb) {         // edge stages: per-lane 64-bit addresses, rows / columns out of range read the zero block
-        const uint32_t dst0 = smem_lds + (uint32_t)(((kb % T2_NST) * T2_STAGE + sub * T2_SUB + 256 * (wave & 1)) * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t r = k_begin + (int64_t)kb * rows_per_stage + ld_rowoff + 4 * q + lrow;
-            const uint16_t* src = (r < k_end && col_ok) ? E + r * ld + ld_col0 + lchunk * 8 : zsrc;
-            const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(64 * q * 16));
+        for (int p = 0; p < LPS; ++p) {
+            int lds_u4, col0, rowoff;
+            piece_geom(p, lds_u4, col0, rowoff);
+            const int64_t r = k_begin + (int64_t)kb * rows_per_stage + rowoff + lrow;
+            const bool col_ok = (col0 + lchunk * 8) < d;                        // d % 8 == 0: a chunk is in or out as a whole
+            const uint16_t* src = (r < k_end && col_ok) ? E + r * ld + col0 + lchunk * 8 : zsrc;
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(smem_lds + (uint32_t)(((kb % NSTG) * STG + lds_u4) * 16));
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
         }
     };
@@ -169,16 +195,26 @@ __device__ __forceinline__ void tile256_wave(
     const int tr_row = 8 * (grp >> 1) + (t16 >> 2), tr_col = 16 * (grp & 1) + 4 * (t16 & 3);
     uint32_t foff[NF];
     int fcol[NF];                            // global column of this lane's element of F[i] (column sums, shifts)
-    int fslab[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
-        int slab, f;
-        if constexpr (ROLE == t256::XR) { slab = (i < 4) ? 0 : 1; f = (i < 4) ? job.a0 + i : job.b0 + (i - 4); }
-        else { slab = job.slab; f = RD::frag[i]; }
+        int subslab, f;                      // which 8 KiB sub-slab of the stage, and the fragment's index in its superblock
+        bool from_a;
+        if constexpr (XZT) {
+            from_a = i < 4;
+            f = from_a ? 4 * xh + i : job.b0 + (i - 4);
+            subslab = 3 * quartet + (from_a ? 0 : 1 + (f >> 2));
+        } else if constexpr (ROLE == t256::XR) {
+            from_a = i < 4;
+            f = from_a ? job.a0 + i : job.b0 + (i - 4);
+            subslab = (from_a ? 0 : 2) + (f >> 2);
+        } else {
+            from_a = job.slab == 0;
+            f = RD::frag[i];
+            subslab = 2 * job.slab + (f >> 2);
+        }
         const int col = 32 * (f & 3) + tr_col;
-        foff[i] = (uint32_t)((2 * slab + (f >> 2)) * (T2_SUB * 16) + tr_row * 256 + (((col >> 3) ^ ((tr_row & 3) << 2)) << 4) + ((col >> 2) & 1) * 8);
-        fcol[i] = (slab == 0 ? colA : colB) + 32 * f + li;
-        fslab[i] = slab;
+        foff[i] = (uint32_t)(subslab * (T2_SUB * 16) + tr_row * 256 + (((col >> 3) ^ ((tr_row & 3) << 2)) << 4) + ((col >> 2) & 1) * 8);
+        fcol[i] = (from_a ? colA : colB) + 32 * f + li;
     }
     uint32_t cs[NF];                         // SHIFT: this lane's shift per fragment, packed twice
 #pragma unroll
@@ -188,8 +224,8 @@ __device__ __forceinline__ void tile256_wave(
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const uint32_t h = cv[fcol[i]]; cs[i] = h | (h << 16); }
     }
-    auto rows_left_at = [&](int kb, int ks, int slab) -> int64_t {
-        return k_end - (k_begin + (int64_t)kb * rows_per_stage + ((zt && slab) ? T2_KB : 0) + ks * 16 + 8 * kg);
+    auto rows_left_at = [&](int kb, int ks) -> int64_t {
+        return k_end - (k_begin + (int64_t)kb * rows_per_stage + my_rowoff + ks * 16 + 8 * kg);
     };
 
     f32x16 acc[NB];
@@ -204,28 +240,29 @@ __device__ __forceinline__ void tile256_wave(
     double csum[2] = {0.0, 0.0};
     float csq[2] = {0.f, 0.f};
 
-    uint4 F0[NF], F1[NF];                    // the fragments of the stage in hand: k-step 0 / 1 (SHIFT: see mma below)
-    // LOAD half of a stage: every transpose read of the stage, then this wave's four LDS-DMA pieces of stage kb + NST - 1
+    uint4 F0[NF], F1[NF];                    // the fragments of the stage in hand: k-step 0 / 1
+    // LOAD half of a stage: every transpose read of the stage
     auto load_frags = [&](int kb) {
 #ifdef T2_ABL_NOREAD                         // ablation (scripts/probes/tile256_bench.hip): no transpose reads
         if (kb > 0) return;
 #endif
-        const uint32_t base = smem_lds + (uint32_t)((kb % T2_NST) * T2_STAGE * 16);
+        const uint32_t base = smem_lds + (uint32_t)((kb % NSTG) * STG * 16);
 #pragma unroll
         for (int i = 0; i < NF; ++i) F0[i] = t2_frag(base + foff[i]);
 #pragma unroll
         for (int i = 0; i < NF; ++i) F1[i] = t2_frag(base + foff[i] + 4096);
     };
-    // MFMA half of a stage
+    // MFMA half of a stage; `refill`: this wave's LDS-DMA pieces of stage kb + NSTG - 1 go BETWEEN the MFMAs (a piece holds the wave
+    // ~60 cycles among bare MFMAs, 100-185 among the transpose reads of the load half -- MI355X_MICROARCH.md)
     auto mma = [&](int kb, auto refill) {
-        if constexpr (SHIFT) {
-            if (decltype(refill)::value) issue_fast(kb + T2_NST - 1);              // x - c = x' + e, one k-step at a time (register budget)
+        if constexpr (SHIFT) {              // x - c = x' + e, one k-step at a time (register budget)
+            if (decltype(refill)::value) issue_fast(kb + NSTG - 1);
             const bool full = kb < nfast;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 X[NF], R[NF];
 #pragma unroll
-                for (int i = 0; i < NF; ++i) t2_split2(ks ? F1[i] : F0[i], cs[i], full ? 8 : rows_left_at(kb, ks, fslab[i]), X[i], R[i]);
+                for (int i = 0; i < NF; ++i) t2_split2(ks ? F1[i] : F0[i], cs[i], full ? 8 : rows_left_at(kb, ks), X[i], R[i]);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     acc[b] = mfma_h16<KIND>(X[RD::fa[b]], X[RD::fb[b]], acc[b]);
@@ -239,31 +276,22 @@ __device__ __forceinline__ void tile256_wave(
             }
             return;
         }
-        // hot stages: this wave's four LDS-DMA pieces of stage kb + NST - 1 go BETWEEN the MFMAs (a piece holds the wave ~60
-        // cycles among bare MFMAs, 100-185 among the transpose reads of the load half -- MI355X_MICROARCH.md)
 #ifdef T2_ABL_NOMMA                          // ablation: no MFMAs (the fragments stay live through a cheap VALU use)
 #pragma unroll
         for (int i = 0; i < NF; ++i) acc[0][i] += __uint_as_float((F0[i].x ^ F0[i].y ^ F0[i].z ^ F0[i].w ^ F1[i].x ^ F1[i].y ^ F1[i].z ^ F1[i].w) & 0x007fffffu);
-        if (decltype(refill)::value) issue_fast(kb + T2_NST - 1);
+        if (decltype(refill)::value) issue_fast(kb + NSTG - 1);
         return;
 #endif
+        constexpr int PH = LPS / 2;          // pieces per k-step: behind MFMA 1, 3 (, 5)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            acc[b] = mfma_h16<KIND>(F0[RD::fa[b]], F0[RD::fb[b]], acc[b]);
-#ifndef T2_OPT_DMA_IN_LOAD
-            if (decltype(refill)::value && (b == 1 || b == 5)) {
-                __builtin_amdgcn_sched_barrier(0); piece_fast(kb + T2_NST - 1, b == 1 ? 0 : 1); __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
-        }
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            acc[b] = mfma_h16<KIND>(F1[RD::fa[b]], F1[RD::fb[b]], acc[b]);
-#ifndef T2_OPT_DMA_IN_LOAD
-            if (decltype(refill)::value && (b == 1 || b == 5)) {
-                __builtin_amdgcn_sched_barrier(0); piece_fast(kb + T2_NST - 1, b == 1 ? 2 : 3); __builtin_amdgcn_sched_barrier(0);
+            for (int b = 0; b < NB; ++b) {
+                acc[b] = ks ? mfma_h16<KIND>(F1[RD::fa[b]], F1[RD::fb[b]], acc[b]) : mfma_h16<KIND>(F0[RD::fa[b]], F0[RD::fb[b]], acc[b]);
+                if (decltype(refill)::value && (b & 1) && (b >> 1) < PH) {
+                    __builtin_amdgcn_sched_barrier(0); piece_fast(kb + NSTG - 1, PH * ks + (b >> 1)); __builtin_amdgcn_sched_barrier(0);
+                }
             }
-#endif
         }
 #ifndef T2_OPT_NOCOLSUM
         if constexpr (CSUM) {
@@ -275,41 +303,32 @@ __device__ __forceinline__ void tile256_wave(
         }
 #endif
     };
-    // this wave's pieces of stage `kb + 1` have landed once at most (stages issued beyond it) x 4 of its loads are outstanding
+    // this wave's pieces of stage `kb + 1` have landed once at most (stages issued beyond it) x LPS of its loads are outstanding
     auto wait_next = [&](int kb) {
         if (kb + 1 >= nkb) return;
-        const int last = (kb + T2_NST - 1 < nkb - 1) ? kb + T2_NST - 1 : nkb - 1;       // youngest stage issued so far
-        wait_vmcnt_upto<4>(last - (kb + 1));
+        const int last = (kb + NSTG - 1 < nkb - 1) ? kb + NSTG - 1 : nkb - 1;         // youngest stage issued so far
+        wait_vmcnt_upto<LPS>(last - (kb + 1));
     };
-    static_assert(T2_NST <= 8, "wait_vmcnt_upto counts at most seven stages");
+    static_assert(NSTG <= 8, "wait_vmcnt_upto counts at most seven stages");
 
-#ifndef T2_OPT_NO_PINGPONG
     // ---- PING-PONG.  The two waves of a SIMD are wave w and wave w + 4: the quartets run HALF A STAGE APART, so that while one
-    // wave of every SIMD is in its load half (24 transpose reads + 4 LDS-DMA pieces, each of which holds the wave for 100+
-    // cycles) the other one keeps the matrix pipe busy with its 16-18 MFMAs.  (With both in the same phase -- the first version
-    // -- a stage took ~2600 cycles: DMA issue, reads and 1088 cycles of MFMAs one after the other.)  Half-steps h, a barrier b_h
-    // after each:    quartet 0:  L(0) b0 M(0) b1 L(1) b2 M(1) b3 ...          quartet 1:  --  b0 L(0) b1 M(0) b2 L(1) b3 ...
+    // wave of every SIMD is in its load half (transpose reads) the other one keeps the matrix pipe busy with its 16-18 MFMAs and
+    // issues its LDS-DMA pieces between them.  (With both in the same phase -- the first version -- a stage took ~2600 cycles: DMA
+    // issue, reads and 1088 cycles of MFMAs one after the other.)  Half-steps h, a barrier b_h after each:
+    //     quartet 0:  L(0) b0 M(0) b1 L(1) b2 M(1) b3 ...          quartet 1:  --  b0 L(0) b1 M(0) b2 L(1) b3 ...
     //   * a wave waits for its OWN pieces of stage k + 1 at the end of L(k): both quartets have done so before b_{2k+1}, the
     //     barrier in front of the first L(k + 1);
-    //   * the slot of stage k - 1 is refilled in L(k): its last readers (quartet 1 in L(k - 1), reads drained by lgkmcnt(0))
+    //   * the slot of stage k - 1 is refilled in M(k): its last readers (quartet 1 in L(k - 1), reads drained by lgkmcnt(0))
     //     are behind b_{2k-1}.
-    const int quartet = wave >> 2;
-    for (int s0 = 0; s0 < T2_NST - 1 && s0 < nkb; ++s0) issue(s0);
-    {
-        wait_vmcnt_upto<4>(((nkb < T2_NST - 1) ? nkb : T2_NST - 1) - 1);               // stages issued beyond stage 0
-    }
+    for (int s0 = 0; s0 < NSTG - 1 && s0 < nkb; ++s0) issue(s0);
+    wait_vmcnt_upto<LPS>(((nkb < NSTG - 1) ? nkb : NSTG - 1) - 1);                    // stages issued beyond stage 0
     t2_phase_barrier();
-    if (quartet == 1) t2_phase_barrier();                                     // b0
-    const int hot = nfast - (T2_NST - 1) > 0 ? nfast - (T2_NST - 1) : 0;               // stages whose refill is a whole stage
+    if (quartet == 1) t2_phase_barrier();                                               // b0
+    const int hot = nfast - (NSTG - 1) > 0 ? nfast - (NSTG - 1) : 0;                  // stages whose refill is a whole stage
     int kb = 0;
     for (; kb < hot; ++kb) {                 // no branches: the refill (SGPR-base pieces) rides in the MFMA half
         load_frags(kb);
-#ifdef T2_OPT_DMA_IN_LOAD
-        issue_fast(kb + T2_NST - 1);
-        wait_vmcnt<4 * (T2_NST - 2)>();
-#else
-        wait_vmcnt<4 * (T2_NST - 3)>();      // in flight at this point: stages kb + 1 .. kb + NST - 2; kb + 1 must have landed
-#endif
+        wait_vmcnt<LPS * (NSTG - 3)>();      // in flight at this point: stages kb + 1 .. kb + NSTG - 2; kb + 1 must have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         t2_phase_barrier();
         mma(kb, std::true_type{});
@@ -317,42 +336,56 @@ __device__ __forceinline__ void tile256_wave(
     }
     for (; kb < nkb; ++kb) {
         load_frags(kb);
-        if (kb + T2_NST - 1 < nkb) issue(kb + T2_NST - 1);
+        if (kb + NSTG - 1 < nkb) issue(kb + NSTG - 1);
         wait_next(kb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         t2_phase_barrier();
         mma(kb, std::false_type{});
         if (!(quartet == 1 && kb == nkb - 1)) t2_phase_barrier();
     }
-#else
-    // (probe only) both quartets in the same phase: wait, barrier, refill, reads, MFMAs
-    for (int s0 = 0; s0 < T2_NST - 1 && s0 < nkb; ++s0) issue(s0);
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int ahead = (nkb - 1 - kb < T2_NST - 2) ? (nkb - 1 - kb) : (T2_NST - 2);
-        if (ahead >= 2) wait_vmcnt<8>(); else if (ahead == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kb + T2_NST - 1 < nkb) issue(kb + T2_NST - 1);
-        load_frags(kb);
-        mma(kb, std::false_type{});
+
+    // ---- combined items (ZC, XZ): quartet 1 hands its blocks to quartet 0 through LDS (the ring is idle: every piece issued
+    // has landed and been read), which adds them to its own -- 36 / 32 partial blocks per workgroup instead of 72 / 64
+    const bool combined = t256::combined_type(type);
+    if (combined) {
+        float4* box = reinterpret_cast<float4*>(smem) + (size_t)(wave & 3) * (9 * 256);
+        if (quartet == 1) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    box[(b * 4 + q) * 64 + lane] = make_float4(acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]);
+        }
+        __syncthreads();
+        if (quartet == 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = box[(b * 4 + q) * 64 + lane];
+                    acc[b][4 * q] += v.x; acc[b][4 * q + 1] += v.y; acc[b][4 * q + 2] += v.z; acc[b][4 * q + 3] += v.w;
+                }
+        }
     }
-#endif
 
     // ---- epilogue: blocks, fragment major -- float4 (q, lane) of block b = registers 4q..4q+3 = rows 8q + 4 (lane >> 5) + 0..3
     // of column lane & 31
-    float4* out = reinterpret_cast<float4*>(s.partials + ((int64_t)split * L.NT + ti) * t256::ITEM_STRIDE) + (size_t)(9 * wave) * 256;
+    if (!combined || quartet == 0) {
+        float4* out = reinterpret_cast<float4*>(s.partials + ((int64_t)split * L.NT + ti) * t256::ITEM_STRIDE) + (size_t)(9 * wave) * 256;
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            out[(b * 4 + q) * 64 + lane] = make_float4(acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]);
+            for (int q = 0; q < 4; ++q)
+                out[(b * 4 + q) * 64 + lane] = make_float4(acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]);
+    }
 
     if constexpr (CSUM) {
-        // column sums of this wave's two fragments over the rows it saw; a Z item's second quartet (slab B) writes the second row
+        // column sums of this wave's two fragments over the rows it saw; the second quartet of a Z / ZC item writes the second row
         const int dpad = L.nsb * t256::SB;
-        const int half = (zt && job.slab) ? 1 : 0;
+        const int half = (zlike && job.slab) ? 1 : 0;
         double* cp = s.colpart + ((int64_t)split * 2 + half) * dpad;
         int64_t my_rows = k_end - k_begin;
-        if (zt) {       // rows of the 64-row stages that fall into this quartet's half
+        if (zlike) {    // rows of the 64-row stages that fall into this quartet's half
             const int64_t whole = my_rows / 64, rem = my_rows - whole * 64;
             my_rows = whole * 32 + (half ? (rem > 32 ? rem - 32 : 0) : (rem < 32 ? rem : 32));
         }
@@ -404,12 +437,16 @@ __global__ __launch_bounds__(512) void moments_tile256(T256Launch L) {
     const int type = L.type[ti], sa = L.sa[ti], sb = L.sb[ti];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const t256::WaveJob job = t256::wave_job(type, wave);
+    if (type == t256::TYPE_XZ0 || type == t256::TYPE_XZ1) {      // (workgroup-uniform)
+        tile256_wave<KIND, t256::XR, SHIFT, true>(L, s, split, ti, type, sa, sb, job, smem_dyn);
+        return;
+    }
     switch (job.role) {              // wave-uniform: every wave runs ONE of these loops, all with the same stage count and barriers
-        case t256::TRI_LO: tile256_wave<KIND, t256::TRI_LO, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
-        case t256::TRI_HI: tile256_wave<KIND, t256::TRI_HI, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
-        case t256::RECT_C: tile256_wave<KIND, t256::RECT_C, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
-        case t256::RECT_D: tile256_wave<KIND, t256::RECT_D, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
-        default: tile256_wave<KIND, t256::XR, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
+        case t256::TRI_LO: tile256_wave<KIND, t256::TRI_LO, SHIFT, false>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
+        case t256::TRI_HI: tile256_wave<KIND, t256::TRI_HI, SHIFT, false>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
+        case t256::RECT_C: tile256_wave<KIND, t256::RECT_C, SHIFT, false>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
+        case t256::RECT_D: tile256_wave<KIND, t256::RECT_D, SHIFT, false>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
+        default: tile256_wave<KIND, t256::XR, SHIFT, false>(L, s, split, ti, type, sa, sb, job, smem_dyn); break;
     }
 }
 
@@ -428,7 +465,7 @@ struct R256Launch {
     R256Job job[kMaxSets];
     const t256::BlockSrc* table;             // device: n_blocks(8 nsb) entries
     int d, nsb, NT, nblk, sl;                // sl = split lanes per output group (1, 4 or 16)
-    uint8_t z_sb;                            // superblock whose column sums have a second row (Z item), or 255
+    uint32_t two_mask;                       // bit a: superblock a's column sums have a second row (its triangle came from a Z / ZC item)
 };
 
 __global__ __launch_bounds__(256) void moments_reduce256(R256Launch R) {
@@ -452,7 +489,7 @@ __global__ __launch_bounds__(256) void moments_reduce256(R256Launch R) {
         if (block == tile_blocks && threadIdx.x == 0) j.acc[0] = j.overwrite ? j.n_add : j.acc[0] + j.n_add;
         double t = 0.0;
         if (a < R.d) {
-            const bool two = (a / t256::SB) == (int)R.z_sb;
+            const bool two = (R.two_mask >> (a / t256::SB)) & 1u;
             const double* cp = j.colpart + a;
             int sp = l;
             for (; sp + 28 < S; sp += 32) {
@@ -515,7 +552,7 @@ __global__ __launch_bounds__(256) void moments_reduce256(R256Launch R) {
         }
         if (unshift) {                        // + c_a s'_b + s'_a c_b + n c_a c_b, split by split (see reduce_body)
             const int ga = 32 * bi + 8 * (e >> 6) + 4 * ((e & 63) >> 5), gb = 32 * bj + (e & 31);
-            const bool two_a = (ga / t256::SB) == (int)R.z_sb, two_b = (gb / t256::SB) == (int)R.z_sb;
+            const bool two_a = (R.two_mask >> (ga / t256::SB)) & 1u, two_b = (R.two_mask >> (gb / t256::SB)) & 1u;
             for (int sp = sl; sp < S; sp += SL) {
                 const double nq = rows_of(sp);
                 const uint16_t* cv = j.cvec + (int64_t)sp * dpad;

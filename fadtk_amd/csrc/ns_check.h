@@ -29,6 +29,13 @@ struct NsState {
     int upd_skip[2];
     double res[kMaxIter];
     double tr[kMaxIter];
+    // Scaled steps (round 4): (Y, Z) <- mu_k (Y, Z) before iteration k, folded into T_k = 1.5 mu I - 0.5 mu^3 Z Y.  With every
+    // eigenvalue x^2 of Z Y in [l_k^2, 1], mu_k^2 = 3 / (1 + l_k + l_k^2) is the scaling of the cubic x (3 - x^2) / 2 that lifts the
+    // lower end fastest (Chen & Chow); l_{k+1} = mu l (3 - mu^2 l^2) / 2.  Small eigenvalues then grow ~6.75x per step instead
+    // of 2.25x: a k^-2 product takes 13 iterations instead of 20, k^-4 20 instead of 36 (scripts/ns_emulate_scaled.py).
+    // mu[k] = 1 once l_k >= 0.9 (and always for flat spectra): the plain iteration, whose rules close the problem.  Written by
+    // ns_prepare, read by ns_first, the T product (gemm_f64.hip) and the check.
+    double mu[kMaxIter];
 };
 constexpr int kStateInts = sizeof(NsState) / sizeof(int);
 
@@ -104,7 +111,9 @@ __device__ __forceinline__ void ns_check_block(const NsCheckArgs& a, int64_t b, 
     for (int i = tid; i < a.nslots; i += 256) s += partials[i];
     const double sumsq = block_sum(s, red);
     if (tid != 0) return;
-    const double res = 2.0 * sqrt(sumsq);           // ||I - ZY||_F = 2 ||T - I||_F
+    // ||I - ZY||_F = 2 ||T - I||_F; with a scaled step T = 1.5 mu I - 0.5 mu^3 ZY and the partials hold (T - (1.5 mu - 0.5 mu^3) I)^2
+    const double mu_k = st->mu[k];
+    const double res = 2.0 * sqrt(sumsq) / (mu_k * mu_k * mu_k);
     st->res[k] = res; st->tr[k] = tr;
     const bool finite = (res == res) && !isinf(res) && (tr == tr) && !isinf(tr);
     const double tr_prev = st->tr_last;

@@ -24,18 +24,21 @@ int main(int argc, char** argv) {
     std::vector<uint16_t*> E(npairs * sets);
     for (auto& p : E) { hipMalloc(&p, (size_t)n * d * 2 + 4096); fill<<<2048, 256>>>(p, (size_t)n * d, (uint32_t)(&p - E.data()) * 7919u); }
     T256Launch L; memset(&L, 0, sizeof(L));
-    L.nsets = sets; L.d = d; L.nsb = nsb; L.NT = t256::item_types(nsb, L.type, L.sa, L.sb);
-    const int kb = (nsb & 1) ? 64 : 32;
+    const int plan = getenv("T2_PLAN") ? atoi(getenv("T2_PLAN")) : 0;
+    L.nsets = sets; L.d = d; L.nsb = nsb; L.plan = plan; L.NT = t256::item_types(nsb, L.type, L.sa, L.sb, plan);
+    const int kb = (plan == 1 || (nsb & 1)) ? 64 : 32;
+    const size_t lds = plan == 1 ? kT256LdsCombined : kT256Lds;
     int64_t r = ((n * sets * L.NT + n_cu - 1) / n_cu + kb - 1) / kb * kb;
     while (sets * ((n + r - 1) / r) * L.NT > n_cu && r < 8192) r += kb;
     if (getenv("T2_ROWS")) r = atoll(getenv("T2_ROWS"));             // probe: rows per split that are NOT a multiple of the stage
     const int S = (int)((n + r - 1) / r);
+    printf("plan %d: ", plan);
     printf("d=%d n=%ld: %d item types, %d splits of %ld rows per set, %d workgroups\n", d, (long)n, L.NT, S, (long)r, sets * S * L.NT);
     std::vector<t256::BlockSrc> tab(t256::n_blocks(8 * nsb));
-    if (!t256::build_block_table(nsb, tab.data())) return 1;
+    if (!t256::build_block_table(nsb, tab.data(), plan)) return 1;
     t256::BlockSrc* dtab; hipMalloc(&dtab, tab.size() * sizeof(tab[0])); hipMemcpy(dtab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice);
     R256Launch R; memset(&R, 0, sizeof(R));
-    R.table = dtab; R.d = d; R.nsb = nsb; R.NT = L.NT; R.nblk = t256::n_blocks(8 * nsb); R.z_sb = (nsb & 1) ? nsb - 1 : 255;
+    R.table = dtab; R.d = d; R.nsb = nsb; R.NT = L.NT; R.nblk = t256::n_blocks(8 * nsb); R.two_mask = plan == 1 ? ((1u << nsb) - 1u) : ((nsb & 1) ? (1u << (nsb - 1)) : 0u);
     int* flags; hipMalloc(&flags, 64); hipMemset(flags, 0, 64);
     int item = 0;
     for (int i = 0; i < sets; ++i) {
@@ -51,7 +54,7 @@ int main(int argc, char** argv) {
         j.n_add = (double)n; j.S = S; j.overwrite = 1; j.rows_per_split = r; j.n_rows = n;
     }
     L.total = item;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256LdsCombined);
     hipEvent_t e[4]; for (auto& x : e) hipEventCreate(&x);
     for (int sl : {8, 4, 2, 1}) {
         R.sl = sl;
@@ -61,7 +64,7 @@ int main(int argc, char** argv) {
         for (int it = -2; it < reps; ++it) {
             for (int i = 0; i < sets; ++i) L.set[i].E = E[((it + 2) % npairs) * sets + i];
             hipEventRecord(e[0]);
-            moments_tile256<FAD_F16, false><<<L.total, 512, kT256Lds>>>(L);
+            moments_tile256<FAD_F16, false><<<L.total, 512, lds>>>(L);
             hipEventRecord(e[1]);
             moments_reduce256<<<dim3(blocks, sets), 256>>>(R);
             hipEventRecord(e[2]);
