@@ -50,6 +50,11 @@ struct fad_moments {
     int blocktab_nsb = 0, blocktab_plan = -1;
     int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
+    // the segment tables of the last fused update_segmented call, kept on the host: a caller feeding groups of the SAME file sizes
+    // (30-second clips: every file 2250 frames) finds them on the device already -- no H2D copy in front of the tile kernel
+    std::vector<int64_t> seg_cached_offsets; int64_t seg_cached_n = -1; int seg_cached_S = 0; int64_t seg_cached_runs = 0, seg_cached_max = 0;
+    size_t seg_cached_bytes_runs = 0, seg_cached_bytes_first = 0;
+    std::vector<int64_t> sizes_cached; const void* sizes_cached_at = nullptr;      // ... and the sizes of update_file_means (in `scratch`)
     void* tab_host = nullptr; size_t tab_host_cap = 0;     // pinned staging of the segment tables of update_segmented
     hipEvent_t tab_ev = nullptr;           // recorded behind the upload of tab_host: the next call waits before rewriting it
     int* shift_flag = nullptr;             // device int[2], ping-pong between updates
@@ -534,6 +539,7 @@ static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int
     }
     first[n_segments] = np;
     FAD_TRY(h->seg_tab.reserve(tab_bytes));
+    h->seg_cached_n = -1;                          // (the fused path's tables, if any, are overwritten)
     FAD_HIP_TRY(hipMemcpyAsync(h->seg_tab.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
     FAD_HIP_TRY(hipEventRecord(h->tab_ev, st));
     const int64_t* dfirst = static_cast<const int64_t*>(h->seg_tab.p);
@@ -727,13 +733,25 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
         int64_t n_runs = 0, covered = 0;
         for (int64_t sg = 0; sg < n_segments; ++sg) { const int64_t len = offsets[sg + 1] - offsets[sg]; n_runs += len > 0 ? cdiv(len, kCap) : 1; covered += len; }
         fused = covered == n && offsets[0] == 0 && n_runs > 0 && covered / n_runs >= 256 && n_runs < (1 << 30);
-        if (fused) {
+        const bool same_tables = fused && h->seg_cached_n == n && (int64_t)h->seg_cached_offsets.size() == n_segments + 1 && h->seg_tab.p &&
+                                 memcmp(h->seg_cached_offsets.data(), offsets, (size_t)(n_segments + 1) * sizeof(int64_t)) == 0;
+        SegPlan sp;
+        char* dev = nullptr;
+        size_t bytes_runs = 0, bytes_first = 0;
+        if (same_tables) {
+            // the very segment list of the previous call: its tables are on the device already
+            bytes_runs = h->seg_cached_bytes_runs; bytes_first = h->seg_cached_bytes_first;
+            dev = static_cast<char*>(h->seg_tab.p);
+            sp.runs = reinterpret_cast<const SegRun*>(dev);
+            sp.split_first_run = reinterpret_cast<const int*>(dev + bytes_runs + bytes_first);
+            sp.n_runs = (int)h->seg_cached_runs; sp.S = h->seg_cached_S; sp.max_split_rows = h->seg_cached_max;
+        } else if (fused) {
             // target rows per split: what the uniform planner would choose, but never above the fp32 cap
             SplitPlan up;
             plan_splits(1, &n, d, H_BT, H_KB, h->n_cu, 2, 256, kCap, &up);
             const int64_t target = up.rows_per_split;
             // host tables: runs | seg_first_run (int64) | split_first_run (int32)
-            const size_t bytes_runs = (size_t)n_runs * sizeof(SegRun), bytes_first = (size_t)(n_segments + 1) * sizeof(int64_t);
+            bytes_runs = (size_t)n_runs * sizeof(SegRun); bytes_first = (size_t)(n_segments + 1) * sizeof(int64_t);
             const size_t bytes_split = (size_t)(n_runs + 1) * sizeof(int);
             char* host = nullptr;
             FAD_TRY(stage_tables(h, bytes_runs + bytes_first + bytes_split, &host));
@@ -767,11 +785,15 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
             FAD_TRY(h->seg_tab.reserve(bytes_runs + bytes_first + bytes_split));
             FAD_HIP_TRY(hipMemcpyAsync(h->seg_tab.p, host, bytes_runs + bytes_first + (size_t)(S + 1) * sizeof(int), hipMemcpyHostToDevice, st));
             FAD_HIP_TRY(hipEventRecord(h->tab_ev, st));
-            char* dev = static_cast<char*>(h->seg_tab.p);
-            SegPlan sp;
+            dev = static_cast<char*>(h->seg_tab.p);
             sp.runs = reinterpret_cast<const SegRun*>(dev);
             sp.split_first_run = reinterpret_cast<const int*>(dev + bytes_runs + bytes_first);
             sp.n_runs = (int)nr; sp.S = S; sp.max_split_rows = max_rows > 0 ? max_rows : H_KB;
+            h->seg_cached_offsets.assign(offsets, offsets + n_segments + 1);
+            h->seg_cached_n = n; h->seg_cached_S = S; h->seg_cached_runs = nr; h->seg_cached_max = sp.max_split_rows;
+            h->seg_cached_bytes_runs = bytes_runs; h->seg_cached_bytes_first = bytes_first;
+        }
+        if (fused) {
             fad_moments* hh = h;
             FAD_TRY(update_device_multi(1, &hh, &drows, &n, &dld, dtype, st, &sp));
             const int nt = (int)cdiv(d, H_BT);
@@ -821,11 +843,18 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
         dsums = reinterpret_cast<const double*>(base);
     }
     if (!sizes_dev) {                              // through the handle's pinned staging: no pageable copy on the stream
-        char* host = nullptr;
-        FAD_TRY(stage_tables(exact, sizes_bytes, &host));
-        memcpy(host, sizes, sizes_bytes);
-        FAD_HIP_TRY(hipMemcpyAsync(base + sums_bytes, host, sizes_bytes, hipMemcpyHostToDevice, st));
-        FAD_HIP_TRY(hipEventRecord(exact->tab_ev, st));
+        // (the same sizes as last time, still at the same place of the scratch area: nothing to upload -- groups of equally long files)
+        const bool same = exact->sizes_cached_at == base + sums_bytes && (int64_t)exact->sizes_cached.size() == n_files &&
+                          memcmp(exact->sizes_cached.data(), sizes, sizes_bytes) == 0;
+        if (!same) {
+            char* host = nullptr;
+            FAD_TRY(stage_tables(exact, sizes_bytes, &host));
+            memcpy(host, sizes, sizes_bytes);
+            FAD_HIP_TRY(hipMemcpyAsync(base + sums_bytes, host, sizes_bytes, hipMemcpyHostToDevice, st));
+            FAD_HIP_TRY(hipEventRecord(exact->tab_ev, st));
+            exact->sizes_cached.assign(sizes, sizes + n_files);
+            exact->sizes_cached_at = base + sums_bytes;
+        }
         dsizes = reinterpret_cast<const int64_t*>(base + sums_bytes);
     }
     double* r_exact = reinterpret_cast<double*>(base + ((in_bytes + 15) & ~(size_t)15));
@@ -932,6 +961,7 @@ int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* c
     double* dmu = mu; double* dcov = cov;
     if (!on_device) {
         FAD_TRY(hm->scratch.reserve(((size_t)d * d + d) * sizeof(double)));
+        hm->sizes_cached_at = nullptr;             // (the scratch area is overwritten: a cached sizes upload is gone)
         dcov = static_cast<double*>(hm->scratch.p);
         dmu = dcov + (size_t)d * d;
     }
@@ -953,7 +983,7 @@ int fad_moments_trim(fad_moments_t* h, int64_t keep_bytes) {
     if (h->stage.cap > (size_t)keep_bytes || h->scratch.cap > (size_t)keep_bytes) {
         FAD_HIP_TRY(hipDeviceSynchronize());       // nothing enqueued may still read what is freed
         if (h->stage.cap > (size_t)keep_bytes) h->stage.release();
-        if (h->scratch.cap > (size_t)keep_bytes) h->scratch.release();
+        if (h->scratch.cap > (size_t)keep_bytes) { h->scratch.release(); h->sizes_cached_at = nullptr; }
     }
     return FAD_OK;
 }

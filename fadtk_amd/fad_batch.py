@@ -159,6 +159,7 @@ def embed_and_accumulate(directory: Union[str, Path], ml, workers: int = 8, comp
     _cache_embedding_batch(dist.shard(files), ml, workers, feeder=_DeviceFeeder(stats), **kwargs)
     import torch
     shared.extra.copy_(torch.tensor([stats.n_short, stats.n_empty], dtype=torch.float64))
+    stats.join()                                                       # (the per-file mean terms ride on a side stream)
     shared.allreduce()                                                 # the one collective of the data path
     stats.n_short, stats.n_empty = (int(round(v)) for v in shared.extra.cpu().tolist())
     mu, cov = stats.finish()

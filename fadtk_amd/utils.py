@@ -87,6 +87,8 @@ def _round_like(values: np.ndarray, dtype: np.dtype) -> np.ndarray:
 
 
 _DT_CODES = {np.dtype(np.float16): 0, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
+import os as _os
+_SIDE_STREAM = _os.environ.get("FAD_ONLINE_SIDE_STREAM") == "1"
 
 
 class OnlineStats:
@@ -108,6 +110,7 @@ class OnlineStats:
         else:
             self.frames = Moments(d, device)
             self.exact, self.rounded, self.weighted = (Moments(d, device) for _ in range(3)) if compat else (None, None, None)
+        self._side = None         # side stream of the per-file mean terms (device inputs), see add_group
         self.n_short = 0          # files with fewer than two frames (np.cov -> NaN)
         self.n_empty = 0
         self.n_files = 0
@@ -137,12 +140,36 @@ class OnlineStats:
             code = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}.get(rows.dtype, 3)
         else:
             code = _DT_CODES.get(np.asarray(rows).dtype, 3)
-        type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code)
+        if on_dev and _SIDE_STREAM:
+            # (opt-in, FAD_ONLINE_SIDE_STREAM=1.  Measured at config 4, profiles/r04d_c4.txt: the 41 us of these kernels disappear from
+            # the stream, but the HBM-bound tile kernel they run beside loses 80 us -- their workgroups take LDS a second tile
+            # workgroup of the CU needs -- so the default keeps them in line.)
+            # The three small accumulators of the per-file mean terms (rows + a float64 tile kernel + its reduce: ~40 us per group)
+            # depend on nothing but this group's per-file sums: on a stream of their own they run under the NEXT group's tile
+            # kernel instead of between two of them.  join() orders them in front of whatever reads the accumulators.
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=rows.device)
+            main = torch.cuda.current_stream(rows.device)
+            ready = torch.cuda.Event(); ready.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code)
+                sums.record_stream(self._side)
+        else:
+            type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code)
         count()
+
+    def join(self):
+        """Order the side stream's work (per-file mean terms of device groups) in front of the current stream: call before the
+        accumulators are read, exported or all-reduced (pieces() / finish() do)."""
+        if self._side is not None:
+            import torch
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     def pieces(self):
         """(packed frames, sum_f n_f m~_f, sum_f n_f m_f m_f^T, sum_f n_f m~_f m~_f^T) as host arrays."""
         d = self.d
+        self.join()
         packed = self.frames.export()
         if not self.compat:
             return packed, None, None, None
