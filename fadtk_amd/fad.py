@@ -366,13 +366,16 @@ class FrechetAudioDistance:
         for i, e in enumerate(embds):
             if e is not None and i not in set(ok):
                 log.error(f"Embedding of {_files[i]} has shape {e.shape}; expected [*, {np.shape(mu)[-1]}]")
-        if ok:
-            dtypes = {embds[i].dtype for i in ok}
-            cast = (lambda a: a) if len(dtypes) == 1 else (lambda a: a.astype(np.float64))
-            rows = np.concatenate([cast(embds[i]) for i in ok], axis=0)
-            offs = np.concatenate([[0], np.cumsum([embds[i].shape[0] for i in ok])])
+        # one batched call per embedding dtype: the reference takes np.mean of every file in ITS dtype (fad.py:373, Q1), so files
+        # cached as float16 and float32 in one directory must not be cast to a common type before their means are rounded
+        by_dtype = {}
+        for i in ok:
+            by_dtype.setdefault(embds[i].dtype, []).append(i)
+        for group in by_dtype.values():
+            rows = np.concatenate([embds[i] for i in group], axis=0)
+            offs = np.concatenate([[0], np.cumsum([embds[i].shape[0] for i in group])])
             vals, status = hip.frechet_batched(mu, cov, rows, offs, mean_mode=1, device=self.device_index)
-            for j, i in enumerate(ok):
+            for j, i in enumerate(group):
                 if status[j] == 0 or status[j] == -8:
                     scores[i] = np.float64(vals[j])
                 else:
