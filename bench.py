@@ -8,11 +8,12 @@ Workload (BASELINE.json configs[2], "C3"): two synthetic float16 embedding matri
 hot path over that batch -- one FAD score:
 
     moments(A, B)      hand-written HIP, fp16 MFMA E^T E + column sums -> (n, sum x, sum xxT) of BOTH sets in one launch
-                       of each kernel (fad_moments_update_multi)
+                       of each kernel (fad_moments_update_multi; D = 512: the 256-column-slab kernel, moments_tile256.h)
     [N>1]              ONE in-place all-reduce (RCCL/xGMI) over the buffer that holds both sets' packed float64
                        statistics (fadtk_amd.dist.SharedStats -- the same object the product's --gpus path uses)
-    frechet(A, B)      finalise (mu, Sigma) x2, Newton-Schulz sqrt(S1 S2): fp32 MFMA iterations + one fp64 correction
-                       (fp64 throughout when the product is ill-conditioned), the reference's float16 mean term
+    frechet(A, B)      finalise (mu, Sigma) x2, Newton-Schulz sqrt(S1 S2): split-float16 MFMA iterations + exact int8-MFMA products +
+                       one float64-accurate correction (float64 throughout when the product is ill-conditioned), the reference's
+                       float16 mean term.  The chains of the scores in flight run as ONE batch of eight (--batch).
 
 i.e. exactly one FAD score over the union of all ranks' rows.  With N GPUs every rank holds its own
 100k-row shard of both sets (weak scaling: rows grow with N), so `value` is reported in
