@@ -200,18 +200,18 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
                 const float s1 = S(pf), val = s1 * s1 / S(2.0f * pf);
                 if (val > pr) lo = pf; else hi = pf;
             }
-            const double p = (double)pf, dn = (double)d;
-            l = pow(dn, -0.5 * p) / 3.0;
+            l = (double)(exp2f(-0.5f * pf * lg) * (1.0f / 3.0f));
             if (l > 0.5) l = 0.5;
             if (l < 1e-5) l = 1e-5;
         }
-        for (int k = 0; k < kMaxIter; ++k) {
-            double m = 1.0;
-            if (scaled && l < 0.9) {
-                m = sqrt(3.0 / (1.0 + l + l * l));
+        {
+            int k = 0;
+            for (; k < kMaxIter && scaled && l < 0.9; ++k) {          // (a dozen steps at most: 1e-5 -> 0.9)
+                const double m = sqrt(3.0 / (1.0 + l + l * l));
                 l = m * l * (3.0 - m * m * l * l) / 2.0;
+                st->mu[k] = m;
             }
-            st->mu[k] = m;
+            for (; k < kMaxIter; ++k) st->mu[k] = 1.0;
         }
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(tr1 == tr1) || !(tr2 == tr2) || isinf(tr1) ||
                          isinf(tr2) || !(mean_term == mean_term) || isinf(mean_term);
@@ -362,6 +362,8 @@ struct Pool {
     static constexpr int kSlots = 8;
     Workspace slot[kSlots];
     int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
+    bool lp_hopeless = false;                       // ... or gave up on at once (a decaying spectrum): the next score enqueues iteration 0
+                                                    // and the closing kernel only -- the LAUNCH count follows the history, never the value
     int f64_iters = 0;                              // ... and the float64 iteration (single pair), 0 = not known yet
     int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
     int fast = -1;                                  // FAD_FRECHET_FAST (read once): 0 = round 2's twelve-launch float32 chain
@@ -1272,6 +1274,7 @@ static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Work
         int want = ws.pool ? ws.pool->lp_iters : 5;
         if (want < 2) want = 2;
         if (want > kMaxLow) want = kMaxLow;
+        if (ws.pool && ws.pool->lp_hopeless) want = 1;       // (a pair that does iterate is topped up by mixed_finish)
         return fast_enqueue(ws, want);
     }
     // A = C1 C2 with its tile statistics from the epilogue and the mean term from a spare workgroup (one launch instead of
@@ -1308,6 +1311,7 @@ static int mixed_finish(Workspace& ws, MixedResult* res) {
     *res = *m.hres;
     if (res->status == 0) res->status = 2;
     if (res->status == 1 && res->decided_at >= 0 && ws.pool) ws.pool->lp_iters = res->decided_at + 1;
+    if (ws.pool && ws.job.fast) ws.pool->lp_hopeless = res->status == 2 && res->iters < 0;      // given up before the first check
     return FAD_OK;
 }
 
