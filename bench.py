@@ -53,7 +53,7 @@ FAD_F16 = 0                             # fad_dtype code: the reference's float1
 DEFAULT_INFLIGHT = 3
 
 
-N_PAIRS = 3                              # distinct (A, B) pairs rotated through the timed loop: 3 x 204.8 MB = 614 MB > the 256 MiB
+N_PAIRS = 4                              # distinct (A, B) pairs rotated through the timed loop: 4 x 204.8 MB = 819 MB > the 256 MiB
                                          # Infinity Cache, so every step streams its frames from HBM (a caller scores each set once)
 
 
@@ -435,6 +435,9 @@ def main():
                     help="batched chains (the default schedule): the moments of B consecutive steps, then ONE square-root chain for the B "
                          "scores (fad_frechet_from_moments_multi_begin: nine launches carry all B); three such batches in flight, one stream "
                          "each; 0 = the lane schedule of round 3 (one stream and one chain per score, --inflight of them)")
+    ap.add_argument("--moments-group", type=int, default=4,
+                    help="batched schedule: the moments of this many consecutive steps in ONE launch of the tile kernel and ONE reduce "
+                         "(fad_moments_update_multi over 2 x M frame matrices, 8 at most); 1 = one launch per step")
     ap.add_argument("--chain-cus", type=int, default=0,
                     help="experiment (profiles/r04*_streams.txt): confine the square-root chains to this many CUs per XCD (CU-masked "
                          "streams) and the moments kernels to the others; 0 = no masks")
@@ -644,6 +647,7 @@ def main():
         run_steps = run_steps_grouped
 
     BATCH = 0 if G else max(0, min(int(args.batch), 8))
+    MG = max(1, min(int(args.moments_group), 4, BATCH)) if BATCH else 1          # steps per moments launch (2 sets each, 8 at most)
     if BATCH:
         NB_FLY = 3
         # (--single-stream: all batches on ONE stream -- no two kernels ever overlap, the tile kernel's HIP-event time is the kernel alone)
@@ -653,6 +657,7 @@ def main():
             for ln in blanes[q]:
                 ln.stream = ln.cstream = bstreams[q]
         bjobs = [None] * NB_FLY
+        launch_sets = {}                    # id(leader handle) -> frame matrices of every launch recorded on it (cleared where timing starts)
 
         def run_steps_batched(count, marks=None, rotate=True, lanes=None):
             """Batched schedule (--batch B): per batch, the moments of B steps and then ONE chain for their B scores on the batch's
@@ -678,8 +683,28 @@ def main():
                     collect(q)
                 m = min(BATCH, count - i)
                 t = pc()
-                for k in range(m):
-                    blanes[q][k].feed(pairs[(i + k) % N_PAIRS] if rotate else pairs[0])
+                if MG > 1:
+                    # the moments of MG steps in ONE launch of each kernel (fad_moments_update_multi takes up to 8 frame matrices): the
+                    # 256 workgroups of the tile kernel then hold MG x longer row ranges -- one set of partial tiles per LAUNCH, not per
+                    # step -- and the reduce runs once (scripts/probe_sets.py: 108 / 75 / 70 / 68 us per pair at 1 / 2 / 3 / 4 pairs)
+                    for k0 in range(0, m, MG):
+                        grp = blanes[q][k0:min(k0 + MG, m)]
+                        launch_sets.setdefault(id(grp[0].ma), []).append(2 * len(grp))
+                        with torch.cuda.stream(bstreams[q]):
+                            for ln in grp:
+                                ln.ma.reset(); ln.mb.reset()
+                            hip.Moments.update_multi([h for ln in grp for h in (ln.ma, ln.mb)],
+                                                     [x for kk in range(len(grp)) for x in (pairs[(i + k0 + kk) % N_PAIRS] if rotate else pairs[0])])
+                            if distributed:
+                                grp[0].fed.record()
+                                with torch.cuda.stream(comm_stream):
+                                    comm_stream.wait_event(grp[0].fed)
+                                    for ln in grp:
+                                        dist.all_reduce(ln.shared.buffer)
+                                        ln.reduced.record()
+                else:
+                    for k in range(m):
+                        blanes[q][k].feed(pairs[(i + k) % N_PAIRS] if rotate else pairs[0])
                 host_s[0] += pc() - t
                 t = pc()
                 with torch.cuda.stream(bstreams[q]):
@@ -716,9 +741,13 @@ def main():
     # three events on every step), and the benchmark should not throttle what it measures.
     # (batched schedule: two lanes of every batch stream are sampled -- the first and the middle update of a batch -- so that the
     # average covers launches that run beside another batch's chain as well as those that do not)
-    timed_handles = ([blanes[q][k].ma for q in range(3) for k in sorted({0, BATCH // 2})] if BATCH else [lanes[0].ma])
+    # (... with --moments-group M > 1: every launch -- the leader of each group of M steps carries the events)
+    sampled_slots = (sorted({0, BATCH // 2}) if MG == 1 else list(range(0, BATCH, MG))) if BATCH else []
+    timed_handles = ([blanes[q][k].ma for q in range(3) for k in sampled_slots] if BATCH else [lanes[0].ma])
     for hnd in timed_handles:
         hnd.set_timing(2)
+    if BATCH:
+        launch_sets.clear()
     fence()
     marks = [time.perf_counter()]
     host_s[:] = [0.0, 0.0, 0.0]
@@ -731,15 +760,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = np.diff(np.array(marks)) * 1e3
-    kernel_samples, variant = [], -1                                   # (queried here: the side blocks below record more launches)
-    for hnd in timed_handles:
-        try:
-            k_ms, _, variant = hnd.last_timing()
-            kernel_samples.append(k_ms)
-        except Exception:       # noqa: BLE001  (a sampled lane that saw no update in a short timed region)
-            pass
-        hnd.set_timing(False)
-    kernel_ms = float(np.mean(kernel_samples))
+    def collect_kernel_ms(handles):
+        """-> (mean duration of the tile kernel per launch [ms], launches, mean frame matrices per launch, variant) over the launches
+        the handles recorded since set_timing"""
+        tot_ms, launches, sets_tot, var = 0.0, 0, 0, -1
+        for hnd in handles:
+            try:
+                k_ms, _, var_h = hnd.last_timing()                       # mean over this handle's recorded launches
+            except Exception:       # noqa: BLE001  (a sampled lane that saw no update in a short region)
+                hnd.set_timing(False)
+                continue
+            var = var_h
+            sets_h = launch_sets.get(id(hnd)) if (BATCH and MG > 1) else None
+            n_h = len(sets_h) if sets_h else 1
+            tot_ms += k_ms * n_h; launches += n_h; sets_tot += sum(sets_h) if sets_h else SETS * n_h
+            hnd.set_timing(False)
+        return (tot_ms / launches if launches else float("nan")), launches, (sets_tot / launches if launches else SETS), var
+
+    kernel_ms, timed_launches_seen, launch_sets_mean, variant = collect_kernel_ms(timed_handles)   # (queried here: the side blocks record more launches)
 
     # ---- side blocks, outside the timed region: the same K steps five more times (median: the timed region above is a few
     # milliseconds long, one outlier moves it), and K steps that re-feed ONE pair -- 204.8 MB, which fit the 256 MiB Infinity
@@ -755,12 +793,30 @@ def main():
     same_pair_s = [block(False) for _ in range(3)] if side else []
     # ... and K steps in the other stream layout: by default that is ONE stream for all scores in flight -- no two kernels overlap, the
     # tile kernel's duration there is the kernel alone
-    per_stream_s, per_stream_kernel_ms = [], None
-    if side and n_lanes > 1 and not G:                      # the OTHER stream layout (one stream for all lanes / one per lane)
-        lanes_s = all_lanes if BATCH else [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
-        if BATCH:                                            # (batched schedule: the other layout = round 3's lanes on ONE stream)
-            for ln in lanes_s:
-                ln.stream = ln.cstream = torch.cuda.current_stream(device)
+    per_stream_s, per_stream_kernel_ms, per_stream_sets = [], None, SETS
+    if side and BATCH:
+        # batched schedule: the same batches, every one on the OTHER stream layout (ONE stream unless --single-stream was given)
+        other = ([torch.cuda.current_stream(device)] * NB_FLY if not args.single_stream else [torch.cuda.Stream(device=device) for _ in range(NB_FLY)])
+        saved = list(bstreams)
+        bstreams[:] = other
+        for q in range(NB_FLY):
+            for ln in blanes[q]:
+                ln.stream = ln.cstream = bstreams[q]
+        run_steps(min(args.steps, BATCH))
+        for rep in range(3):
+            if rep == 2:                                     # what the overlap does to the tile kernel itself (last block)
+                for hnd in timed_handles:
+                    hnd.set_timing(2)
+                launch_sets.clear()
+            fence(); t0 = time.perf_counter(); run_steps(args.steps); fence()
+            per_stream_s.append(time.perf_counter() - t0)
+        per_stream_kernel_ms, _, per_stream_sets, _ = collect_kernel_ms(timed_handles)
+        bstreams[:] = saved
+        for q in range(NB_FLY):
+            for ln in blanes[q]:
+                ln.stream = ln.cstream = bstreams[q]
+    elif side and n_lanes > 1 and not G:                    # the OTHER stream layout (one stream for all lanes / one per lane)
+        lanes_s = [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
         run_steps_lanes(min(args.steps, 6), None, True, lanes_s)
         for rep in range(3):
             if rep == 2:
@@ -769,14 +825,13 @@ def main():
             per_stream_s.append(time.perf_counter() - t0)
         per_stream_kernel_ms = lanes_s[0].ma.last_timing()[0]
         lanes_s[0].ma.set_timing(False)
-        if not BATCH:
-            for ln in lanes_s:
-                ln.shared.close()
+        for ln in lanes_s:
+            ln.shared.close()
 
-    # ONE launch of the tile kernel covers both sets (recorded on the first handle of lane 0: steps 0, n_lanes, 2 n_lanes ...)
+    # launches of the tile kernel the events covered inside the timed region
     timed_launches = -(-args.steps // n_lanes)
     if BATCH:
-        timed_launches = sum(1 for i in range(args.steps) if (i % BATCH) in {0, BATCH // 2})
+        timed_launches = timed_launches_seen
     if G:
         timed_launches = sum(1 for i in range(args.steps) if (i % G == 0 and (i // G) % NGRP == 0))
 
@@ -816,21 +871,26 @@ def main():
         return
 
     n_gpus = world
-    flops = SETS * 2.0 * N_ROWS * DIM * DIM                # algorithmic, per launch
+    LSETS = launch_sets_mean if BATCH else SETS            # frame matrices per launch of the tile kernel in the timed region (mean)
+    flops = LSETS * 2.0 * N_ROWS * DIM * DIM               # algorithmic, per launch
     achieved = flops / (kernel_ms * 1e-3) / 1e12
     nt = -(-DIM // 128)
     # issued: upper-triangular 128 x 128 tiles, 32 MFMAs per 32-row stage off the diagonal, 20 on it; the 256-column-slab kernel
     # issues the 32 x 32 blocks on and above the diagonal (136 of 256 at D = 512: the same count)
-    issued = SETS * 2.0 * N_ROWS * 128 * 128 * (nt * (nt - 1) // 2 + nt * 20.0 / 32.0)
+    issued = LSETS * 2.0 * N_ROWS * 128 * 128 * (nt * (nt - 1) // 2 + nt * 20.0 / 32.0)
     if variant == 2:
         nb = -(-DIM // 32)
-        issued = SETS * 2.0 * N_ROWS * 32 * 32 * (nb * (nb + 1) // 2)
+        issued = LSETS * 2.0 * N_ROWS * 32 * 32 * (nb * (nb + 1) // 2)
     traffic, traffic_src = None, None
     tpath = ROOT / "profiles" / "moments_traffic.json"     # separate rocprofv3 --pmc passes of this same command
     if tpath.exists():
         try:
             tj = json.loads(tpath.read_text())
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            by_sets = tj.get("by_sets_per_launch", {}).get(str(int(round(LSETS))))
+            if by_sets:                                          # the pass that measured launches of this many frame matrices
+                traffic, traffic_src = by_sets.get("hbm_bytes_per_launch"), by_sets.get("source")
+            elif int(round(LSETS)) == SETS:
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:       # noqa: BLE001
             traffic = None
     # Frechet chain, by route (diag["route"]): 2 = eight launches: split-float16 products (3 MFMA terms each: iteration 0 needs one
@@ -881,7 +941,7 @@ def main():
         "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,
         "value_repeat_median": float(np.median([n_gpus * args.steps / t for t in repeat_s])) if repeat_s else None,
         "input_rotation": {"pairs": N_PAIRS, "bytes": N_PAIRS * SETS * N_ROWS * DIM * 2,
-                           "note": "step i feeds pair i % 3: the working set of the timed loop (614 MB) exceeds the 256 MiB Infinity "
+                           "note": f"step i feeds pair i % {N_PAIRS}: the working set of the timed loop ({N_PAIRS * SETS * N_ROWS * DIM * 2 / 1e6:.0f} MB) exceeds the 256 MiB Infinity "
                                    "Cache, every step streams its 204.8 MB from HBM"},
         "value_repeat_blocks": {"median": float(np.median([n_gpus * args.steps / t for t in repeat_s])) if repeat_s else None,
                                 "min": min(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None,
@@ -900,8 +960,10 @@ def main():
                              "note": "host wall-clock inside the timed loop: what the Python loop spends enqueueing (the device is never waited "
                                      "for there) and in FrechetJob.result (which waits for the oldest score in flight)"},
         "scores_in_flight": (3 * BATCH if BATCH else n_lanes), "lane_streams": bool(args.lane_streams and n_lanes > 1),
-        "schedule": (f"batched: moments of {BATCH} steps, then ONE square-root chain for their {BATCH} scores (fad_frechet_from_moments_multi_begin), "
-                     "3 batches in flight on 3 streams" if BATCH else (f"grouped ({G})" if G else f"lanes: one chain per score, {n_lanes} in flight")),
+        "moments_group": MG,
+        "schedule": (f"batched: moments of {BATCH} steps ({MG} steps = {2 * MG} frame matrices per launch of the tile kernel and of the reduce: "
+                     f"fad_moments_update_multi), then ONE square-root chain for their {BATCH} scores (fad_frechet_from_moments_multi_begin), "
+                     + ("3 batches in flight on ONE stream" if args.single_stream else "3 batches in flight on 3 streams") if BATCH else (f"grouped ({G})" if G else f"lanes: one chain per score, {n_lanes} in flight")),
         "step_ms_spread": {"min": float(step_ms.min()), "p10": float(np.percentile(step_ms, 10)), "median": float(np.median(step_ms)),
                            "p90": float(np.percentile(step_ms, 90)), "max": float(step_ms.max())},
         "breakdown_ms": {"moments_both_sets": float(np.median(bm)) if bm else None, "frechet": fr_ms,
@@ -911,7 +973,7 @@ def main():
                      "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_source": traffic_src or "not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                                       "this command, committed under profiles/ (FETCH_SIZE doubled per the gfx950 note)",
-                     "kernel_ms": kernel_ms, "kernel_ms_samples": timed_launches, "sets_per_launch": SETS, "algorithmic_flops_per_launch": flops,
+                     "kernel_ms": kernel_ms, "kernel_ms_samples": timed_launches, "sets_per_launch": LSETS, "algorithmic_flops_per_launch": flops,
                      # only the upper-triangular 128 x 128 tiles of the symmetric result are issued
                      "issued_flops_per_launch": issued, "frac_issued": issued / (kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                      # utilisation of the matrix pipe comes from ISSUED flops; `frac` above credits the symmetry
@@ -919,16 +981,19 @@ def main():
                      "mfma_util_note": "issued MFMA flops (the 32 x 32 blocks on and above the diagonal; on 128 x 128 tiles: upper-triangular "
                                        "tiles, 20 of 32 MFMAs on a diagonal tile) / kernel time / dense fp16 peak; `frac` = algorithmic "
                                        "2 N D^2 per set over the same time",
-                     "algorithmic_bytes_per_launch": SETS * N_ROWS * DIM * 2,
-                     "hbm_GBps_algorithmic": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
-                     "hbm_frac_of_8TBps": SETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": LSETS * N_ROWS * DIM * 2,
+                     "hbm_GBps_algorithmic": LSETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
+                     "hbm_frac_of_8TBps": LSETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "contended": bool(BATCH or (args.lane_streams and n_lanes > 1)),
-                     "contended_note": "the timed loop runs one stream per score in flight: this kernel shares the CUs with the square-root "
-                                       "chain of the previous score, and kernel_ms / achieved / frac above include that; `alone` = the "
-                                       "same launches with all scores on one stream (no two kernels overlap), side block of this run",
-                     "alone": ({"kernel_ms": per_stream_kernel_ms, "achieved": flops / (per_stream_kernel_ms * 1e-3) / 1e12,
-                                "frac": flops / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                                "mfma_util": issued / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}
+                     "contended_note": "kernel_ms = the dispatch's own begin -> end stamps (hipExtLaunchKernel start / stop events on the "
+                                       "launch's stream: the interval rocprofv3 --kernel-trace reports), sampled inside the timed loop, "
+                                       "where other streams' kernels (the square-root chains of earlier scores) may hold CUs while it "
+                                       "starts; `alone` = the same launches with all scores on one stream (no two kernels overlap), "
+                                       "side block of this run",
+                     "alone": ({"kernel_ms": per_stream_kernel_ms, "sets_per_launch": per_stream_sets,
+                                "achieved": flops * (per_stream_sets / LSETS) / (per_stream_kernel_ms * 1e-3) / 1e12,
+                                "frac": flops * (per_stream_sets / LSETS) / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                "mfma_util": issued * (per_stream_sets / LSETS) / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}
                                if (args.lane_streams and per_stream_kernel_ms) else None)},
         "roofline_frechet": {"route": {2: "eight launches: split-float16 Newton-Schulz + exact int8-MFMA products (csrc/ns_fast.h)",
                                        1: "float32 Newton-Schulz on the f32 MFMA + float64 correction", 0: "all-float64 iteration"}[route],

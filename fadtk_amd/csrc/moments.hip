@@ -26,6 +26,7 @@
 //   partials     [split][tile][BT][BT]   (BT = 128 fp32 | 64 fp64), fragment-major inside a 128x128 tile
 //   colpart      [split][nt*BT] fp64
 #include "fad_common.h"
+#include <hip/hip_ext.h>
 #include "moments_kernels.h"
 #include "moments_tile256.h"
 #include <dlfcn.h>
@@ -300,15 +301,20 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
         h->last_variant = 2;
     }
     L.total = item;
-    if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
-    if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
+    // timing: the two events take the dispatch's OWN begin / end stamps (what rocprofv3 reports for the kernel), not the stream's
+    // idle-to-idle interval -- with several streams in flight an event recorded ahead of the launch also counts the time the
+    // dispatch waits for another stream's workgroups to leave the CUs
+    if (ev) hipExtLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), (uint32_t)lds_bytes, st, ev[0], ev[1], 0u, L);
+    else hipLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
     if (any_guard)       // second pass of the shift guard: same geometry, gated per set; rewrites the flagged sets' partials and column sums
         hipLaunchKernelGGL((moments_tile256<FAD_F16, true>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
     R.sl = (max_s > 32) ? 16 : (max_s > 8) ? 4 : 1;
     const int G = 256 / R.sl;
     const int blocks = (int)cdiv((int64_t)R.nblk * 256, G) + (int)cdiv(d, 64);
-    hipLaunchKernelGGL(moments_reduce256, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, R);
+    // 8 KiB of dynamic LDS the kernel never touches: 10 instead of 20 of its workgroups per CU.  Measured at config 3
+    // (scripts/probes/tile256_overlap.hip): tile + reduce 92 -> 84 us per update with 4-12 KiB of padding, 86 with 20 KiB;
+    // D = 768 / 1024 within 1 %.
+    hipLaunchKernelGGL(moments_reduce256, dim3((unsigned)blocks, (unsigned)count), dim3(256), 8192, st, R);
     if (ev && h0->timing == 1) FAD_HIP_TRY(hipEventRecord(ev[2], st));
     FAD_HIP_TRY(hipGetLastError());
     for (int i = 0; i < count; ++i) hs[i]->fresh = false;
