@@ -693,6 +693,12 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
         double s0 = 0.0, s1 = 0.0;
         const int SC = r.SC;
         int sp = 0;
+        for (; sp + 7 < SC; sp += 8) {             // eight loads in flight: this walk is a latency chain (a quarter of a 16 us reduce)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = colpart[(int64_t)(sp + u) * dpad + a];
+            s0 += (v[0] + v[1]) + (v[2] + v[3]); s1 += (v[4] + v[5]) + (v[6] + v[7]);
+        }
         for (; sp + 1 < SC; sp += 2) { s0 += colpart[(int64_t)sp * dpad + a]; s1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
         if (sp < SC) s0 += colpart[(int64_t)sp * dpad + a];
         if (unshift) {                             // sum x = s' + n c, split by split
@@ -744,6 +750,18 @@ __device__ __forceinline__ void reduce_body(const ReduceSrc& r, int d, double* _
                     s[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
                     s[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
                     s[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+                }
+            }
+            if constexpr (sizeof(PT) == 8) {           // (float64 partials: the fp64 kernel's, or the first stage's sums)
+                for (; sp + 3 * SL < S; sp += 4 * SL) {
+                    double2 v[8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[2 * u] = *reinterpret_cast<const double2*>(ph + (sp + u * SL) * stride);
+                        v[2 * u + 1] = *reinterpret_cast<const double2*>(ph + (sp + u * SL) * stride + 2);
+                    }
+                    s[0] += (v[0].x + v[2].x) + (v[4].x + v[6].x); s[1] += (v[0].y + v[2].y) + (v[4].y + v[6].y);
+                    s[2] += (v[1].x + v[3].x) + (v[5].x + v[7].x); s[3] += (v[1].y + v[3].y) + (v[5].y + v[7].y);
                 }
             }
             for (; sp < S; sp += SL) {
@@ -828,7 +846,10 @@ __global__ __launch_bounds__(256) void moments_reduce(ReduceLaunch R) {
 // at small D: every run of <= 8192 rows is one split).  Block (x, c) sums the splits of chunk c for 256 output
 // groups (four loads in flight per thread) into fp64 partials laid out like moments_reduce<double, BT> expects;
 // trailing x-blocks do the same for the column partials.
-constexpr int PRESUM_CHUNK = 32;
+#ifndef FAD_PRESUM_CHUNK
+#define FAD_PRESUM_CHUNK 32
+#endif
+constexpr int PRESUM_CHUNK = FAD_PRESUM_CHUNK;
 template <int BT>
 __global__ __launch_bounds__(256) void moments_presum(
     const float* __restrict__ partials, const double* __restrict__ colpart, int S, int SC, int T, int nt, int group_blocks,
@@ -846,18 +867,30 @@ __global__ __launch_bounds__(256) void moments_presum(
     const int s0 = c * PRESUM_CHUNK, s1 = (s0 + PRESUM_CHUNK < S) ? s0 + PRESUM_CHUNK : S;
     const int dpad = nt * BT;
     if ((int)blockIdx.x >= group_blocks) {
-        const int a = ((int)blockIdx.x - group_blocks) * 256 + threadIdx.x;
-        if (a >= dpad) return;
-        // the colpart rows (SC of them: one per split, or one per run) are shared out evenly over the chunks
+        // the colpart rows (SC of them: one per split, or one per run -- 4096 files of a config-4 update) are shared out evenly over
+        // the chunks; eight loads in flight per thread, and at D = 128 the block's other 128 threads take every second row (the walk
+        // of 256 rows, two at a time, was most of this kernel's 35 us)
+        __shared__ double colred[256];
+        const int lanes = (dpad <= 128) ? 2 : 1, cpb = 256 / lanes;
+        const int a = ((int)blockIdx.x - group_blocks) * cpb + (int)threadIdx.x % cpb, l = (int)threadIdx.x / cpb;
         const int per = (SC + (int)gridDim.y - 1) / (int)gridDim.y;
         const int c0 = c * per, c1 = (c0 + per < SC) ? c0 + per : SC;
-        double t0 = 0.0, t1 = 0.0;
-        int sp = c0;
-        for (; sp + 1 < c1; sp += 2) { t0 += colpart[(int64_t)sp * dpad + a]; t1 += colpart[(int64_t)(sp + 1) * dpad + a]; }
-        if (sp < c1) t0 += colpart[(int64_t)sp * dpad + a];
-        if (unshift)
-            for (int q = c0; q < c1; ++q) t1 += rows_of(q) * f16_bits_to_f64(cvec[(int64_t)q * dpad + a]);
-        colpart2[(int64_t)c * dpad + a] = t0 + t1;
+        double t = 0.0;
+        if (a < dpad) {
+            int sp = c0 + l;
+            for (; sp + 7 * lanes < c1; sp += 8 * lanes) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = colpart[(int64_t)(sp + u * lanes) * dpad + a];
+                t += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; sp < c1; sp += lanes) t += colpart[(int64_t)sp * dpad + a];
+            if (unshift)
+                for (int q = c0 + l; q < c1; q += lanes) t += rows_of(q) * f16_bits_to_f64(cvec[(int64_t)q * dpad + a]);
+        }
+        colred[threadIdx.x] = t;
+        __syncthreads();
+        if (l == 0 && a < dpad) colpart2[(int64_t)c * dpad + a] = (lanes == 2) ? colred[threadIdx.x] + colred[threadIdx.x + cpb] : t;
         return;
     }
     constexpr int per_tile = BT * BT / 4;
@@ -869,6 +902,18 @@ __global__ __launch_bounds__(256) void moments_presum(
     const int64_t stride = (int64_t)T * TS32;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     int sp = s0;
+    for (; sp + 7 < s1; sp += 8) {                 // eight loads in flight (a chunk of 8 splits: all of them)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (sp + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) {
+            s[0] += ((double)v[u].x + (double)v[u + 1].x) + ((double)v[u + 2].x + (double)v[u + 3].x);
+            s[1] += ((double)v[u].y + (double)v[u + 1].y) + ((double)v[u + 2].y + (double)v[u + 3].y);
+            s[2] += ((double)v[u].z + (double)v[u + 1].z) + ((double)v[u + 2].z + (double)v[u + 3].z);
+            s[3] += ((double)v[u].w + (double)v[u + 1].w) + ((double)v[u + 2].w + (double)v[u + 3].w);
+        }
+    }
     for (; sp + 3 < s1; sp += 4) {
         const float4 v0 = *reinterpret_cast<const float4*>(p + sp * stride);
         const float4 v1 = *reinterpret_cast<const float4*>(p + (sp + 1) * stride);
