@@ -20,7 +20,7 @@ CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libfad_hip.so"
 ARCH = "gfx950"
-SOURCES = ["common.cpp", "host_stage.cpp", "moments.hip", "gemm_f64.hip", "gemm_f32.hip", "frechet.hip", "logmel.hip", "resample.hip"]
+SOURCES = ["common.cpp", "host_stage.cpp", "moments.hip", "gemm_f64.hip", "gemm_f32.hip", "frechet_f64.hip", "frechet.hip", "frechet_songs.hip", "logmel.hip", "resample.hip"]
 HEADERS = [*sorted(CSRC.glob("*.h")), PKG.parent / "include" / "fad_hip.h"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-x", "hip"]

@@ -112,7 +112,7 @@ int gemm_f64_launch(int d, const GemmType* types, int ntypes, int64_t batch, con
 int gemm_f64_slots(int d, int ntypes, int64_t batch, int device);
 int gemm_f64_slots_max(int d);
 
-// ---- Newton-Schulz trace-sqrt driver (frechet.hip) ---------------------------------------
+// ---- Newton-Schulz trace-sqrt driver (frechet_f64.hip: run_ns; workspaces in frechet_internal.h) ---------------------------------------
 struct NsWorkspace {
     DevBuf mats;      // 6 * d*d doubles: A, Y0, Y1, Z0, Z1, T
     DevBuf small;     // partials, per-iteration stats, flags

@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(
 
 // ------------------------------------------------------------------------------------------
 // Per-song covariances on the float16 tile body (frechet.hip: the batched per-song chain, songs of at least D + 1 float16 frames).
-// Round 2 formed them on the float64 MFMA (song_cov_mfma, frechet.hip): 3.0 ms of a 10.5 ms call for 2000 songs of [2250 x 128],
+// Round 2 formed them on the float64 MFMA (song_cov_mfma, frechet_songs.hip): 3.0 ms of a 10.5 ms call for 2000 songs of [2250 x 128],
 // 1.0 of 8.5 ms for 32 songs of [1500 x 768] (profiles/r03j_*).  Here a song is what a split is to moments_tile_h16_tr, in its
 // SHIFTED form: every column is shifted by c = float16(mean) (the exact mean is known: the statistics kernel ran), the rows enter
 // the MFMAs as the error-free pair x - c = x' + e, the products are exact in float32 and what is summed is centred -- float32-sum

@@ -40,7 +40,7 @@ struct Gemm32Args {
 
 
 // Extras of the two fp64 products of the mixed-precision route whose epilogues also produce statistics (gemm_f64.hip,
-// gemm_f64_kernel MODE 1 / 2).  stats: tile statistics in the layout of ns_tilestats (frechet.hip).
+// gemm_f64_kernel MODE 1 / 2).  stats: tile statistics in the layout of ns_tilestats (frechet_f64.hip).
 struct NsProductExt {
     double* stats;
     // MODE 1 (A = C1 C2): the spare workgroup's mean term

@@ -87,7 +87,7 @@ def calc_frechet_distance(mu1, cov1, mu2, cov2, eps: float = 1e-6, device: int =
 
         d^2 = ||mu1 - mu2||^2 + Tr(cov1) + Tr(cov2) - 2 Tr sqrt(cov1 cov2)
 
-    Tr sqrt(cov1 cov2) comes from the GPU (Newton-Schulz in float64, see csrc/frechet.hip); the
+    Tr sqrt(cov1 cov2) comes from the GPU (Newton-Schulz, see csrc/frechet.hip and csrc/frechet_f64.hip); the
     O(D) terms are formed here with numpy so that the reference's dtype behaviour carries over
     (float16 means give a float16 ``diff.dot(diff)``).  Returns ``np.float64``.
     Raises AssertionError on shape mismatch (fad.py:78-81) and ValueError when the product has no

@@ -43,7 +43,7 @@ def run(c1, c2, scaled, l0=None, max_iter=80):
     u = min(np.linalg.norm(a, "fro"), np.linalg.norm(a, 1), np.linalg.norm(a, np.inf))
     if scaled:
         c = u
-    else:                                   # the shipped rule (frechet.hip ns_prepare)
+    else:                                   # the shipped rule (frechet_f64.hip ns_prepare)
         c = max(u / 2.5, np.linalg.norm(a, "fro") ** 2 / np.trace(a))
     y, z = a / c, np.eye(d)
     l = l0
