@@ -228,7 +228,7 @@ def _song_chain_roofline(nsongs, frames, d, seconds, iters):
     return {"bound": "mfma", "achieved": (cov_flops + it_flops + i8_ops) / seconds / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "T(FL)OP/s issued (f16 + int8)",
             "frac": ideal / seconds, "issued": {"f16_cov_flops": cov_flops, "f16_iteration_flops": it_flops, "i8_ops": i8_ops, "iterations_assumed": iters},
             "note": "frac = time the issued MFMA work needs at the dense peaks (f16 2.5 PFLOP/s, int8 5 POP/s) / whole call time; iterations as measured "
-                    "for these songs (condition numbers of a few hundred: 9-12)"}
+                    "for these songs (condition numbers of a few thousand: 6-8 with the scaled steps of round 4, 7-12 before)"}
 
 
 def extra_c5_frames(torch, hip, device):
@@ -260,7 +260,7 @@ def extra_c5_frames(torch, hip, device):
     rel = float(np.nanmax(np.abs(sc5[:n_cpu] - want) / np.abs(want)))
     return {"songs": nsongs, "dim": d5, "frames_per_song": frames, "ms": dt5 * 1e3, "ms_spread": spread(ms), "songs_per_s": nsongs / dt5,
             "ok": int((st5 == 0).sum()), "max_rel_err_vs_oracle_sample": rel,
-            "roofline": _song_chain_roofline(nsongs, frames, d5, dt5, iters=11),
+            "roofline": _song_chain_roofline(nsongs, frames, d5, dt5, iters=8),
             "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": "BLAS threads as numpy finds them", "kind": "port",
                              "sample": f"{n_cpu} of the same songs through the oracle (np.cov + eig + sqrtm per song, fad.py:373-378), "
                                        "one after the other", "seconds": dt_cpu},
@@ -298,7 +298,7 @@ def extra_c4_songs(torch, hip, device):
     return {"songs": nsongs, "dim": d4, "frames_per_song": frames, "ms": dt * 1e3, "ms_spread": spread(ms), "songs_per_s": nsongs / dt,
             "ok": int((stt == 0).sum()), "max_rel_err_vs_oracle_sample": rel,
             "GBps_frames": songs.numel() * 2 / dt / 1e9,
-            "roofline": _song_chain_roofline(nsongs, frames, d4, dt, iters=9),
+            "roofline": _song_chain_roofline(nsongs, frames, d4, dt, iters=6),
             "note": "as per_song_config5_encoder_frames, but D = 128: the whole Newton-Schulz iteration of a song runs in ONE workgroup, iterates in "
                     "LDS and registers (ns_fast_res.h)",
             "cpu_baseline": {"value": n_cpu / dt_cpu, "unit": "songs/s", "cores": "BLAS threads as numpy finds them", "kind": "port",

@@ -38,6 +38,8 @@ SongKnobs SongKnobs::from_env() {
     k.gram = !off("FAD_SONG_GRAM"); k.stats16 = !off("FAD_SONG_STATS16"); k.cov16 = !off("FAD_SONG_COV16"); k.sym = !off("FAD_SONG_SYM");
     if (const char* e = getenv("FAD_SONG_SYM_MAX_FRAMES_PER_DIM")) k.sym_max_mult = (int64_t)atoll(e);
     if (const char* e = getenv("FAD_FAST_TRACE")) k.trace = e[0] == '1';
+    k.scaled = !off("FAD_SONG_SCALED");
+    if (const char* e = getenv("FAD_SONG_L0_SCALE")) { const double v = atof(e); if (v > 0.0) k.l0_scale = v; }
     return k;
 }
 
@@ -502,6 +504,9 @@ int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipSt
     // knobs.res (FAD_SONG_RES) = 0: D = 128 iterates through the batched kernels like the other dimensions (tests compare)
     const bool resident = d == 128 && knobs.res != 0;
     const bool res_full = resident && knobs.res != 1;            // 1: only the iteration resident; default: the exact products too
+    // scaled Newton-Schulz steps per song (ns_check.h): the 128 x 128-tile family only (iteration 0, T and U all run there for d >= 256)
+    const bool scaled_steps = knobs.scaled && big && d >= 256;
+    const bool scaled_res = knobs.scaled && resident;                 // ... and the resident kernel of D = 128
     const size_t dd = (size_t)d * d;
     const int nb = d / 32;
     const SongBlock L = song_block(d);
@@ -550,6 +555,7 @@ int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipSt
         memset(&g, 0, sizeof(g));
         g.d = d; g.gen = gen; g.hA = hdr_b; g.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr)); g.pstride = (int64_t)L.stride;
         g.st = st0; g.s32 = s32_0;
+        g.scaled = scaled_steps ? 1 : 0; g.l0_scale = knobs.l0_scale;
         return g;
     };
     {
@@ -573,6 +579,7 @@ int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipSt
             r.gen = gen; r.max_low = kMaxLow; r.thr_pred = pred_threshold(ws.pool, d); r.hA = hdr_b; r.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdr));
             r.pstride = (int64_t)L.stride; r.A64 = A64; r.statsA = stats; r.st = st0; r.s32 = s32_0;
             r.Y[0] = Y[0]; r.Y[1] = Y[1]; r.Z[0] = Z[0]; r.Z[1] = Z[1];
+            r.scaled = scaled_res ? 1 : 0; r.l0_scale = 2.0 * knobs.l0_scale;          // (D = 128: 6 iterations at the full estimate, 7 at half of it)
             if (res_full) {
                 // ... and the two exact products with it: A = Sigma_b Sigma_s in front, the correction behind; the host record is this kernel's
                 r.Adig = dig_b; r.Bdig = reinterpret_cast<uint4*>(at(L.digS)); r.hstride = (int64_t)hs;
@@ -601,7 +608,7 @@ int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipSt
             const int cur = k & 1;
             nsf::SplitArgs g = split_args();
             g.A[0] = Z[cur]; g.B[0] = Y[cur]; g.C[0] = T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f;
-            g.partials = partials; g.skip = &s32_0->done;
+            g.partials = partials; g.skip = &s32_0->done; g.k = k;
             if (big) FAD_TRY(fast_split_big(d, nsf::SP_T, g, st, (unsigned)B, device));
             else fast_split(d, nsf::SP_T, g, st, (unsigned)B);
             g = split_args();
@@ -646,6 +653,11 @@ int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipSt
             if (trace)
                 fprintf(stderr, "[fad fast songs] song %lld: status %d iters %d decided_at %d res %.3e est %.3e tr %.6e c %.3e (words bad %d done %d ok %d failed %d skipped %d)\n",
                         (long long)b, r.status, r.iters, r.decided_at, r.res, r.est, r.tr_scaled, r.c, hw[0], hw[1], hw[5], hw[6], hw[11]);
+            if (trace && b == 0) {
+                fprintf(stderr, "[fad fast songs] song 0 residuals:");
+                for (int q = 1; q < 16 && q <= r.iters; ++q) fprintf(stderr, " %.3e", hv[4 + q]);
+                fprintf(stderr, "\n");
+            }
         }
         if (!pending) break;
         upto = kMaxLow;

@@ -156,21 +156,7 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
         double l = 1.0;
         if (scaled) {
             c = u;
-            // (float arithmetic on the hardware's exp2 / log2: the double pow() of a first version made this one thread take 90 us)
-            const float pr = (float)(trA * trA / trA2), lg = __log2f((float)d);
-            auto S = [&](float p) {                 // sum_{k=1..d} k^-p, trapezoid rule on the integral
-                if (fabsf(p - 1.0f) < 1e-4f) return 0.5f * (1.0f + exp2f(-lg)) + lg * 0.69314718f;
-                return 0.5f * (1.0f + exp2f(-p * lg)) + (exp2f((1.0f - p) * lg) - 1.0f) / (1.0f - p);
-            };
-            float lo = 0.0f, hi = 8.0f, pf = 4.0f;
-            for (int it = 0; it < 20; ++it) {
-                pf = 0.5f * (lo + hi);
-                const float s1 = S(pf), val = s1 * s1 / S(2.0f * pf);
-                if (val > pr) lo = pf; else hi = pf;
-            }
-            l = (double)(exp2f(-0.5f * pf * lg) * (1.0f / 3.0f));
-            if (l > 0.5) l = 0.5;
-            if (l < 1e-5) l = 1e-5;
+            l = ns_l0_from_participation((float)(trA * trA / trA2), d);
         }
         {
             int k = 0;

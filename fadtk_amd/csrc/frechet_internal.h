@@ -155,6 +155,9 @@ struct SongKnobs {
     bool sym = true;            // FAD_SONG_SYM: the symmetric route sqrt(Sigma_b) Sigma_s sqrt(Sigma_b) for long songs
     int64_t sym_max_mult = 8;   // FAD_SONG_SYM_MAX_FRAMES_PER_DIM
     bool trace = false;         // FAD_FAST_TRACE: one stderr line per song of the low-precision chain
+    double l0_scale = 0.5;      // FAD_SONG_L0_SCALE: multiplier on the x_min estimate the scaled steps start from (measured 3 / 2 / 1 / 0.5 / 0.25:
+                                // 10 / 10 / 9 / 8 / 8 iterations at 32 x [1500 x 768], 10 / 9 / 8 / 7 / 8 at [1200 x 512], 7 / 6 / 6 / 7 / 8 at [2250 x 128])
+    bool scaled = true;         // FAD_SONG_SCALED: scaled Newton-Schulz steps on the 128 x 128-tile family of the low-precision chain
     static SongKnobs from_env();
 };
 // covs: B covariances [d x d] float64 on the device; -> tr_sqrt[b] and ok[b] (1: accepted, 0: hand the song to the float64 routes)

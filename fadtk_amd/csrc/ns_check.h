@@ -36,7 +36,53 @@ struct NsState {
     // mu[k] = 1 once l_k >= 0.9 (and always for flat spectra): the plain iteration, whose rules close the problem.  Written by
     // ns_prepare, read by ns_first, the T product (gemm_f64.hip) and the check.
     double mu[kMaxIter];
+    // lower bound of the eigenvalues x of the CURRENT iterate's sqrt(Z Y) (batched low-precision chain, ns_fast_big.h: the step scale
+    // of iteration k + 1 is set by the check of iteration k from this bound and the residual it has just measured)
+    double l_cur;
 };
+
+// x_min estimate for the scaled steps: invert PR(p) = (sum k^-p)^2 / sum k^-2p, k = 1..d, for the exponent p of a power-law spectrum
+// with participation ratio pr = (tr A)^2 / tr(A^2), then x_min = d^(-p/2) / 3 (a third: safety).  Float arithmetic on the hardware's
+// exp2 / log2 (the double pow() of a first version took 90 us on one thread).
+__device__ __forceinline__ double ns_l0_from_participation(float pr, int d) {
+    const float lg = __log2f((float)d);
+    auto S = [&](float p) {                 // sum_{k=1..d} k^-p, trapezoid rule on the integral
+        if (fabsf(p - 1.0f) < 1e-4f) return 0.5f * (1.0f + exp2f(-lg)) + lg * 0.69314718f;
+        return 0.5f * (1.0f + exp2f(-p * lg)) + (exp2f((1.0f - p) * lg) - 1.0f) / (1.0f - p);
+    };
+    float lo = 0.0f, hi = 8.0f, pf = 4.0f;
+    for (int it = 0; it < 20; ++it) {
+        pf = 0.5f * (lo + hi);
+        const float s1 = S(pf), val = s1 * s1 / S(2.0f * pf);
+        if (val > pr) lo = pf; else hi = pf;
+    }
+    double l = (double)(exp2f(-0.5f * pf * lg) * (1.0f / 3.0f));
+    if (l > 0.5) l = 0.5;
+    if (l < 1e-5) l = 1e-5;
+    return l;
+}
+// the bound after a step of GIVEN scale mu (x -> mu x (3 - mu^2 x^2) / 2 is increasing on [0, 1 / mu])
+__device__ __forceinline__ double ns_step_scale_with(double mu, double& l) {
+    l = mu * l * (3.0 - mu * mu * l * l) / 2.0;
+    if (l > 1.0) l = 1.0;
+    return mu;
+}
+// Cap on a step scale from the residual r = ||I - Z Y||_F of the iterate it is applied to: were the spectrum concentrated at
+// x^2 = 1 - r / sqrt(d) (the root mean square of 1 - x^2), mu^2 = 1 / x^2 would put it on the peak of the cubic; a larger scale -- from
+// a lower bound l that lags far behind a nearly converged iterate whose r is still above 1 -- throws the bulk back (measured: a start
+// at a tenth of the x_min estimate ended in a growing residual and the float64 fallback; with the cap it costs one or two iterations).
+__device__ __forceinline__ double ns_scale_cap(double res, int d) {
+    double rr = res / sqrt((double)d);
+    if (!(rr < 0.66)) rr = 0.66;
+    return sqrt(1.0 / (1.0 - rr));
+}
+// One scaled step: with every x in [l, 1], mu^2 = 3 / (1 + l + l^2) (1 once l >= 0.9); l <- mu l (3 - mu^2 l^2) / 2.
+__device__ __forceinline__ double ns_step_scale(double& l) {
+    if (!(l < 0.9)) { l = l * (3.0 - l * l) / 2.0; return 1.0; }
+    const double m = sqrt(3.0 / (1.0 + l + l * l));
+    l = m * l * (3.0 - m * m * l * l) / 2.0;
+    return m;
+}
 constexpr int kStateInts = sizeof(NsState) / sizeof(int);
 
 struct NsCheckArgs {

@@ -578,6 +578,8 @@ struct SplitArgs {
     // SP_U: the check of iteration k rides on the launch (blockIdx.z == 2)
     int k, max_low, nslots;
     int nprob, nprob_pad;                // ns_fast_big.h: problems of the batch, and that rounded up to a multiple of 8
+    double l0_scale;                     // ... multiplier on the x_min estimate of ns_l0_from_participation
+    int scaled;                          // ns_fast_big.h: scaled steps -- T_k = 1.5 mu I - 0.5 mu^3 Z Y with mu = st->mu[k] per problem (ns_check.h)
     double thr_pred;
     const double* chk_partials;
 };
@@ -586,7 +588,7 @@ struct SplitArgs {
 // float32 leg, gemm_f32.hip: ns32_check).
 template <int NT = 512> __device__ __forceinline__ void nsf_check(const SplitArgs& g, int64_t po, double* red) {
     Ns32State* st = adv(g.s32, po);
-    const NsState* st64 = adv(g.st, po);
+    NsState* st64 = adv(g.st, po);
     const double* chk_partials = adv(g.chk_partials, po);
     const int k = g.k;
     if (st->finished || st64->done) {
@@ -597,8 +599,21 @@ template <int NT = 512> __device__ __forceinline__ void nsf_check(const SplitArg
     for (int i = threadIdx.x; i < g.nslots; i += NT) s[0] += chk_partials[i];
     wg8_sum<1, NT / 64>(s, red);
     if (threadIdx.x != 0) return;
-    const double res = 2.0 * sqrt(s[0]);
+    // (scaled step: the partials hold (T - (1.5 mu - 0.5 mu^3) I)^2 = (0.5 mu^3)^2 (I - Z Y)^2)
+    const double mu_k = g.scaled ? st64->mu[k] : 1.0;
+    const double res = 2.0 * sqrt(s[0]) / (mu_k * mu_k * mu_k);
     if (k < 16) st->res[k] = res;
+    if (g.scaled && k + 1 < kMaxIter) {
+        // scale of iteration k + 1: every x of iterate k lies above the schedule's bound -- and, once the residual is below 1, above
+        // sqrt(1 - res) (|1 - x^2| <= ||I - Z Y||) -- so a bound that was too careful stops over-scaling as soon as the iterate shows it
+        double l = st64->l_cur;
+        if (res == res && res < 1.0) { const double lr = sqrt(1.0 - res); if (lr > l) l = lr; }
+        (void)ns_step_scale_with(mu_k, l);                        // iterate k + 1's bound under the step this launch is taking
+        double ln = l, mn = ns_step_scale(ln);
+        const double cap = ns_scale_cap(res, g.d);                 // (iterate k + 1's own residual is not known yet: iterate k's)
+        st64->mu[k + 1] = mn < cap ? mn : cap;
+        st64->l_cur = l;
+    }
     const double prev = (k > 0 && k <= 16) ? st->res[k - 1] : 1e300;
     const bool finite = (res == res) && !isinf(res);
     // (round 3 ended "k >= 8 and still above 1" here: a song of 2 D frames -- condition number of a few hundred, residual ~1 at
@@ -612,7 +627,7 @@ template <int NT = 512> __device__ __forceinline__ void nsf_check(const SplitArg
         return;
     }
     const double bound = 0.75 * res * res + 0.25 * res * res * res;
-    if (bound <= (st->strict ? 2e-6 : g.thr_pred)) {              // Y_{k+1} (this launch's update) is final
+    if (bound <= (st->strict ? 2e-6 : g.thr_pred) && mu_k == 1.0) {      // Y_{k+1} (this launch's update, a plain step) is final
         st->ok = 1; st->skip_corr = 0; st->finished = 1; st->done = 1; st->final_iter = k + 1; st->decided_at = k; st->upd_skip[(k + 1) & 1] = 1;
     }
 }

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     const MatHdr* hA = adv(g.hA, (int64_t)song * g.astride);        // (astride = 0: the songs' shared baseline; pairs: per problem)
     if (hdr_bad(hA, hB, g.gen)) return;
     double inv_c = 0.0, inv_cn = 0.0;
+    float m1 = 1.5f, m3 = 0.5f;                                      // SP_FIRST: 1.5 mu_0, 0.5 mu_0^3
     if constexpr (MODE == SP_FIRST) {
         // ---- the scale, as nsf_split<FIRST> derives it (every workgroup, identically, from nsf_i8<A>'s 32 x 32 tile statistics);
         // the ring is not in use yet: it holds the per-tile maxima meanwhile
@@ -94,6 +95,20 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
         const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
+        // Scaled steps (g.scaled): a spectrum that is not flat -- participation ratio below 0.8 d: songs of a few D frames, a baseline
+        // whose variances differ by dimension -- starts from c = u >= rho(A) (every x = sqrt(lambda / c) in (0, 1]) and lifts the lower
+        // end by mu_k per step (ns_check.h); flat spectra keep the start near 1 above, which needs no lifting.
+        const bool scaled = g.scaled && !bad && !zero && !hopeless && u > 0.0 && trA * trA < 0.8 * (double)d * fro2;
+        double mu0 = 1.0;
+        if (scaled) {
+            c = u;
+            double l = ns_l0_from_participation((float)(trA * trA / fro2), d) * g.l0_scale;      // (||A||_F^2 >= tr A^2: the estimate errs low)
+            if (l > 0.5) l = 0.5;
+            mu0 = ns_step_scale(l);
+            if (tile == 0 && tid == 0) { double ln = l; st_p->mu[0] = mu0; st_p->mu[1] = ns_step_scale(ln); st_p->l_cur = l; }
+        } else if (g.scaled && tile == 0 && tid == 0) {
+            st_p->mu[0] = 1.0; st_p->mu[1] = 1.0; st_p->l_cur = 1.0;
+        }
         if (tile == 0 && tid == 0) {
             NsState* st = st_p; Ns32State* s32 = adv(g.s32, po);
             st->c = zero ? 1.0 : c * hdr_inv_s12(hA, hB);
@@ -109,6 +124,7 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
         if (bad || zero || hopeless) return;
         inv_cn = 1.0 / c;
         inv_c = inv_cn / hdr_inv_s12(hA, hB);
+        m1 = (float)(1.5 * mu0); m3 = (float)(0.5 * mu0 * mu0 * mu0);
         __syncthreads();                                             // the maxima have been read: the ring may fill
     } else {
         if (g.skip && *adv(g.skip, po) != 0) return;
@@ -185,7 +201,11 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     // ---- epilogue, per wave: its four 32 x 32 blocks one after the other through a [32][33] float area of its own
     float* fin = reinterpret_cast<float*>(ring) + wave * (32 * 33 + 32);
     const int kg = lane >> 5, r = lane & 31;
-    const float alpha = (MODE == SP_T) ? g.alpha : 1.f, beta = (MODE == SP_T) ? g.beta_eye : 0.f;
+    float alpha = (MODE == SP_T) ? g.alpha : 1.f, beta = (MODE == SP_T) ? g.beta_eye : 0.f, gamma = g.gamma;
+    if (MODE == SP_T && g.scaled) {                                  // this problem's step scale (set by FIRST / the previous check)
+        const double m = adv(g.st, po)->mu[g.k];
+        alpha = (float)(-0.5 * m * m * m); beta = (float)(1.5 * m); gamma = beta + alpha;
+    }
     const SplitMat Cm = adv(g.C[zi], po);
     const bool with_digits = (MODE == SP_U) && zi == 0 && g.Cdig[0];
     uint4* dig = with_digits ? adv(g.Cdig[0], po) : nullptr;
@@ -205,8 +225,8 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
                     const int q = (reg & 3) + 8 * (reg >> 2);
                     const float y0 = (float)(A64[(int64_t)q * d] * inv_c);
                     const float y2 = (float)((double)(acc0[i][j][reg] + acc1[i][j][reg] * kLoInv) * (inv_cn * inv_cn));
-                    fin[(q + 4 * kg) * 33 + r] = 1.5f * y0 - 0.5f * y2;
-                    z1[reg] = ((by == bx && q + 4 * kg == r) ? 1.5f : 0.f) - 0.5f * y0;
+                    fin[(q + 4 * kg) * 33 + r] = m1 * y0 - m3 * y2;
+                    z1[reg] = ((by == bx && q + 4 * kg == r) ? m1 : 0.f) - m3 * y0;
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
                 const int q = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
                 const bool dg = (by == bx) && (q == r);
                 const float v = alpha * (acc0[i][j][reg] + acc1[i][j][reg] * kLoInv) + (dg ? beta : 0.f);
-                if constexpr (MODE == SP_T) { const double e = (double)v - (dg ? (double)g.gamma : 0.0); ss += e * e; }
+                if constexpr (MODE == SP_T) { const double e = (double)v - (dg ? (double)gamma : 0.0); ss += e * e; }
                 fin[q * 33 + r] = v;
             }
             __builtin_amdgcn_wave_barrier();

@@ -44,6 +44,7 @@ struct ResArgs {
     // FULL
     const uint4* Adig; const uint4* Bdig;        // digit planes of s_b Sigma_b (shared) and of (s_s Sigma_s)^T (per song)
     int64_t hstride; double* stats; int* host_words; double* host_vals;      // pinned host: what nsf_i8<G> leaves per problem
+    int scaled; double l0_scale;         // scaled steps (ns_check.h), as ns_fast_big.h
 };
 
 // position of element (row, col) of a matrix stored as A-operand pieces in LDS: byte offset of its hi half (lo: + 1024)
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void nsf_res128(ResArgs g) {
 
     // ---- the scale (what nsf_split<FIRST> does): c = max(u / 2.9, ||A||_F^2 / tr A), u >= the spectral radius
     double c, inv_c;
+    double mu = 1.0, l_cur = 1.0;             // step scale of the iteration at hand and the lower bound of its iterate's x (scaled steps)
     {
         double inf_b = 1e300, one_b = 1e300;
         double v2[2] = {0.0, 0.0};
@@ -169,6 +171,12 @@ __global__ __launch_bounds__(256) void nsf_res128(ResArgs g) {
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
         const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
+        if (g.scaled && !bad && !zero && !hopeless && u > 0.0 && trA * trA < 0.8 * (double)d * fro2) {       // (ns_fast_big.h: SP_FIRST)
+            c = u;
+            l_cur = ns_l0_from_participation((float)(trA * trA / fro2), d) * g.l0_scale;
+            if (l_cur > 0.5) l_cur = 0.5;
+            mu = ns_step_scale(l_cur);
+        }
         if (tid == 0) {
             st->c = zero ? 1.0 : c * hdr_inv_s12(g.hA, hB);
             st->tr1 = tr1; st->tr2 = tr2;
@@ -239,13 +247,14 @@ __global__ __launch_bounds__(256) void nsf_res128(ResArgs g) {
     f16x8 Yh[8], Yl[8], Zh[8], Zl[8], Th[8], Tl[8];
     {
         const double* A64 = adv(g.A64, po) + (int64_t)(4 * kg) * d + 32 * j + n;       // (FULL: this lane's own stores of phase 0)
+        const float a0 = (float)(0.5 * mu * mu * mu), b0 = (float)(1.5 * mu);            // T0 = 1.5 mu_0 I - 0.5 mu_0^3 Y0
 #pragma unroll
         for (int rbo = 0; rbo < 4; ++rbo)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 float y0 = (float)(A64[(int64_t)(32 * rbo + rowc(reg)) * d] * inv_c);
                 asm volatile("" : "+v"(y0));                 // (or the two roundings fuse into an emulated double -> half conversion)
-                const float t0 = ((rbo == j && rowc(reg) + 4 * kg == n) ? 1.5f : 0.f) - 0.5f * y0;
+                const float t0 = ((rbo == j && rowc(reg) + 4 * kg == n) ? b0 : 0.f) - a0 * y0;
                 _Float16 h, l;
                 split16(y0, h, l); Yh[2 * rbo + (reg >> 3)][reg & 7] = h; Yl[2 * rbo + (reg >> 3)][reg & 7] = l;
                 split16(t0, h, l); Th[2 * rbo + (reg >> 3)][reg & 7] = h; Tl[2 * rbo + (reg >> 3)][reg & 7] = l;
@@ -266,22 +275,32 @@ __global__ __launch_bounds__(256) void nsf_res128(ResArgs g) {
     double prev = 1e300;
     for (int k = 1;; ++k) {
         float ss = 0.f;
-        product(P, Yh, Yl, Th, Tl, [&](int rbo, int reg, float m) {      // M_j = Z Y_j -> T_j = 1.5 I_j - 0.5 M_j
+        {   // this iteration's step scale: mu (1 without scaled steps) from the bound of iterate k
+            double lk = l_cur;
+            mu = g.scaled ? ns_step_scale(lk) : 1.0;
+            if (g.scaled && k > 1) { const double cap = ns_scale_cap(prev, d); if (cap < mu) mu = cap; }     // (prev: the residual of iterate k - 1)
+        }
+        const float ak = (float)(0.5 * mu * mu * mu), gk = (float)(1.5 * mu - 0.5 * mu * mu * mu);
+        product(P, Yh, Yl, Th, Tl, [&](int rbo, int reg, float m) {      // M_j = Z Y_j -> T_j = 1.5 mu I_j - 0.5 mu^3 M_j
             const bool dg = rbo == j && rowc(reg) + 4 * kg == n;
-            const float e = (dg ? 0.5f : 0.f) - 0.5f * m;               // T - I
+            const float e = (dg ? ak : 0.f) - ak * m;                   // T - (1.5 mu - 0.5 mu^3) I
             ss += e * e;
-            return dg ? e + 1.f : e;
+            return dg ? e + gk : e;
         });
-        // r_k = ||I - Z_k Y_k||_F = 2 ||T_k - I||_F, the same for every thread; then the rules of nsf_check
+        // r_k = ||I - Z_k Y_k||_F = ||T_k - gamma I||_F / (0.5 mu^3), the same for every thread; then the rules of nsf_check
         double s1[1] = {(double)ss};
         wg8_sum<1, 4>(s1, red);                              // (two barriers: every wave is done reading P as Z)
-        const double res = 2.0 * sqrt(s1[0]);
+        const double res = sqrt(s1[0]) / (0.5 * mu * mu * mu);
+        if (g.scaled) {                                      // bound of iterate k + 1 (nsf_check)
+            if (res == res && res < 1.0) { const double lr = sqrt(1.0 - res); if (lr > l_cur) l_cur = lr; }
+            (void)ns_step_scale_with(mu, l_cur);
+        }
         if (tid == 0 && k < 16) s32->res[k] = res;
         const bool finite = (res == res) && !isinf(res);
         if (!finite || k + 1 >= g.max_low || (k >= 4 && res > prev && res > 1e-3)) { failed = 1; final_iter = k; decided_at = k; break; }
         if (res <= 1e-3 && (res > 0.3 * prev || res <= 1e-6)) { ok = 1; final_iter = k; decided_at = k; break; }      // at the floor: Y_k is final
         const double bound = 0.75 * res * res + 0.25 * res * res * res;
-        const bool last = bound <= g.thr_pred;               // Y_{k+1} is final
+        const bool last = bound <= g.thr_pred && mu == 1.0;  // Y_{k+1} is final (the update about to run is a plain step)
         prev = res;
         scatter(P, Th, Tl);                                  // T_k becomes the left factor of Z' = T Z
         product(Q, Th, Tl, Yh, Yl, ident);                   // Y'_j = Y T_j  (the old column block of Y is not needed any more)
