@@ -502,7 +502,7 @@ def main():
     masked = args.chain_cus > 0 and args.lane_streams and n_lanes > 1
 
     class Lane:
-        def __init__(self, k, own=None, mstream=None):
+        def __init__(self, k, own=None, mstream=None, shared=None):
             own = (args.lane_streams and n_lanes > 1) if own is None else own
             self.stream = torch.cuda.Stream(device=device) if own else torch.cuda.current_stream(device)
             self.cstream = self.stream                                   # where the square-root chain goes
@@ -513,8 +513,12 @@ def main():
                 # --chain-cus C: moments on CUs [C, 32) of every XCD, chains on CUs [0, C) (FAD_MOMENTS_CUS tells the planner)
                 self.stream = hip.cu_masked_stream(range(args.chain_cus, 32), local_rank)
                 self.cstream = hip.cu_masked_stream(range(0, args.chain_cus), local_rank)
-            self.shared = fdist.SharedStats(DIM, SETS, local_rank)
-            self.ma, self.mb = self.shared.moments
+            if shared is not None:                                       # (a slot of a group's buffer: --moments-group)
+                self.shared, slot = shared
+                self.ma, self.mb = self.shared.moments[2 * slot], self.shared.moments[2 * slot + 1]
+            else:
+                self.shared = fdist.SharedStats(DIM, SETS, local_rank)
+                self.ma, self.mb = self.shared.moments
             self.job = None
             self.fed = torch.cuda.Event(); self.reduced = torch.cuda.Event()
 
@@ -652,7 +656,10 @@ def main():
         NB_FLY = 3
         # (--single-stream: all batches on ONE stream -- no two kernels ever overlap, the tile kernel's HIP-event time is the kernel alone)
         bstreams = [torch.cuda.current_stream(device)] * NB_FLY if args.single_stream else [torch.cuda.Stream(device=device) for _ in range(NB_FLY)]
-        blanes = [[Lane(k, own=False) for k in range(BATCH)] for _ in range(NB_FLY)]
+        # the statistics of the steps that share a moments launch live in ONE device buffer (2 M packed accumulators): with several
+        # ranks their exchange is ONE in-place all-reduce per launch (16.8 MB at M = 4) instead of one per step
+        gshared = [[fdist.SharedStats(DIM, SETS * MG, local_rank) for _ in range(-(-BATCH // MG))] for _ in range(NB_FLY)] if MG > 1 else None
+        blanes = [[Lane(k, own=False, shared=((gshared[q][k // MG], k % MG) if MG > 1 else None)) for k in range(BATCH)] for q in range(NB_FLY)]
         for q in range(NB_FLY):
             for ln in blanes[q]:
                 ln.stream = ln.cstream = bstreams[q]
@@ -699,8 +706,9 @@ def main():
                                 grp[0].fed.record()
                                 with torch.cuda.stream(comm_stream):
                                     comm_stream.wait_event(grp[0].fed)
+                                    gs = grp[0].shared
+                                    dist.all_reduce(gs.buffer[: 2 * len(grp) * gs.stride])        # the group's statistics: one collective
                                     for ln in grp:
-                                        dist.all_reduce(ln.shared.buffer)
                                         ln.reduced.record()
                 else:
                     for k in range(m):
@@ -932,8 +940,8 @@ def main():
                                "moments of both sets + Newton-Schulz Frechet, inputs resident in HBM "
                                f"({N_PAIRS} distinct pairs rotated: every step reads its frames from HBM, not from the Infinity Cache)",
                    "rows_per_set_per_gpu": N_ROWS, "dim": DIM,
-                   "sharding": "rows sharded over ranks; ONE in-place all-reduce over the buffer holding both sets' packed "
-                               f"(n, sum x, sum xxT) fp64 [2 x {plen} doubles]" if distributed else "single GPU, no collective",
+                   "sharding": ("rows sharded over ranks; ONE in-place all-reduce per moments launch over the buffer holding the packed "
+                                f"(n, sum x, sum xxT) fp64 of its {2 * MG if BATCH else 2} sets [{2 * MG if BATCH else 2} x {plen} doubles]") if distributed else "single GPU, no collective",
                    "collective_backend": coll_backend, "collective_ranks": coll_ranks},
         "fad": fad0, "fad_pair": ("pair 0 (seeds 10 / 11: the golden G7 pair) on this rank's rows" if not args.timed_only else "last timed step"),
         "fad_last_timed_step": fad, "timed_only": bool(args.timed_only), "chain_cus_per_xcd": int(args.chain_cus), "group": G, "batched_chains": BATCH,
