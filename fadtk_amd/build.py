@@ -23,7 +23,7 @@ ARCH = "gfx950"
 SOURCES = ["common.cpp", "host_stage.cpp", "moments.hip", "gemm_f64.hip", "gemm_f32.hip", "frechet_f64.hip", "frechet.hip", "frechet_songs.hip", "logmel.hip", "resample.hip"]
 HEADERS = [*sorted(CSRC.glob("*.h")), PKG.parent / "include" / "fad_hip.h"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result", "-x", "hip"]
+         "-Wno-unused-result", *os.environ.get("FAD_EXTRA_HIPCC_FLAGS", "").split(), "-x", "hip"]      # (ablation builds: -DFAD_BIG_ABL_...)
 
 
 def _hipcc() -> str:

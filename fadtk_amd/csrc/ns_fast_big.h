@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
+#ifdef FAD_BIG_ABL_NOLOOP                                          // ablation (scripts/probe_chain8.py): no k loop, the epilogue alone
+    const int nks = 0;
+#else
     const int nks = d >> 4;
+#endif
 
     // ---- loads: wave w moves pieces 4 w .. 4 w + 3 of a stage (waves 0, 1: the A side, row blocks 2 (w & 1) + {0, 1}; waves 2, 3: the
     // B side), hi and lo plane of a block being 2 KiB in a row.  Wave-uniform 64-bit base in SGPRs + the lane's 16-byte offset (the
@@ -197,6 +201,9 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
             }
     }
     __syncthreads();                                           // every wave has left the ring: it is scratch now
+#ifdef FAD_BIG_ABL_NOEPI                                           // ablation: the k loop alone
+    if (acc0[0][0][0] != 12345.678f) return;
+#endif
 
     // ---- epilogue, per wave: its four 32 x 32 blocks one after the other through a [32][33] float area of its own
     float* fin = reinterpret_cast<float*>(ring) + wave * (32 * 33 + 32);
