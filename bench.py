@@ -664,6 +664,7 @@ def main():
             for ln in blanes[q]:
                 ln.stream = ln.cstream = bstreams[q]
         bjobs = [None] * NB_FLY
+        MGv = [MG]                          # (a side block below re-runs the loop with one launch per step)
         launch_sets = {}                    # id(leader handle) -> frame matrices of every launch recorded on it (cleared where timing starts)
 
         def run_steps_batched(count, marks=None, rotate=True, lanes=None):
@@ -690,6 +691,7 @@ def main():
                     collect(q)
                 m = min(BATCH, count - i)
                 t = pc()
+                MG = MGv[0]
                 if MG > 1:
                     # the moments of MG steps in ONE launch of each kernel (fad_moments_update_multi takes up to 8 frame matrices): the
                     # 256 workgroups of the tile kernel then hold MG x longer row ranges -- one set of partial tiles per LAUNCH, not per
@@ -799,6 +801,14 @@ def main():
     side = args.steps > 0 and not args.timed_only
     repeat_s = [block(True) for _ in range(5)] if side else []
     same_pair_s = [block(False) for _ in range(3)] if side else []
+    # ... and the same batches with ONE moments launch per step (--moments-group 1: what the line reported before the launches were grouped)
+    per_step_launch_s = []
+    if side and BATCH and MG > 1 and not distributed:
+        MGv[0] = 1
+        run_steps(BATCH)
+        per_step_launch_s = [block(True) for _ in range(3)]
+        MGv[0] = MG
+        run_steps(BATCH)
     # ... and K steps in the other stream layout: by default that is ONE stream for all scores in flight -- no two kernels overlap, the
     # tile kernel's duration there is the kernel alone
     per_stream_s, per_stream_kernel_ms, per_stream_sets = [], None, SETS
@@ -960,6 +970,9 @@ def main():
             "blocks": len(per_stream_s), "tile_kernel_ms": per_stream_kernel_ms,
             "note": ("the same K steps with all scores in flight on ONE stream (--single-stream): no two kernels overlap" if args.lane_streams
                      else "the same K steps with one HIP stream per score in flight: chains and moments kernels of consecutive scores overlap")},
+        "value_one_moments_launch_per_step": ({"median": float(np.median([n_gpus * args.steps / t for t in per_step_launch_s])), "blocks": len(per_step_launch_s),
+                                               "note": "the same K steps with --moments-group 1: a tile-kernel launch, a guard launch and a reduce per step (2 frame "
+                                                       "matrices each) instead of one of each per 4 steps"} if per_step_launch_s else None),
         "value_same_pair": {"median": float(np.median([n_gpus * args.steps / t for t in same_pair_s])) if same_pair_s else None,
                             "blocks": len(same_pair_s),
                             "note": "K steps that re-feed ONE pair (204.8 MB: Infinity-Cache resident) -- the loop rounds 1-2 timed"},
