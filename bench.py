@@ -651,7 +651,7 @@ def main():
         run_steps = run_steps_grouped
 
     BATCH = 0 if G else max(0, min(int(args.batch), 8))
-    MG = max(1, min(int(args.moments_group), 4, BATCH)) if BATCH else 1          # steps per moments launch (2 sets each, 8 at most)
+    MG = max(1, min(int(args.moments_group), 8, BATCH)) if BATCH else 1          # steps per moments launch (2 sets each, 16 at most)
     if BATCH:
         NB_FLY = 3
         # (--single-stream: all batches on ONE stream -- no two kernels ever overlap, the tile kernel's HIP-event time is the kernel alone)

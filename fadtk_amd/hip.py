@@ -114,9 +114,9 @@ class Moments:
 
     @staticmethod
     def update_multi(accs: Sequence["Moments"], blocks: Sequence) -> None:
-        """``accs[i].update(blocks[i])`` for up to 8 accumulators of one dimension with ONE launch of each kernel
+        """``accs[i].update(blocks[i])`` for up to 16 accumulators of one dimension with ONE launch of each kernel
         (``fad_moments_update_multi``); every block must be a device tensor of one common dtype."""
-        assert 1 <= len(accs) == len(blocks) <= 8
+        assert 1 <= len(accs) == len(blocks) <= 16
         views = [K.rows_view(b) for b in blocks]
         code = views[0][4]
         for a, v in zip(accs, views):

@@ -79,7 +79,7 @@ int64_t fad_moments_packed_len(const fad_moments_t* h);      /* 1 + D + D*D     
 int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
                        int on_device, void* stream);
 
-/* Feed `count` (1..8) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE
+/* Feed `count` (1..16) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE
  * launch of each kernel: rows[i] (a DEVICE pointer, n[i] frames, pitch ld[i]) goes to hs[i].  The two datasets of a
  * FAD score (fad.py:292-302 calls calc_embd_statistics / load_stats twice), the 25 resamples of score_inf
  * (fad.py:333-341) ...: the workgroup slots of the GPU are shared out over all sets in proportion to their rows,

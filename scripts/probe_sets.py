@@ -8,10 +8,10 @@ from fadtk_amd import hip  # noqa: E402
 dev = torch.device("cuda", 0)
 n, d = 100_000, 512
 g = torch.Generator(device=dev); g.manual_seed(1)
-pool = [(torch.randn((n, d), generator=g, device=dev) * (1 + 0.1 * (k % 2)) + 0.01 * k).to(torch.float16) for k in range(16)]
-for sets in (2, 4, 6, 8):
+pool = [(torch.randn((n, d), generator=g, device=dev) * (1 + 0.1 * (k % 2)) + 0.01 * k).to(torch.float16) for k in range(32)]
+for sets in (2, 4, 8, 12, 16):
     accs = [hip.Moments(d) for _ in range(sets)]
-    groups = [pool[i:i + sets] for i in range(0, 16 - sets + 1, sets)]
+    groups = [pool[i:i + sets] for i in range(0, 32 - sets + 1, sets)]
     for a in accs: a.reset()
     hip.Moments.update_multi(accs, groups[0]); torch.cuda.synchronize()
     accs[0].set_timing(1)
