@@ -279,12 +279,19 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
 // workgroup tiles a batch of 32 songs of D = 768 pulled 295 KB of digit planes per tile through the L2s (5.4 GB per launch,
 // 0.76 / 0.95 ms: profiles/r03o_c5_kernel_stats.csv); here a block costs 28 KB.
 constexpr int kI8BigStage = 36 * 64;                               // uint4 per stage
-constexpr size_t kI8BigLds = (size_t)2 * kI8BigStage * 16 + 256;
+// Ring depth: two stages (two workgroups per CU).  Measured with four (counted waits, two younger stages in flight, one workgroup per
+// CU): the same 35-37 us per launch for eight pairs of D = 512 and the same 3.9 ms for 32 songs of [1500 x 768] -- the kernel is bound
+// by its 30 / 26 int8 MFMAs per wave and k-step (12.9 us of a launch at the dense int8 rate) and its float64 epilogue, not by the loads.
+#ifndef FAD_I8_BIG_STAGES
+#define FAD_I8_BIG_STAGES 2
+#endif
+constexpr int kI8BigStages = FAD_I8_BIG_STAGES;
+constexpr size_t kI8BigLds = (size_t)kI8BigStages * kI8BigStage * 16 + 256;
 
 template <int MODE>
 __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob_pad) {
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
-    double* red = reinterpret_cast<double*>(ring + 2 * kI8BigStage);
+    double* red = reinterpret_cast<double*>(ring + kI8BigStages * kI8BigStage);
     constexpr int kUmin = (MODE == I8_A) ? kUminA : kUminG;
     constexpr int kGroups = 2 * (kDigits - 1) - kUmin + 1;
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
                 const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
                 const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
                 const uint64_t ub = ((uint64_t)hi << 32) | lo;
-                const uint32_t m0v = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(((ks & 1) * kI8BigStage + q * 64) * 16));
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(((ks % kI8BigStages) * kI8BigStage + q * 64) * 16));
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
             }
         }
@@ -348,12 +355,18 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
     for (int u = 0; u < kGroups; ++u)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[u][q] = 0;
-    issue(0);
+    static_assert(kI8BigStages >= 2 && kI8BigStages <= 4, "the counted waits below cover two younger stages at most");
+    for (int ks = 0; ks < kI8BigStages - 1 && ks < nks; ++ks) issue(ks);
+    const bool five = wave < 4;                                    // pieces this wave moves per stage: five (waves 0..3) or four
     for (int ks = 0; ks < nks; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // stage ks is there for every wave; the other stage is free
-        if (ks + 1 < nks) issue(ks + 1);
-        const i32x4* st = reinterpret_cast<const i32x4*>(ring + (ks & 1) * kI8BigStage) + lane;
+        // stage ks must have landed; up to kI8BigStages - 2 younger stages stay in flight (the count has to be an immediate)
+        const int ahead = (nks - 1 - ks < kI8BigStages - 2) ? (nks - 1 - ks) : (kI8BigStages - 2);
+        if (ahead == 2) { if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (ahead == 1) { if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // stage ks is there for every wave; the slot of stage ks - 1 is free
+        if (ks + kI8BigStages - 1 < nks) issue(ks + kI8BigStages - 1);
+        const i32x4* st = reinterpret_cast<const i32x4*>(ring + (ks % kI8BigStages) * kI8BigStage) + lane;
         i32x4 a[kDigits], b[kDigits];
 #pragma unroll
         for (int p = 0; p < kDigits; ++p) { a[p] = st[(wr * 6 + p) * 64]; b[p] = st[(24 + wc * 6 + p) * 64]; }
