@@ -49,6 +49,7 @@ struct fad_moments {
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
     fad::DevBuf blocktab;                  // 256-column-slab kernel: where every 32 x 32 block's partial sums sit (tile256_roles.h)
     int blocktab_nsb = 0, blocktab_plan = -1;
+    int r256_sl = 0;                       // FAD_MOMENTS_R256_SL (read at creation; experiments): split lanes of moments_reduce256, 0 = by the split count
     int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
     // the segment tables of the last fused update_segmented call, kept on the host: a caller feeding groups of the SAME file sizes
@@ -308,7 +309,11 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
     else hipLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
     if (any_guard)       // second pass of the shift guard: same geometry, gated per set; rewrites the flagged sets' partials and column sums
         hipLaunchKernelGGL((moments_tile256<FAD_F16, true>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
-    R.sl = (max_s > 32) ? 16 : (max_s > 8) ? 4 : 1;
+    // split lanes per output group: one thread walks all splits of its four outputs with eight loads in flight.  Measured
+    // (scripts/probe_reduce_sl.py, guard + reduce): 2 sets x 43 splits 22.2 / 22.8 / 22.3 / 23.3 / 26.1 us at 1 / 2 / 4 / 8 / 16 lanes,
+    // 8 sets x 10 splits 26.5 / 28.3 / 32.3 / 37.6 / 58.9 us -- the LDS combine and the extra threads cost more than the shorter walks save.
+    R.sl = (max_s > 128) ? 4 : 1;
+    if (h0->r256_sl == 1 || h0->r256_sl == 2 || h0->r256_sl == 4 || h0->r256_sl == 8 || h0->r256_sl == 16) R.sl = h0->r256_sl;
     const int G = 256 / R.sl;
     const int blocks = (int)cdiv((int64_t)R.nblk * 256, G) + (int)cdiv(d, 64);
     // 8 KiB of dynamic LDS the kernel never touches: 10 instead of 20 of its workgroups per CU.  Measured at config 3
@@ -602,6 +607,8 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     h->tile256 = !(t2 && t2[0] == '0');
     const char* pl = getenv("FAD_MOMENTS_PLAN");
     h->tile256_plan = (pl && (pl[0] == '0' || pl[0] == '1')) ? pl[0] - '0' : -1;
+    const char* rs = getenv("FAD_MOMENTS_R256_SL");
+    h->r256_sl = rs ? atoi(rs) : 0;
     const char* nc = getenv("FAD_MOMENTS_CUS");        // plan for fewer CUs than the device has (a CU-masked stream)
     if (nc && atoi(nc) >= 8 && atoi(nc) < h->n_cu) h->n_cu = atoi(nc);
     *out = h;
