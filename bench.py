@@ -419,8 +419,13 @@ def main():
                          "Frechet job); the moments of step i and the Frechet chain of step i-1 are enqueued before the score of "
                          "step i-N is collected (3 or more keep the device busy); 1 = every step waits for its score")
     ap.add_argument("--single-stream", action="store_true",
-                    help="all scores in flight on ONE stream (rounds 1-3a: no two kernels ever overlap) instead of one HIP stream per "
-                         "score in flight")
+                    help="all scores in flight on ONE stream: no two kernels ever overlap.  The default of the batched schedule (the tile "
+                         "kernel's duration inside the timed loop is then the kernel alone: what `roofline` reports); for --batch 0 it "
+                         "replaces one HIP stream per score in flight")
+    ap.add_argument("--multi-stream", action="store_true",
+                    help="batched schedule: one HIP stream per batch in flight (three): ~10 %% more scores/s -- the idle CUs of one "
+                         "batch's small launches take another batch's kernels -- but a dispatch's duration then includes the time it "
+                         "waits for another stream's workgroups to leave the CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (used under rocprofv3 "
                                                              "so that the kernel statistics hold the config-3 launches only)")
@@ -438,10 +443,14 @@ def main():
     ap.add_argument("--moments-group", type=int, default=4,
                     help="batched schedule: the moments of this many consecutive steps in ONE launch of the tile kernel and ONE reduce "
                          "(fad_moments_update_multi over 2 x M frame matrices, 8 at most); 1 = one launch per step")
+    ap.add_argument("--moments-stream", action="store_true",
+                    help="batched schedule: every moments launch on ONE stream of its own, the chains on the batch streams (experiment)")
     ap.add_argument("--chain-cus", type=int, default=0,
                     help="experiment (profiles/r04*_streams.txt): confine the square-root chains to this many CUs per XCD (CU-masked "
                          "streams) and the moments kernels to the others; 0 = no masks")
     args = ap.parse_args()
+    if int(args.batch) > 0 and not int(args.group) and not args.multi_stream:
+        args.single_stream = True                                        # the batched schedule's default layout
     args.lane_streams = not args.single_stream
     if args.timed_only:
         args.no_extras = True; args.no_cpu_baseline = True
@@ -664,6 +673,10 @@ def main():
             for ln in blanes[q]:
                 ln.stream = ln.cstream = bstreams[q]
         bjobs = [None] * NB_FLY
+        # --moments-stream: ALL moments launches on one stream of their own (no two tile kernels ever compete for the CUs), the chains on
+        # the batch streams behind an event
+        mstream_b = torch.cuda.Stream(device=device) if (args.moments_stream and not args.single_stream) else None
+        bdone = [torch.cuda.Event() for _ in range(NB_FLY)]
         MGv = [MG]                          # (a side block below re-runs the loop with one launch per step)
         launch_sets = {}                    # id(leader handle) -> frame matrices of every launch recorded on it (cleared where timing starts)
 
@@ -699,7 +712,7 @@ def main():
                     for k0 in range(0, m, MG):
                         grp = blanes[q][k0:min(k0 + MG, m)]
                         launch_sets.setdefault(id(grp[0].ma), []).append(2 * len(grp))
-                        with torch.cuda.stream(bstreams[q]):
+                        with torch.cuda.stream(mstream_b if mstream_b is not None else bstreams[q]):
                             for ln in grp:
                                 ln.ma.reset(); ln.mb.reset()
                             hip.Moments.update_multi([h for ln in grp for h in (ln.ma, ln.mb)],
@@ -717,7 +730,11 @@ def main():
                         blanes[q][k].feed(pairs[(i + k) % N_PAIRS] if rotate else pairs[0])
                 host_s[0] += pc() - t
                 t = pc()
+                if mstream_b is not None and MG > 1:                     # (--moments-stream: the chain waits for the batch's moments)
+                    bdone[q].record(mstream_b)
                 with torch.cuda.stream(bstreams[q]):
+                    if mstream_b is not None and MG > 1:
+                        torch.cuda.current_stream().wait_event(bdone[q])
                     if distributed:
                         for k in range(m):
                             torch.cuda.current_stream().wait_event(blanes[q][k].reduced)
@@ -965,11 +982,13 @@ def main():
                                 "min": min(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None,
                                 "max": max(n_gpus * args.steps / t for t in repeat_s) if repeat_s else None, "blocks": len(repeat_s),
                                 "note": "the same K steps repeated outside the timed region (rank 0's clock)"},
-        ("value_single_stream" if args.lane_streams else "value_stream_per_score"): {
+        ("value_single_stream" if args.lane_streams else ("value_three_batch_streams" if BATCH else "value_stream_per_score")): {
             "median": float(np.median([n_gpus * args.steps / t for t in per_stream_s])) if per_stream_s else None,
             "blocks": len(per_stream_s), "tile_kernel_ms": per_stream_kernel_ms,
             "note": ("the same K steps with all scores in flight on ONE stream (--single-stream): no two kernels overlap" if args.lane_streams
-                     else "the same K steps with one HIP stream per score in flight: chains and moments kernels of consecutive scores overlap")},
+                     else ("the same K steps with one HIP stream per batch in flight (--multi-stream): the idle CUs of one batch's small launches "
+                           "take another batch's kernels; `tile_kernel_ms` there includes the time a dispatch waits for CUs" if BATCH
+                           else "the same K steps with one HIP stream per score in flight: chains and moments kernels of consecutive scores overlap"))},
         "value_one_moments_launch_per_step": ({"median": float(np.median([n_gpus * args.steps / t for t in per_step_launch_s])), "blocks": len(per_step_launch_s),
                                                "note": "the same K steps with --moments-group 1: a tile-kernel launch, a guard launch and a reduce per step (2 frame "
                                                        "matrices each) instead of one of each per 4 steps"} if per_step_launch_s else None),
@@ -1005,7 +1024,7 @@ def main():
                      "algorithmic_bytes_per_launch": LSETS * N_ROWS * DIM * 2,
                      "hbm_GBps_algorithmic": LSETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9,
                      "hbm_frac_of_8TBps": LSETS * N_ROWS * DIM * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "contended": bool(BATCH or (args.lane_streams and n_lanes > 1)),
+                     "contended": bool(args.lane_streams and (BATCH or n_lanes > 1)),
                      "contended_note": "kernel_ms = the dispatch's own begin -> end stamps (hipExtLaunchKernel start / stop events on the "
                                        "launch's stream: the interval rocprofv3 --kernel-trace reports), sampled inside the timed loop, "
                                        "where other streams' kernels (the square-root chains of earlier scores) may hold CUs while it "
@@ -1015,7 +1034,10 @@ def main():
                                 "achieved": flops * (per_stream_sets / LSETS) / (per_stream_kernel_ms * 1e-3) / 1e12,
                                 "frac": flops * (per_stream_sets / LSETS) / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                                 "mfma_util": issued * (per_stream_sets / LSETS) / (per_stream_kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}
-                               if (args.lane_streams and per_stream_kernel_ms) else None)},
+                               if (args.lane_streams and per_stream_kernel_ms) else
+                               ({"kernel_ms": kernel_ms, "sets_per_launch": LSETS, "achieved": achieved, "frac": achieved / MFMA_F16_PEAK_TFLOPS,
+                                 "mfma_util": issued / (kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                 "note": "the timed loop runs on ONE stream: this IS the kernel alone"} if BATCH else None))},
         "roofline_frechet": {"route": {2: "eight launches: split-float16 Newton-Schulz + exact int8-MFMA products (csrc/ns_fast.h)",
                                        1: "float32 Newton-Schulz on the f32 MFMA + float64 correction", 0: "all-float64 iteration"}[route],
                              "bound": "launch chain: ~4.2 us per dependent launch before it does anything, then the CU's vector-memory "
