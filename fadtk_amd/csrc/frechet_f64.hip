@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ns_prepare(const double* __restrict__ sta
     if (tid == 0) {
         if (s32) {                                   // the low-precision leg starts from a clean state as well
             s32->done = 0; s32->finished = 0; s32->ok = 0; s32->final_iter = -1; s32->failed = 0;
-            s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = 0;
+            s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = 0; s32->grew = 0;
             s32->res[0] = 1e300;
         }
         // Scale: the iteration needs every eigenvalue of A/c below 3 (above, Y converges to a NEGATIVE root).

@@ -18,7 +18,7 @@ struct Ns32State {
     int skip_corr;       // 1 until `ok`: keeps the fp64 correction GEMM off
     int decided_at;      // iteration whose check closed the problem (the host sizes the next call's batch by it)
     int strict;          // 1: predict the final iterate only from the fp32 floor (set for a retry, see ns32_finish)
-    int pad;
+    int grew;            // scaled steps: the previous check saw the residual grow (one bump after an over-scaled step is not a failure)
     double res[16];
 };
 

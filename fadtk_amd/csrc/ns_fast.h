@@ -618,7 +618,12 @@ template <int NT = 512> __device__ __forceinline__ void nsf_check(const SplitArg
     const bool finite = (res == res) && !isinf(res);
     // (round 3 ended "k >= 8 and still above 1" here: a song of 2 D frames -- condition number of a few hundred, residual ~1 at
     //  iteration 8, at the float32 floor by 11 -- never got through; only a residual that GROWS above the floor is hopeless)
-    if (!finite || k + 1 >= g.max_low || (k >= 4 && res > prev && res > 1e-3)) {
+    // (scaled steps: a lower bound far too small over-scales an iterate once -- the residual bumps by 5-20 % -- before the refined bound
+    //  and the cap take over: scripts/ns_emulate_adaptive.py; only two growing residuals in a row give up there)
+    const bool grows = k >= 4 && res > prev && res > 1e-3;
+    const bool give_up = grows && (!g.scaled || st->grew);
+    st->grew = grows ? 1 : 0;
+    if (!finite || k + 1 >= g.max_low || give_up) {
         st->failed = 1; st->finished = 1; st->done = 1; st->final_iter = k; st->decided_at = k; st->upd_skip[(k + 1) & 1] = 1;
         return;
     }
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
             st->final_iter = zero ? 0 : -1; st->conv = zero ? 1 : 0;
             st->nonfinite = bad ? 1 : 0; st->done = (bad || zero) ? 1 : 0; st->finished = (bad || zero) ? 1 : 0;
             s32->done = 0; s32->finished = 0; s32->ok = 0; s32->final_iter = -1; s32->failed = 0;
-            s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = 0;
+            s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = 0; s32->grew = 0;
             s32->res[0] = 1e300;
             if (bad || zero || hopeless) { s32->done = 1; s32->finished = 1; s32->failed = 1; s32->upd_skip[0] = 1; s32->upd_skip[1] = 1; }
         }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void nsf_res128(ResArgs g) {
             st->final_iter = zero ? 0 : -1; st->conv = zero ? 1 : 0;
             st->nonfinite = bad ? 1 : 0; st->done = (bad || zero) ? 1 : 0; st->finished = (bad || zero) ? 1 : 0;
             s32->done = 0; s32->finished = 0; s32->ok = 0; s32->final_iter = -1; s32->failed = 0;
-            s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = 0;
+            s32->upd_skip[0] = 0; s32->upd_skip[1] = 0; s32->skip_corr = 1; s32->decided_at = -1; s32->strict = 0; s32->grew = 0;
             s32->res[0] = 1e300;
             if (bad || zero || hopeless) { s32->done = 1; s32->finished = 1; s32->failed = 1; s32->upd_skip[0] = 1; s32->upd_skip[1] = 1; snapshot(false, true); }
         }
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void nsf_res128(ResArgs g) {
     // ---- iterations k = 1 ..: P holds Z_k, Q holds Y_k as left factors; (Yh, Yl), (Zh, Zl) their column blocks j
     int final_iter = -1, decided_at = -1, ok = 0, failed = 0;
     double prev = 1e300;
+    bool grew = false;
     for (int k = 1;; ++k) {
         float ss = 0.f;
         {   // this iteration's step scale: mu (1 without scaled steps) from the bound of iterate k
@@ -297,7 +298,10 @@ __global__ __launch_bounds__(256) void nsf_res128(ResArgs g) {
         }
         if (tid == 0 && k < 16) s32->res[k] = res;
         const bool finite = (res == res) && !isinf(res);
-        if (!finite || k + 1 >= g.max_low || (k >= 4 && res > prev && res > 1e-3)) { failed = 1; final_iter = k; decided_at = k; break; }
+        const bool grows = k >= 4 && res > prev && res > 1e-3;
+        const bool give_up = grows && (!g.scaled || grew);          // (nsf_check: one bump after an over-scaled step is not a failure)
+        grew = grows;
+        if (!finite || k + 1 >= g.max_low || give_up) { failed = 1; final_iter = k; decided_at = k; break; }
         if (res <= 1e-3 && (res > 0.3 * prev || res <= 1e-6)) { ok = 1; final_iter = k; decided_at = k; break; }      // at the floor: Y_k is final
         const double bound = 0.75 * res * res + 0.25 * res * res * res;
         const bool last = bound <= g.thr_pred && mu == 1.0;  // Y_{k+1} is final (the update about to run is a plain step)

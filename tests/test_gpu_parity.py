@@ -1213,7 +1213,7 @@ def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
 def test_songs_scaled_steps_agree_with_plain_steps_and_with_the_oracle(F, monkeypatch, d, frames):
     """Round 4: scaled Newton-Schulz steps per song (ns_check.h: step scale from a lower bound of sqrt(lambda / c) that the check of
     every iteration refines from the residual and caps by it).  Songs whose variances differ by dimension (products with condition
-    numbers of a few thousand, bench.py's per-song extras): scaled (default), plain (FAD_SONG_SCALED=0) and scaled from a start ten
+    numbers of a few thousand, bench.py's per-song extras): scaled (default), plain (FAD_SONG_SCALED=0) and scaled from a start thirty
     times too small / three times too large (FAD_SONG_L0_SCALE) all give the oracle's scores (fad.py:373-378) -- and the chain itself
     accepts every song (FAD_SONG_FAST=2 raises if it accepts none; status 0 for all)."""
     from fadtk_amd import hip
@@ -1228,7 +1228,7 @@ def test_songs_scaled_steps_agree_with_plain_steps_and_with_the_oracle(F, monkey
     want = O.individual_scores(mu_b, cov_b, sg[:4], run_sqrtm=False)
     monkeypatch.setenv("FAD_SONG_FAST", "2")
     got = {}
-    for name, env in (("scaled", {}), ("plain", {"FAD_SONG_SCALED": "0"}), ("start / 10", {"FAD_SONG_L0_SCALE": "0.05"}), ("start x 3", {"FAD_SONG_L0_SCALE": "1.5"})):
+    for name, env in (("scaled", {}), ("plain", {"FAD_SONG_SCALED": "0"}), ("start / 30", {"FAD_SONG_L0_SCALE": "0.0167"}), ("start x 3", {"FAD_SONG_L0_SCALE": "1.5"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         scores, status = hip.frechet_batched(mu_b, cov_b, rows, offs, mean_mode=1)
@@ -1237,7 +1237,7 @@ def test_songs_scaled_steps_agree_with_plain_steps_and_with_the_oracle(F, monkey
         assert (status == 0).all(), (name, status)
         np.testing.assert_allclose(scores[:4], want, rtol=2e-6, err_msg=name)
         got[name] = scores
-    for name in ("plain", "start / 10", "start x 3"):
+    for name in ("plain", "start / 30", "start x 3"):
         np.testing.assert_allclose(got[name], got["scaled"], rtol=1e-7, err_msg=name)
 
 

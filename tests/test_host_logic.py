@@ -160,3 +160,27 @@ def test_tile256_role_tables_cover_the_upper_triangle(tmp_path):
     assert r.returncode == 0, r.stdout
     assert "nsb=2: 2 item types, 136 blocks per split, 136 output blocks ok" in r.stdout
     assert "nsb=3: 5 item types" in r.stdout and "nsb=8: 32 item types" in r.stdout
+
+
+def test_adaptive_step_scales_never_give_up_and_need_fewer_iterations_than_plain_steps():
+    """The rule that sets the per-song step scale of the batched low-precision chain (csrc/ns_check.h, csrc/ns_fast.h: nsf_check), emulated
+    on eigenvalues (scripts/ns_emulate_adaptive.py): from a thirtieth to three times the x_min estimate the capped rule closes every problem
+    (a negative count = the chain's 'residual grows' rule would have handed the song to the float64 routes), at the shipped start (half the
+    estimate; the resident D = 128 kernel: the estimate) in no more iterations than the plain step from the old scale c = u / 2.9 needs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ns_emulate_adaptive", ROOT / "scripts" / "ns_emulate_adaptive.py")
+    E = importlib.util.module_from_spec(spec); spec.loader.exec_module(E)
+    rng = np.random.default_rng(7)
+    for d, n, lo, hi, shipped in ((256, 600, 0.5, 1.5, 0.5), (128, 2250, 0.6, 1.4, 1.0)):
+        x, pr = E.song_spectrum(rng, d, n, lo, hi)
+        est = E.l0_estimate(pr, d)
+        counts = {sc: E.run(x, min(est * sc, 0.5), cap=True) for sc in (0.03, 0.1, 0.25, 0.5, 1.0, 2.0, 3.0)}
+        assert all(0 < c < 16 for c in counts.values()), counts
+        # plain steps from c = u / 2.9 (x larger by sqrt(2.9), every mu = 1): the round-3 chain
+        xp = x * np.sqrt(2.9)
+        k, res = 0, 1e300
+        while res > 1e-3 and k < 40:
+            xp = xp * (3 - xp * xp) / 2
+            res = float(np.sqrt(np.sum((1 - xp * xp) ** 2)))
+            k += 1
+        assert counts[shipped] <= k, (counts, k)
