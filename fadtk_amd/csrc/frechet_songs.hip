@@ -41,6 +41,21 @@ template <> __device__ __forceinline__ double round_like_input<r_bf16>(double v)
     return (double)__uint_as_float(u & 0xffff0000u);
 }
 
+// The song's mean of column `a` as the reference's np.mean(embd, axis=0) returns it (fad.py:48, mean_mode = 1).  float16 / bfloat16
+// frames: numpy accumulates them in float32 and rounds the quotient to the frames' type -- the rounded exact mean (checked against numpy).
+// float32 frames: numpy adds the rows one after the other IN float32 and divides by n in float32, 1e-6 off the rounded exact mean for a few
+// thousand frames -- up to 5e-5 of a small score (tests/test_gpu_fuzz.py); one thread walks the column in that order.
+template <typename TIn>
+__device__ __forceinline__ double mean_like_reference(const TIn* __restrict__ rows, int64_t ld, int a, int64_t r0, int64_t r1, double m_exact) {
+    if constexpr (std::is_same<TIn, float>::value) {
+        float acc = 0.f;
+        for (int64_t r = r0; r < r1; ++r) acc = acc + rows[r * ld + a];
+        return (r1 > r0) ? (double)(acc / (float)(r1 - r0)) : 0.0;
+    } else {
+        return round_like_input<TIn>(m_exact);
+    }
+}
+
 // One workgroup per song: exact fp64 mean, mean as the reference sees it, ||mu_b - mean||^2,
 // tr Sigma_s = sum ||x - mean||^2 / (n - 1), and for two-frame songs the difference row d = x1 - x2.
 template <typename TIn>
@@ -57,7 +72,7 @@ __global__ __launch_bounds__(256) void song_stats(const TIn* __restrict__ rows, 
         double sum = 0.0;
         for (int64_t r = r0; r < r1; ++r) sum += ld_f64<TIn>(rows, r * ld + a);
         const double m = (n > 0) ? sum / (double)n : 0.0;
-        const double mr = mean_mode ? round_like_input<TIn>(m) : m;
+        const double mr = mean_mode ? mean_like_reference<TIn>(rows, ld, a, r0, r1, m) : m;
         if (mean_exact) mean_exact[s * d + a] = m;
         double sq = 0.0;
         for (int64_t r = r0; r < r1; ++r) { const double c = ld_f64<TIn>(rows, r * ld + a) - m; sq += c * c; }
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ r
     psum[rl][cl] = sq;
     __syncthreads();
     if (rl == 0 && ok) {
-        const double mr = mean_mode ? round_like_input<TIn>(m) : m;
+        const double mr = mean_mode ? mean_like_reference<TIn>(rows, ld, a, r0, r1, m) : m;
         if (mean_exact) mean_exact[s * d + a] = m;
         ts = (psum[0][cl] + psum[1][cl]) + (psum[2][cl] + psum[3][cl]);
         const double df = mu_b[a] - mr;

@@ -156,7 +156,8 @@ def test_fuzz_per_song_scores_fast_chain_against_float64_routes_and_oracle(monke
         rel_o = np.abs(fast - want) / np.abs(want)
         rel_f = np.abs(fast - f64) / np.abs(f64)
         print(f"{what} max rel vs oracle {rel_o.max():.2e} vs float64 routes {rel_f.max():.2e}")
-        # float32 frames: the reference's np.mean accumulates them in float32 (pairwise), ~1e-7 off the rounded exact mean this library
-        # forms -- 1e-5 of a small score, inside the 1e-4 bar (fadtk itself stores float16 embeddings: model_loader.py:47-48)
-        assert (rel_o <= (tol if dt == np.float16 else 5e-5)).all(), (what, rel_o)
+        # float32 frames: the reference's np.mean (fad.py:48) adds the rows one after the other in float32 -- 1e-6 off the rounded exact
+        # mean, which cost up to 5e-5 of a small score until round 4; the statistics kernels now walk the column in numpy's order
+        # (frechet_songs.hip: mean_like_reference), so float32 frames meet the same bound as float16 ones
+        assert (rel_o <= tol).all(), (what, rel_o)
         assert (rel_f <= tol).all(), (what, rel_f)
