@@ -73,6 +73,7 @@ SIGNATURES = {
     "fad_moments_finalize": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(_I64), C.c_int, _P]),
     "fad_moments_trim": (C.c_int, [_P, _I64]),
     "fad_moments_set_timing": (C.c_int, [_P, C.c_int]),
+    "fad_moments_set_reference_mean": (C.c_int, [_P, C.c_int]),
     "fad_moments_last_timing": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "fad_stream_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(_P)]),
     "fad_stream_destroy": (C.c_int, [C.c_int, _P]),

@@ -49,6 +49,10 @@ struct fad_moments {
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
     fad::DevBuf blocktab;                  // 256-column-slab kernel: where every 32 x 32 block's partial sums sit (tile256_roles.h)
     int blocktab_nsb = 0, blocktab_plan = -1;
+    bool ref_mean = false;                 // fad_moments_set_reference_mean: keep numpy's float32 running column sums beside the exact ones
+    fad::DevBuf runsum;                         // ... [d] floats
+    bool runsum_covers = true;             // ... they cover exactly the rows the accumulator holds (an empty handle: trivially)
+    bool runsum_live = false;              // ... a running-sum kernel has written them since the handle was created / reset
     int r256_sl = 0;                       // FAD_MOMENTS_R256_SL (read at creation; experiments): split lanes of moments_reduce256, 0 = by the split count
     int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
@@ -122,6 +126,12 @@ static int ensure_kernel_attrs(int device) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
         }
     }
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_f16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_f16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
     done[device] = true;
     return FAD_OK;
 }
@@ -329,6 +339,52 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
 // One pass over `count` frame matrices (DEVICE pointers), all of the handles' dimension, dtype and device:
 // tile kernel (one launch for all sets) -> gated fp64 redo (one launch) -> reduce (one launch).
 // `seg` (count == 1, fp16/bf16 aligned input only): segment-aligned splits; colpart then has one row per run.
+// numpy's float32 running column sums (moments_kernels.h: moments_running_colsum) for the handles that asked for them: one launch for
+// all of them, in front of the update's other kernels (float64 frames: numpy's sum is the exact one to 1e-16 -- nothing to do)
+static int running_sums(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n, const int64_t* ld, int dtype,
+                        hipStream_t st) {
+    if (dtype == FAD_F64) {                                          // (numpy's float64 sum IS the exact one to 1e-16: finalize takes that)
+        for (int i = 0; i < count; ++i)
+            if (n[i] > 0) hs[i]->runsum_covers = false;
+        return FAD_OK;
+    }
+    RunSumLaunch L;
+    memset(&L, 0, sizeof(L));
+    int m = 0;
+    for (int i = 0; i < count; ++i) {
+        fad_moments* h = hs[i];
+        if (n[i] <= 0) continue;
+        if (h->fresh) h->runsum_covers = true;                      // (reset: both are empty again)
+        if (!h->ref_mean) { h->runsum_covers = false; continue; }   // rows the running sums will never see
+        if (!h->runsum_covers) continue;                            // (imported / exchanged statistics: the order is lost for good)
+        FAD_TRY(h->runsum.reserve((size_t)h->d * sizeof(float)));
+        RunSumJob& j = L.job[m++];
+        j.rows = rows[i]; j.n = n[i]; j.ld = ld[i]; j.run = static_cast<float*>(h->runsum.p);
+        j.start_zero = (h->fresh || !h->runsum_live) ? 1 : 0;        // (a new handle is empty without having been reset: its buffer is not)
+        h->runsum_live = true;
+    }
+    if (!m) return FAD_OK;
+    L.d = hs[0]->d;
+    FAD_TRY(ensure_kernel_attrs(hs[0]->device));
+    const dim3 grid((unsigned)cdiv(L.d, kRunCols), (unsigned)m);
+    const size_t es = dtype_size(dtype);
+    bool wide = (L.d % (int)(16 / es)) == 0;
+    for (int i = 0; i < m && wide; ++i)
+        wide = ((reinterpret_cast<uintptr_t>(L.job[i].rows) & 15u) == 0) && ((L.job[i].ld * (int64_t)es) % 16 == 0);
+    if (dtype == FAD_F16) {
+        if (wide) hipLaunchKernelGGL((moments_running_colsum<raw_f16, true>), grid, dim3(256), kRunLds, st, L);
+        else hipLaunchKernelGGL((moments_running_colsum<raw_f16, false>), grid, dim3(256), kRunLds, st, L);
+    } else if (dtype == FAD_BF16) {
+        if (wide) hipLaunchKernelGGL((moments_running_colsum<raw_bf16, true>), grid, dim3(256), kRunLds, st, L);
+        else hipLaunchKernelGGL((moments_running_colsum<raw_bf16, false>), grid, dim3(256), kRunLds, st, L);
+    } else {
+        if (wide) hipLaunchKernelGGL((moments_running_colsum<float, true>), grid, dim3(256), kRunLds, st, L);
+        else hipLaunchKernelGGL((moments_running_colsum<float, false>), grid, dim3(256), kRunLds, st, L);
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
 static int update_device_multi(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n,
                                const int64_t* ld, int dtype, hipStream_t st, const SegPlan* seg = nullptr) {
     fad_moments* h0 = hs[0];
@@ -344,6 +400,7 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
     for (int i = 0; i < count; ++i) if (n[i] > n_max) n_max = n[i];
     const bool use_h16 = aligned && !h0->force_generic && (n_max >= 16 * (int64_t)d || seg);
 
+    FAD_TRY(running_sums(count, hs, rows, n, ld, dtype, st));
     hipEvent_t* ev = nullptr;
     FAD_TRY(timing_events(h0, &ev));
     h0->last_sets = count;
@@ -622,7 +679,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     if (h->shift_flag) (void)hipFree(h->shift_flag);
     h->partials64.release(); h->colpart64.release(); h->cvec.release(); h->presum.release(); h->presum_col.release(); h->blocktab.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
-    h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release();
+    h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release(); h->runsum.release();
     if (h->tab_host) (void)hipHostFree(h->tab_host);
     if (h->tab_ev) (void)hipEventDestroy(h->tab_ev);
     if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
@@ -644,6 +701,7 @@ int fad_moments_reset(fad_moments_t* h, void* stream) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
     (void)stream;
     h->fresh = true;
+    h->runsum_live = false; h->runsum_covers = true;
     return FAD_OK;
 }
 
@@ -661,6 +719,7 @@ int fad_moments_bind(fad_moments_t* h, double* device_packed) {
     h->acc = device_packed;
     h->owns_acc = false;
     h->fresh = true;                               // bind = adopt the buffer and reset
+    h->runsum_live = false; h->runsum_covers = true;
     return FAD_OK;
 }
 
@@ -921,6 +980,7 @@ int fad_moments_import(fad_moments_t* h, const double* packed, int on_device, vo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t bytes = (size_t)packed_len(h->d) * sizeof(double);
     h->fresh = false;                              // the whole accumulator is overwritten
+    h->runsum_covers = false;                      // (statistics from elsewhere: no row order to follow)
     FAD_HIP_TRY(hipMemcpyAsync(h->acc, packed, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
     return FAD_OK;
@@ -939,6 +999,7 @@ int fad_moments_allreduce(fad_moments_t* h, void* rccl_comm, void* stream) {
         return reinterpret_cast<allreduce_fn>(sym);
     }();
     if (!fn) return set_error(FAD_ERR_INVALID, "no RCCL in this process (ncclAllReduce not found)");
+    h->runsum_covers = false;                      // (the sum of several ranks' statistics has no row order)
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     FAD_TRY(settle(h, st));
@@ -979,7 +1040,7 @@ int fad_moments_finalize(const fad_moments_t* h, int ddof, double* mu, double* c
         dmu = dcov + (size_t)d * d;
     }
     hipLaunchKernelGGL(moments_finalize_kernel, dim3((unsigned)cdiv((int64_t)d * d, 256)), dim3(256), 0, st,
-                       h->acc, d, ddof, dmu, dcov);
+                       h->acc, d, ddof, dmu, dcov, (h->ref_mean && h->runsum_covers && h->runsum_live && !h->fresh) ? static_cast<const float*>(h->runsum.p) : nullptr);
     FAD_HIP_TRY(hipGetLastError());
     if (!on_device) {
         FAD_HIP_TRY(hipMemcpyAsync(cov, dcov, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -998,6 +1059,12 @@ int fad_moments_trim(fad_moments_t* h, int64_t keep_bytes) {
         if (h->stage.cap > (size_t)keep_bytes) h->stage.release();
         if (h->scratch.cap > (size_t)keep_bytes) { h->scratch.release(); h->sizes_cached_at = nullptr; }
     }
+    return FAD_OK;
+}
+
+int fad_moments_set_reference_mean(fad_moments_t* h, int enabled) {
+    if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
+    h->ref_mean = enabled != 0;
     return FAD_OK;
 }
 

@@ -1053,15 +1053,105 @@ __global__ __launch_bounds__(256) void packed_axpy(double* __restrict__ dst, con
     if (g < len) dst[g] += src[g];
 }
 
+// The column sums the way the reference's np.mean(embd_lst, axis=0) forms them (fadtk/fad.py:48): numpy adds the rows one after the
+// other in float32 (float16 frames are widened first), so a [100000 x 512] matrix of frames around 0.5 ends 1e-5 off the exact sum and
+// the float16-rounded mean differs from the rounded exact mean by one ulp in a few dimensions -- 2e-5 .. 5e-4 of a small Frechet distance
+// (measured with the oracle at offsets of 0.5 .. 3 standard deviations x 10).  There is no parallel form of a float32 running sum: one lane
+// per column walks the rows in order (16 loads in flight), 0.3 ms per 100 k rows on a few CUs; opt-in per handle
+// (fad_moments_set_reference_mean), carried across updates like numpy carries it across the rows of the concatenated matrix.
+__device__ __forceinline__ float load_as_float(const raw_f16* p) { return h16_to_f32<FAD_F16>(p->b); }
+__device__ __forceinline__ float load_as_float(const raw_bf16* p) { return h16_to_f32<FAD_BF16>(p->b); }
+__device__ __forceinline__ float load_as_float(const float* p) { return *p; }
+struct RunSumJob { const void* rows; int64_t n, ld; float* run; int start_zero; };
+struct RunSumLaunch { RunSumJob job[kMaxSets]; int d; };
+// Workgroup = 16 columns (d / 16 workgroups per matrix: the walk is latency-bound per CU -- ~32 KB in flight against ~2 us -- so it
+// is spread over many CUs): waves 1..3 stage tiles of 1024 rows x 16 columns through LDS with 16-byte loads (two tiles: the next one travels
+// while this one is walked), lanes 0..15 of wave 0 walk their columns down the tile -- the dependent float32 adds are the critical path.
+// Measured for [100000 x 512] float16: one lane per column reading global memory directly 2.4 ms (sixteen two-byte loads of latency at a
+// time); 64 columns per workgroup, every wave staging and wave 0 adding 7.9 ms (the adds waited for the wave's own loads); 64 columns with a
+// dedicated adding wave 1.8 ms; 16 columns per workgroup with tiles of 256 rows 0.59 ms (one load latency per tile); this form: DESIGN.md 4.1b.  WIDE = rows and pitch 16-byte aligned.
+constexpr int kRunRows = 1024, kRunCols = 16;                 // (a tile's loads cover one latency: 64 KiB a tile, two tiles of dynamic LDS)
+constexpr size_t kRunLds = (size_t)2 * kRunRows * kRunCols * sizeof(float);
+template <typename TIn, bool WIDE>
+__global__ __launch_bounds__(256) void moments_running_colsum(RunSumLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float run_lds[];
+    float (*tile)[kRunRows][kRunCols] = reinterpret_cast<float (*)[kRunRows][kRunCols]>(run_lds);      // [2]: rows of 16 floats, no padding needed
+    const RunSumJob& j = L.job[blockIdx.y];
+    const int c0 = blockIdx.x * kRunCols, tid = threadIdx.x;
+    if (j.n <= 0) return;
+    const TIn* base = static_cast<const TIn*>(j.rows);
+    constexpr int EPV = 16 / (int)sizeof(TIn);                     // elements per 16-byte load: 8 (float16 / bfloat16) or 4 (float32)
+    constexpr int CPR = kRunCols / EPV;                            // 16-byte chunks per row of the tile
+    const int lt = tid - 64;                                       // loader index 0..191 (waves 1..3)
+    auto stage = [&](int buf, int64_t r0) {
+        if (lt < 0) return;
+        if constexpr (WIDE) {
+            constexpr int RPP = 192 / CPR;                         // rows per pass
+            constexpr int NP = (kRunRows + RPP - 1) / RPP;
+            const int q = lt % CPR, ro = lt / CPR;
+            uint4 w[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {                         // every load of the tile in flight at once
+                const int rr = p * RPP + ro;
+                const int64_t r = r0 + rr;
+                w[p] = (rr < kRunRows && r < j.n && c0 + q * EPV < L.d) ? *reinterpret_cast<const uint4*>(base + r * j.ld + c0 + q * EPV)
+                                                                        : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int rr = p * RPP + ro;
+                if (rr < kRunRows) {
+                    const TIn* e = reinterpret_cast<const TIn*>(&w[p]);
+#pragma unroll
+                    for (int u = 0; u < EPV; ++u) tile[buf][rr][q * EPV + u] = load_as_float(e + u);
+                }
+            }
+        } else {
+            const int cl = lt % kRunCols, ro = lt / kRunCols;      // 12 rows x 16 columns per pass
+            for (int rr = ro; rr < kRunRows; rr += 192 / kRunCols) {
+                const int64_t r = r0 + rr;
+                tile[buf][rr][cl] = (c0 + cl < L.d && r < j.n) ? load_as_float(base + r * j.ld + c0 + cl) : 0.f;
+            }
+        }
+    };
+    const bool col_ok = tid < kRunCols && c0 + tid < L.d;
+    float s = (col_ok && !j.start_zero) ? j.run[c0 + tid] : 0.f;
+    const int64_t ntiles = (j.n + kRunRows - 1) / kRunRows;
+    stage(0, 0);
+    __syncthreads();
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < ntiles) stage(buf ^ 1, (t + 1) * kRunRows);    // waves 1..3: the next tile, while wave 0 adds
+        if (tid < kRunCols) {
+            const int64_t left = j.n - t * kRunRows;
+            const int rows_here = left < kRunRows ? (int)left : kRunRows;
+            if (rows_here == kRunRows) {
+                for (int r0 = 0; r0 < kRunRows; r0 += 64) {        // 64 LDS reads ahead of the 64 dependent adds
+                    float v[64];
+#pragma unroll
+                    for (int u = 0; u < 64; ++u) v[u] = tile[buf][r0 + u][tid];
+#pragma unroll
+                    for (int u = 0; u < 64; ++u) s = s + v[u];
+                }
+            } else {
+                for (int r = 0; r < rows_here; ++r) s = s + tile[buf][r][tid];
+            }
+        }
+        __syncthreads();
+    }
+    if (col_ok) j.run[c0 + tid] = s;
+}
+
 // mu = sum/n ; cov = (M - sum sum^T / n) / (n - ddof)
+// (`run`: the float32 running column sums above -- then mu = float32(run / float32(n)), numpy's quotient)
 __global__ __launch_bounds__(256) void moments_finalize_kernel(
     const double* __restrict__ acc_packed, int d, int ddof, double* __restrict__ mu,
-    double* __restrict__ cov) {
+    double* __restrict__ cov, const float* __restrict__ run = nullptr) {
     const double n = acc_packed[0];
     const double* sum = acc_packed + 1;
     const double* M = acc_packed + 1 + d;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < d && mu) mu[g] = sum[g] / n;
+    if (g < d && mu) mu[g] = run ? (double)(run[g] / (float)n) : sum[g] / n;
     if (g >= (int64_t)d * d) return;
     const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
     cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit

@@ -52,14 +52,17 @@ def _thread_accumulator(d: int, device: int):
         if len(pool) >= 4:
             pool.pop(next(iter(pool))).close()
         acc = pool[(device, d)] = hip.Moments(d, device)
+        acc.set_reference_mean(True)                   # mu as np.mean forms it (float32 running sum over the rows): calc_embd_statistics
     return acc
 
 
 def calc_embd_statistics(embd_lst, device: int = 0):
     """Mean and covariance of a frame matrix [N x D] (fadtk/fad.py:42-48), computed on the GPU.
 
-    Returns (mu, cov) with numpy's dtypes: mu in the input's float dtype (float16 embeddings give a
-    float16 mean, rounded from an exact float64 column sum), cov float64 with ddof = 1.
+    Returns (mu, cov) with numpy's dtypes: mu in the input's float dtype, formed the way np.mean forms it -- the rows added one
+    after the other in float32, the quotient in float32, then the cast (``Moments.set_reference_mean``: bit for bit numpy's float16 /
+    float32 mean, which for frames with a sizeable offset is NOT the rounded exact mean) --, cov float64 with ddof = 1 from exact
+    float64 sums.
     """
     n = embd_lst.shape[0]
     assert n >= 2, (f"FAD requires at least two embedding window frames, you have {tuple(embd_lst.shape)}."

@@ -79,6 +79,17 @@ int64_t fad_moments_packed_len(const fad_moments_t* h);      /* 1 + D + D*D     
 int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
                        int on_device, void* stream);
 
+/* Reference-order means (off by default).  The reference's np.mean(embd_lst, axis=0) (fadtk/fad.py:48) adds the rows one after the
+ * other in float32 (float16 frames widened first) and divides by n in float32: for frames with a sizeable offset the float16-rounded
+ * result differs from the rounded EXACT mean -- what fad_moments_finalize returns otherwise -- by one ulp in a few dimensions, worth
+ * 2e-5 .. 5e-4 of a small Frechet distance.  With the switch on, every update also carries numpy's float32 running column sums (one lane
+ * per column walks the rows in order: ~0.3 ms per 100 k rows, on a few CUs, beside the update's other kernels) and
+ * fad_moments_finalize returns mu = float32(run / float32(n)) widened to double; the covariance is unchanged.  Covers plain updates
+ * (fad_moments_update / _multi, host or device rows, float16 / bfloat16 / float32) in the order they are fed; statistics that were imported,
+ * all-reduced or fed while the switch was off have no row order: finalize then falls back to the exact mean.  Not used by the
+ * fad_frechet_from_moments* chains (their mean term takes the rounded exact mean, `mean_dtype`). */
+int fad_moments_set_reference_mean(fad_moments_t* h, int enabled);
+
 /* Feed `count` (1..16) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE
  * launch of each kernel: rows[i] (a DEVICE pointer, n[i] frames, pitch ld[i]) goes to hs[i].  The two datasets of a
  * FAD score (fad.py:292-302 calls calc_embd_statistics / load_stats twice), the 25 resamples of score_inf

@@ -50,13 +50,9 @@ def test_moments_match_np_cov(F, n, d, dtype):
     np.testing.assert_array_equal(cov, cov.T)                # exactly symmetric, like dsyrk
     if dtype == np.float64:
         np.testing.assert_allclose(mu, mu_o, rtol=1e-13, atol=1e-15)
-    elif dtype == np.float32:                                # numpy's own fp32 running sum is the noisy side here
-        np.testing.assert_allclose(mu, mu_o, rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(mu, x.astype(np.float64).mean(0).astype(np.float32), rtol=0, atol=0)
-    else:                                                    # <= 1 ulp of fp16 (numpy sums fp16 in fp32, then rounds)
-        ulp = np.spacing(np.abs(mu_o).astype(mu_o.dtype)).astype(np.float64)
-        assert np.all(np.abs(mu.astype(np.float64) - mu_o.astype(np.float64)) <= ulp)
-        assert np.mean(mu == mu_o) > 0.95
+    else:                                                    # numpy's own mean, bit for bit: the rows added one after the other in float32
+        np.testing.assert_array_equal(mu, mu_o)              # (round 4: fad_moments_set_reference_mean; before: the rounded exact mean,
+                                                             #  within one float16 ulp of numpy's and equal to it in > 95 % of the columns)
 
 
 def test_moments_golden_g1(F, golden, golden_dir):
@@ -1207,6 +1203,42 @@ def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
     with pytest.raises(RuntimeError):                                         # only songs the chain cannot take: strict mode must say so
         monkeypatch.setenv("FAD_SONG_FAST", "2")
         hip.frechet_batched(mu_b, cov_b, np.concatenate([flat, steep]), [0, flat.shape[0], flat.shape[0] + steep.shape[0]], mean_mode=1)
+
+
+@pytest.mark.parametrize("dtype,n,d,offset", [(np.float16, 60000, 256, 3.0), (np.float16, 20001, 128, 0.5), (np.float32, 30000, 96, 3.0), (np.float16, 513, 512, 10.0)])
+def test_calc_embd_statistics_returns_numpys_own_mean_for_frames_with_an_offset(F, dtype, n, d, offset):
+    """np.mean(embd_lst, axis=0) (fadtk/fad.py:48) adds the rows one after the other in float32: for frames with an offset the float16
+    result is NOT the rounded exact mean in a few dimensions (worth 2e-5 .. 5e-4 of a small FAD at config-3 size).  calc_embd_statistics
+    carries numpy's running sums on the GPU (fad_moments_set_reference_mean) and returns numpy's mean bit for bit -- from host rows (staged
+    in blocks), from a device tensor, and across two updates of one handle; the covariance stays the exact one."""
+    import torch
+    from fadtk_amd import hip
+    rng = np.random.default_rng(n + d)
+    x = (np.maximum(rng.standard_normal((n, d)) * 0.3 + offset, 0)).astype(dtype)
+    want_mu = np.mean(x, axis=0)
+    mu, cov = F.calc_embd_statistics(x)
+    assert mu.dtype == want_mu.dtype
+    np.testing.assert_array_equal(mu, want_mu)
+    want_cov = np.cov(x, rowvar=False)
+    np.testing.assert_allclose(cov, want_cov, rtol=0, atol=2e-6 * np.abs(want_cov).max())
+    mu_t, _ = F.calc_embd_statistics(torch.from_numpy(x).cuda())
+    np.testing.assert_array_equal(mu_t, want_mu)
+    if dtype == np.float16 and offset >= 3.0 and n >= 60000:
+        exact = x.astype(np.float64).mean(0).astype(np.float16)
+        assert (exact != want_mu).any(), "the case should show the difference this test is about"
+    with hip.Moments(d) as acc:                       # two updates: the running sums are carried like numpy carries them over the rows
+        acc.set_reference_mean(True)
+        acc.update(x[: n // 3]); acc.update(x[n // 3:])
+        mu2, _, _ = acc.finalize()
+        np.testing.assert_array_equal(mu2.astype(np.float32).astype(dtype), want_mu)
+        acc.reset()                                   # ... and a reset starts them again
+        acc.update(x[: n // 2])
+        mu3, _, _ = acc.finalize()
+        np.testing.assert_array_equal(mu3.astype(np.float32).astype(dtype), np.mean(x[: n // 2], axis=0))
+    with hip.Moments(d) as plain:                     # the switch off: the exact mean, as before
+        plain.update(x)
+        mu4, _, _ = plain.finalize()
+        np.testing.assert_allclose(mu4, x.astype(np.float64).mean(0), rtol=2e-6)      # (float16 frames: column sums of bounded float32 runs)
 
 
 @pytest.mark.parametrize("d,frames", [(128, 2250), (512, 1200)])
