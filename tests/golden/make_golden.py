@@ -91,6 +91,11 @@ def g2():
     out["c1_iid_f64"] = dict(zip(("fad", "tr1", "tr2"), _fd(a64, b64)))
     sa, sb = R.shifted_pair()
     out["shifted"] = dict(zip(("fad", "tr1", "tr2"), _fd(sa, sb)))
+    # the same at 60000 rows: np.mean's float32 running sum (fad.py:48) is then 1e-5 off the exact column sums and the float16 means
+    # differ from the rounded exact means in some dimensions (round 4: fad_moments_set_reference_mean reproduces numpy's)
+    la, lb = R.shifted_pair(n=60000)
+    out["shifted_long"] = dict(zip(("fad", "tr1", "tr2"), _fd(la, lb)))
+    out["shifted_long"]["in_checksum"] = [R.checksum(la), R.checksum(lb)]
     for d in (64, 512):
         x1 = R.decaying_rows(30, 4 * d, d, basis_seed=40)
         x2 = R.decaying_rows(31, 4 * d, d, basis_seed=40, gain=1.1)

@@ -482,11 +482,14 @@ def _pair_stats(a, b):
     return m1, c1, m2, c2
 
 
-@pytest.mark.parametrize("case", ["c1_iid", "c1_iid_f32", "c1_iid_f64", "shifted"])
+@pytest.mark.parametrize("case", ["c1_iid", "c1_iid_f32", "c1_iid_f64", "shifted", "shifted_long"])
 def test_frechet_golden_pairs(F, golden, case):
+    # (shifted_long: 60000 float16 rows at |mu| / sigma ~ 7 -- the reference's np.mean is a float32 running sum there, five of its
+    #  float16 means are not the rounded exact ones, and with those the FAD would be 1.4e-3 off this fixture: fad_moments_set_reference_mean)
     g = golden["g2"][case]
     a, b = {"c1_iid": R.c1_pair, "c1_iid_f32": lambda: R.c1_pair(np.float32),
-            "c1_iid_f64": lambda: R.c1_pair(np.float64), "shifted": R.shifted_pair}[case]()
+            "c1_iid_f64": lambda: R.c1_pair(np.float64), "shifted": R.shifted_pair,
+            "shifted_long": lambda: R.shifted_pair(n=60000)}[case]()
     fad = F.calc_frechet_distance(*_pair_stats(a, b))
     assert isinstance(fad, np.float64)
     assert abs(fad - g["fad"]) / abs(g["fad"]) < 1e-9
