@@ -266,7 +266,8 @@ static FastBufs fast_bufs(Workspace& ws, int d) {
 // K1 on `stream`: mu of both sets and (from packed moments) their covariances into the slot's staging area, state reset, scales,
 // digit planes.  acc1 == nullptr: the caller's device matrices cov1 / cov2 are used as they are.
 static int fast_prepare(Workspace& ws, int d, int ddof, const double* acc1, const double* acc2, const double* cov1, const double* cov2,
-                        const double* mu1, const double* mu2, int mean_dtype, double* mus, double* covs, hipStream_t st) {
+                        const double* mu1, const double* mu2, int mean_dtype, double* mus, double* covs, hipStream_t st,
+                        const float* run1 = nullptr, const float* run2 = nullptr) {
     void* const before = ws.fast.p;
     FAD_TRY(ws.fast.reserve(fast_bytes(d)));
     FAD_TRY(ws.small.reserve(ns_small_bytes(d, 1)));
@@ -277,6 +278,7 @@ static int fast_prepare(Workspace& ws, int d, int ddof, const double* acc1, cons
     nsf::PrepArgs a;
     memset(&a, 0, sizeof(a));
     a.acc[0] = acc1; a.acc[1] = acc2; a.cov_in[0] = cov1; a.cov_in[1] = cov2; a.mu_in[0] = mu1; a.mu_in[1] = mu2;
+    a.run[0] = run1; a.run[1] = run2;
     a.d = d; a.ddof = ddof; a.gen = ws.job.gen; a.mean_dtype = mean_dtype;
     a.mus = mus; a.covs = covs;
     a.dig[0] = f.digC[0]; a.dig[1] = f.digC[1];
@@ -738,7 +740,10 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
 
     nsf::PrepArgs pa;
     memset(&pa, 0, sizeof(pa));
-    for (int b = 0; b < B; ++b) { pa.accs[2 * b] = moments_packed(h1[b]); pa.accs[2 * b + 1] = moments_packed(h2[b]); }
+    for (int b = 0; b < B; ++b) {
+        pa.accs[2 * b] = moments_packed(h1[b]); pa.accs[2 * b + 1] = moments_packed(h2[b]);
+        pa.runs[2 * b] = moments_runsum(h1[b]); pa.runs[2 * b + 1] = moments_runsum(h2[b]);
+    }
     pa.acc[0] = pa.accs[0]; pa.acc[1] = pa.accs[1];
     pa.d = d; pa.ddof = ddof; pa.gen = gen; pa.mean_dtype = mean_dtype;
     pa.mus = reinterpret_cast<double*>(at(L.mus)); pa.covs = reinterpret_cast<double*>(at(L.covs));
@@ -1006,9 +1011,11 @@ static int stage_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, 
     ws.job.cov1 = s; ws.job.cov2 = s + dd; ws.job.mu1 = s + 2 * dd; ws.job.mu2 = s + 2 * dd + d;
     if (fast_eligible(ws, d, max_iter, tol)) {     // the eight-launch chain: its first kernel does this staging as well
         ws.job.fast = true;
-        return fast_prepare(ws, d, ddof, moments_packed(h1), moments_packed(h2), nullptr, nullptr, nullptr, nullptr, mean_dtype, s + 2 * dd, s, st);
+        return fast_prepare(ws, d, ddof, moments_packed(h1), moments_packed(h2), nullptr, nullptr, nullptr, nullptr, mean_dtype, s + 2 * dd, s, st,
+                            moments_runsum(h1), moments_runsum(h2));
     }
-    enqueue_finalize_for_frechet(moments_packed(h1), moments_packed(h2), d, ddof, s + 2 * dd, s, static_cast<NsState*>(ws.small.p), st);
+    enqueue_finalize_for_frechet(moments_packed(h1), moments_packed(h2), d, ddof, s + 2 * dd, s, static_cast<NsState*>(ws.small.p), st,
+                                 moments_runsum(h1), moments_runsum(h2));
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
 }

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void add_diag(double* __restrict__ M, int d, d
 __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __restrict__ acc1,
                                                             const double* __restrict__ acc2, int d, int ddof,
                                                             double* __restrict__ mus, double* __restrict__ covs,
-                                                            NsState* __restrict__ st) {
+                                                            NsState* __restrict__ st, const float* __restrict__ run1 = nullptr,
+                                                            const float* __restrict__ run2 = nullptr) {
     const double* acc = blockIdx.y ? acc2 : acc1;
     double* mu = mus + (int64_t)blockIdx.y * d;
     double* cov = covs + (int64_t)blockIdx.y * d * d;
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __rest
             st->upd_skip[0] = 0; st->upd_skip[1] = 0;
         }
     }
-    if (g < d) mu[g] = sum[g] / n;
+    const float* run = blockIdx.y ? run2 : run1;                    // (numpy's running sums: ns_fast.h, PrepArgs::run)
+    if (g < d) mu[g] = run ? (double)(run[g] / (float)n) : sum[g] / n;
     if (g >= (int64_t)d * d) return;
     const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
     cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit
@@ -364,8 +366,8 @@ void enqueue_add_diag(double* M, int d, double eps, hipStream_t stream) {
     hipLaunchKernelGGL(add_diag, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, stream, M, d, eps);
 }
 void enqueue_finalize_for_frechet(const double* acc1, const double* acc2, int d, int ddof, double* mus, double* covs, NsState* st,
-                                  hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_for_frechet, dim3((unsigned)cdiv((int64_t)d * d, 256), 2), dim3(256), 0, stream, acc1, acc2, d, ddof, mus, covs, st);
+                                  hipStream_t stream, const float* run1, const float* run2) {
+    hipLaunchKernelGGL(finalize_for_frechet, dim3((unsigned)cdiv((int64_t)d * d, 256), 2), dim3(256), 0, stream, acc1, acc2, d, ddof, mus, covs, st, run1, run2);
 }
 void enqueue_ns_prepare(const double* stats_all, int d, int nb, const double* mu1, int64_t m1, const double* mu2, int64_t m2,
                         int mean_dtype, NsState* st_all, int mean_given, Ns32State* s32, int64_t B, hipStream_t stream) {

@@ -16,6 +16,7 @@ const double* moments_packed(const fad_moments* h);
 int moments_settle(const fad_moments* h, hipStream_t st);      // pending reset -> zeros
 int moments_device(const fad_moments* h);
 int moments_dim(const fad_moments* h);
+const float* moments_runsum(const fad_moments* h);          // numpy's running column sums when they cover the handle's rows, else nullptr
 
 constexpr int kStatScal = 8;                         // doubles per tile: sumsq, cross, trA, tr1, tr2, (3 spare)
 static inline int64_t stat_blocks(int d) { return cdiv(d, 32); }
@@ -136,7 +137,7 @@ int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_
 void enqueue_clear_states(NsState* st, int64_t B, hipStream_t stream);                 // per-call reset of B iteration states
 void enqueue_add_diag(double* M, int d, double eps, hipStream_t stream);               // M += eps I (fad.py:94-99)
 void enqueue_finalize_for_frechet(const double* acc1, const double* acc2, int d, int ddof, double* mus, double* covs, NsState* st,
-                                  hipStream_t stream);                                   // packed moments -> (mu, Sigma) x 2
+                                  hipStream_t stream, const float* run1 = nullptr, const float* run2 = nullptr);   // packed moments -> (mu, Sigma) x 2
 void enqueue_ns_prepare(const double* stats_all, int d, int nb, const double* mu1, int64_t m1, const double* mu2, int64_t m2,
                         int mean_dtype, NsState* st_all, int mean_given, Ns32State* s32, int64_t B, hipStream_t stream);
 

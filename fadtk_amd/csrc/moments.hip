@@ -1115,6 +1115,9 @@ int fad_moments_last_timing(fad_moments_t* h, float* ms_main, float* ms_reduce, 
 namespace fad {
 const double* moments_packed(const fad_moments* h) { return h->acc; }
 int moments_settle(const fad_moments* h, hipStream_t st) { return settle(h, st); }
+const float* moments_runsum(const fad_moments* h) {
+    return (h->ref_mean && h->runsum_covers && h->runsum_live && !h->fresh) ? static_cast<const float*>(h->runsum.p) : nullptr;
+}
 int moments_device(const fad_moments* h) { return h->device; }
 int moments_dim(const fad_moments* h) { return h->d; }
 }

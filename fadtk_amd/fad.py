@@ -314,6 +314,9 @@ class FrechetAudioDistance:
         with torch.cuda.device(dev):
             base = hip.Moments(d, self.device_index).import_(packed)
             accs = [hip.Moments(d, self.device_index) for _ in range(8)]
+            if code is not None:
+                for a in accs:                            # the resamples' means as np.mean forms them (fad.py:48: a float32 running sum)
+                    a.set_reference_mean(True)
             try:
                 pos = 0
                 while pos < len(order):

@@ -86,8 +86,9 @@ int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld
  * per column walks the rows in order: ~0.3 ms per 100 k rows, on a few CUs, beside the update's other kernels) and
  * fad_moments_finalize returns mu = float32(run / float32(n)) widened to double; the covariance is unchanged.  Covers plain updates
  * (fad_moments_update / _multi, host or device rows, float16 / bfloat16 / float32) in the order they are fed; statistics that were imported,
- * all-reduced or fed while the switch was off have no row order: finalize then falls back to the exact mean.  Not used by the
- * fad_frechet_from_moments* chains (their mean term takes the rounded exact mean, `mean_dtype`). */
+ * all-reduced or fed while the switch was off have no row order: finalize then falls back to the exact mean.  The
+ * fad_frechet_from_moments* entry points take the same mean for their mean term (then rounded as `mean_dtype` asks) from a handle whose
+ * running sums cover its rows, the exact one otherwise. */
 int fad_moments_set_reference_mean(fad_moments_t* h, int enabled);
 
 /* Feed `count` (1..16) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE
