@@ -40,7 +40,7 @@ def _fd(a, b):
     return O.frechet_distance(m1, c1, m2, c2, run_sqrtm=False), np.trace(c1), np.trace(c2)
 
 
-@pytest.mark.parametrize("case", ["c1_iid", "c1_iid_f32", "c1_iid_f64", "shifted", "identical"])
+@pytest.mark.parametrize("case", ["c1_iid", "c1_iid_f32", "c1_iid_f64", "shifted", "shifted_long", "identical"])
 def test_g2_frechet_pairs(golden, case):
     g = golden["g2"][case]
     if case == "c1_iid" or case == "identical":
@@ -51,6 +51,9 @@ def test_g2_frechet_pairs(golden, case):
         a, b = R.c1_pair(np.float32)
     elif case == "c1_iid_f64":
         a, b = R.c1_pair(np.float64)
+    elif case == "shifted_long":             # 60000 rows: the reference's float16 means come out of a float32 running sum (fad.py:48)
+        a, b = R.shifted_pair(n=60000)
+        assert R.checksum(a) == pytest.approx(g["in_checksum"][0], rel=1e-12)
     else:
         a, b = R.shifted_pair()
     fad, t1, t2 = _fd(a, b)
