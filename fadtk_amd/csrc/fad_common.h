@@ -37,6 +37,10 @@ int host_to_device_2d(void* dst, size_t dpitch, const void* src, size_t spitch, 
                       hipStream_t st);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// The quotient np.mean forms from its float32 running sum (fadtk/fad.py:48 -> numpy _methods._mean: true_divide(float32 sum, intp
+// count) resolves to the float64 loop and is cast back to float32).  Identical to a float32 division while n is a float32 value
+// (n < 2^24, or even above it); for larger odd row counts only this form is numpy's.
+__host__ __device__ __forceinline__ double numpy_mean_of_f32_sum(float run, double n) { return (double)(float)((double)run / n); }
 static inline size_t dtype_size(int dt) {
     switch (dt) { case FAD_F16: case FAD_BF16: return 2; case FAD_F32: return 4; case FAD_F64: return 8; }
     return 0;

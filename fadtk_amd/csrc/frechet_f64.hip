@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void finalize_for_frechet(const double* __rest
         }
     }
     const float* run = blockIdx.y ? run2 : run1;                    // (numpy's running sums: ns_fast.h, PrepArgs::run)
-    if (g < d) mu[g] = run ? (double)(run[g] / (float)n) : sum[g] / n;
+    if (g < d) mu[g] = run ? numpy_mean_of_f32_sum(run[g], n) : sum[g] / n;
     if (g >= (int64_t)d * d) return;
     const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
     cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit

@@ -41,18 +41,30 @@ template <> __device__ __forceinline__ double round_like_input<r_bf16>(double v)
     return (double)__uint_as_float(u & 0xffff0000u);
 }
 
-// The song's mean of column `a` as the reference's np.mean(embd, axis=0) returns it (fad.py:48, mean_mode = 1).  float16 / bfloat16
-// frames: numpy accumulates them in float32 and rounds the quotient to the frames' type -- the rounded exact mean (checked against numpy).
-// float32 frames: numpy adds the rows one after the other IN float32 and divides by n in float32, 1e-6 off the rounded exact mean for a few
-// thousand frames -- up to 5e-5 of a small score (tests/test_gpu_fuzz.py); one thread walks the column in that order.
+// The song's mean of column `a` as the reference's np.mean(embd, axis=0) returns it (fad.py:48, mean_mode = 1): numpy widens float16 /
+// bfloat16 frames to float32, adds the rows ONE AFTER THE OTHER in float32, divides (fad_common.h: numpy_mean_of_f32_sum) and rounds the
+// quotient to the frames' type.  For a few thousand frames the float32 running sum ends ~1e-6 off the exact one: the float32 mean differs
+// in its last bits (up to 5e-5 of a small score, tests/test_gpu_fuzz.py), the float16 mean by one ulp in ~0.3 % of the dimensions when the
+// frames carry an offset (rounds 1-4 returned the rounded EXACT mean for 16-bit frames; fixture g4.shifted holds the walk to the
+// reference's own scores).  One thread walks the column in that order, eight loads in flight; float64 frames: numpy's sum is the exact one.
+template <typename TIn> __device__ __forceinline__ float ld_f32(const TIn* p, int64_t i) { return (float)ld_f64<TIn>(p, i); }
 template <typename TIn>
 __device__ __forceinline__ double mean_like_reference(const TIn* __restrict__ rows, int64_t ld, int a, int64_t r0, int64_t r1, double m_exact) {
-    if constexpr (std::is_same<TIn, float>::value) {
-        float acc = 0.f;
-        for (int64_t r = r0; r < r1; ++r) acc = acc + rows[r * ld + a];
-        return (r1 > r0) ? (double)(acc / (float)(r1 - r0)) : 0.0;
+    if constexpr (std::is_same<TIn, double>::value) {
+        return m_exact;
     } else {
-        return round_like_input<TIn>(m_exact);
+        if (r1 <= r0) return 0.0;
+        float acc = 0.f;
+        int64_t r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_f32<TIn>(rows, (r + u) * ld + a);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + v[u];
+        }
+        for (; r < r1; ++r) acc = acc + ld_f32<TIn>(rows, r * ld + a);
+        return round_like_input<TIn>(numpy_mean_of_f32_sum(acc, (double)(r1 - r0)));
     }
 }
 
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict
             for (int l = 0; l < 16; ++l) { s1 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2]; s2 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2 + 1]; }
             const double first = (n > 0) ? ld_f64<r_f16>(reinterpret_cast<const r_f16*>(rows), r0 * ld + a) : 0.0;
             const double m = (n > 0) ? first + s1 / (double)n : 0.0;
-            const double mr = mean_mode ? round_like_input<r_f16>(m) : m;
+            const double mr = mean_mode ? mean_like_reference<r_f16>(reinterpret_cast<const r_f16*>(rows), ld, a, r0, r1, m) : m;
             if (mean_exact) mean_exact[s * d + a] = m;
             const double df = mu_b[a] - mr;
             mt = df * df;
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(256) void pair_stats_diff(const TIn* __restrict__ r
         const double x1 = ld_f64<TIn>(rows, r0 * ld + a), x2 = ld_f64<TIn>(rows, (r0 + 1) * ld + a);
         dm[r * d + a] = x1 - x2;
         const double m = (x1 + x2) / 2.0;
-        const double mr = mean_mode ? round_like_input<TIn>(m) : m;
+        const double mr = mean_mode ? mean_like_reference<TIn>(rows, ld, a, r0, r0 + 2, m) : m;      // (two frames: float32(x1 + x2) / 2, rounded)
         const double c1 = x1 - m, c2 = x2 - m;
         ts += c1 * c1 + c2 * c2;
         const double df = mu_b[a] - mr;

@@ -53,6 +53,7 @@ struct fad_moments {
     fad::DevBuf runsum;                         // ... [d] floats
     bool runsum_covers = true;             // ... they cover exactly the rows the accumulator holds (an empty handle: trivially)
     bool runsum_live = false;              // ... a running-sum kernel has written them since the handle was created / reset
+    hipEvent_t rs_fork = nullptr, rs_join = nullptr;   // ... the walk runs on the device's side stream between these two (running_sums)
     int r256_sl = 0;                       // FAD_MOMENTS_R256_SL (read at creation; experiments): split lanes of moments_reduce256, 0 = by the split count
     int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
@@ -126,6 +127,7 @@ static int ensure_kernel_attrs(int device) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
         }
     }
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum_h16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsLds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_f16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_f16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
@@ -341,8 +343,27 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
 // `seg` (count == 1, fp16/bf16 aligned input only): segment-aligned splits; colpart then has one row per run.
 // numpy's float32 running column sums (moments_kernels.h: moments_running_colsum) for the handles that asked for them: one launch for
 // all of them, in front of the update's other kernels (float64 frames: numpy's sum is the exact one to 1e-16 -- nothing to do)
+// The walk's stream: one per device (high priority: its 32 workgroups per matrix should be placed before the tile kernel's fill the
+// chip; they fit BESIDE a tile workgroup).  FAD_MOMENTS_RUNSUM_SIDE=0 (read once) keeps the walk in line on the caller's stream.
+static hipStream_t runsum_side_stream(int device) {
+    static std::mutex mu;
+    static hipStream_t side[64] = {nullptr};
+    static int enabled = -1;
+    std::lock_guard<std::mutex> lk(mu);
+    if (enabled < 0) { const char* e = getenv("FAD_MOMENTS_RUNSUM_SIDE"); enabled = (e && e[0] == '0') ? 0 : 1; }
+    if (!enabled || device < 0 || device >= 64) return nullptr;
+    if (!side[device]) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        if (hipStreamCreateWithPriority(&side[device], hipStreamNonBlocking, hi) != hipSuccess) { side[device] = nullptr; (void)hipGetLastError(); }
+    }
+    return side[device];
+}
+
+// -> *joined: an event the caller's stream has to wait for before the update returns (the walk reads the caller's rows), or nullptr
 static int running_sums(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n, const int64_t* ld, int dtype,
-                        hipStream_t st) {
+                        hipStream_t st, hipEvent_t* joined) {
+    *joined = nullptr;
     if (dtype == FAD_F64) {                                          // (numpy's float64 sum IS the exact one to 1e-16: finalize takes that)
         for (int i = 0; i < count; ++i)
             if (n[i] > 0) hs[i]->runsum_covers = false;
@@ -364,16 +385,31 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
         h->runsum_live = true;
     }
     if (!m) return FAD_OK;
-    L.d = hs[0]->d;
-    FAD_TRY(ensure_kernel_attrs(hs[0]->device));
+    fad_moments* h0 = hs[0];
+    L.d = h0->d;
+    FAD_TRY(ensure_kernel_attrs(h0->device));
     const dim3 grid((unsigned)cdiv(L.d, kRunCols), (unsigned)m);
     const size_t es = dtype_size(dtype);
     bool wide = (L.d % (int)(16 / es)) == 0;
     for (int i = 0; i < m && wide; ++i)
         wide = ((reinterpret_cast<uintptr_t>(L.job[i].rows) & 15u) == 0) && ((L.job[i].ld * (int64_t)es) % 16 == 0);
-    if (dtype == FAD_F16) {
-        if (wide) hipLaunchKernelGGL((moments_running_colsum<raw_f16, true>), grid, dim3(256), kRunLds, st, L);
-        else hipLaunchKernelGGL((moments_running_colsum<raw_f16, false>), grid, dim3(256), kRunLds, st, L);
+    // float16 rows, aligned: the form that fits beside the tile kernel, on the side stream -- behind everything the caller's stream holds
+    // so far (the rows may still be on their way), and the caller's stream waits for it before the update returns
+    hipStream_t run_st = st;
+    if (dtype == FAD_F16 && wide) {
+        if (hipStream_t side = runsum_side_stream(h0->device)) {
+            if (!h0->rs_fork) {
+                FAD_HIP_TRY(hipEventCreateWithFlags(&h0->rs_fork, hipEventDisableTiming));
+                FAD_HIP_TRY(hipEventCreateWithFlags(&h0->rs_join, hipEventDisableTiming));
+            }
+            FAD_HIP_TRY(hipEventRecord(h0->rs_fork, st));
+            FAD_HIP_TRY(hipStreamWaitEvent(side, h0->rs_fork, 0));
+            run_st = side;
+        }
+        hipLaunchKernelGGL(moments_running_colsum_h16, grid, dim3(256), kRsLds, run_st, L);
+        if (run_st != st) { FAD_HIP_TRY(hipEventRecord(h0->rs_join, run_st)); *joined = h0->rs_join; }
+    } else if (dtype == FAD_F16) {
+        hipLaunchKernelGGL((moments_running_colsum<raw_f16, false>), grid, dim3(256), kRunLds, st, L);
     } else if (dtype == FAD_BF16) {
         if (wide) hipLaunchKernelGGL((moments_running_colsum<raw_bf16, true>), grid, dim3(256), kRunLds, st, L);
         else hipLaunchKernelGGL((moments_running_colsum<raw_bf16, false>), grid, dim3(256), kRunLds, st, L);
@@ -385,8 +421,23 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
     return FAD_OK;
 }
 
+static int update_device_multi_impl(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n,
+                                    const int64_t* ld, int dtype, hipStream_t st, const SegPlan* seg);
 static int update_device_multi(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n,
                                const int64_t* ld, int dtype, hipStream_t st, const SegPlan* seg = nullptr) {
+    // numpy's running column sums first (on the side stream where they fit beside the tile kernel), then the update's own kernels;
+    // the caller's stream leaves the update only when the walk has read the rows as well
+    hipEvent_t joined = nullptr;
+    FAD_TRY(running_sums(count, hs, rows, n, ld, dtype, st, &joined));
+    const int rc = update_device_multi_impl(count, hs, rows, n, ld, dtype, st, seg);
+    if (joined) {
+        const hipError_t e = hipStreamWaitEvent(st, joined, 0);
+        if (e != hipSuccess && rc == FAD_OK) return set_error(FAD_ERR_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+static int update_device_multi_impl(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n,
+                                    const int64_t* ld, int dtype, hipStream_t st, const SegPlan* seg) {
     fad_moments* h0 = hs[0];
     const int d = h0->d;
     const bool is16 = (dtype == FAD_F16 || dtype == FAD_BF16);
@@ -400,7 +451,6 @@ static int update_device_multi(int count, fad_moments* const* hs, const void* co
     for (int i = 0; i < count; ++i) if (n[i] > n_max) n_max = n[i];
     const bool use_h16 = aligned && !h0->force_generic && (n_max >= 16 * (int64_t)d || seg);
 
-    FAD_TRY(running_sums(count, hs, rows, n, ld, dtype, st));
     hipEvent_t* ev = nullptr;
     FAD_TRY(timing_events(h0, &ev));
     h0->last_sets = count;
@@ -682,6 +732,8 @@ int fad_moments_destroy(fad_moments_t* h) {
     h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release(); h->runsum.release();
     if (h->tab_host) (void)hipHostFree(h->tab_host);
     if (h->tab_ev) (void)hipEventDestroy(h->tab_ev);
+    if (h->rs_fork) (void)hipEventDestroy(h->rs_fork);
+    if (h->rs_join) (void)hipEventDestroy(h->rs_join);
     if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
     delete h;
     return FAD_OK;
@@ -926,8 +978,12 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
             FAD_HIP_TRY(hipEventRecord(exact->tab_ev, st));
             exact->sizes_cached.assign(sizes, sizes + n_files);
             exact->sizes_cached_at = base + sums_bytes;
+        } else if (exact->tab_ev) {
+            FAD_HIP_TRY(hipStreamWaitEvent(st, exact->tab_ev, 0));       // (the cached copy may have been uploaded on another stream)
         }
         dsizes = reinterpret_cast<const int64_t*>(base + sums_bytes);
+    } else {
+        exact->sizes_cached_at = nullptr;          // (device sizes: the row blocks below start where a cached host copy would sit)
     }
     double* r_exact = reinterpret_cast<double*>(base + ((in_bytes + 15) & ~(size_t)15));
     double* r_round = r_exact + cells;
@@ -957,6 +1013,10 @@ int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream
     const int64_t len = packed_len(dst->d);
     FAD_TRY(settle(dst, static_cast<hipStream_t>(stream)));
     FAD_TRY(settle(src, static_cast<hipStream_t>(stream)));
+    // (rows from another handle have no place in dst's row order: numpy's running sums no longer cover what the accumulator holds --
+    //  finalize and the Frechet entry points fall back to the exact mean, as after import / allreduce.  An EMPTY src changes nothing,
+    //  but whether it is empty is known on the device only: any merge gives the order up.)
+    dst->runsum_covers = false;
     hipLaunchKernelGGL(packed_axpy, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        dst->acc, src->acc, len);
     FAD_HIP_TRY(hipGetLastError());

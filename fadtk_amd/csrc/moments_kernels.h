@@ -1142,8 +1142,138 @@ __global__ __launch_bounds__(256) void moments_running_colsum(RunSumLaunch L) {
     if (col_ok) j.run[c0 + tid] = s;
 }
 
+// The same walk for float16 rows (the reference's storage type, model_loader.py:47-48) in a form that runs BESIDE the 256-column tile
+// kernel: 25 KiB of LDS and at most 64 VGPRs per wave -- what one CU has left next to a tile workgroup (128 KiB, 2 x 224 registers per
+// SIMD) -- so that update_device_multi can put it on a stream of its own (moments.hip: running_sums).  What sets its pace is the
+// instruction stream of the ONE wave that adds: a wave issues an instruction every ~4 cycles, so the kernel above (a 4-byte LDS read and
+// an add per row: ~11.5 cycles per row measured) becomes
+//   * the tile in LDS as float16, column-major ([16 columns][384 rows + 8]): one ds_read_b128 brings EIGHT consecutive rows of the lane's
+//     column (pitch 784 bytes: the 16 lanes' 16-byte pieces fall into 16 different bank groups);
+//   * one v_fma_mix_f32 per row: s <- fma(float(h), 1.0f, s) widens the float16 operand inside the instruction; the product with one
+//     is exact, so the result is the correctly rounded float32 sum s + h -- numpy's add, bit for bit;
+// ~4.5 issue slots per row.  Waves 1..3 feed it: per tile a loader thread owns one PAIR of rows (2 x 32 bytes = four 16-byte loads, issued
+// two tiles ahead and held in registers meanwhile: ~1.5 us of cover), packs the pair's halves column by column and writes 16 dwords
+// (conflict-free: the lanes of a wave write consecutive dwords of one column).  Workgroups whose columns share the rows' 128-byte lines
+// (four column blocks) are dealt to ONE XCD (b % 8), so that a line crosses the fabric once.
+constexpr int kRsRows = 384, kRsPitch = kRsRows + 8, kRsCols = 16;      // pitch in halves
+constexpr size_t kRsLds = (size_t)2 * kRsCols * kRsPitch * sizeof(uint16_t);
+typedef _Float16 rs_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rs_add8(float s, const uint4& w, float one) {
+    const uint32_t q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rs_h2 h; __builtin_memcpy(&h, &q[i], 4);
+        s = __builtin_fmaf((float)h[0], one, s);
+        s = __builtin_fmaf((float)h[1], one, s);
+    }
+    return s;
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void moments_running_colsum_h16(RunSumLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t rs_lds[];                       // [2][16][kRsPitch]
+    const RunSumJob& j = L.job[blockIdx.y];
+    if (j.n <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int cb = blockIdx.x;
+    if ((gridDim.x & 31) == 0) { const int w = blockIdx.x & 31; cb = (blockIdx.x & ~31) + 4 * (w & 7) + (w >> 3); }
+    const int c0 = cb * kRsCols;
+    const uint16_t* base = static_cast<const uint16_t*>(j.rows);
+    const int64_t ntiles = (j.n + kRsRows - 1) / kRsRows;
+    // ---- loaders (waves 1..3): thread lt owns rows 2 lt, 2 lt + 1 of a tile
+    const int lt = tid - 64;
+    // (rows past the end and columns past d are never walked / written back: their addresses are clamped, their values do not matter)
+    const int q1 = (c0 + 8 < L.d) ? 8 : 0;                              // (d is a multiple of 8, not necessarily of 16)
+    auto issue = [&](uint4 (&r)[4], int64_t t) {
+        const int64_t row = t * kRsRows + 2 * lt;
+        const int64_t ra_ = row < j.n ? row : j.n - 1, rb_ = row + 1 < j.n ? row + 1 : j.n - 1;
+        const uint16_t* pa = base + ra_ * j.ld + c0;
+        const uint16_t* pb = base + rb_ * j.ld + c0;
+        r[0] = *reinterpret_cast<const uint4*>(pa);
+        r[1] = *reinterpret_cast<const uint4*>(pa + q1);
+        r[2] = *reinterpret_cast<const uint4*>(pb);
+        r[3] = *reinterpret_cast<const uint4*>(pb + q1);
+    };
+    auto dump = [&](const uint4 (&r)[4], int buf) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(rs_lds + (size_t)buf * kRsCols * kRsPitch) + lt;      // dword lt of a column = rows 2 lt, 2 lt + 1
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t lo[4] = {r[q].x, r[q].y, r[q].z, r[q].w}, hi[4] = {r[2 + q].x, r[2 + q].y, r[2 + q].z, r[2 + q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dst[(size_t)(8 * q + 2 * i) * (kRsPitch / 2)] = (lo[i] & 0xffffu) | (hi[i] << 16);
+                dst[(size_t)(8 * q + 2 * i + 1) * (kRsPitch / 2)] = (lo[i] >> 16) | (hi[i] & 0xffff0000u);
+            }
+        }
+    };
+    // ---- the adding wave: lanes 0..15 walk their column down the tile, 32 rows of reads ahead of the adds
+    const bool adder = wave == 0 && lane < kRsCols;
+    const bool col_ok = adder && c0 + lane < L.d;
+    float s = (col_ok && !j.start_zero) ? j.run[c0 + lane] : 0.f;
+    float one = 1.0f;
+    asm volatile("" : "+v"(one));                                      // (opaque: keeps the fma, which takes the float16 operand as it is)
+    auto walk = [&](int buf, int rows_here) {
+        const uint4* col = reinterpret_cast<const uint4*>(rs_lds + ((size_t)buf * kRsCols + lane) * kRsPitch);
+        int r = 0;
+        if (rows_here >= 32) {
+            uint4 cur[4], nxt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = col[u];
+            for (; r + 32 <= rows_here; r += 32) {
+                const bool more = r + 64 <= rows_here;
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) nxt[u] = col[(r >> 3) + 4 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s = rs_add8(s, cur[u], one);
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+                }
+            }
+        }
+        for (; r + 8 <= rows_here; r += 8) s = rs_add8(s, col[r >> 3], one);
+        if (r < rows_here) {
+            const uint4 w = col[r >> 3];
+            const uint32_t q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (r + i < rows_here) { rs_h2 h; __builtin_memcpy(&h, &q[i >> 1], 4); s = __builtin_fmaf((float)h[i & 1], one, s); }
+            }
+        }
+    };
+    auto rows_of = [&](int64_t t) { const int64_t left = j.n - t * kRsRows; return left < kRsRows ? (int)left : kRsRows; };
+    // Two roles, two loops (wave-uniform branch; every wave passes the same barriers): the register sets of the loaders (two tiles in
+    // flight) and of the adding wave (64 rows of operands) never live side by side -- the kernel has to stay within 64 VGPRs
+    if (wave == 0) {
+        __syncthreads();
+        for (int64_t t = 0; t < ntiles; t += 2) {
+            if (adder) walk(0, rows_of(t));
+            __syncthreads();
+            if (t + 1 >= ntiles) break;
+            if (adder) walk(1, rows_of(t + 1));
+            __syncthreads();
+        }
+    } else {
+        uint4 ra[4], rb[4];
+        issue(ra, 0);
+        if (1 < ntiles) issue(rb, 1);
+        dump(ra, 0);
+        if (2 < ntiles) issue(ra, 2);
+        __syncthreads();
+        for (int64_t t = 0; t < ntiles; t += 2) {
+            if (t + 1 < ntiles) { dump(rb, 1); if (t + 3 < ntiles) issue(rb, t + 3); }
+            __syncthreads();
+            if (t + 1 >= ntiles) break;
+            if (t + 2 < ntiles) { dump(ra, 0); if (t + 4 < ntiles) issue(ra, t + 4); }
+            __syncthreads();
+        }
+    }
+    if (col_ok) j.run[c0 + lane] = s;
+}
+
 // mu = sum/n ; cov = (M - sum sum^T / n) / (n - ddof)
-// (`run`: the float32 running column sums above -- then mu = float32(run / float32(n)), numpy's quotient)
+// (`run`: the float32 running column sums above -- then mu = float32(float64(run) / n), numpy's quotient: fad_common.h)
 __global__ __launch_bounds__(256) void moments_finalize_kernel(
     const double* __restrict__ acc_packed, int d, int ddof, double* __restrict__ mu,
     double* __restrict__ cov, const float* __restrict__ run = nullptr) {
@@ -1151,7 +1281,7 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(
     const double* sum = acc_packed + 1;
     const double* M = acc_packed + 1 + d;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < d && mu) mu[g] = run ? (double)(run[g] / (float)n) : sum[g] / n;
+    if (g < d && mu) mu[g] = run ? numpy_mean_of_f32_sum(run[g], n) : sum[g] / n;
     if (g >= (int64_t)d * d) return;
     const int a = (int)(g / d), b = (int)(g - (int64_t)a * d);
     cov[g] = (M[g] - (sum[a] * sum[b]) / n) / (n - (double)ddof);   // commutative: cov == cov^T bit for bit

@@ -188,7 +188,7 @@ struct PrepArgs {
     // the spare workgroup as for a single pair.
     int batch; int64_t pstride;
     const double* accs[16];
-    // numpy's float32 running column sums of a set (fad_moments_set_reference_mean), or nullptr: then its mean is float32(run / float32(n))
+    // numpy's float32 running column sums of a set (fad_moments_set_reference_mean), or nullptr: then its mean is float32(float64(run) / n)
     // -- what np.mean returns before its final cast (fad.py:48) -- instead of the exact sum / n
     const float* run[2]; const float* runs[16];
 };
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
             const double* acq = pairs ? a.accs[(blockIdx.y & ~1u) + q] : a.acc[q];
             const float* rq = pairs ? a.runs[(blockIdx.y & ~1u) + q] : a.run[q];
             for (int i = tid; i < d; i += 256) {
-                const double m = acq ? ((rq ? (double)(rq[i] / (float)acq[0]) : acq[1 + i] / acq[0])) : a.mu_in[q][i];   // (as finalize_for_frechet)
+                const double m = acq ? ((rq ? numpy_mean_of_f32_sum(rq[i], acq[0]) : acq[1 + i] / acq[0])) : a.mu_in[q][i];   // (as finalize_for_frechet)
                 mu_lds[q * 1024 + i] = m;
                 if (acq) mus[(int64_t)q * d + i] = m;
             }

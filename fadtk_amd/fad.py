@@ -262,8 +262,13 @@ class FrechetAudioDistance:
         values = None
         try:                                          # (both routes run on the HIP library; only WHERE the frames live differs)
             values = self._score_inf_points_on_device(mu_base, cov_base, embeds, picks)
-        except (ImportError, RuntimeError) as e:      # no torch to hold the frames in HBM, or not enough of it (torch's OOM is a
-            log.info(f"FAD-inf: device route not available ({type(e).__name__}), scoring point by point")      # RuntimeError): host arrays, one point at a time
+        except ImportError as e:                      # no torch to hold the frames in HBM: host arrays, one point at a time
+            log.info(f"FAD-inf: device route not available ({type(e).__name__}), scoring point by point")
+            values = None
+        except RuntimeError as e:                     # not enough HBM for frames + resamples (torch's OOM is a RuntimeError) -- and
+            if "out of memory" not in str(e).lower() and "hipMalloc" not in str(e):  # nothing else: a failure of the library itself must not be scored twice
+                raise
+            log.warning(f"FAD-inf: device route ran out of memory ({e}), scoring point by point")
             values = None
         if values is None:
             values = self._score_inf_points_sequential(mu_base, cov_base, embeds, picks)

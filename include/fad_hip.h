@@ -83,8 +83,8 @@ int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld
  * other in float32 (float16 frames widened first) and divides by n in float32: for frames with a sizeable offset the float16-rounded
  * result differs from the rounded EXACT mean -- what fad_moments_finalize returns otherwise -- by one ulp in a few dimensions, worth
  * 2e-5 .. 5e-4 of a small Frechet distance.  With the switch on, every update also carries numpy's float32 running column sums (one lane
- * per column walks the rows in order: ~0.3 ms per 100 k rows, on a few CUs, beside the update's other kernels) and
- * fad_moments_finalize returns mu = float32(run / float32(n)) widened to double; the covariance is unchanged.  Covers plain updates
+ * per column walks the rows in order, on a stream of its own beside the update's other kernels: csrc/moments_kernels.h) and
+ * fad_moments_finalize returns mu = float32(float64(run) / n) (numpy's quotient) widened to double; the covariance is unchanged.  Covers plain updates
  * (fad_moments_update / _multi, host or device rows, float16 / bfloat16 / float32) in the order they are fed; statistics that were imported,
  * all-reduced or fed while the switch was off have no row order: finalize then falls back to the exact mean.  The
  * fad_frechet_from_moments* entry points take the same mean for their mean term (then rounded as `mean_dtype` asks) from a handle whose
