@@ -126,6 +126,15 @@ __global__ __launch_bounds__(256) void ns32_finish(const double* __restrict__ st
 }
 
 constexpr int kMaxLow = 14;
+// Pairs on the eight-launch chain (round 5): scaled steps take a k^-1 spectrum (condition 3e5 of the product) to the float32-class floor in
+// 12-13 iterations; below an x_min estimate of kWideL0Min the float64 route is the right one (scripts/ns_emulate_verify.py)
+constexpr int kMaxLowWide = 22;
+constexpr double kWideL0Scale = 0.5, kWideL0Min = 1.5e-4;
+static bool wide_enabled(Pool* p) {
+    if (p && p->lp_wide < 0) { const char* e = getenv("FAD_FRECHET_WIDE"); p->lp_wide = (e && e[0] == '0') ? 0 : 1; }
+    return !p || p->lp_wide != 0;
+}
+static int max_low_of(const Workspace& ws) { return (ws.job.fast && wide_enabled(ws.pool)) ? kMaxLowWide : kMaxLow; }
 
 // When may the check of iteration k declare Y_{k+1} final from the bound b = 3/4 r_k^2 + 1/4 r_k^3 on its residual?
 // The fp64 correction leaves an error of about (||Z||^3/8 + ||Z||/2) b^2 (ns32_finish: est, with ||R|| <~ b), which has
@@ -228,17 +237,18 @@ struct FastBufs {
     uint4* digC[2];
     nsf::SplitMat P, Y[2], Z[2], T;
     uint4 *digY[2], *digYt[2];
-    // pinned host memory behind NsState + MixedResult: what the correction kernel leaves for fast_decide
-    int* host_words; double* host_vals; double* host_stats;
+    nsf::SplitMat Rv, Pv, Ev;                       // verification: kVerScale R, P' = Z R', E' = kVerScale (I - Z Y)
+    // pinned host memory behind NsState + MixedResult: what the correction kernel leaves for fast_decide (and the verification's record)
+    int* host_words; double* host_vals; double* host_stats; double* host_vstats;
 };
 static size_t fast_bytes(int d) {
     const size_t dd = (size_t)d * d;
-    return 256 + 2 * 6 * dd + 6 * 8 * dd + 4 * 6 * dd + 256;
+    return 256 + 2 * 6 * dd + 6 * 8 * dd + 4 * 6 * dd + 3 * 8 * dd + 256;
 }
 static size_t fast_pinned_bytes(int d) {
     const size_t nb = (size_t)d / 32;
     return sizeof(NsState) + sizeof(MixedResult) + 64 + nsf::kHostWords * sizeof(int) + nsf::kHostVals * sizeof(double) +
-           (nsf::kTileStats + 2) * nb * nb * sizeof(double) + 64;
+           (nsf::kTileStats + 2 + nsf::kVerStats) * nb * nb * sizeof(double) + 128;
 }
 static FastBufs fast_bufs(Workspace& ws, int d) {
     const size_t dd = (size_t)d * d;
@@ -252,12 +262,19 @@ static FastBufs fast_bufs(Workspace& ws, int d) {
         m->at = reinterpret_cast<uint4*>(p); p += 4 * dd;
     }
     for (int i = 0; i < 2; ++i) { f.digY[i] = reinterpret_cast<uint4*>(p); p += 6 * dd; f.digYt[i] = reinterpret_cast<uint4*>(p); p += 6 * dd; }
+    nsf::SplitMat* vmats[3] = {&f.Rv, &f.Pv, &f.Ev};
+    for (nsf::SplitMat* m : vmats) {
+        m->a = reinterpret_cast<uint4*>(p); p += 4 * dd;
+        m->at = reinterpret_cast<uint4*>(p); p += 4 * dd;
+    }
     char* h = static_cast<char*>(ws.pinned);
-    f.host_words = nullptr; f.host_vals = nullptr; f.host_stats = nullptr;
+    f.host_words = nullptr; f.host_vals = nullptr; f.host_stats = nullptr; f.host_vstats = nullptr;
     if (h && ws.pinned_cap >= fast_pinned_bytes(d)) {
+        const size_t nb2 = ((size_t)d / 32) * ((size_t)d / 32);
         h += ((sizeof(NsState) + sizeof(MixedResult) + 63) / 64) * 64;
         f.host_vals = reinterpret_cast<double*>(h); h += nsf::kHostVals * sizeof(double);
-        f.host_stats = reinterpret_cast<double*>(h); h += (nsf::kTileStats + 2) * ((size_t)d / 32) * ((size_t)d / 32) * sizeof(double);
+        f.host_stats = reinterpret_cast<double*>(h); h += (nsf::kTileStats + 2) * nb2 * sizeof(double);
+        f.host_vstats = reinterpret_cast<double*>(h); h += nsf::kVerStats * nb2 * sizeof(double);
         f.host_words = reinterpret_cast<int*>(h);
     }
     return f;
@@ -292,9 +309,25 @@ static int fast_prepare(Workspace& ws, int d, int ddof, const double* acc1, cons
 template <int NS> static void fast_launch_split(int mode, unsigned t, unsigned B, const nsf::SplitArgs& g, hipStream_t st) {
     if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_FIRST>), dim3(t, t, B), dim3(512), 0, st, g);
     else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_T>), dim3(t, t, B), dim3(512), 0, st, g);
+    else if (mode == nsf::SP_V2) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_V2>), dim3(t, t, 2 * B), dim3(512), 0, st, g);
+    else if (mode == nsf::SP_V3) hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_V3>), dim3(t, t, B), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((nsf::nsf_split<NS, nsf::SP_U>), dim3(t, t, 3 * B), dim3(512), 0, st, g);
 }
-static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st, unsigned B = 1) {
+// The two verification launches (ns_fast.h: SP_V2 / SP_V3) behind a correction whose R' planes are in place: for every problem of the
+// batch with a final iterate.  Records land in pinned host memory (vstats / vwords, hstride apart).
+static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st, unsigned B);
+static void fast_verify_launch(int d, unsigned B, nsf::SplitArgs g, const nsf::SplitMat (&Y)[2], const nsf::SplitMat (&Z)[2], const nsf::SplitMat& Rv,
+                               const nsf::SplitMat& Pv, const nsf::SplitMat& Ev, const Ns32State* s32, double* vstats, int* vwords, int64_t hstride,
+                               hipStream_t st) {
+    g.sel = &s32->final_iter; g.skip = &s32->skip_corr;
+    g.Zf[0] = Z[0]; g.Zf[1] = Z[1]; g.Yf[0] = Y[0]; g.Yf[1] = Y[1];
+    g.vstats = vstats; g.vwords = vwords; g.hstride = hstride;
+    g.B[0] = Rv; g.C[0] = Pv; g.C[1] = Ev;
+    fast_split(d, nsf::SP_V2, g, st, B);
+    g.B[0] = Pv; g.A[1] = Ev; g.C[0] = nsf::SplitMat{nullptr, nullptr}; g.C[1] = nsf::SplitMat{nullptr, nullptr};
+    fast_split(d, nsf::SP_V3, g, st, B);
+}
+static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st, unsigned B) {
     const unsigned t = (unsigned)(d / 32);
     switch (d) {
         case 128: fast_launch_split<1>(mode, t, B, g, st); break;
@@ -348,6 +381,23 @@ static void fast_i8(int d, int mode, const nsf::I8Args& g, hipStream_t st, unsig
 }
 
 // iterations [ws.job.k, upto) of the chain, then the exact correction, whose partials land in pinned host memory
+static nsf::SplitArgs fast_split_args(Workspace& ws, const MixedBufs& m, const FastBufs& f, int d) {
+    nsf::SplitArgs g;
+    memset(&g, 0, sizeof(g));
+    g.d = d; g.gen = ws.job.gen; g.hA = f.hdr; g.hB = f.hdr + 1; g.st = m.dstate; g.s32 = m.s32;
+    if (wide_enabled(ws.pool)) { g.scaled = 1; g.lp_wide = 1; g.l0_scale = kWideL0Scale; g.l0_min = kWideL0Min; }
+    return g;
+}
+static int fast_verify_enqueue(Workspace& ws) {
+    const int d = ws.job.d;
+    MixedBufs m = mixed_bufs(ws, d);
+    FastBufs f = fast_bufs(ws, d);
+    f.host_words[13] = 0;
+    fast_verify_launch(d, 1, fast_split_args(ws, m, f, d), f.Y, f.Z, f.Rv, f.Pv, f.Ev, m.s32, f.host_vstats, f.host_words, 0, ws.job.stream);
+    FAD_HIP_TRY(hipGetLastError());
+    FAD_HIP_TRY(hipEventRecord(ws.done_ev, ws.job.stream));
+    return FAD_OK;
+}
 static int fast_enqueue(Workspace& ws, int upto) {
     const int d = ws.job.d;
     hipStream_t stream = ws.job.stream;
@@ -355,10 +405,9 @@ static int fast_enqueue(Workspace& ws, int upto) {
     FastBufs f = fast_bufs(ws, d);
     if (!f.host_words) return set_error(FAD_ERR_ALLOC, "pinned result area of the fast Frechet chain is missing");
     const int nslots = (d / 32) * (d / 32);
+    const int max_low = max_low_of(ws);
     for (int& k = ws.job.k; k < upto; ++k) {
-        nsf::SplitArgs g;
-        memset(&g, 0, sizeof(g));
-        g.d = d; g.gen = ws.job.gen; g.hA = f.hdr; g.hB = f.hdr + 1; g.st = m.dstate; g.s32 = m.s32;
+        nsf::SplitArgs g = fast_split_args(ws, m, f, d);
         if (k == 0) {
             // A = C1 C2 (exact) + its statistics + the mean term, then iteration 0: Y1 = Y0 T0, Z1 = T0
             nsf::I8Args a;
@@ -368,24 +417,23 @@ static int fast_enqueue(Workspace& ws, int upto) {
             fast_i8(d, nsf::I8_A, a, stream);
             g.A[0] = f.P; g.B[0] = f.P; g.C[0] = f.Y[1]; g.C[1] = f.Z[1]; g.Cdig[0] = f.digY[1]; g.Cdig_t[0] = f.digYt[1];
             g.A64 = m.A; g.statsA = m.tilestats;
-            fast_split(d, nsf::SP_FIRST, g, stream);
+            fast_split(d, nsf::SP_FIRST, g, stream, 1);
             continue;
         }
         const int cur = k & 1;
-        // T = (3I - Z Y)/2 and the residual partials of iteration k
+        // T = (3I - Z Y)/2 (scaled steps: 1.5 mu I - 0.5 mu^3 Z Y, mu from the device) and the residual partials of iteration k
         g.A[0] = f.Z[cur]; g.B[0] = f.Y[cur]; g.C[0] = f.T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f;
-        g.partials = m.partials; g.skip = &m.s32->done;
-        fast_split(d, nsf::SP_T, g, stream);
+        g.partials = m.partials; g.skip = &m.s32->done; g.k = k;
+        fast_split(d, nsf::SP_T, g, stream, 1);
         // Y <- Y T, Z <- T Z + the check of iteration k as an extra workgroup
-        memset(&g, 0, sizeof(g));
-        g.d = d; g.gen = ws.job.gen; g.hA = f.hdr; g.hB = f.hdr + 1; g.st = m.dstate; g.s32 = m.s32;
+        g = fast_split_args(ws, m, f, d);
         g.A[0] = f.Y[cur]; g.B[0] = f.T; g.C[0] = f.Y[cur ^ 1];
         g.A[1] = f.T; g.B[1] = f.Z[cur]; g.C[1] = f.Z[cur ^ 1];
         g.Cdig[0] = f.digY[cur ^ 1]; g.Cdig_t[0] = f.digYt[cur ^ 1];
         g.skip = &m.s32->upd_skip[k & 1];
-        g.k = k; g.max_low = kMaxLow; g.nslots = nslots; g.chk_partials = m.partials;
+        g.k = k; g.max_low = max_low; g.nslots = nslots; g.chk_partials = m.partials;
         g.thr_pred = pred_threshold(ws.pool, d);
-        fast_split(d, nsf::SP_U, g, stream);
+        fast_split(d, nsf::SP_U, g, stream, 1);
     }
     // exact correction on the final iterate (which of the ping-pong buffers: known on the device only)
     nsf::I8Args a;
@@ -394,10 +442,16 @@ static int fast_enqueue(Workspace& ws, int upto) {
     a.d = d; a.gen = ws.job.gen; a.hA = f.hdr; a.hB = f.hdr + 1; a.skip = &m.s32->skip_corr; a.stats = f.host_stats; a.st = m.dstate; a.A64in = m.A;
     a.Y[0] = f.Y[0]; a.Y[1] = f.Y[1]; a.Z[0] = f.Z[0]; a.Z[1] = f.Z[1];
     a.s32 = m.s32; a.host_words = f.host_words; a.host_vals = f.host_vals;
+    const bool wide = wide_enabled(ws.pool);
+    if (wide) { a.Rv = f.Rv; a.scaled = 1; }
     f.host_words[12] = 0;                          // (the kernel stamps the snapshot with this score's token)
+    f.host_words[13] = 0;                          // (... and the verification its own)
     fast_i8(d, nsf::I8_G, a, stream);
     FAD_HIP_TRY(hipGetLastError());
     if (!ws.done_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&ws.done_ev, hipEventDisableTiming));
+    // a thread whose last score needed the verification products gets them behind the correction at once (the LAUNCH count follows the
+    // history, never the value: a score the norm bound accepts ignores the record)
+    if (wide && ws.pool && ws.pool->lp_verify) return fast_verify_enqueue(ws);
     FAD_HIP_TRY(hipEventRecord(ws.done_ev, stream));
     return FAD_OK;
 }
@@ -406,7 +460,10 @@ static int fast_enqueue(Workspace& ws, int upto) {
 // neglected terms, accept / reject -- what ns32_finish does on the device for the float32 chain, minus a launch.
 // hw / hv / hsx: what nsf_i8<G> left for ONE problem.  -> status 1 accepted, 2 rejected, 4 a predicted final iterate was rejected
 // (the iteration may go on from it), 0 not finished yet.
-static void fast_decide_one(const int* hw, const double* hv, const double* hsx, int nb, MixedResult* out) {
+// hvx (pairs on the wide chain, else nullptr): the verification record of SP_V3, [nb * nb][kVerStats]; valid when hw[13] carries the token.
+// -> additionally status 5: the norm bound rejects the correction and no verification record is there yet -- enqueue the two launches.
+static void fast_decide_one(const int* hw, const double* hv, const double* hsx, int nb, MixedResult* out, const double* hvx = nullptr,
+                            int gen = 0, int max_low = kMaxLow) {
     MixedResult o;
     memset(&o, 0, sizeof(o));
     const bool bad = hw[0] != 0;
@@ -429,22 +486,49 @@ static void fast_decide_one(const int* hw, const double* hv, const double* hsx, 
             if (rs > zinf) zinf = rs;                // >= the largest row sum of |Z| over row block x
             if (cs > zone) zone = cs;                // >= the largest column sum over column block x
         }
-        const int fi = hw[7], fm = fi < 16 ? (fi < 0 ? 0 : fi) : 15;
-        double res = hv[4 + fm];
-        if (hw[8] == fi - 1) { const double rp = hv[4 + (fi - 1 < 16 ? (fi - 1 < 0 ? 0 : fi - 1) : 15)]; res = 0.75 * rp * rp + 0.25 * rp * rp * rp; if (res < 2e-6) res = 2e-6; }
+        const int fi = hw[7];
+        double res = hv[4 + ns32_slot(fi)];
+        if (hw[8] == fi - 1) { const double rp = hv[4 + ns32_slot(fi - 1)]; res = 0.75 * rp * rp + 0.25 * rp * rp * rp; if (res < 2e-6) res = 2e-6; }
         const double zn = std::sqrt(zinf * zone), rn = std::sqrt(r2);
-        const double trs = tr + 0.5 * corr;
-        const double est = zn * zn * zn * rn * rn / 8.0 + zn * res * rn / 2.0;
-        const bool finite = std::isfinite(trs) && std::isfinite(est);
-        o.tr_scaled = trs; o.res = res; o.est = est;
+        double trs = tr + 0.5 * corr;
+        double est = zn * zn * zn * rn * rn / 8.0 + zn * res * rn / 2.0;
+        bool finite = std::isfinite(trs) && std::isfinite(est);
         // accepted when the bound on the neglected terms is below 1e-9 of the trace, or moves the DISTANCE by less than 1e-5 of
         // itself (10x inside the 1e-4 bar AS A BOUND: it overestimates the true error 10..10^5 times, most for spread spectra
         // where the norm bound of Z is 3-4x its 2-norm and enters cubed -- a song of 2 D frames, condition 400: bound 2e-8 of the
         // trace, true error 2e-13, scripts/ns_emulate_split.py)
-        const double fad = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs;
-        const bool accept = finite && (est <= 1e-9 * std::fabs(trs) || 2.0 * std::sqrt(o.c) * est <= 1e-5 * std::fabs(fad));
+        double fad = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs;
+        bool accept = finite && (est <= 1e-9 * std::fabs(trs) || 2.0 * std::sqrt(o.c) * est <= 1e-5 * std::fabs(fad));
+        const bool scaled = hvx && hw[14] != 0;
+        bool need_verify = false;
+        if (!accept && finite && hvx) {
+            // The norm bound says nothing for ill-conditioned products (||Z|| ~ 500 for a k^-1 spectrum, cubed).  The verification products
+            // measure what it bounds (ns_fast.h): with P = Z R and E = I - Z Y,  1/2 tr(E P) completes the first-order term (Z is only an
+            // approximate inverse of Y), and 1/8 |tr(Z P P)| ESTIMATES the second-order one -- it overestimates the commuting part and was
+            // seen 0.7 .. 10x the true error (scripts/ns_emulate_verify.py: k^-0.25 .. k^-1.25, D = 512), hence the factor 4; what remains
+            // is O(||E||^2 ||P||).  Accepted when that moves the distance by less than 1e-5 of itself.
+            if (hw[13] == gen) {
+                const double inv = 1.0 / ((double)nsf::kVerScale * (double)nsf::kVerScale);
+                double qp = 0.0, ep = 0.0, pp = 0.0, ee = 0.0;
+                for (int t = 0; t < nb * nb; ++t) { qp += hvx[nsf::kVerStats * t]; ep += hvx[nsf::kVerStats * t + 1]; pp += hvx[nsf::kVerStats * t + 2]; ee += hvx[nsf::kVerStats * t + 3]; }
+                qp *= inv; ep *= inv; pp *= inv; ee *= inv;
+                const double trs_v = trs + 0.5 * ep;
+                const double est_v = 4.0 * std::fabs(qp) / 8.0 + ee * std::sqrt(pp);
+                const double fad_v = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs_v;
+                const bool fin_v = std::isfinite(trs_v) && std::isfinite(est_v);
+                if (fin_v && (est_v <= 1e-9 * std::fabs(trs_v) || 2.0 * std::sqrt(o.c) * est_v <= 1e-5 * std::fabs(fad_v))) {
+                    accept = true; trs = trs_v; est = est_v; fad = fad_v; o.pad = 1;      // (pad = 1: accepted on the verification record)
+                }
+            } else {
+                need_verify = true;
+            }
+        }
+        o.tr_scaled = trs; o.res = res; o.est = est;
         o.status = accept ? 1 : 2;
-        if (!accept && finite && !strict && hw[8] == fi - 1 && fi + 1 < kMaxLow) o.status = 4;
+        // a PREDICTED final iterate the correction cannot absorb: the iteration goes on from it (plain steps only -- a scaled chain sits on
+        // its float32-class floor by then, more iterations change nothing)
+        if (!accept && finite && !strict && !scaled && hw[8] == fi - 1 && fi + 1 < max_low) o.status = 4;
+        else if (!accept && need_verify) o.status = 5;
     }
     *out = o;
 }
@@ -454,7 +538,8 @@ static int fast_decide(Workspace& ws) {
     MixedBufs m = mixed_bufs(ws, d);
     FastBufs f = fast_bufs(ws, d);
     if (f.host_words[12] != ws.job.gen) return set_error(FAD_ERR_HIP, "the correction kernel of the fast Frechet chain left no result");
-    fast_decide_one(f.host_words, f.host_vals, f.host_stats, nb, m.hres);
+    const bool wide = wide_enabled(ws.pool);
+    fast_decide_one(f.host_words, f.host_vals, f.host_stats, nb, m.hres, wide ? f.host_vstats : nullptr, ws.job.gen, max_low_of(ws));
     if (m.hres->status == 4) {
         // the iterate was taken as final on a PREDICTED residual and the correction cannot absorb it: nothing is lost --
         // (Y_f, Z_f) are intact, the iteration goes on from there and only the float32 floor ends it now
@@ -488,9 +573,14 @@ static SongBlock song_block(int d) {
     b.stride = o;
     return b;
 }
+// per problem in pinned host memory: [kHostVals doubles | (kTileStats + 2) nb^2 doubles | kHostWords ints | kVerStats nb^2 doubles]
+static size_t host_vstats_off(int d) {
+    const size_t nb = (size_t)d / 32;
+    return (nsf::kHostVals + (nsf::kTileStats + 2) * nb * nb) * sizeof(double) + ((nsf::kHostWords * sizeof(int) + 7) & ~(size_t)7);
+}
 static size_t song_host_stride(int d) {
     const size_t nb = (size_t)d / 32;
-    return ((nsf::kHostVals + (nsf::kTileStats + 2) * nb * nb) * sizeof(double) + nsf::kHostWords * sizeof(int) + 63) & ~(size_t)63;
+    return (host_vstats_off(d) + nsf::kVerStats * nb * nb * sizeof(double) + 63) & ~(size_t)63;
 }
 int64_t fast_songs_capacity(int d, size_t budget_bytes) {
     const int64_t n = (int64_t)(budget_bytes / song_block(d).stride);
@@ -675,7 +765,7 @@ int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipSt
 // flight: their chains are enqueued as ONE batch).  Every buffer of pair b lives b * stride bytes behind pair 0's.
 // ==========================================================================================
 struct PairBlock {
-    size_t hdrA, hdrB, st, s32, partials, stats, A64, P, Y[2], Z[2], T, digA, digB, digY[2], digYt[2], mus, covs, stride;
+    size_t hdrA, hdrB, st, s32, partials, stats, A64, P, Y[2], Z[2], T, digA, digB, digY[2], digYt[2], mus, covs, Rv, Pv, Ev, stride;
 };
 static PairBlock pair_block(int d) {
     const size_t dd = (size_t)d * d, nb = (size_t)d / 32;
@@ -688,8 +778,34 @@ static PairBlock pair_block(int d) {
     b.digA = take(6 * dd); b.digB = take(6 * dd);
     b.digY[0] = take(6 * dd); b.digYt[0] = take(6 * dd); b.digY[1] = take(6 * dd); b.digYt[1] = take(6 * dd);
     b.mus = take(2 * (size_t)d * sizeof(double)); b.covs = take(2 * dd * sizeof(double));
+    b.Rv = take(8 * dd); b.Pv = take(8 * dd); b.Ev = take(8 * dd);      // verification planes (ns_fast.h: SP_V2 / SP_V3)
     b.stride = o;
     return b;
+}
+
+// the two verification launches for the B pairs of the slot's batch (32 x 32-tile kernels: a rare, short stage)
+static int pairs_verify_enqueue(Workspace& ws, int d, int B, hipStream_t st) {
+    const size_t dd = (size_t)d * d;
+    const PairBlock L = pair_block(d);
+    const size_t hs = song_host_stride(d);
+    char* blk = static_cast<char*>(ws.fast_pairs.p);
+    char* hpin = static_cast<char*>(ws.fast_pairs_pin);
+    auto at = [&](size_t off) { return blk + off; };
+    auto mat = [&](size_t off) { nsf::SplitMat m; m.a = reinterpret_cast<uint4*>(at(off)); m.at = reinterpret_cast<uint4*>(at(off + 4 * dd)); return m; };
+    nsf::SplitArgs g;
+    memset(&g, 0, sizeof(g));
+    g.d = d; g.gen = ws.multi.gen; g.hA = reinterpret_cast<nsf::MatHdr*>(at(L.hdrA)); g.hB = reinterpret_cast<nsf::MatHdr*>(at(L.hdrB));
+    g.pstride = (int64_t)L.stride; g.astride = (int64_t)L.stride;
+    g.st = reinterpret_cast<NsState*>(at(L.st)); g.s32 = reinterpret_cast<Ns32State*>(at(L.s32));
+    const nsf::SplitMat Y[2] = {mat(L.Y[0]), mat(L.Y[1])}, Z[2] = {mat(L.Z[0]), mat(L.Z[1])};
+    const int nb = d / 32;
+    int* h_words = reinterpret_cast<int*>(hpin + (nsf::kHostVals + (size_t)(nsf::kTileStats + 2) * nb * nb) * sizeof(double));
+    double* h_vstats = reinterpret_cast<double*>(hpin + host_vstats_off(d));
+    for (int b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + (size_t)b * hs)[13] = 0;
+    fast_verify_launch(d, (unsigned)B, g, Y, Z, mat(L.Rv), mat(L.Pv), mat(L.Ev), g.s32, h_vstats, h_words, (int64_t)hs, st);
+    FAD_HIP_TRY(hipGetLastError());
+    FAD_HIP_TRY(hipEventRecord(ws.done_ev, st));
+    return FAD_OK;
 }
 
 // enqueue: K1 (pairs mode) .. K8 for B pairs; nothing is waited for
@@ -702,6 +818,9 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
     const char* big_env = getenv("FAD_PAIRS_BIG");
     const long big_min = big_env ? atol(big_env) : 3;
     const bool big = big_min > 0 && B >= big_min && d >= 256;
+    // (scaled steps: iteration 0 of the 32 x 32-tile family takes them as well; the batch only needs them on ONE family at a time)
+    const bool wide = wide_enabled(ws.pool);
+    const int max_low = wide ? kMaxLowWide : kMaxLow;
     const int device = ws.job.device;
     const PairBlock L = pair_block(d);
     const size_t hs = song_host_stride(d);
@@ -757,6 +876,7 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
         memset(&g, 0, sizeof(g));
         g.d = d; g.gen = gen; g.hA = hA; g.hB = hB; g.pstride = (int64_t)L.stride; g.astride = (int64_t)L.stride;
         g.st = st0; g.s32 = s32_0;
+        if (wide) { g.scaled = 1; g.lp_wide = 1; g.l0_scale = kWideL0Scale; g.l0_min = kWideL0Min; }
         return g;
     };
     {
@@ -773,19 +893,19 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
     }
     int want = ws.pool ? ws.pool->lp_iters : 5;
     if (want < 2) want = 2;                          // (a pair that is not through after the blind batch goes the single way)
-    if (want > kMaxLow) want = kMaxLow;
+    if (want > max_low) want = max_low;
     for (int k = 1; k < want; ++k) {
         const int cur = k & 1;
         nsf::SplitArgs g = split_args();
         g.A[0] = Z[cur]; g.B[0] = Y[cur]; g.C[0] = T; g.alpha = -0.5f; g.beta_eye = 1.5f; g.gamma = 1.0f;
-        g.partials = partials; g.skip = &s32_0->done;
+        g.partials = partials; g.skip = &s32_0->done; g.k = k;
         if (big) FAD_TRY(fast_split_big(d, nsf::SP_T, g, st, (unsigned)B, device));
         else fast_split(d, nsf::SP_T, g, st, (unsigned)B);
         g = split_args();
         g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1];
         if (!big) { g.Cdig[0] = digY[cur ^ 1]; g.Cdig_t[0] = digYt[cur ^ 1]; }
         g.skip = &s32_0->upd_skip[k & 1];
-        g.k = k; g.max_low = kMaxLow; g.nslots = big ? (d / 128) * (d / 128) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
+        g.k = k; g.max_low = max_low; g.nslots = big ? (d / 128) * (d / 128) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
         if (big) FAD_TRY(fast_split_big(d, nsf::SP_U, g, st, (unsigned)B, device));
         else fast_split(d, nsf::SP_U, g, st, (unsigned)B);
     }
@@ -803,12 +923,15 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
         a.d = d; a.gen = gen; a.hA = hA; a.hB = hB; a.pstride = (int64_t)L.stride; a.astride = (int64_t)L.stride; a.hstride = (int64_t)hs;
         a.skip = &s32_0->skip_corr; a.stats = h_stats; a.st = st0; a.A64in = A64;
         a.Y[0] = Y[0]; a.Y[1] = Y[1]; a.Z[0] = Z[0]; a.Z[1] = Z[1]; a.s32 = s32_0; a.host_words = h_words; a.host_vals = h_vals;
-        for (int b = 0; b < B; ++b) reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + (size_t)b * hs)[12] = 0;
+        if (wide) { a.Rv = mat(L.Rv); a.scaled = 1; }
+        for (int b = 0; b < B; ++b) { int* w = reinterpret_cast<int*>(reinterpret_cast<char*>(h_words) + (size_t)b * hs); w[12] = 0; w[13] = 0; }
         if (big) FAD_TRY(fast_i8_big(d, nsf::I8_G, a, st, (unsigned)B, device));
         else fast_i8(d, nsf::I8_G, a, st, (unsigned)B);
     }
     FAD_HIP_TRY(hipGetLastError());
     if (!ws.done_ev) FAD_HIP_TRY(hipEventCreateWithFlags(&ws.done_ev, hipEventDisableTiming));
+    // (a thread whose last scores needed the verification products gets them behind the correction at once: fast_enqueue)
+    if (wide && ws.pool && ws.pool->lp_verify) return pairs_verify_enqueue(ws, d, B, st);
     FAD_HIP_TRY(hipEventRecord(ws.done_ev, st));
     return FAD_OK;
 }
@@ -834,7 +957,7 @@ static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Work
         ws.job.mu1 = pb.mu1; ws.job.mu2 = pb.mu2; ws.job.mean_dtype = pb.mean_dtype;
         int want = ws.pool ? ws.pool->lp_iters : 5;
         if (want < 2) want = 2;
-        if (want > kMaxLow) want = kMaxLow;
+        if (want > max_low_of(ws)) want = max_low_of(ws);
         if (ws.pool && ws.pool->lp_hopeless) want = 1;       // (a pair that does iterate is topped up by mixed_finish)
         return fast_enqueue(ws, want);
     }
@@ -855,23 +978,36 @@ static int mixed_begin(const NsProblem& pb, int device, hipStream_t stream, Work
 // -> FAD_OK with res->status 1 (accepted: res holds the pieces) or 2 (run the fp64 iteration).
 static int mixed_finish(Workspace& ws, MixedResult* res) {
     MixedBufs m = mixed_bufs(ws, ws.job.d);
+    const int max_low = max_low_of(ws);
+    bool asked = false;
     for (;;) {
         FAD_HIP_TRY(hipEventSynchronize(ws.done_ev));
         if (ws.job.fast) FAD_TRY(fast_decide(ws));
+        if (m.hres->status == 5) {                 // the correction needs the verification products: two launches, one more wait
+            if (asked) { m.hres->status = 2; break; }                    // (no record came back: the float64 route)
+            asked = true;
+            FAD_TRY(fast_verify_enqueue(ws));
+            continue;
+        }
         if (m.hres->status == 4) {                 // predicted final iterate rejected: go on from it (state re-armed on the device)
             ws.job.k = m.hres->iters;
             m.hres->status = 0;
-        } else if (m.hres->status != 0 || ws.job.k >= kMaxLow) {
+        } else if (m.hres->status != 0 || ws.job.k >= max_low) {
             break;
         }
-        if (ws.job.k >= kMaxLow) break;
-        const int upto = (ws.job.k + 2 < kMaxLow) ? ws.job.k + 2 : kMaxLow;
+        if (ws.job.k >= max_low) break;
+        // (the wide chain tops up four iterations at a time: a decaying spectrum needs 10-13, and every trip to the host costs 20-30 us)
+        const int step = (ws.job.fast && max_low > kMaxLow) ? 4 : 2;
+        const int upto = (ws.job.k + step < max_low) ? ws.job.k + step : max_low;
         FAD_TRY(ws.job.fast ? fast_enqueue(ws, upto) : mixed_enqueue(ws, upto));
     }
     *res = *m.hres;
     if (res->status == 0) res->status = 2;
     if (res->status == 1 && res->decided_at >= 0 && ws.pool) ws.pool->lp_iters = res->decided_at + 1;
-    if (ws.pool && ws.job.fast) ws.pool->lp_hopeless = res->status == 2 && res->iters < 0;      // given up before the first check
+    if (ws.pool && ws.job.fast) {
+        ws.pool->lp_hopeless = res->status == 2 && res->iters < 0;      // given up before the first check
+        ws.pool->lp_verify = res->status == 1 && res->pad == 1;         // accepted on the verification record: the next score gets it unasked
+    }
     return FAD_OK;
 }
 
@@ -1122,32 +1258,49 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
         const size_t hs = song_host_stride(d);
         const char* hpin = static_cast<const char*>(ws.fast_pairs_pin);
         const size_t off_stats = nsf::kHostVals * sizeof(double), off_words = off_stats + (size_t)(nsf::kTileStats + 2) * nb * nb * sizeof(double);
+        const size_t off_vstats = host_vstats_off(d);
+        const bool wide = wide_enabled(ws.pool);
         int learnt = -1;
-        for (int b = 0; b < count; ++b) {
-            const double* hv = reinterpret_cast<const double*>(hpin + (size_t)b * hs);
-            const double* hx = reinterpret_cast<const double*>(hpin + (size_t)b * hs + off_stats);
-            const int* hw = reinterpret_cast<const int*>(hpin + (size_t)b * hs + off_words);
-            if (hw[12] != m.gen) continue;              // (no record: the single route decides)
-            MixedResult r;
-            fast_decide_one(hw, hv, hx, nb, &r);
-            if (r.too_few0 || r.too_few1) {
-                if (rc == FAD_OK) rc = set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
-                out_fad[b] = NAN; done[b] = true;
-                continue;
+        bool any_verified = false;
+        for (int round = 0; round < 2; ++round) {
+            bool ask = false;
+            for (int b = 0; b < count; ++b) {
+                if (done[b]) continue;
+                const double* hv = reinterpret_cast<const double*>(hpin + (size_t)b * hs);
+                const double* hx = reinterpret_cast<const double*>(hpin + (size_t)b * hs + off_stats);
+                const int* hw = reinterpret_cast<const int*>(hpin + (size_t)b * hs + off_words);
+                const double* hvx = reinterpret_cast<const double*>(hpin + (size_t)b * hs + off_vstats);
+                if (hw[12] != m.gen) continue;              // (no record: the single route decides)
+                MixedResult r;
+                fast_decide_one(hw, hv, hx, nb, &r, wide ? hvx : nullptr, m.gen, wide ? kMaxLowWide : kMaxLow);
+                if (r.too_few0 || r.too_few1) {
+                    if (rc == FAD_OK) rc = set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
+                    out_fad[b] = NAN; done[b] = true;
+                    continue;
+                }
+                if (r.status == 5 && round == 0) { ask = true; continue; }       // its correction needs the verification products
+                if (r.status != 1) continue;
+                const double tr_sqrt = sqrt(r.c) * r.tr_scaled;
+                out_fad[b] = r.mean_term + r.tr1 + r.tr2 - 2.0 * tr_sqrt;
+                if (diag) {
+                    fad_diag_t& q = diag[b];
+                    memset(&q, 0, sizeof(q));
+                    q.iters = r.iters + 1; q.converged = 3; q.used_eps = 0; q.route = 2;
+                    q.residual = r.res; q.scale = r.c; q.mean_term = r.mean_term; q.tr1 = r.tr1; q.tr2 = r.tr2; q.tr_sqrt = tr_sqrt;
+                }
+                if (r.decided_at + 1 > learnt) learnt = r.decided_at + 1;
+                if (r.pad == 1) any_verified = true;
+                done[b] = true;
             }
-            if (r.status != 1) continue;
-            const double tr_sqrt = sqrt(r.c) * r.tr_scaled;
-            out_fad[b] = r.mean_term + r.tr1 + r.tr2 - 2.0 * tr_sqrt;
-            if (diag) {
-                fad_diag_t& q = diag[b];
-                memset(&q, 0, sizeof(q));
-                q.iters = r.iters + 1; q.converged = 3; q.used_eps = 0; q.route = 2;
-                q.residual = r.res; q.scale = r.c; q.mean_term = r.mean_term; q.tr1 = r.tr1; q.tr2 = r.tr2; q.tr_sqrt = tr_sqrt;
-            }
-            if (r.decided_at + 1 > learnt) learnt = r.decided_at + 1;
-            done[b] = true;
+            if (!ask) break;
+            // two more launches for the whole batch (pairs without a final iterate skip), one more wait
+            const int rv = pairs_verify_enqueue(ws, d, count, j.stream);
+            if (rv != FAD_OK) { if (rc == FAD_OK) rc = rv; break; }
+            const hipError_t e2 = hipEventSynchronize(ws.done_ev);
+            if (e2 != hipSuccess) { ws.busy = false; return set_error(FAD_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e2)); }
         }
         if (learnt > 0 && ws.pool) ws.pool->lp_iters = learnt;
+        if (ws.pool && wide) ws.pool->lp_verify = any_verified;
     }
     ws.busy = false;                               // the slot is free again: the single route below takes any free one
     ws.multi = Workspace::Multi();

@@ -80,6 +80,9 @@ struct Pool {
     int lp_iters = 5;                               // iterations the low-precision leg needed last time on this thread
     bool lp_hopeless = false;                       // ... or gave up on at once (a decaying spectrum): the next score enqueues iteration 0
                                                     // and the closing kernel only -- the LAUNCH count follows the history, never the value
+    bool lp_verify = false;                         // ... or whose correction needed the verification products (ns_fast.h: SP_V2 / SP_V3): the next
+                                                    // score enqueues them behind the correction at once instead of after a trip to the host
+    int lp_wide = -1;                               // FAD_FRECHET_WIDE (read once): 0 = the chain only serves flat spectra, as in round 4
     int f64_iters = 0;                              // ... and the float64 iteration (single pair), 0 = not known yet
     int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
     int fast = -1;                                  // FAD_FRECHET_FAST (read once): 0 = round 2's twelve-launch float32 chain

@@ -19,8 +19,10 @@ struct Ns32State {
     int decided_at;      // iteration whose check closed the problem (the host sizes the next call's batch by it)
     int strict;          // 1: predict the final iterate only from the fp32 floor (set for a retry, see ns32_finish)
     int grew;            // scaled steps: the previous check saw the residual grow (one bump after an over-scaled step is not a failure)
-    double res[16];
+    double res[16];      // residual of iteration k at slot k & 15 (ns32_slot): the chains of more than 16 iterations (scaled steps on
+                         // decaying spectra) keep the last sixteen
 };
+__host__ __device__ __forceinline__ int ns32_slot(int k) { return k < 0 ? 0 : (k & 15); }
 
 struct Gemm32Args {
     const float* A[2]; const float* B[2]; float* C[2];

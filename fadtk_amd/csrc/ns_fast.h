@@ -375,7 +375,20 @@ struct I8Args {
     const Ns32State* s32;
     int* host_words;                             // pinned host: snapshot of the state words the host decides from (kHostWords ints)
     double* host_vals;                           // ... and doubles (kHostVals)
+    SplitMat Rv;                                 // I8_G, or {nullptr}: split planes of kVerScale R (both orientations) for the verification products
+    int scaled;                                  // I8_G: the chain ran with SplitArgs::scaled (host word 14 then tells whether THIS problem took scaled steps)
 };
+// The verification of a correction the norm bound cannot vouch for (frechet.hip: fast_decide_one; ill-conditioned products, where
+// ||Z||^3 ||R||^2 overestimates the neglected terms 10^5..10^8 times): with P = Z R and E = I - Z Y,
+//     tr sqrt(A/c) = tr Y + 1/2 tr(Z R) + 1/2 tr(E P) - [second order]  + O(||E||^2 ||P||),   [second order] ~ 1/8 tr(Z P P)
+// (Y^-1 = (I - E)^-1 Z; the second-order term of the root at Y^2 in the direction R is sum_ij R_ij R_ji / (2 y_i y_j (y_i + y_j)) in Y's
+// eigenbasis, which 1/8 tr(Z P P) = sum_ij R_ij R_ji (y_i + y_j) / (8 y_i^2 y_j^2) overestimates by (y_i + y_j)^2 / (4 y_i y_j) >= 1
+// for the symmetrisable products at hand).  Two launches on the split-float16 kernels: SP_V2 forms P' = Z R' (R' = kVerScale R, so
+// that float16 holds it) and E' = kVerScale (I - Z Y) side by side, SP_V3 forms Q' = Z P' and leaves per tile
+//     sum Q'_ij P'_ji | sum E'_ij P'_ji | sum P'_ij^2 | sum E'_ij^2        (kVerStats doubles, pinned host memory)
+// -- estimates and a small correction: float32-class products are ample.  scripts/ns_emulate_verify.py emulates the whole rule.
+constexpr float kVerScale = 4096.f;
+constexpr int kVerStats = 4;
 
 template <int NS8, int MODE>
 __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
@@ -385,6 +398,7 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
     // tree through two slots.)
     __shared__ __attribute__((aligned(16))) double part[2 * 32 * 33];
     __shared__ float fin[32 * 33];
+    __shared__ float finR[(MODE == I8_G) ? 32 * 33 : 1];      // I8_G: kVerScale R of the tile, for the verification products (g.Rv)
     __shared__ double red[8 * 4];
     constexpr int kUmin = (MODE == I8_A) ? kUminA : kUminG;
     constexpr int kGroups = 2 * (kDigits - 1) - kUmin + 1;
@@ -406,6 +420,7 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
             hv[0] = st->c; hv[1] = st->tr1; hv[2] = st->tr2; hv[3] = st->mean_term;
 #pragma unroll
             for (int q = 0; q < 16; ++q) hv[4 + q] = s->res[q];
+            hw[14] = (g.scaled && st->mu[0] != 1.0) ? 1 : 0;
             hw[12] = g.gen;                                          // the snapshot belongs to this score
         }
     }
@@ -541,7 +556,9 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
             v3[2] = (double)used16(reinterpret_cast<const _Float16*>(Ym.a + yi)[hy], reinterpret_cast<const _Float16*>(Ym.a + yi + 64)[hy]);
         }
         fin[rr * 33 + 2 * cp] = fabsf((float)z0); fin[rr * 33 + 2 * cp + 1] = fabsf((float)z1);      // |Z[col0 + c][row0 + r]| at (r, c)
+        finR[rr * 33 + 2 * cp] = (float)(R0 * (double)kVerScale); finR[rr * 33 + 2 * cp + 1] = (float)(R1 * (double)kVerScale);
         __syncthreads();
+        if (g.Rv.a && tid < 256) store_tile_planes(finR, adv(g.Rv, po), ty, tx, d, tid);
         if (tid < 32) { for (int q = 0; q < 32; ++q) m += fin[q * 33 + tid]; }                         // fixed c: part of ROW col0 + c of Z
         else if (tid < 64) { for (int c = 0; c < 32; ++c) m += fin[(tid - 32) * 33 + c]; }             // fixed r: part of COLUMN row0 + r of Z
     }
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(512) void nsf_i8(I8Args g) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // K3 .. K7: products on split-float16 operands.  Workgroup tile 32 x 32, 512 threads; wave w owns the k-steps [w NS, (w + 1) NS)
 // of 16 k each (d = 128 NS).
-enum { SP_FIRST = 0, SP_T = 1, SP_U = 2 };
+enum { SP_FIRST = 0, SP_T = 1, SP_U = 2, SP_V2 = 3, SP_V3 = 4 };
 struct SplitArgs {
     int d, gen;
     const MatHdr* hA; const MatHdr* hB;  // headers of the two covariances (hA: the shared baseline in a batch of songs)
@@ -586,6 +603,14 @@ struct SplitArgs {
     int scaled;                          // ns_fast_big.h: scaled steps -- T_k = 1.5 mu I - 0.5 mu^3 Z Y with mu = st->mu[k] per problem (ns_check.h)
     double thr_pred;
     const double* chk_partials;
+    // pairs (frechet.hip: fast_enqueue / pairs_enqueue): lp_wide = 1 lets the chain take decaying spectra on scaled steps -- the
+    // participation-ratio rule only applies without it -- as long as the x_min estimate stays above l0_min (below, float16 cannot hold Z
+    // and the float32-class products cannot resolve the small eigenvalues: the float64 route)
+    int lp_wide; double l0_min;
+    // SP_V2 / SP_V3: the final iterate's planes are (Zf, Yf)[*sel & 1]; B[0] = R' (V2) / P' (V3); C[0] = P', C[1] = E' (V2); E' read back as
+    // A[1] (V3); vstats: [tiles][kVerStats] per problem (pinned host, hstride apart); vwords: the problem's host words (slot 13 = gen)
+    const int* sel; SplitMat Zf[2], Yf[2];
+    double* vstats; int* vwords; int64_t hstride;
 };
 
 // Decision of iteration k from r_k = ||I - Z_k Y_k||_F = 2 ||T_k - I||_F (one workgroup; the rules are those of round 2's
@@ -606,7 +631,7 @@ template <int NT = 512> __device__ __forceinline__ void nsf_check(const SplitArg
     // (scaled step: the partials hold (T - (1.5 mu - 0.5 mu^3) I)^2 = (0.5 mu^3)^2 (I - Z Y)^2)
     const double mu_k = g.scaled ? st64->mu[k] : 1.0;
     const double res = 2.0 * sqrt(s[0]) / (mu_k * mu_k * mu_k);
-    if (k < 16) st->res[k] = res;
+    st->res[ns32_slot(k)] = res;
     if (g.scaled && k + 1 < kMaxIter) {
         // scale of iteration k + 1: every x of iterate k lies above the schedule's bound -- and, once the residual is below 1, above
         // sqrt(1 - res) (|1 - x^2| <= ||I - Z Y||) -- so a bound that was too careful stops over-scaling as soon as the iterate shows it
@@ -618,7 +643,7 @@ template <int NT = 512> __device__ __forceinline__ void nsf_check(const SplitArg
         st64->mu[k + 1] = mn < cap ? mn : cap;
         st64->l_cur = l;
     }
-    const double prev = (k > 0 && k <= 16) ? st->res[k - 1] : 1e300;
+    const double prev = (k > 0) ? st->res[ns32_slot(k - 1)] : 1e300;
     const bool finite = (res == res) && !isinf(res);
     // (round 3 ended "k >= 8 and still above 1" here: a song of 2 D frames -- condition number of a few hundred, residual ~1 at
     //  iteration 8, at the float32 floor by 11 -- never got through; only a residual that GROWS above the floor is hopeless)
@@ -648,7 +673,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     __shared__ float fin2[32 * 33];
     __shared__ double red[8 * 4];
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
-    constexpr int ZPER = (MODE == SP_U) ? 3 : 1;         // z-slices per problem
+    constexpr int ZPER = (MODE == SP_U) ? 3 : ((MODE == SP_V2) ? 2 : 1);         // z-slices per problem
     const int64_t po = (int64_t)(blockIdx.z / ZPER) * g.pstride;
     const int zs = (int)(blockIdx.z % ZPER);
     if constexpr (MODE == SP_U) {
@@ -660,18 +685,26 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     const MatHdr* hB = adv(g.hB, po);
     const MatHdr* hA = adv(g.hA, (int64_t)(blockIdx.z / ZPER) * g.astride);
     if (hdr_bad(hA, hB, g.gen)) return;
-    const int zi = (MODE == SP_U) ? zs : 0;
+    const int zi = (MODE == SP_U || MODE == SP_V2) ? zs : 0;
     int ty, tx; tile_of_block(ty, tx);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 5, r = lane & 31;
     const int row0 = ty * 32, col0 = tx * 32;
+    constexpr bool VER = (MODE == SP_V2 || MODE == SP_V3);
+    if constexpr (VER) {
+        if (g.skip && *adv(g.skip, po) != 0) return;                 // (no final iterate: nothing to verify)
+        if (MODE == SP_V3 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+            adv(g.vwords, (int64_t)blockIdx.z * g.hstride)[13] = g.gen;         // the verification record belongs to this score
+    }
+    const int par = VER ? (*adv(g.sel, po) & 1) : 0;                 // which of the ping-pong iterates is final
 
     // every load of the product is issued before anything else: the operands were written by the previous kernel from all
     // eight XCDs, the first touch of a panel is an L2 miss, and one exposed latency is all this kernel should pay
     f16x8 ah[NS], al[NS], bh[NS], bl[NS];
     {
-        const SplitMat Am = adv(g.A[zi], po);
-        const SplitMat Bm = adv(g.B[zi], po);
+        // V2: P' = Z R' (slice 0), Z Y (slice 1); V3: Q' = Z P'
+        const SplitMat Am = adv(VER ? g.Zf[par] : g.A[zi], po);
+        const SplitMat Bm = adv((MODE == SP_V2 && zs == 1) ? g.Yf[par] : g.B[VER ? 0 : zi], po);
         const f16x8* pa = reinterpret_cast<const f16x8*>(Am.a + fa_idx(ty, wave * NS, 0, lane, d));
         const f16x8* pb = reinterpret_cast<const f16x8*>(Bm.at + fa_idx(tx, wave * NS, 0, lane, d));
 #pragma unroll
@@ -679,6 +712,7 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
     }
     const int rr = tid >> 4, cp = tid & 15;
     double inv_c = 0.0, inv_cn = 0.0;
+    float m1 = 1.5f, m3 = 0.5f;                                      // SP_FIRST: 1.5 mu_0, 0.5 mu_0^3
     double2 a2 = make_double2(0.0, 0.0);
     if constexpr (MODE == SP_FIRST) {
         a2 = *reinterpret_cast<const double2*>(adv(g.A64, po) + (int64_t)(row0 + rr) * d + col0 + 2 * cp);    // this thread's elements of A
@@ -716,9 +750,24 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         const double mean_term = st_p->mean_term, tr1 = hA->tr, tr2 = hB->tr;
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
-        // the float32-class iteration only serves spectra that are flat within a few hundred: participation ratio (tr A)^2 / ||A||_F^2 >= d/4
-        // ... and whose bulk is not far below the largest covariance entries: A lives on a fixed-point grid of 2^-41 relative to those
-        const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
+        // Which products the float32-class iteration serves.  Its bulk must not lie far below the largest covariance entries (A lives
+        // on a fixed-point grid of 2^-41 relative to those).  Without scaled steps (g.lp_wide = 0): spectra flat within a few hundred
+        // only -- participation ratio (tr A)^2 / ||A||_F^2 >= d/4.  With them: whatever the x_min estimate puts above g.l0_min
+        // (ns_fast_big.h: nsf_big<SP_FIRST> is the batch's form of this block).
+        const bool flat = trA * trA >= 0.25 * (double)d * fro2;
+        const bool scaled = g.scaled && !bad && !zero && u > 0.0 && trA * trA < 0.8 * (double)d * fro2;
+        double l0 = 1.0;
+        if (scaled) { l0 = ns_l0_from_participation((float)(trA * trA / fro2), d) * g.l0_scale; if (l0 > 0.5) l0 = 0.5; }
+        const bool hopeless = !bad && !zero && (c < 0.0078125 || (g.lp_wide ? (scaled && l0 < g.l0_min) || (!scaled && !flat) : !flat));
+        double mu0 = 1.0;
+        if (scaled && !hopeless) {
+            c = u;                                               // every x = sqrt(lambda / c) in (0, 1]: the steps lift the lower end
+            double l = l0;
+            mu0 = ns_step_scale(l);
+            if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { double ln = l; st_p->mu[0] = mu0; st_p->mu[1] = ns_step_scale(ln); st_p->l_cur = l; }
+        } else if (g.scaled && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+            st_p->mu[0] = 1.0; st_p->mu[1] = 1.0; st_p->l_cur = 1.0;
+        }
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
             NsState* st = st_p; Ns32State* s32 = adv(g.s32, po);
             st->c = zero ? 1.0 : c * hdr_inv_s12(hA, hB);     // in the caller's units: A / st->c = (s1 s2 A) / c
@@ -734,7 +783,8 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         if (bad || zero || hopeless) return;
         inv_cn = 1.0 / c;                                // for the normalised product P P
         inv_c = inv_cn / hdr_inv_s12(hA, hB);          // for A in the caller's units: 1 / st->c
-    } else {
+        m1 = (float)(1.5 * mu0); m3 = (float)(0.5 * mu0 * mu0 * mu0);
+    } else if constexpr (!VER) {
         if (g.skip && *adv(g.skip, po) != 0) return;
     }
     f32x16 acc0, acc1;
@@ -756,24 +806,49 @@ __global__ __launch_bounds__(512) void nsf_split(SplitArgs g) {
         for (int reg = 0; reg < 16; ++reg) part[wave * (32 * 33) + ((reg & 3) + 8 * (reg >> 2) + 4 * kg) * 33 + r] += acc0[reg] + acc1[reg] * kLoInv;
     }
     __syncthreads();
-    const float alpha = (MODE == SP_T) ? g.alpha : 1.f, beta = (MODE == SP_T) ? g.beta_eye : 0.f;
+    float alpha = (MODE == SP_T) ? g.alpha : 1.f, beta = (MODE == SP_T) ? g.beta_eye : 0.f, gamma = g.gamma;
+    if (MODE == SP_T && g.scaled) {                                  // this problem's step scale (set by FIRST / the previous check)
+        const double m = adv(g.st, po)->mu[g.k];
+        alpha = (float)(-0.5 * m * m * m); beta = (float)(1.5 * m); gamma = beta + alpha;
+    }
     double ss = 0.0;
+    double v4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int o = rr * 33 + 2 * cp + q;
         const float sum = (part[o] + part[(32 * 33) + o]) + (part[2 * (32 * 33) + o] + part[3 * (32 * 33) + o]);
         const bool dg = (row0 + rr) == (col0 + 2 * cp + q);
         if constexpr (MODE == SP_FIRST) {
-            // Y0 = A/c; the product is P P = (c Y0)^2 in normalised units: Y1 = Y0 T0 = 1.5 Y0 - 0.5 Y0^2, Z1 = T0 = 1.5 I - 0.5 Y0
+            // Y0 = A/c; the product is P P = (c Y0)^2 in normalised units: Y1 = mu0 Y0 T0 = 1.5 mu0 Y0 - 0.5 mu0^3 Y0^2, Z1 = T0 = 1.5 mu0 I - 0.5 mu0^3 Y0
             const float y0 = (float)((q ? a2.y : a2.x) * inv_c);
             const float y2 = (float)((double)sum * (inv_cn * inv_cn));
-            fin[o] = 1.5f * y0 - 0.5f * y2;
-            fin2[o] = (dg ? 1.5f : 0.f) - 0.5f * y0;
+            fin[o] = m1 * y0 - m3 * y2;
+            fin2[o] = (dg ? m1 : 0.f) - m3 * y0;
+        } else if constexpr (MODE == SP_V2) {
+            fin[o] = zs ? ((dg ? 1.f : 0.f) - sum) * kVerScale : sum;        // E' = kVerScale (I - Z Y)  |  P' = Z R'
+        } else if constexpr (MODE == SP_V3) {
+            // Q'_ij (this thread's) pairs with P'_ji -- the mirror element, read from the ^T planes at (i, j) -- and so does E'_ij
+            const int gr = row0 + rr, gc = col0 + 2 * cp;             // (gc even: both elements of the pair sit in one piece)
+            int half;
+            const size_t pi = fa_elem(gr, gc, 0, d, half);
+            const SplitMat Pm = adv(g.B[0], po), Em = adv(g.A[1], po);
+            const float pt = used16(reinterpret_cast<const _Float16*>(Pm.at + pi)[half + q], reinterpret_cast<const _Float16*>(Pm.at + pi + 64)[half + q]);
+            const float pij = used16(reinterpret_cast<const _Float16*>(Pm.a + pi)[half + q], reinterpret_cast<const _Float16*>(Pm.a + pi + 64)[half + q]);
+            const float eij = used16(reinterpret_cast<const _Float16*>(Em.a + pi)[half + q], reinterpret_cast<const _Float16*>(Em.a + pi + 64)[half + q]);
+            v4[0] += (double)sum * (double)pt; v4[1] += (double)eij * (double)pt; v4[2] += (double)pij * (double)pij; v4[3] += (double)eij * (double)eij;
         } else {
             const float v = alpha * sum + (dg ? beta : 0.f);
             fin[o] = v;
-            if constexpr (MODE == SP_T) { const double e = (double)v - (dg ? (double)g.gamma : 0.0); ss += e * e; }
+            if constexpr (MODE == SP_T) { const double e = (double)v - (dg ? (double)gamma : 0.0); ss += e * e; }
         }
+    }
+    if constexpr (MODE == SP_V3) {
+        wg8_sum<4>(v4, red);
+        if (tid == 0) {
+            double* o = adv(g.vstats, (int64_t)blockIdx.z * g.hstride) + (size_t)kVerStats * (ty * gridDim.x + tx);
+            o[0] = v4[0]; o[1] = v4[1]; o[2] = v4[2]; o[3] = v4[3];
+        }
+        return;
     }
     __syncthreads();
     const bool with_digits = ((MODE == SP_FIRST) || (MODE == SP_U && zi == 0)) && g.Cdig[0] != nullptr;     // (batches digitise the final Y only)

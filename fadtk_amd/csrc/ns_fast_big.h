@@ -94,16 +94,21 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
         const double mean_term = st_p->mean_term, tr1 = hA->tr, tr2 = hB->tr;
         const bool bad = !(fro2 == fro2) || isinf(fro2) || !(trA == trA) || isinf(trA) || !(mean_term == mean_term) || isinf(mean_term);
         const bool zero = !bad && !(c > 0.0);
-        const bool hopeless = !bad && !zero && (trA * trA < 0.25 * (double)d * fro2 || c < 0.0078125);
         // Scaled steps (g.scaled): a spectrum that is not flat -- participation ratio below 0.8 d: songs of a few D frames, a baseline
         // whose variances differ by dimension -- starts from c = u >= rho(A) (every x = sqrt(lambda / c) in (0, 1]) and lifts the lower
         // end by mu_k per step (ns_check.h); flat spectra keep the start near 1 above, which needs no lifting.
-        const bool scaled = g.scaled && !bad && !zero && !hopeless && u > 0.0 && trA * trA < 0.8 * (double)d * fro2;
+        // Which products the chain serves at all: as nsf_split<SP_FIRST> (ns_fast.h) -- songs (g.lp_wide = 0) keep the participation-ratio
+        // rule, pairs (g.lp_wide = 1) go by the x_min estimate.
+        const bool flat = trA * trA >= 0.25 * (double)d * fro2;
+        const bool want_scaled = g.scaled && !bad && !zero && u > 0.0 && trA * trA < 0.8 * (double)d * fro2;
+        double l0 = 1.0;
+        if (want_scaled) { l0 = ns_l0_from_participation((float)(trA * trA / fro2), d) * g.l0_scale; if (l0 > 0.5) l0 = 0.5; }      // (||A||_F^2 >= tr A^2: the estimate errs low)
+        const bool hopeless = !bad && !zero && (c < 0.0078125 || (g.lp_wide ? (want_scaled && l0 < g.l0_min) || (!want_scaled && !flat) : !flat));
+        const bool scaled = want_scaled && !hopeless;
         double mu0 = 1.0;
         if (scaled) {
             c = u;
-            double l = ns_l0_from_participation((float)(trA * trA / fro2), d) * g.l0_scale;      // (||A||_F^2 >= tr A^2: the estimate errs low)
-            if (l > 0.5) l = 0.5;
+            double l = l0;
             mu0 = ns_step_scale(l);
             if (tile == 0 && tid == 0) { double ln = l; st_p->mu[0] = mu0; st_p->mu[1] = ns_step_scale(ln); st_p->l_cur = l; }
         } else if (g.scaled && tile == 0 && tid == 0) {
@@ -319,6 +324,7 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
             hv[0] = st->c; hv[1] = st->tr1; hv[2] = st->tr2; hv[3] = st->mean_term;
 #pragma unroll
             for (int q = 0; q < 16; ++q) hv[4 + q] = s->res[q];
+            hw[14] = (g.scaled && st->mu[0] != 1.0) ? 1 : 0;
             hw[12] = g.gen;
         }
     }
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
         for (int reg = 0; reg < 16; ++reg) {
             const int q = (reg & 3) + 8 * (reg >> 2), gr = row0 + q + 4 * kg, gc = col0 + n;
             const double R = A64[(int64_t)q * d] * inv_c - gp[reg];
+            gp[reg] = R;                                           // (kept for the verification planes below)
             int half;
             const size_t zi = fa_elem(gr, gc, 0, d, half);         // Z^T[gr][gc] = Z[gc][gr] pairs with R[gr][gc] in tr(Z R)
             const double z = (double)used16(reinterpret_cast<const _Float16*>(Zm.at + zi)[half], reinterpret_cast<const _Float16*>(Zm.at + zi + 64)[half]);
@@ -453,6 +460,17 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
             scal[0] = v3[0]; scal[1] = v3[1]; scal[2] = v3[2]; scal[3] = 0.0;
             double* zmax = stats + (size_t)kTileStats * nb * nb + 2 * (size_t)(by * nb + bx);
             zmax[0] = mrow; zmax[1] = mcol;
+        }
+    }
+    if constexpr (MODE == I8_G) {
+        if (g.Rv.a) {                                              // kVerScale R of this wave's block, both orientations (ns_fast.h: SP_V2 reads them)
+            __builtin_amdgcn_wave_barrier();                       // (the |Z| sums above have read the area)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) fin[((reg & 3) + 8 * (reg >> 2) + 4 * kg) * 33 + n] = (float)(gp[reg] * (double)kVerScale);
+            __builtin_amdgcn_wave_barrier();
+            const SplitMat Rm = adv(g.Rv, po);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) store_tile_planes(fin, Rm, by, bx, d, pass * 64 + lane);
         }
     }
     (void)red;

@@ -131,6 +131,8 @@ static double scale_from_stats(const std::vector<double>& rec, int d) {
 template <int NS> static void launch_split(int mode, unsigned t, const SplitArgs& g) {
     if (mode == SP_FIRST) hipLaunchKernelGGL((nsf_split<NS, SP_FIRST>), dim3(t, t, 1), dim3(512), 0, 0, g);
     else if (mode == SP_T) hipLaunchKernelGGL((nsf_split<NS, SP_T>), dim3(t, t, 1), dim3(512), 0, 0, g);
+    else if (mode == SP_V2) hipLaunchKernelGGL((nsf_split<NS, SP_V2>), dim3(t, t, 2), dim3(512), 0, 0, g);
+    else if (mode == SP_V3) hipLaunchKernelGGL((nsf_split<NS, SP_V3>), dim3(t, t, 1), dim3(512), 0, 0, g);
     else hipLaunchKernelGGL((nsf_split<NS, SP_U>), dim3(t, t, 3), dim3(512), 0, 0, g);
 }
 static void run_split(int d, int mode, const SplitArgs& g) {
@@ -325,6 +327,83 @@ static void check_dim(int d) {
         report("K3: digit planes of Y1^T", edt, std::ldexp(1.0, -41) * 1.01);
     }
 
+    {   // ---------------- K3 with scaled steps (pairs on the wide chain): a decaying stand-in, c = u, Y1 = mu0 Y0 T0, Z1 = T0 with T0 = 1.5 mu0 I - 0.5 mu0^3 Y0
+        std::vector<float> Pq(dd); std::vector<double> Aq(dd), Pdq(dd), statsQ;
+        for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) {
+            const double v = (r == c ? 1.0 / (1.0 + r) : 0.0) + 1e-5 * nd(rng);
+            Pdq[(size_t)r * d + c] = v; Pq[(size_t)r * d + c] = (float)v; Aq[(size_t)r * d + c] = v * inv_s12;
+        }
+        tile_stats(Pdq, d, statsQ);
+        SplitMat Pq_m = alloc_split(d), Yq = alloc_split(d), Zq = alloc_split(d);
+        double* d_Aq = dmalloc<double>(dd); double* d_sq = dmalloc<double>((size_t)(kTileStats + 2) * nb * nb);
+        upload_split(Pq_m, Pq, d); h2d(d_Aq, Aq);
+        { std::vector<double> full((size_t)(kTileStats + 2) * nb * nb, 0.0); std::copy(statsQ.begin(), statsQ.end(), full.begin()); h2d(d_sq, full); }
+        NsState* d_stq = dmalloc<NsState>(1); Ns32State* d_s32q = dmalloc<Ns32State>(1);
+        CK(hipMemset(d_stq, 0, sizeof(NsState))); CK(hipMemset(d_s32q, 0, sizeof(Ns32State)));
+        SplitArgs q; memset(&q, 0, sizeof(q));
+        q.d = d; q.gen = gen; q.hA = d_hdr; q.hB = d_hdr + 1; q.st = d_stq; q.s32 = d_s32q;
+        q.A[0] = Pq_m; q.B[0] = Pq_m; q.C[0] = Yq; q.C[1] = Zq; q.A64 = d_Aq; q.statsA = d_sq;
+        q.scaled = 1; q.lp_wide = 1; q.l0_scale = 0.5; q.l0_min = 1e-6;
+        run_split(d, SP_FIRST, q);
+        NsState sq = d2h(d_stq, 1)[0]; Ns32State s32q = d2h(d_s32q, 1)[0];
+        // u = min(Frobenius, tile bounds): recompute as scale_from_stats does, without the / 2.9 and the weighted mean
+        double fro2 = 0.0, inf_b = 0.0, one_b = 0.0;
+        for (int t = 0; t < nb * nb; ++t) fro2 += statsQ[(size_t)kTileStats * t];
+        for (int x = 0; x < nb; ++x) {
+            double a = 0.0, b = 0.0;
+            for (int y = 0; y < nb; ++y) { a += statsQ[(size_t)kTileStats * (x * nb + y) + 2]; b += statsQ[(size_t)kTileStats * (y * nb + x) + 3]; }
+            inf_b = std::fmax(inf_b, a); one_b = std::fmax(one_b, b);
+        }
+        double u = std::sqrt(fro2); if (inf_b < u) u = inf_b; if (one_b < u) u = one_b;
+        report("K3 scaled: c = u (caller's units)", std::fabs(sq.c - u * inv_s12) / (u * inv_s12), 1e-12);
+        report("K3 scaled: state armed", (double)(s32q.failed | s32q.done | s32q.finished | sq.done | sq.nonfinite), 0.0);
+        const double mu0 = sq.mu[0];
+        report("K3 scaled: 1 < mu0 <= sqrt(3), mu[1] and l_cur set", (mu0 > 1.0 && mu0 <= 1.7320509 && sq.mu[1] >= 1.0 && sq.mu[1] <= 1.7320509 && sq.l_cur > 0.0 && sq.l_cur < 1.0) ? 0.0 : 1.0, 0.0);
+        printf("      (mu0 %.4f mu1 %.4f l_cur %.3e)\n", mu0, sq.mu[1], sq.l_cur);
+        std::vector<float> Pu(dd); for (size_t i = 0; i < dd; ++i) Pu[i] = host_round_split(Pq[i]);
+        const std::vector<double> PP = host_mm(Pu, Pu, d);
+        const double inv_cn = 1.0 / u, inv_c = inv_cn / inv_s12;
+        const float m1 = (float)(1.5 * mu0), m3 = (float)(0.5 * mu0 * mu0 * mu0);
+        HostSplit y1 = fetch_split(Yq, d), z1 = fetch_split(Zq, d);
+        double e = 0.0, ez = 0.0;
+        for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) {
+            const size_t i = (size_t)r * d + c;
+            const float y0 = (float)(Aq[i] * inv_c);
+            const double want = (double)m1 * (double)y0 - (double)m3 * PP[i] * (inv_cn * inv_cn);
+            e = std::fmax(e, std::fabs((double)y1.x[i] - want));
+            ez = std::fmax(ez, std::fabs((double)z1.x[i] - (double)host_round_split(((r == c) ? m1 : 0.f) - m3 * y0)));
+        }
+        report("K3 scaled: Y1 = 1.5 mu0 Y0 - 0.5 mu0^3 Y0^2 vs float64", e, 3e-6);
+        report("K3 scaled: Z1 = T0", ez, 0.0);
+        // the x_min rule: with l0_min above the estimate the chain must decline the product
+        CK(hipMemset(d_stq, 0, sizeof(NsState))); CK(hipMemset(d_s32q, 0, sizeof(Ns32State)));
+        q.l0_min = 0.4;
+        run_split(d, SP_FIRST, q);
+        Ns32State s32r = d2h(d_s32q, 1)[0];
+        report("K3 scaled: an x_min estimate below l0_min declines the product", (s32r.failed && s32r.done && s32r.finished) ? 0.0 : 1.0, 0.0);
+        // scaled T: alpha / beta from the device's mu[k]
+        SplitMat Tq = alloc_split(d); double* d_pq = dmalloc<double>((size_t)nb * nb);
+        CK(hipMemset(d_s32q, 0, sizeof(Ns32State)));
+        NsState sset = sq; sset.mu[1] = 1.25; h2d(d_stq, std::vector<NsState>{sset});
+        HostSplit hyq = fetch_split(Yq, d), hzq = fetch_split(Zq, d);
+        memset(&q, 0, sizeof(q));
+        q.d = d; q.gen = gen; q.hA = d_hdr; q.hB = d_hdr + 1; q.st = d_stq; q.s32 = d_s32q; q.scaled = 1; q.k = 1;
+        q.A[0] = Zq; q.B[0] = Yq; q.C[0] = Tq; q.alpha = -0.5f; q.beta_eye = 1.5f; q.gamma = 1.0f; q.partials = d_pq; q.skip = &d_s32q->done;
+        run_split(d, SP_T, q);
+        HostSplit htq = fetch_split(Tq, d);
+        const std::vector<double> ZYq = host_mm(hzq.x, hyq.x, d);
+        const float al = (float)(-0.5 * 1.25 * 1.25 * 1.25), be = (float)(1.5 * 1.25);
+        double et = 0.0, ssq = 0.0;
+        for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) {
+            const double want = (double)al * ZYq[(size_t)r * d + c] + (r == c ? (double)be : 0.0);
+            et = std::fmax(et, std::fabs((double)htq.x[(size_t)r * d + c] - want));
+            const double qq = want - (r == c ? (double)(be + al) : 0.0); ssq += qq * qq;
+        }
+        auto partq = d2h(d_pq, (size_t)nb * nb); double gotq = 0.0; for (double v : partq) gotq += v;
+        report("K4 scaled: T = 1.5 mu I - 0.5 mu^3 Z Y with the device's mu", et, 4e-6);
+        report("K4 scaled: residual partials (relative)", std::fabs(gotq - ssq) / ssq, 1e-3);
+    }
+
     // ---------------- K4: T = 1.5 I - 0.5 Z Y with residual partials (operands: what K3 left)
     HostSplit hy = fetch_split(Y[1], d), hz = fetch_split(Z[1], d);
     memset(&g, 0, sizeof(g));
@@ -386,7 +465,57 @@ static void check_dim(int d) {
         ig.Adig = d_digY[0]; ig.Bdig = d_digYt[0]; ig.Adig_alt = d_digY[1]; ig.Bdig_alt = d_digYt[1]; ig.sel = &d_s32->final_iter;
         ig.d = d; ig.gen = gen; ig.hA = d_hdr; ig.hB = d_hdr + 1; ig.skip = &d_s32->skip_corr; ig.stats = d_stats; ig.st = d_st; ig.A64in = d_A64;
         ig.Y[0] = Y[0]; ig.Y[1] = Y[1]; ig.Z[0] = Z[0]; ig.Z[1] = Z[1]; ig.s32 = d_s32; ig.host_words = d_words; ig.host_vals = d_vals;
+        SplitMat Rv = alloc_split(d), Pv = alloc_split(d), Ev = alloc_split(d);
+        ig.Rv = Rv; ig.scaled = 1;
         run_i8(d, I8_G, ig);
+        {   // ---------------- the verification products (SP_V2 / SP_V3) on what K8 left
+            HostSplit hr = fetch_split(Rv, d);
+            double er = 0.0, rmax = 0.0;
+            std::vector<float> Rs(dd);
+            for (size_t i = 0; i < dd; ++i) {
+                const double R = A2[i] / st.c - G[i];
+                Rs[i] = hr.x[i];
+                er = std::fmax(er, std::fabs((double)hr.x[i] - R * kVerScale)); rmax = std::fmax(rmax, std::fabs(R * kVerScale));
+            }
+            report("K8: planes of kVerScale R (relative to max |R'|)", er / rmax, 2e-3);       // (G = Y Y exact vs the host's product of rounded operands: R itself carries 1e-10)
+            report("K8: planes of R'^T hold the same values", max_abs_diff(hr.x, hr.xt), 0.0);
+            double* d_vst = dmalloc<double>((size_t)kVerStats * nb * nb);
+            SplitArgs v; memset(&v, 0, sizeof(v));
+            v.d = d; v.gen = gen; v.hA = d_hdr; v.hB = d_hdr + 1; v.st = d_st; v.s32 = d_s32;
+            v.sel = &d_s32->final_iter; v.skip = &d_s32->skip_corr; v.Zf[0] = Z[0]; v.Zf[1] = Z[1]; v.Yf[0] = Y[0]; v.Yf[1] = Y[1];
+            v.vstats = d_vst; v.vwords = d_words; v.hstride = 0;
+            v.B[0] = Rv; v.C[0] = Pv; v.C[1] = Ev;
+            run_split(d, SP_V2, v);
+            HostSplit hp = fetch_split(Pv, d), he = fetch_split(Ev, d);
+            const std::vector<double> ZR = host_mm(hz2.x, Rs, d), ZY2 = host_mm(hz2.x, hy2.x, d);
+            double ep = 0.0, ee = 0.0, pmax = 0.0, emax = 0.0;
+            for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) {
+                const size_t i = (size_t)r * d + c;
+                ep = std::fmax(ep, std::fabs((double)hp.x[i] - ZR[i])); pmax = std::fmax(pmax, std::fabs(ZR[i]));
+                const double ew = ((r == c ? 1.0 : 0.0) - ZY2[i]) * kVerScale;
+                ee = std::fmax(ee, std::fabs((double)he.x[i] - ew)); emax = std::fmax(emax, std::fabs(ew));
+            }
+            report("V2: P' = Z R' (relative to max |P'|)", ep / pmax, 1e-5);
+            report("V2: E' = kVerScale (I - Z Y) (absolute, in units of kVerScale x float32 eps)", ee / (kVerScale * 1.2e-7), 8.0);
+            report("V2: planes of P'^T / E'^T hold the same values", std::fmax(max_abs_diff(hp.x, hp.xt), max_abs_diff(he.x, he.xt)), 0.0);
+            v.B[0] = Pv; v.A[1] = Ev; v.C[0] = SplitMat{nullptr, nullptr}; v.C[1] = SplitMat{nullptr, nullptr};
+            run_split(d, SP_V3, v);
+            auto vs = d2h(d_vst, (size_t)kVerStats * nb * nb);
+            const std::vector<double> ZP = host_mm(hz2.x, hp.x, d);
+            double qp = 0.0, epq = 0.0, pp = 0.0, e2 = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0, qpabs = 0.0, epabs = 0.0;
+            for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) {
+                const size_t i = (size_t)r * d + c, it = (size_t)c * d + r;
+                qp += ZP[i] * (double)hp.x[it]; epq += (double)he.x[i] * (double)hp.x[it]; pp += (double)hp.x[i] * (double)hp.x[i]; e2 += (double)he.x[i] * (double)he.x[i];
+                qpabs += std::fabs(ZP[i] * (double)hp.x[it]); epabs += std::fabs((double)he.x[i] * (double)hp.x[it]);
+            }
+            for (int k = 0; k < nb * nb; ++k) { g0 += vs[kVerStats * k]; g1 += vs[kVerStats * k + 1]; g2 += vs[kVerStats * k + 2]; g3 += vs[kVerStats * k + 3]; }
+            report("V3: sum Q'_ij P'_ji (relative to the sum of magnitudes)", std::fabs(g0 - qp) / qpabs, 1e-5);
+            report("V3: sum E'_ij P'_ji (relative to the sum of magnitudes)", std::fabs(g1 - epq) / epabs, 1e-6);
+            report("V3: sum P'^2", std::fabs(g2 - pp) / pp, 1e-6);
+            report("V3: sum E'^2", std::fabs(g3 - e2) / e2, 1e-6);
+            auto hw2 = d2h(d_words, kHostWords);
+            report("V3: record stamped with the score's token", hw2[13] == gen ? 0.0 : 1.0, 0.0);
+        }
         auto sg = d2h(d_stats, (size_t)(kTileStats + 2) * nb * nb);
         auto hw = d2h(d_words, kHostWords); auto hv = d2h(d_vals, kHostVals);
         double corr = 0.0, r2 = 0.0, trY = 0.0, c_got = 0.0, r_got = 0.0, t_got = 0.0;

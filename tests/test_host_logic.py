@@ -184,3 +184,25 @@ def test_adaptive_step_scales_never_give_up_and_need_fewer_iterations_than_plain
             res = float(np.sqrt(np.sum((1 - xp * xp) ** 2)))
             k += 1
         assert counts[shipped] <= k, (counts, k)
+
+
+def test_wide_chain_acceptance_rule_emulated():
+    """Round 5's acceptance rule for pairs with a DECAYING spectrum (csrc/ns_fast.h: SP_V2 / SP_V3; frechet.hip: fast_decide_one), emulated in
+    numpy on split-float16 arithmetic (scripts/ns_emulate_verify.py), D = 256: a k^-1 pair finishes on the chain, the norm bound says nothing
+    (it is orders of magnitude above the bar), the verification products accept it and the TRUE error of the corrected trace is inside
+    the estimate and far inside 1e-5 of the distance; a k^-2 pair is declined before it starts (its x_min estimate is below what float16 can
+    carry) -- the float64 route."""
+    import importlib.util
+    import warnings
+    spec = importlib.util.spec_from_file_location("ns_emulate_verify", ROOT / "scripts" / "ns_emulate_verify.py")
+    E = importlib.util.module_from_spec(spec); spec.loader.exec_module(E)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flat = E.emulate(*E.bench_pair(0.0, d=256, n=20000))
+        k1 = E.emulate(*E.bench_pair(1.0, d=256, n=20000))
+        k2 = E.emulate(*E.bench_pair(2.0, d=256, n=20000))
+    assert flat["route"] == "chain" and flat["accepted_by"] == "norm bound" and flat["fad_rel_err"] < 1e-8, flat
+    assert k1["route"] == "chain" and k1["scaled"] and k1["accepted_by"] == "verification", k1
+    assert k1["norm_bound_fad"] > 1e-3 and k1["iters"] <= 14, k1
+    assert k1["fad_rel_err"] <= k1["verify_est_fad"] <= 1e-5, k1
+    assert k2["route"] == "declined", k2
