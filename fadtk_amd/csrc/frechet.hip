@@ -129,7 +129,10 @@ constexpr int kMaxLow = 14;
 // Pairs on the eight-launch chain (round 5): scaled steps take a k^-1 spectrum (condition 3e5 of the product) to the float32-class floor in
 // 12-13 iterations; below an x_min estimate of kWideL0Min the float64 route is the right one (scripts/ns_emulate_verify.py)
 constexpr int kMaxLowWide = 22;
-constexpr double kWideL0Scale = 0.5, kWideL0Min = 1.5e-4;
+// (start = kWideL0Scale x the x_min estimate of ns_l0_from_participation, which is a third of the power-law model's x_min: emulated at
+//  0.5 / 1 / 2 / 3: 12 / 12 / 11 / 10 iterations for k^-1, 9 / 8 / 7 / 7 for k^-0.5; a start above the true x_min only slows the smallest
+//  eigenvalues down, and the k^-1 pair's true x_min is 7x the estimate)
+constexpr double kWideL0Scale = 2.0, kWideL0Min = 6e-4;
 static bool wide_enabled(Pool* p) {
     if (p && p->lp_wide < 0) { const char* e = getenv("FAD_FRECHET_WIDE"); p->lp_wide = (e && e[0] == '0') ? 0 : 1; }
     return !p || p->lp_wide != 0;
@@ -506,7 +509,7 @@ static void fast_decide_one(const int* hw, const double* hv, const double* hsx, 
             // measure what it bounds (ns_fast.h): with P = Z R and E = I - Z Y,  1/2 tr(E P) completes the first-order term (Z is only an
             // approximate inverse of Y), and 1/8 |tr(Z P P)| ESTIMATES the second-order one -- it overestimates the commuting part and was
             // seen 0.7 .. 10x the true error (scripts/ns_emulate_verify.py: k^-0.25 .. k^-1.25, D = 512), hence the factor 4; what remains
-            // is O(||E||^2 ||P||).  Accepted when that moves the distance by less than 1e-5 of itself.
+            // is O(||E||^2 ||P||).  Accepted when that (factor included) moves the distance by less than 4e-6 of itself: ~1e-6 expected.
             if (hw[13] == gen) {
                 const double inv = 1.0 / ((double)nsf::kVerScale * (double)nsf::kVerScale);
                 double qp = 0.0, ep = 0.0, pp = 0.0, ee = 0.0;
@@ -516,7 +519,7 @@ static void fast_decide_one(const int* hw, const double* hv, const double* hsx, 
                 const double est_v = 4.0 * std::fabs(qp) / 8.0 + ee * std::sqrt(pp);
                 const double fad_v = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs_v;
                 const bool fin_v = std::isfinite(trs_v) && std::isfinite(est_v);
-                if (fin_v && (est_v <= 1e-9 * std::fabs(trs_v) || 2.0 * std::sqrt(o.c) * est_v <= 1e-5 * std::fabs(fad_v))) {
+                if (fin_v && (est_v <= 1e-9 * std::fabs(trs_v) || 2.0 * std::sqrt(o.c) * est_v <= 4e-6 * std::fabs(fad_v))) {
                     accept = true; trs = trs_v; est = est_v; fad = fad_v; o.pad = 1;      // (pad = 1: accepted on the verification record)
                 }
             } else {

@@ -53,6 +53,7 @@ struct fad_moments {
     fad::DevBuf runsum;                         // ... [d] floats
     bool runsum_covers = true;             // ... they cover exactly the rows the accumulator holds (an empty handle: trivially)
     bool runsum_live = false;              // ... a running-sum kernel has written them since the handle was created / reset
+    fad::DevBuf seg_run, seg_off;          // per-file running sums (fad_moments_update_segmented_ref) and the offsets they are walked by
     hipEvent_t rs_fork = nullptr, rs_join = nullptr;   // ... the walk runs on the device's side stream between these two (running_sums)
     int r256_sl = 0;                       // FAD_MOMENTS_R256_SL (read at creation; experiments): split lanes of moments_reduce256, 0 = by the split count
     int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
@@ -816,8 +817,39 @@ int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* co
     return update_device_multi(m, live_h, live_rows, live_n, live_ld, dtype, static_cast<hipStream_t>(stream));
 }
 
-int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
-                                 const int64_t* offsets, int64_t n_segments, double* seg_sums,
+// numpy's float32 running column sums of every segment (device rows) -> dout [n_segments x d] float32 (device)
+static int segment_running_sums_device(fad_moments* h, const void* drows, int64_t dld, int dtype, const int64_t* offsets, int64_t n_segments,
+                                       float* dout, hipStream_t st) {
+    const int d = h->d;
+    FAD_TRY(h->seg_off.reserve((size_t)(n_segments + 1) * sizeof(int64_t)));
+    // (pageable source: the runtime stages it before the call returns)
+    FAD_HIP_TRY(hipMemcpyAsync(h->seg_off.p, offsets, (size_t)(n_segments + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    const int64_t* doff = static_cast<const int64_t*>(h->seg_off.p);
+    const size_t es = dtype_size(dtype);
+    const bool wide = (dtype == FAD_F16 || dtype == FAD_BF16) && d % 8 == 0 && (dld * (int64_t)es) % 16 == 0 && (reinterpret_cast<uintptr_t>(drows) & 15u) == 0;
+    const int64_t items = n_segments * (wide ? d / 8 : d);
+    const dim3 grid((unsigned)cdiv(items, 256));
+    switch (dtype) {
+        case FAD_F16:
+            if (wide) hipLaunchKernelGGL((segment_running_sums<raw_f16, true>), grid, dim3(256), 0, st, static_cast<const raw_f16*>(drows), dld, d, doff, n_segments, dout);
+            else hipLaunchKernelGGL((segment_running_sums<raw_f16, false>), grid, dim3(256), 0, st, static_cast<const raw_f16*>(drows), dld, d, doff, n_segments, dout);
+            break;
+        case FAD_BF16:
+            if (wide) hipLaunchKernelGGL((segment_running_sums<raw_bf16, true>), grid, dim3(256), 0, st, static_cast<const raw_bf16*>(drows), dld, d, doff, n_segments, dout);
+            else hipLaunchKernelGGL((segment_running_sums<raw_bf16, false>), grid, dim3(256), 0, st, static_cast<const raw_bf16*>(drows), dld, d, doff, n_segments, dout);
+            break;
+        case FAD_F32:
+            hipLaunchKernelGGL((segment_running_sums<float, false>), grid, dim3(256), 0, st, static_cast<const float*>(drows), dld, d, doff, n_segments, dout);
+            break;
+        default:
+            return set_error(FAD_ERR_INVALID, "running sums of float64 frames are the exact sums: pass seg_runsums = NULL");
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
+static int update_segmented_impl(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                                 const int64_t* offsets, int64_t n_segments, double* seg_sums, float* seg_runsums,
                                  int on_device, void* stream) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
     if (n < 0 || ld < h->d) return set_error(FAD_ERR_SHAPE, "n=%lld ld=%lld d=%d", (long long)n, (long long)ld, h->d);
@@ -935,12 +967,37 @@ int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, 
                                        hipMemcpyDeviceToHost, st));
         }
     }
+    if (seg_runsums && n_segments > 0) {
+        // the second walk over the rows the reference's per-file np.mean asks for (utils.py:16): they have just been read by the tile
+        // kernel -- a group of files that fits the Infinity Cache is served from there
+        float* drun = seg_runsums;
+        if (!on_device) {
+            FAD_TRY(h->seg_run.reserve((size_t)n_segments * h->d * sizeof(float)));
+            drun = static_cast<float*>(h->seg_run.p);
+        }
+        FAD_TRY(segment_running_sums_device(h, drows, dld, dtype, offsets, n_segments, drun, st));
+        if (!on_device)
+            FAD_HIP_TRY(hipMemcpyAsync(seg_runsums, drun, (size_t)n_segments * h->d * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
     if (!on_device) FAD_HIP_TRY(hipStreamSynchronize(st));
     return FAD_OK;
 }
 
-int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
-                                  const double* seg_sums, const int64_t* sizes, int64_t n_files, int dtype,
+int fad_moments_update_segmented(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                                 const int64_t* offsets, int64_t n_segments, double* seg_sums,
+                                 int on_device, void* stream) {
+    return update_segmented_impl(h, rows, n, ld, dtype, offsets, n_segments, seg_sums, nullptr, on_device, stream);
+}
+
+int fad_moments_update_segmented_ref(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                                     const int64_t* offsets, int64_t n_segments, double* seg_sums, float* seg_runsums,
+                                     int on_device, void* stream) {
+    if (seg_runsums && dtype == FAD_F64) return set_error(FAD_ERR_INVALID, "float64 frames: numpy's sum is the exact one, pass seg_runsums = NULL");
+    return update_segmented_impl(h, rows, n, ld, dtype, offsets, n_segments, seg_sums, seg_runsums, on_device, stream);
+}
+
+static int update_file_means_impl(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
+                                  const double* seg_sums, const float* seg_runsums, const int64_t* sizes, int64_t n_files, int dtype,
                                   int on_device, void* stream) {
     if (!exact || !rounded || !weighted) return set_error(FAD_ERR_INVALID, "handle is NULL");
     if (exact == rounded || exact == weighted || rounded == weighted) return set_error(FAD_ERR_INVALID, "three distinct handles are needed");
@@ -954,7 +1011,14 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
     DeviceGuard g(exact->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t cells = (size_t)n_files * d;
-    const bool sums_dev = (on_device & 1) != 0, sizes_dev = (on_device & 2) != 0;
+    const bool sums_dev = (on_device & 1) != 0, sizes_dev = (on_device & 2) != 0, runs_dev = (on_device & 4) != 0;
+    // numpy's per-file running sums (host array: uploaded into a buffer of their own)
+    const float* druns = seg_runsums;
+    if (seg_runsums && !runs_dev) {
+        FAD_TRY(exact->seg_run.reserve(cells * sizeof(float)));
+        FAD_HIP_TRY(hipMemcpyAsync(exact->seg_run.p, seg_runsums, cells * sizeof(float), hipMemcpyHostToDevice, st));
+        druns = static_cast<const float*>(exact->seg_run.p);
+    }
     // scratch of `exact`: [sums | sizes] as far as they arrive from the host, then the three row blocks
     const size_t sums_bytes = sums_dev ? 0 : cells * sizeof(double);
     const size_t sizes_bytes = sizes_dev ? 0 : (size_t)n_files * sizeof(int64_t);
@@ -990,10 +1054,10 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
     double* r_weight = r_round + cells;
     const dim3 grid((unsigned)cdiv((int64_t)cells, 256));
     switch (dtype) {
-        case FAD_F16: hipLaunchKernelGGL((file_mean_rows<FAD_F16>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
-        case FAD_BF16: hipLaunchKernelGGL((file_mean_rows<FAD_BF16>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
-        case FAD_F32: hipLaunchKernelGGL((file_mean_rows<FAD_F32>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
-        default: hipLaunchKernelGGL((file_mean_rows<FAD_F64>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight); break;
+        case FAD_F16: hipLaunchKernelGGL((file_mean_rows<FAD_F16>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight, druns); break;
+        case FAD_BF16: hipLaunchKernelGGL((file_mean_rows<FAD_BF16>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight, druns); break;
+        case FAD_F32: hipLaunchKernelGGL((file_mean_rows<FAD_F32>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight, druns); break;
+        default: hipLaunchKernelGGL((file_mean_rows<FAD_F64>), grid, dim3(256), 0, st, dsums, dsizes, n_files, d, r_exact, r_round, r_weight, (const float*)nullptr); break;
     }
     FAD_HIP_TRY(hipGetLastError());
     fad_moments* hs[3] = {exact, rounded, weighted};
@@ -1001,8 +1065,20 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
     const int64_t ns[3] = {n_files, n_files, n_files};
     const int64_t lds[3] = {d, d, d};
     FAD_TRY(update_device_multi(3, hs, rows, ns, lds, FAD_F64, st));
-    if (!sums_dev) FAD_HIP_TRY(hipStreamSynchronize(st));          // the caller's host sums were read asynchronously
+    if (!sums_dev || (seg_runsums && !runs_dev)) FAD_HIP_TRY(hipStreamSynchronize(st));          // the caller's host arrays were read asynchronously
     return FAD_OK;
+}
+
+int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
+                                  const double* seg_sums, const int64_t* sizes, int64_t n_files, int dtype,
+                                  int on_device, void* stream) {
+    return update_file_means_impl(exact, rounded, weighted, seg_sums, nullptr, sizes, n_files, dtype, on_device & 3, stream);
+}
+
+int fad_moments_update_file_means_ref(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
+                                      const double* seg_sums, const float* seg_runsums, const int64_t* sizes, int64_t n_files, int dtype,
+                                      int on_device, void* stream) {
+    return update_file_means_impl(exact, rounded, weighted, seg_sums, seg_runsums, sizes, n_files, dtype, on_device, stream);
 }
 
 int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream) {

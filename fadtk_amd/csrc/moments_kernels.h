@@ -1033,16 +1033,19 @@ __device__ __forceinline__ double round_mean_like(double v) {
     } else if constexpr (DT == FAD_F32) return (double)(float)v;
     else return v;
 }
+// (seg_runsums: numpy's float32 running column sums of every file -- segment_running_sums below --, or nullptr: then m~ is the rounded
+//  EXACT mean, which differs from np.mean's by one ulp in ~0.3 % of the columns of a long file whose frames carry an offset)
 template <int DT>
 __global__ __launch_bounds__(256) void file_mean_rows(const double* __restrict__ seg_sums, const int64_t* __restrict__ sizes,
                                                       int64_t n_files, int d, double* __restrict__ exact,
-                                                      double* __restrict__ rounded, double* __restrict__ weighted) {
+                                                      double* __restrict__ rounded, double* __restrict__ weighted,
+                                                      const float* __restrict__ seg_runsums = nullptr) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= n_files * d) return;
     const int64_t f = g / d;
     const double n = (double)sizes[f];
     double m = 0.0, mr = 0.0;
-    if (n > 0.0) { m = seg_sums[g] / n; mr = round_mean_like<DT>(m); }
+    if (n > 0.0) { m = seg_sums[g] / n; mr = round_mean_like<DT>((seg_runsums && DT != FAD_F64) ? numpy_mean_of_f32_sum(seg_runsums[g], n) : m); }
     const double rt = sqrt(n);
     exact[g] = rt * m; rounded[g] = rt * mr; weighted[g] = n * mr;
 }
@@ -1145,31 +1148,21 @@ __global__ __launch_bounds__(256) void moments_running_colsum(RunSumLaunch L) {
 // The same walk for float16 rows (the reference's storage type, model_loader.py:47-48) in a form that runs BESIDE the 256-column tile
 // kernel: 25 KiB of LDS and at most 64 VGPRs per wave -- what one CU has left next to a tile workgroup (128 KiB, 2 x 224 registers per
 // SIMD) -- so that update_device_multi can put it on a stream of its own (moments.hip: running_sums).  What sets its pace is the
-// instruction stream of the ONE wave that adds: a wave issues an instruction every ~4 cycles, so the kernel above (a 4-byte LDS read and
-// an add per row: ~11.5 cycles per row measured) becomes
-//   * the tile in LDS as float16, column-major ([16 columns][384 rows + 8]): one ds_read_b128 brings EIGHT consecutive rows of the lane's
-//     column (pitch 784 bytes: the 16 lanes' 16-byte pieces fall into 16 different bank groups);
-//   * one v_fma_mix_f32 per row: s <- fma(float(h), 1.0f, s) widens the float16 operand inside the instruction; the product with one
-//     is exact, so the result is the correctly rounded float32 sum s + h -- numpy's add, bit for bit;
-// ~4.5 issue slots per row.  Waves 1..3 feed it: per tile a loader thread owns one PAIR of rows (2 x 32 bytes = four 16-byte loads, issued
-// two tiles ahead and held in registers meanwhile: ~1.5 us of cover), packs the pair's halves column by column and writes 16 dwords
-// (conflict-free: the lanes of a wave write consecutive dwords of one column).  Workgroups whose columns share the rows' 128-byte lines
-// (four column blocks) are dealt to ONE XCD (b % 8), so that a line crosses the fabric once.
-constexpr int kRsRows = 384, kRsPitch = kRsRows + 8, kRsCols = 16;      // pitch in halves
-constexpr size_t kRsLds = (size_t)2 * kRsCols * kRsPitch * sizeof(uint16_t);
+// instruction stream of the ONE wave that adds -- a wave issues an instruction every ~4-6 cycles, and every row costs a DEPENDENT add:
+//   * the tile in LDS as float32, column-major ([16 columns][192 rows + 4]): one ds_read_b128 brings FOUR consecutive rows of the lane's
+//     column (pitch 784 bytes: the 16 lanes' 16-byte pieces fall into 16 different bank groups), then four plain v_add_f32 -- 1.25
+//     instructions per row (the kernel above: a 4-byte LDS read and an add per row, ~11.5 cycles per row measured; a first version of
+//     this one kept float16 in LDS and added with v_fma_mix_f32: 21 cycles per row -- the compiler separates dependent mix
+//     instructions by s_nop, r05a);
+//   * waves 1..3 feed it: per tile a loader thread owns ONE row (32 bytes = two 16-byte loads, issued FOUR tiles ahead and held in
+//     registers meanwhile: 768 rows in flight), widens its 16 values and writes them down the 16 columns (conflict-free: the lanes of a
+//     wave write consecutive dwords of one column).
+// Workgroups whose columns share the rows' 128-byte lines (four column blocks) are dealt to ONE XCD (b % 8): a line crosses the fabric once.
+constexpr int kRsRows = 192, kRsPitch = kRsRows + 4, kRsCols = 16;      // pitch in floats
+constexpr size_t kRsLds = (size_t)2 * kRsCols * kRsPitch * sizeof(float);
 typedef _Float16 rs_h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float rs_add8(float s, const uint4& w, float one) {
-    const uint32_t q[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        rs_h2 h; __builtin_memcpy(&h, &q[i], 4);
-        s = __builtin_fmaf((float)h[0], one, s);
-        s = __builtin_fmaf((float)h[1], one, s);
-    }
-    return s;
-}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void moments_running_colsum_h16(RunSumLaunch L) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t rs_lds[];                       // [2][16][kRsPitch]
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];                          // [2][16][kRsPitch]
     const RunSumJob& j = L.job[blockIdx.y];
     if (j.n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1179,97 +1172,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int c0 = cb * kRsCols;
     const uint16_t* base = static_cast<const uint16_t*>(j.rows);
     const int64_t ntiles = (j.n + kRsRows - 1) / kRsRows;
-    // ---- loaders (waves 1..3): thread lt owns rows 2 lt, 2 lt + 1 of a tile
-    const int lt = tid - 64;
-    // (rows past the end and columns past d are never walked / written back: their addresses are clamped, their values do not matter)
-    const int q1 = (c0 + 8 < L.d) ? 8 : 0;                              // (d is a multiple of 8, not necessarily of 16)
-    auto issue = [&](uint4 (&r)[4], int64_t t) {
-        const int64_t row = t * kRsRows + 2 * lt;
-        const int64_t ra_ = row < j.n ? row : j.n - 1, rb_ = row + 1 < j.n ? row + 1 : j.n - 1;
-        const uint16_t* pa = base + ra_ * j.ld + c0;
-        const uint16_t* pb = base + rb_ * j.ld + c0;
-        r[0] = *reinterpret_cast<const uint4*>(pa);
-        r[1] = *reinterpret_cast<const uint4*>(pa + q1);
-        r[2] = *reinterpret_cast<const uint4*>(pb);
-        r[3] = *reinterpret_cast<const uint4*>(pb + q1);
-    };
-    auto dump = [&](const uint4 (&r)[4], int buf) {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(rs_lds + (size_t)buf * kRsCols * kRsPitch) + lt;      // dword lt of a column = rows 2 lt, 2 lt + 1
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t lo[4] = {r[q].x, r[q].y, r[q].z, r[q].w}, hi[4] = {r[2 + q].x, r[2 + q].y, r[2 + q].z, r[2 + q].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dst[(size_t)(8 * q + 2 * i) * (kRsPitch / 2)] = (lo[i] & 0xffffu) | (hi[i] << 16);
-                dst[(size_t)(8 * q + 2 * i + 1) * (kRsPitch / 2)] = (lo[i] >> 16) | (hi[i] & 0xffff0000u);
-            }
-        }
-    };
-    // ---- the adding wave: lanes 0..15 walk their column down the tile, 32 rows of reads ahead of the adds
-    const bool adder = wave == 0 && lane < kRsCols;
-    const bool col_ok = adder && c0 + lane < L.d;
-    float s = (col_ok && !j.start_zero) ? j.run[c0 + lane] : 0.f;
-    float one = 1.0f;
-    asm volatile("" : "+v"(one));                                      // (opaque: keeps the fma, which takes the float16 operand as it is)
-    auto walk = [&](int buf, int rows_here) {
-        const uint4* col = reinterpret_cast<const uint4*>(rs_lds + ((size_t)buf * kRsCols + lane) * kRsPitch);
-        int r = 0;
-        if (rows_here >= 32) {
-            uint4 cur[4], nxt[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cur[u] = col[u];
-            for (; r + 32 <= rows_here; r += 32) {
-                const bool more = r + 64 <= rows_here;
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) nxt[u] = col[(r >> 3) + 4 + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) s = rs_add8(s, cur[u], one);
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-                }
-            }
-        }
-        for (; r + 8 <= rows_here; r += 8) s = rs_add8(s, col[r >> 3], one);
-        if (r < rows_here) {
-            const uint4 w = col[r >> 3];
-            const uint32_t q[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (r + i < rows_here) { rs_h2 h; __builtin_memcpy(&h, &q[i >> 1], 4); s = __builtin_fmaf((float)h[i & 1], one, s); }
-            }
-        }
-    };
     auto rows_of = [&](int64_t t) { const int64_t left = j.n - t * kRsRows; return left < kRsRows ? (int)left : kRsRows; };
-    // Two roles, two loops (wave-uniform branch; every wave passes the same barriers): the register sets of the loaders (two tiles in
-    // flight) and of the adding wave (64 rows of operands) never live side by side -- the kernel has to stay within 64 VGPRs
+    // Two roles, two loops (wave-uniform branch; every wave passes the same barriers): the register sets of the loaders (four tiles in
+    // flight) and of the adding wave (32 rows of operands) never live side by side -- the kernel has to stay within 64 VGPRs
     if (wave == 0) {
+        // ---- the adding wave: lanes 0..15 walk their column down the tile, 16 rows of reads ahead of the adds
+        const bool adder = lane < kRsCols;
+        const bool col_ok = adder && c0 + lane < L.d;
+        float s = (col_ok && !j.start_zero) ? j.run[c0 + lane] : 0.f;
+        auto walk = [&](int buf, int rows_here) {
+            const float4* col = reinterpret_cast<const float4*>(rs_lds + ((size_t)buf * kRsCols + lane) * kRsPitch);
+            auto ld4 = [&](float4 (&v)[4], int r) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = col[(r >> 2) + u];
+            };
+            auto add16 = [&](const float4 (&v)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s = s + v[u].x; s = s + v[u].y; s = s + v[u].z; s = s + v[u].w; }
+            };
+            int r = 0;
+            // two register sets of 16 rows, read turn and turn about: the reads of one travel while the other is added (no copies)
+            float4 va[4], vb[4];
+            if (rows_here >= 16) ld4(va, 0);
+#pragma unroll 1
+            for (; r + 32 <= rows_here; r += 32) {
+                ld4(vb, r + 16);
+                add16(va);
+                if (r + 48 <= rows_here) ld4(va, r + 32);
+                add16(vb);
+            }
+            if (r + 16 <= rows_here) { add16(va); r += 16; }
+            const float* colf = reinterpret_cast<const float*>(col);
+#pragma unroll 1
+            for (; r < rows_here; ++r) s = s + colf[r];
+        };
         __syncthreads();
-        for (int64_t t = 0; t < ntiles; t += 2) {
-            if (adder) walk(0, rows_of(t));
-            __syncthreads();
-            if (t + 1 >= ntiles) break;
-            if (adder) walk(1, rows_of(t + 1));
+        for (int64_t t = 0; t < ntiles; ++t) {
+            if (adder) walk((int)(t & 1), rows_of(t));
             __syncthreads();
         }
+        if (col_ok) j.run[c0 + lane] = s;
     } else {
-        uint4 ra[4], rb[4];
-        issue(ra, 0);
-        if (1 < ntiles) issue(rb, 1);
-        dump(ra, 0);
-        if (2 < ntiles) issue(ra, 2);
+        // ---- loaders (waves 1..3): thread lt owns row lt of a tile.  (Rows past the end and columns past d are never walked / written
+        // back: their addresses are clamped, their values do not matter.)
+        const int lt = tid - 64;
+        const int q1 = (c0 + 8 < L.d) ? 8 : 0;                          // (d is a multiple of 8, not necessarily of 16)
+        auto issue = [&](uint4 (&r)[2], int64_t t) {
+            const int64_t row = t * kRsRows + lt;
+            const uint16_t* p = base + (row < j.n ? row : j.n - 1) * j.ld + c0;
+            r[0] = *reinterpret_cast<const uint4*>(p);
+            r[1] = *reinterpret_cast<const uint4*>(p + q1);
+        };
+        auto dump = [&](const uint4 (&r)[2], int buf) {
+            float* dst = rs_lds + (size_t)buf * kRsCols * kRsPitch + lt;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t w[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rs_h2 h; __builtin_memcpy(&h, &w[i], 4);
+                    dst[(size_t)(8 * q + 2 * i) * kRsPitch] = (float)h[0];
+                    dst[(size_t)(8 * q + 2 * i + 1) * kRsPitch] = (float)h[1];
+                }
+            }
+        };
+        uint4 rg0[2], rg1[2], rg2[2], rg3[2];                            // tile t + 1 + k waits in set (t + 1 + k) & 3
+        issue(rg0, 0);
+        if (1 < ntiles) issue(rg1, 1);
+        if (2 < ntiles) issue(rg2, 2);
+        if (3 < ntiles) issue(rg3, 3);
+        dump(rg0, 0);
+        if (4 < ntiles) issue(rg0, 4);
         __syncthreads();
-        for (int64_t t = 0; t < ntiles; t += 2) {
-            if (t + 1 < ntiles) { dump(rb, 1); if (t + 3 < ntiles) issue(rb, t + 3); }
+        // phase t: the adding wave walks tile t; tile t + 1 goes from its register set into the other buffer, tile t + 5 takes the set
+        for (int64_t t = 0; t < ntiles; t += 4) {
+            // (the scheduling fences keep a set's new loads behind the last use of its old values: without them the compiler holds both)
+            if (t + 1 < ntiles) { dump(rg1, 1); __builtin_amdgcn_sched_barrier(0); if (t + 5 < ntiles) issue(rg1, t + 5); }
             __syncthreads();
             if (t + 1 >= ntiles) break;
-            if (t + 2 < ntiles) { dump(ra, 0); if (t + 4 < ntiles) issue(ra, t + 4); }
+            if (t + 2 < ntiles) { dump(rg2, 0); __builtin_amdgcn_sched_barrier(0); if (t + 6 < ntiles) issue(rg2, t + 6); }
+            __syncthreads();
+            if (t + 2 >= ntiles) break;
+            if (t + 3 < ntiles) { dump(rg3, 1); __builtin_amdgcn_sched_barrier(0); if (t + 7 < ntiles) issue(rg3, t + 7); }
+            __syncthreads();
+            if (t + 3 >= ntiles) break;
+            if (t + 4 < ntiles) { dump(rg0, 0); __builtin_amdgcn_sched_barrier(0); if (t + 8 < ntiles) issue(rg0, t + 8); }
             __syncthreads();
         }
     }
-    if (col_ok) j.run[c0 + lane] = s;
+}
+
+// numpy's float32 running column sums PER FILE (utils.py:16: np.mean of every file; fad.py:377 per song): the rows of file f are
+// [offsets[f], offsets[f + 1]); one thread walks one column (WIDE: the eight columns of a 16-byte piece, 16-bit frames on 16-byte
+// aligned rows) down the file's rows in order, four rows of loads in flight; consecutive threads take consecutive columns of the same
+// file, then the next file.  out: [n_files][d] float32.
+template <typename TIn, bool WIDE>
+__global__ __launch_bounds__(256) void segment_running_sums(const TIn* __restrict__ rows, int64_t ld, int d, const int64_t* __restrict__ offsets,
+                                                            int64_t n_files, float* __restrict__ out) {
+    constexpr int CW = WIDE ? 8 : 1;                                // columns per thread
+    const int ncg = (d + CW - 1) / CW;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= n_files * ncg) return;
+    const int64_t f = item / ncg;
+    const int c0 = (int)(item - f * ncg) * CW;
+    const int64_t r0 = offsets[f], r1 = offsets[f + 1];
+    float s[CW];
+#pragma unroll
+    for (int q = 0; q < CW; ++q) s[q] = 0.f;
+    if constexpr (WIDE) {
+        auto add8 = [&](const uint4& w) {
+            const uint32_t qd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (std::is_same<TIn, raw_f16>::value) {
+                    rs_h2 h; __builtin_memcpy(&h, &qd[i], 4);
+                    s[2 * i] = s[2 * i] + (float)h[0]; s[2 * i + 1] = s[2 * i + 1] + (float)h[1];
+                } else {
+                    s[2 * i] = s[2 * i] + __uint_as_float(qd[i] << 16); s[2 * i + 1] = s[2 * i + 1] + __uint_as_float(qd[i] & 0xffff0000u);
+                }
+            }
+        };
+        const uint16_t* base = reinterpret_cast<const uint16_t*>(rows) + c0;
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (r + u) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add8(v[u]);
+        }
+        for (; r < r1; ++r) add8(*reinterpret_cast<const uint4*>(base + r * ld));
+    } else {
+        int64_t r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = load_as_float(rows + (r + u) * ld + c0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[0] = s[0] + v[u];
+        }
+        for (; r < r1; ++r) s[0] = s[0] + load_as_float(rows + r * ld + c0);
+    }
+#pragma unroll
+    for (int q = 0; q < CW; ++q)
+        if (c0 + q < d) out[f * d + c0 + q] = s[q];
 }
 
 // mu = sum/n ; cov = (M - sum sum^T / n) / (n - ddof)

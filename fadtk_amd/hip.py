@@ -84,9 +84,11 @@ class Moments:
             self._keep = keep          # torch tensor must outlive the enqueued kernels
         return self
 
-    def update_segmented(self, rows, offsets: Sequence[int], want_sums: bool = True, sums_on_device: bool = False):
+    def update_segmented(self, rows, offsets: Sequence[int], want_sums: bool = True, sums_on_device: bool = False, want_runsums: bool = False):
         """Feed files/songs stored back to back; returns per-segment column sums [S x D] float64 -- a numpy array, or
-        (``sums_on_device`` with device rows) a torch CUDA tensor that never leaves HBM."""
+        (``sums_on_device`` with device rows) a torch CUDA tensor that never leaves HBM.  ``want_runsums``: returns ``(sums, runsums)``
+        with numpy's float32 running column sums per segment [S x D] float32 (``fad_moments_update_segmented_ref``; None for float64
+        rows, whose numpy sum is the exact one)."""
         ptr, n, d, ld, code, on_dev, keep = K.rows_view(rows)
         if d != self.d:
             raise AssertionError(f"frame matrix has {d} features, accumulator has {self.d}")
@@ -95,6 +97,8 @@ class Moments:
         sums = None
         sums_ptr = None
         sums_dev = None
+        runs, runs_ptr, runs_dev = None, None, None
+        want_runsums = want_runsums and code != K.FAD_F64 and n_seg > 0
         if want_sums and n_seg > 0:
             if on_dev:
                 import torch
@@ -103,14 +107,28 @@ class Moments:
             else:
                 sums = np.zeros((n_seg, self.d), dtype=np.float64)
                 sums_ptr = sums.ctypes.data
-        K.check(self._lib.fad_moments_update_segmented(
-            self._h, ptr, n, ld, code, off.ctypes.data_as(C.POINTER(C.c_int64)), n_seg, sums_ptr, on_dev,
-            self._stream()), "fad_moments_update_segmented")
+        if want_runsums:
+            if on_dev:
+                import torch
+                runs_dev = torch.empty((n_seg, self.d), dtype=torch.float32, device=keep.device)
+                runs_ptr = runs_dev.data_ptr()
+            else:
+                runs = np.zeros((n_seg, self.d), dtype=np.float32)
+                runs_ptr = runs.ctypes.data
+            K.check(self._lib.fad_moments_update_segmented_ref(
+                self._h, ptr, n, ld, code, off.ctypes.data_as(C.POINTER(C.c_int64)), n_seg, sums_ptr, runs_ptr, on_dev,
+                self._stream()), "fad_moments_update_segmented_ref")
+        else:
+            K.check(self._lib.fad_moments_update_segmented(
+                self._h, ptr, n, ld, code, off.ctypes.data_as(C.POINTER(C.c_int64)), n_seg, sums_ptr, on_dev,
+                self._stream()), "fad_moments_update_segmented")
         if on_dev:
             self._keep = keep
         if sums_dev is not None:
             sums = sums_dev if sums_on_device else sums_dev.cpu().numpy()
-        return sums
+        if runs_dev is not None:
+            runs = runs_dev if sums_on_device else runs_dev.cpu().numpy()
+        return (sums, runs) if want_runsums else sums
 
     @staticmethod
     def update_multi(accs: Sequence["Moments"], blocks: Sequence) -> None:
@@ -134,9 +152,12 @@ class Moments:
             a._keep = v[6]
 
     @staticmethod
-    def update_file_means(exact: "Moments", rounded: "Moments", weighted: "Moments", seg_sums, sizes, dtype_code: int) -> None:
-        """Accumulate the per-file mean rows of the online statistics (``fad_moments_update_file_means``).
-        ``seg_sums`` [F x D] float64 and ``sizes`` [F] int64: both numpy, or both torch CUDA tensors."""
+    def update_file_means(exact: "Moments", rounded: "Moments", weighted: "Moments", seg_sums, sizes, dtype_code: int, seg_runsums=None) -> None:
+        """Accumulate the per-file mean rows of the online statistics (``fad_moments_update_file_means[_ref]``).
+        ``seg_sums`` [F x D] float64 and ``sizes`` [F] int64: both numpy, or both torch CUDA tensors (sizes may stay on the host);
+        ``seg_runsums`` [F x D] float32 (where ``seg_sums`` lives) = numpy's per-file running sums: the rounded means are then the
+        reference's own (utils.py:16), else the rounded exact means."""
+        lib = exact._lib
         if K._is_torch(seg_sums) and seg_sums.is_cuda:
             import torch
             sums_t = seg_sums.to(torch.float64).contiguous()
@@ -147,16 +168,31 @@ class Moments:
             else:                                       # the usual case: sums in HBM, sizes known on the host
                 sz = np.ascontiguousarray(np.asarray(sizes.cpu() if K._is_torch(sizes) else sizes, dtype=np.int64))
                 flag, sizes_ptr, keep = 1, sz.ctypes.data, sz
-            K.check(exact._lib.fad_moments_update_file_means(exact._h, rounded._h, weighted._h, sums_t.data_ptr(),
-                                                             sizes_ptr, n_files, int(dtype_code), flag, exact._stream()),
-                    "fad_moments_update_file_means")
-            exact._keep = (sums_t, keep)
+            if seg_runsums is not None:
+                runs_t = seg_runsums.to(torch.float32).contiguous()
+                assert runs_t.is_cuda and tuple(runs_t.shape) == tuple(sums_t.shape)
+                K.check(lib.fad_moments_update_file_means_ref(exact._h, rounded._h, weighted._h, sums_t.data_ptr(), runs_t.data_ptr(),
+                                                              sizes_ptr, n_files, int(dtype_code), flag | 4, exact._stream()),
+                        "fad_moments_update_file_means_ref")
+                exact._keep = (sums_t, runs_t, keep)
+            else:
+                K.check(lib.fad_moments_update_file_means(exact._h, rounded._h, weighted._h, sums_t.data_ptr(),
+                                                          sizes_ptr, n_files, int(dtype_code), flag, exact._stream()),
+                        "fad_moments_update_file_means")
+                exact._keep = (sums_t, keep)
         else:
             sums = K.f64_host(seg_sums)
             sz = np.ascontiguousarray(np.asarray(sizes, dtype=np.int64))
-            K.check(exact._lib.fad_moments_update_file_means(exact._h, rounded._h, weighted._h, sums.ctypes.data,
-                                                             sz.ctypes.data, int(sums.shape[0]), int(dtype_code), 0, exact._stream()),
-                    "fad_moments_update_file_means")
+            if seg_runsums is not None:
+                runs = np.ascontiguousarray(np.asarray(seg_runsums, dtype=np.float32))
+                assert runs.shape == sums.shape
+                K.check(lib.fad_moments_update_file_means_ref(exact._h, rounded._h, weighted._h, sums.ctypes.data, runs.ctypes.data,
+                                                              sz.ctypes.data, int(sums.shape[0]), int(dtype_code), 0, exact._stream()),
+                        "fad_moments_update_file_means_ref")
+            else:
+                K.check(lib.fad_moments_update_file_means(exact._h, rounded._h, weighted._h, sums.ctypes.data,
+                                                          sz.ctypes.data, int(sums.shape[0]), int(dtype_code), 0, exact._stream()),
+                        "fad_moments_update_file_means")
 
     def merge(self, other: "Moments") -> "Moments":
         K.check(self._lib.fad_moments_merge(self._h, other._h, self._stream()), "fad_moments_merge")

@@ -100,9 +100,13 @@ class OnlineStats:
     (``fad_moments_update_file_means``).  ``buffers`` is a ``dist.SharedStats`` when several ranks feed shards of one
     dataset: their sum is then ONE all-reduce.  Nothing but per-group column sums [files x D] is kept besides."""
 
-    def __init__(self, d: int, device: int = 0, compat: bool = True, shared=None):
+    def __init__(self, d: int, device: int = 0, compat: bool = True, shared=None, ref_means: bool = True):
         from .hip import Moments
         self.d, self.device, self.compat = int(d), int(device), compat
+        # per-file means as np.mean forms them (utils.py:16: a float32 running sum per file, rounded to the file's dtype) -- a second walk
+        # over the group's rows (fad_moments_update_segmented_ref); False: the rounded exact means (one ulp off in ~0.3 % of the columns
+        # of long files whose frames carry an offset; no second walk)
+        self.ref_means = bool(ref_means)
         self.shared = shared
         if shared is not None:          # 4 accumulators when compat, else 1
             self.frames = shared.moments[0]
@@ -134,7 +138,12 @@ class OnlineStats:
             count()
             return
         on_dev = type(rows).__module__.split(".")[0] == "torch" and rows.is_cuda
-        sums = self.frames.update_segmented(rows, offs, want_sums=True, sums_on_device=on_dev)
+        runs = None
+        if self.ref_means:
+            got = self.frames.update_segmented(rows, offs, want_sums=True, sums_on_device=on_dev, want_runsums=True)
+            sums, runs = got if isinstance(got, tuple) else (got, None)
+        else:
+            sums = self.frames.update_segmented(rows, offs, want_sums=True, sums_on_device=on_dev)
         if on_dev:
             import torch
             code = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}.get(rows.dtype, 3)
@@ -153,10 +162,12 @@ class OnlineStats:
             ready = torch.cuda.Event(); ready.record(main)
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ready)
-                type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code)
+                type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code, runs)
                 sums.record_stream(self._side)
+                if runs is not None:
+                    runs.record_stream(self._side)
         else:
-            type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code)
+            type(self.frames).update_file_means(self.exact, self.rounded, self.weighted, sums, sizes, code, runs)
         count()
 
     def join(self):

@@ -123,7 +123,23 @@ int fad_moments_update_file_means(fad_moments_t* exact, fad_moments_t* rounded, 
                                   const double* seg_sums, const int64_t* sizes, int64_t n_files, int dtype,
                                   int on_device, void* stream);
 
-int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream);   /* dst += src */
+/* The two calls above with the reference's OWN per-file means.  np.mean of a float16 (float32) file (utils.py:16; per song fad.py:377)
+ * adds the file's rows one after the other in float32 and rounds the quotient to the file's dtype: for a file of a few thousand frames
+ * with an offset that differs from the rounded exact mean -- what fad_moments_update_file_means forms from seg_sums -- by one ulp in
+ * ~0.3 % of the columns.  fad_moments_update_segmented_ref additionally returns those float32 running column sums per segment
+ * (seg_runsums [n_segments x D] float32, host or device like seg_sums; NULL = none; float16 / bfloat16 / float32 rows: for float64
+ * rows numpy's sum is the exact one) -- a second walk over rows the tile kernel has just read.  fad_moments_update_file_means_ref takes
+ * them (on_device bit 2: seg_runsums is a device pointer; NULL = the rounded exact means) and forms m~_f = round(float32(run_f / n_f)). */
+int fad_moments_update_segmented_ref(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
+                                     const int64_t* offsets, int64_t n_segments, double* seg_sums, float* seg_runsums,
+                                     int on_device, void* stream);
+int fad_moments_update_file_means_ref(fad_moments_t* exact, fad_moments_t* rounded, fad_moments_t* weighted,
+                                      const double* seg_sums, const float* seg_runsums, const int64_t* sizes, int64_t n_files, int dtype,
+                                      int on_device, void* stream);
+
+/* dst += src.  (Rows from another handle have no place in dst's row order: a handle with fad_moments_set_reference_mean on falls back
+ * to the exact mean afterwards, as after import / allreduce.) */
+int fad_moments_merge(fad_moments_t* dst, const fad_moments_t* src, void* stream);
 /* Copy the packed float64 statistics out / in (the buffer an RCCL all-reduce runs over). */
 int fad_moments_export(const fad_moments_t* h, double* packed, int on_device, void* stream);
 int fad_moments_import(fad_moments_t* h, const double* packed, int on_device, void* stream);

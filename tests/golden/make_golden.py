@@ -131,8 +131,19 @@ def g3():
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 mu_nan, cov_nan = ref_utils.calculate_embd_statistics_online(files[:3] + [one])
+        # round 5: long files with |mu| / sigma ~ 7 -- the per-file float16 means (utils.py:16) are numpy's float32 running-sum means
+        sblocks = R.shifted_files(71, 12, 32, min_rows=9000, max_rows=40000)      # (float16 frames near 7 are multiples of 2^-8: the float32 sum is exact below 65536, i.e. ~9400 rows)
+        assert sum(int((b.mean(axis=0) != b.astype(np.float64).mean(axis=0).astype(np.float32).astype(np.float16)).sum()) for b in sblocks) > 0
+        sfiles = []
+        for i, blk in enumerate(sblocks):
+            p = tmp / f"s{i:03d}.npy"
+            np.save(p, blk)
+            sfiles.append(p)
+        mu_s, cov_s = ref_utils.calculate_embd_statistics_online(sfiles)
+        OUT_JSON["g3_shifted"] = {"seed": 71, "n_files": 12, "d": 32, "min_rows": 9000, "max_rows": 40000, "sizes": [int(b.shape[0]) for b in sblocks],
+                                  "in_checksum": float(sum(R.checksum(b) for b in sblocks))}
         np.savez_compressed(HERE / "g3_online.npz", mu=mu, cov=cov, mu_nan=mu_nan,
-                            cov_nan_isnan=np.isnan(cov_nan))
+                            cov_nan_isnan=np.isnan(cov_nan), mu_shifted=mu_s, cov_shifted=cov_s)
         OUT_JSON["g3"] = {"seed": 70, "n_files": 37, "d": 24,
                           "sizes": [int(b.shape[0]) for b in blocks],
                           "in_checksum": float(sum(R.checksum(b) for b in blocks)),
@@ -174,6 +185,26 @@ def g4_g5():
         OUT_JSON["g4"] = {"model": model, "d": d, "names": names, "rows": [5, 9, 2, 33, 12, 7, 1],
                           "songs_seed": 80, "base_seed": 81, "base_n": 400, "csv": text,
                           "glob_sorted": order}
+
+        # round 5: songs of many frames with |mu| / sigma ~ 7 -- np.mean of a float16 song (fad.py:377 -> :48) is the float32 running-sum mean
+        evs = root / "evalshift"
+        (evs / "embeddings" / model).mkdir(parents=True)
+        srows = R.shifted_files(83, 6, d, min_rows=12000, max_rows=30000)
+        assert sum(int((b.mean(axis=0) != b.astype(np.float64).mean(axis=0).astype(np.float32).astype(np.float16)).sum()) for b in srows) > 0
+        snames = [f"s{i}.wav" for i in range(len(srows))]
+        for nm, rows in zip(snames, srows):
+            (evs / nm).write_bytes(b"")
+            np.save(evs / "embeddings" / model / (Path(nm).stem + ".npy"), rows)
+        rngb = np.random.default_rng(84)
+        xb = rngb.standard_normal((4000, d)) * (1.0 + 0.3 * rngb.random(d)) + 7.0
+        mu_sb, cov_sb = xb.mean(axis=0), np.cov(xb, rowvar=False)
+        npz_s = root / "base_shift.npz"
+        np.savez(npz_s, **{f"{model}.mu": mu_sb, f"{model}.cov": cov_sb})
+        csv_s = root / "indiv_shift.csv"
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            fad.score_individual(str(npz_s), evs, csv_s)
+        OUT_JSON["g4_shifted"] = {"model": model, "d": d, "names": snames, "rows": [int(r.shape[0]) for r in srows], "songs_seed": 83, "min_rows": 12000, "max_rows": 30000,
+                                  "base_seed": 84, "base_n": 4000, "csv": csv_s.read_text().replace(str(root), "{ROOT}")}
 
         # G5: load_stats on a directory computes + caches; dtypes of what it wrote
         with contextlib.redirect_stdout(io.StringIO()):

@@ -64,6 +64,18 @@ def ragged_files(seed: int, n_files: int, d: int, dtype=np.float16, min_rows: in
     return out
 
 
+def shifted_files(seed: int, n_files: int, d: int, dtype=np.float16, min_rows: int = 600, max_rows: int = 3000, shift: float = 7.0):
+    """Long per-file frame matrices with |mu| / sigma ~ 7: np.mean's float32 running sum (utils.py:16, fad.py:48) ends ~1e-6 off the exact
+    column sums of a few thousand such rows, and the float16 mean differs from the rounded exact one in some dimensions."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(min_rows, max_rows + 1, size=n_files)
+    out = []
+    for k, n in enumerate(sizes):
+        gain = 0.8 + 0.4 * rng.random()
+        out.append((gain * rng.standard_normal((int(n), d)) + shift + 0.02 * rng.standard_normal(d)).astype(dtype))
+    return out
+
+
 def baseline_stats(seed: int, n: int, d: int):
     """A full-rank float64 baseline (mu, Sigma) -- stand-in for the missing fma_pop.npz."""
     rng = np.random.default_rng(seed)

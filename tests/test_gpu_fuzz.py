@@ -114,10 +114,12 @@ def test_fuzz_frechet_against_oracle(F=None):
         full_rank = min(n1, n2) > d
         err = abs(got - want) / terms
         print(f"{what} err/terms={err:.2e}")
-        assert err <= (1e-10 if full_rank else 1e-6), what
+        # (full rank: 1e-10 of the terms on the float64 route; since round 5 barely-full-rank products -- n = d + 5 rows -- may stay on the
+        #  low-precision chain, whose verification accepts what it estimates at < 4e-6 of the DISTANCE: seen 3e-9 of the terms)
+        assert err <= (2e-8 if full_rank else 1e-6), what
         assert abs(got - want) <= 1e-4 * abs(want) + 1e-10 * terms, what
         worst = max(worst, err if full_rank else 0.0)
-    assert worst < 1e-10
+    assert worst < 2e-8
 
 
 def test_fuzz_per_song_scores_fast_chain_against_float64_routes_and_oracle(monkeypatch):

@@ -897,6 +897,68 @@ def test_online_statistics_golden_g3(F, golden, golden_dir, tmp_path):
     np.testing.assert_allclose(mu_n, z["mu_nan"], rtol=1e-12)
 
 
+def test_online_statistics_shifted_files_take_numpys_per_file_means(F, golden, golden_dir):
+    """Round 5 fixture g3_shifted (the REFERENCE's calculate_embd_statistics_online on 12 float16 files of 9000-40000 frames with
+    |mu| / sigma ~ 7): the per-file float16 means are np.mean's -- a float32 running sum per file (utils.py:16) -- which the online path
+    reproduces with fad_moments_update_segmented_ref / fad_moments_update_file_means_ref, from host blocks and from a device tensor.
+    With ref_means=False (rounds 1-4: rounded exact means) the dataset mean is measurably further from the reference's."""
+    import torch
+    from fadtk_amd.utils import OnlineStats
+    g = golden["g3_shifted"]
+    z = np.load(golden_dir / "g3_online.npz")
+    blocks = R.shifted_files(g["seed"], g["n_files"], g["d"], min_rows=g["min_rows"], max_rows=g["max_rows"])
+    mu, cov = F.dataset_statistics(blocks)
+    np.testing.assert_allclose(mu, z["mu_shifted"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(cov, z["cov_shifted"], rtol=0, atol=1e-5 * np.abs(np.diag(z["cov_shifted"])).max())
+    rows = torch.from_numpy(np.concatenate(blocks)).cuda()
+    sizes = [b.shape[0] for b in blocks]
+    out = {}
+    for ref in (True, False):
+        st = OnlineStats(g["d"], 0, compat=True, ref_means=ref)
+        st.add_group(rows, sizes)
+        out[ref] = st.finish()
+        st.close()
+    np.testing.assert_allclose(out[True][0], z["mu_shifted"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(out[True][1], z["cov_shifted"], rtol=0, atol=1e-5 * np.abs(np.diag(z["cov_shifted"])).max())
+    assert np.abs(out[False][0] - z["mu_shifted"]).max() > 10 * np.abs(out[True][0] - z["mu_shifted"]).max() + 1e-9
+
+
+def test_score_individual_shifted_songs_take_numpys_means(F, golden, tmp_path):
+    """Round 5 fixture g4_shifted (the REFERENCE's score_individual on six float16 songs of 12000-30000 frames with |mu| / sigma ~ 7 against a
+    baseline with the same offset): the per-song mean term uses np.mean's float16 mean (fad.py:377 -> :48), a float32 running sum --
+    csrc/frechet_songs.hip: mean_like_reference walks it for 16-bit frames since round 5."""
+    from pathlib import Path
+    from fadtk_amd import hip
+    g = golden["g4_shifted"]
+    d = g["d"]
+    srows = R.shifted_files(g["songs_seed"], len(g["names"]), d, min_rows=g["min_rows"], max_rows=g["max_rows"])
+    rngb = np.random.default_rng(g["base_seed"])
+    xb = rngb.standard_normal((g["base_n"], d)) * (1.0 + 0.3 * rngb.random(d)) + 7.0
+    mu_b, cov_b = xb.mean(axis=0), np.cov(xb, rowvar=False)
+    want = {ln.rsplit(",", 1)[0].rsplit("/", 1)[1]: float(ln.rsplit(",", 1)[1]) for ln in g["csv"].split("\n")}
+    offs = np.concatenate([[0], np.cumsum([r.shape[0] for r in srows])])
+    scores, status = hip.frechet_batched(mu_b, cov_b, np.concatenate(srows), offs, mean_mode=1)
+    assert (status == 0).all()
+    for nm, sc in zip(g["names"], scores):
+        assert abs(sc - want[nm]) <= 1e-5 * abs(want[nm]), (nm, sc, want[nm])
+    exact, _ = hip.frechet_batched(mu_b, cov_b, np.concatenate(srows), offs, mean_mode=0)      # float64 means: a different (larger) mean term
+    assert max(abs(a - want[nm]) / abs(want[nm]) for nm, a in zip(g["names"], exact)) > 1e-5
+    # ... and through the product's own entry point, CSV order included
+    model = g["model"]
+    evs = tmp_path / "evalshift"
+    (evs / "embeddings" / model).mkdir(parents=True)
+    for nm, rows in zip(g["names"], srows):
+        (evs / nm).write_bytes(b"")
+        np.save(evs / "embeddings" / model / (Path(nm).stem + ".npy"), rows)
+    np.savez(tmp_path / "base_shift.npz", **{f"{model}.mu": mu_b, f"{model}.cov": cov_b})
+    fad = F.FrechetAudioDistance(_Toy(model), audio_load_worker=2, load_model=False)
+    csv = fad.score_individual(str(tmp_path / "base_shift.npz"), evs, tmp_path / "indiv_shift.csv")
+    got = [ln.rsplit(",", 1) for ln in csv.read_text().replace(str(tmp_path), "{ROOT}").split("\n")]
+    wantl = [ln.rsplit(",", 1) for ln in g["csv"].split("\n")]
+    assert [a for a, _ in got] == [a for a, _ in wantl]
+    np.testing.assert_allclose([float(b) for _, b in got], [float(b) for _, b in wantl], rtol=1e-5)
+
+
 # --------------------------------------------------------------------------------- per-song
 class _Toy:
     def __init__(self, name):

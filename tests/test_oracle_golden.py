@@ -140,6 +140,32 @@ def test_g3_online_statistics(golden, golden_dir):
     np.testing.assert_allclose(mu_n, z["mu_nan"], rtol=1e-13)
 
 
+def test_g3_g4_shifted_fixtures_pin_numpys_running_sum_means(golden, golden_dir):
+    """Round 5 fixtures (reference-generated): long float16 files / songs with |mu| / sigma ~ 7, where np.mean's float32 running sum
+    (utils.py:16, fad.py:377 -> :48) gives float16 means that differ from the rounded exact means.  The oracle uses np.mean itself and
+    must reproduce the reference; the rounded-exact-mean variant must NOT (else the fixture pins nothing)."""
+    g = golden["g3_shifted"]
+    z = np.load(golden_dir / "g3_online.npz")
+    blocks = R.shifted_files(g["seed"], g["n_files"], g["d"], min_rows=g["min_rows"], max_rows=g["max_rows"])
+    assert [b.shape[0] for b in blocks] == g["sizes"]
+    mu, cov = O.statistics_online(blocks)
+    np.testing.assert_allclose(mu, z["mu_shifted"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(cov, z["cov_shifted"], rtol=1e-10, atol=1e-12)
+    exact16 = [b.astype(np.float64).mean(axis=0).astype(np.float32).astype(np.float16) for b in blocks]
+    numpy16 = [b.mean(axis=0) for b in blocks]
+    assert sum(int((a != b).sum()) for a, b in zip(exact16, numpy16)) > 0
+    g4 = golden["g4_shifted"]
+    srows = R.shifted_files(g4["songs_seed"], len(g4["names"]), g4["d"], min_rows=g4["min_rows"], max_rows=g4["max_rows"])
+    assert [r.shape[0] for r in srows] == g4["rows"]
+    rngb = np.random.default_rng(g4["base_seed"])
+    xb = rngb.standard_normal((g4["base_n"], g4["d"])) * (1.0 + 0.3 * rngb.random(g4["d"])) + 7.0
+    mu_b, cov_b = xb.mean(axis=0), np.cov(xb, rowvar=False)
+    scores = O.individual_scores(mu_b, cov_b, srows, run_sqrtm=False)
+    want = {ln.rsplit(",", 1)[0].rsplit("/", 1)[1]: float(ln.rsplit(",", 1)[1]) for ln in g4["csv"].split("\n")}
+    for nm, sc in zip(g4["names"], scores):
+        assert abs(sc - want[nm]) <= 1e-9 * abs(want[nm]), (nm, sc, want[nm])
+
+
 def test_g4_individual_csv(golden):
     g = golden["g4"]
     mu_b, cov_b = R.baseline_stats(g["base_seed"], g["base_n"], g["d"])
