@@ -132,7 +132,7 @@ constexpr int kMaxLowWide = 22;
 // (start = kWideL0Scale x the x_min estimate of ns_l0_from_participation, which is a third of the power-law model's x_min: emulated at
 //  0.5 / 1 / 2 / 3: 12 / 12 / 11 / 10 iterations for k^-1, 9 / 8 / 7 / 7 for k^-0.5; a start above the true x_min only slows the smallest
 //  eigenvalues down, and the k^-1 pair's true x_min is 7x the estimate)
-constexpr double kWideL0Scale = 2.0, kWideL0Min = 6e-4;
+constexpr double kWideL0Scale = 3.0, kWideL0Min = 9e-4;
 static bool wide_enabled(Pool* p) {
     if (p && p->lp_wide < 0) { const char* e = getenv("FAD_FRECHET_WIDE"); p->lp_wide = (e && e[0] == '0') ? 0 : 1; }
     return !p || p->lp_wide != 0;
@@ -503,8 +503,14 @@ static void fast_decide_one(const int* hw, const double* hv, const double* hsx, 
         double fad = o.mean_term + o.tr1 + o.tr2 - 2.0 * std::sqrt(o.c) * trs;
         bool accept = finite && (est <= 1e-9 * std::fabs(trs) || 2.0 * std::sqrt(o.c) * est <= 1e-5 * std::fabs(fad));
         const bool scaled = hvx && hw[14] != 0;
+        // a PREDICTED final iterate the correction cannot absorb while the residual behind the prediction was still far from the
+        // float32-class floor: the iteration goes on from it (cheaper than verifying an iterate that is not there yet).  A scaled chain whose
+        // residual has reached the floor changes nothing by iterating: that one is verified.
+        const bool predicted = hw[8] == fi - 1 && fi >= 1;
+        const double r_pred = predicted ? hv[4 + ns32_slot(fi - 1)] : 0.0;
+        const bool can_go_on = predicted && !strict && fi + 1 < max_low && (!scaled || r_pred > 2e-2);
         bool need_verify = false;
-        if (!accept && finite && hvx) {
+        if (!accept && finite && hvx && !can_go_on) {
             // The norm bound says nothing for ill-conditioned products (||Z|| ~ 500 for a k^-1 spectrum, cubed).  The verification products
             // measure what it bounds (ns_fast.h): with P = Z R and E = I - Z Y,  1/2 tr(E P) completes the first-order term (Z is only an
             // approximate inverse of Y), and 1/8 |tr(Z P P)| ESTIMATES the second-order one -- it overestimates the commuting part and was
@@ -528,9 +534,7 @@ static void fast_decide_one(const int* hw, const double* hv, const double* hsx, 
         }
         o.tr_scaled = trs; o.res = res; o.est = est;
         o.status = accept ? 1 : 2;
-        // a PREDICTED final iterate the correction cannot absorb: the iteration goes on from it (plain steps only -- a scaled chain sits on
-        // its float32-class floor by then, more iterations change nothing)
-        if (!accept && finite && !strict && !scaled && hw[8] == fi - 1 && fi + 1 < max_low) o.status = 4;
+        if (!accept && finite && can_go_on) o.status = 4;
         else if (!accept && need_verify) o.status = 5;
     }
     *out = o;

@@ -48,12 +48,16 @@ template <> __device__ __forceinline__ double round_like_input<r_bf16>(double v)
 // frames carry an offset (rounds 1-4 returned the rounded EXACT mean for 16-bit frames; fixture g4.shifted holds the walk to the
 // reference's own scores).  One thread walks the column in that order, eight loads in flight; float64 frames: numpy's sum is the exact one.
 template <typename TIn> __device__ __forceinline__ float ld_f32(const TIn* p, int64_t i) { return (float)ld_f64<TIn>(p, i); }
+// (`run` != nullptr: the song's running sum of this column, walked by segment_running_sums_launch in front of the statistics kernel --
+//  songs of many frames: one thread per column walking 2250 rows inside the statistics kernel cost 0.5 ms of a 2.6 ms call)
 template <typename TIn>
-__device__ __forceinline__ double mean_like_reference(const TIn* __restrict__ rows, int64_t ld, int a, int64_t r0, int64_t r1, double m_exact) {
+__device__ __forceinline__ double mean_like_reference(const TIn* __restrict__ rows, int64_t ld, int a, int64_t r0, int64_t r1, double m_exact,
+                                                      const float* __restrict__ run = nullptr) {
     if constexpr (std::is_same<TIn, double>::value) {
         return m_exact;
     } else {
         if (r1 <= r0) return 0.0;
+        if (run) return round_like_input<TIn>(numpy_mean_of_f32_sum(*run, (double)(r1 - r0)));
         float acc = 0.f;
         int64_t r = r0;
         for (; r + 8 <= r1; r += 8) {
@@ -105,7 +109,7 @@ template <typename TIn>
 __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ rows, int64_t ld, int d,
                                                        const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
                                                        int mean_mode, double* __restrict__ mean_exact,
-                                                       double* __restrict__ part /*[S][chunks][2]*/) {
+                                                       double* __restrict__ part /*[S][chunks][2]*/, const float* __restrict__ runs = nullptr) {
     __shared__ double psum[4][64];
     __shared__ double red[4];
     const int64_t s = blockIdx.x;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ r
     psum[rl][cl] = sq;
     __syncthreads();
     if (rl == 0 && ok) {
-        const double mr = mean_mode ? mean_like_reference<TIn>(rows, ld, a, r0, r1, m) : m;
+        const double mr = mean_mode ? mean_like_reference<TIn>(rows, ld, a, r0, r1, m, runs ? runs + s * d + a : nullptr) : m;
         if (mean_exact) mean_exact[s * d + a] = m;
         ts = (psum[0][cl] + psum[1][cl]) + (psum[2][cl] + psum[3][cl]);
         const double df = mu_b[a] - mr;
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ r
 __global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict__ rows, int64_t ld, int d,
                                                       const int64_t* __restrict__ offsets, const double* __restrict__ mu_b,
                                                       int mean_mode, double* __restrict__ mean_exact, double* __restrict__ var_exact,
-                                                      double* __restrict__ out /*[S][chunks][2]: scal itself when there is one chunk*/) {
+                                                      double* __restrict__ out /*[S][chunks][2]: scal itself when there is one chunk*/,
+                                                      const float* __restrict__ runs = nullptr) {
     // grid (songs, chunks of 128 columns): 16 column groups of 8 side by side, 16 row lanes
     __shared__ double sm[16 * 16 * 8 * 2];               // [row lane][group][column][sum | sum of squares]
     __shared__ double red[4];
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict
             for (int l = 0; l < 16; ++l) { s1 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2]; s2 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2 + 1]; }
             const double first = (n > 0) ? ld_f64<r_f16>(reinterpret_cast<const r_f16*>(rows), r0 * ld + a) : 0.0;
             const double m = (n > 0) ? first + s1 / (double)n : 0.0;
-            const double mr = mean_mode ? mean_like_reference<r_f16>(reinterpret_cast<const r_f16*>(rows), ld, a, r0, r1, m) : m;
+            const double mr = mean_mode ? mean_like_reference<r_f16>(reinterpret_cast<const r_f16*>(rows), ld, a, r0, r1, m, runs ? runs + s * d + a : nullptr) : m;
             if (mean_exact) mean_exact[s * d + a] = m;
             const double df = mu_b[a] - mr;
             mt = df * df;
@@ -655,13 +660,21 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
     double tr_b = 0.0;
     if (others) {                       // (two-frame songs get their scalars from pair_stats_diff)
         const bool stats16_on = knobs.stats16;
+        // songs of many frames: numpy's float32 running sums per song in a kernel of their own (the reference's per-song mean, fad.py:377)
+        const float* runs = nullptr;
+        if (mean_mode && !std::is_same<TIn, double>::value && (h_off[n_songs] - h_off[0]) / n_songs >= 64) {
+            FAD_TRY(ws.songrun.reserve((size_t)n_songs * d * sizeof(float)));
+            const int code = std::is_same<TIn, r_f16>::value ? FAD_F16 : (std::is_same<TIn, r_bf16>::value ? FAD_BF16 : FAD_F32);
+            FAD_TRY(segment_running_sums_launch(drows, ld, d, code, d_off, n_songs, static_cast<float*>(ws.songrun.p), st));
+            runs = static_cast<const float*>(ws.songrun.p);
+        }
         if (std::is_same<TIn, r_f16>::value && stats16_on && (h_off[n_songs] - h_off[0]) / n_songs >= 64 && song_cov_f16_ok(drows, ld, d)) {
             const int chunks = (int)cdiv(d, 128);
             double* part = scal;
             if (chunks > 1) { FAD_TRY(ws.rows2.reserve((size_t)2 * n_songs * chunks * sizeof(double))); part = static_cast<double*>(ws.rows2.p); }
             hipLaunchKernelGGL(song_stats_f16, dim3((unsigned)n_songs, (unsigned)chunks), dim3(256), 0, st,
                                reinterpret_cast<const uint16_t*>(drows), ld, d, d_off, dmu_b, mean_mode, mean_exact,
-                               mean_exact + (size_t)n_songs * d, part);
+                               mean_exact + (size_t)n_songs * d, part, runs);
             var_exact = mean_exact + (size_t)n_songs * d;
             if (chunks > 1) hipLaunchKernelGGL(song_scal_sum, dim3((unsigned)cdiv(2 * n_songs, 256)), dim3(256), 0, st, part, chunks, n_songs, scal);
         } else if ((h_off[n_songs] - h_off[0]) / n_songs >= 64) {
@@ -669,7 +682,7 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
             FAD_TRY(ws.rows2.reserve((size_t)2 * n_songs * chunks * sizeof(double)));
             double* part = static_cast<double*>(ws.rows2.p);
             hipLaunchKernelGGL((song_stats_long<TIn>), dim3((unsigned)n_songs, (unsigned)chunks), dim3(256), 0, st, drows, ld, d, d_off,
-                               dmu_b, mean_mode, mean_exact, part);
+                               dmu_b, mean_mode, mean_exact, part, runs);
             hipLaunchKernelGGL(song_scal_sum, dim3((unsigned)cdiv(2 * n_songs, 256)), dim3(256), 0, st, part, chunks, n_songs, scal);
         } else
             hipLaunchKernelGGL((song_stats<TIn>), dim3((unsigned)n_songs), dim3(256), 0, st, drows, ld, d, d_off, dmu_b,

@@ -680,6 +680,32 @@ static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int
     return FAD_OK;
 }
 
+// numpy's float32 running column sums of every segment (device rows, device offsets) -> dout [n_segments x d] float32 (device)
+int segment_running_sums_launch(const void* drows, int64_t dld, int d, int dtype, const int64_t* doff, int64_t n_segments, float* dout,
+                                hipStream_t st) {
+    const size_t es = dtype_size(dtype);
+    const bool wide = (dtype == FAD_F16 || dtype == FAD_BF16) && d % 8 == 0 && (dld * (int64_t)es) % 16 == 0 && (reinterpret_cast<uintptr_t>(drows) & 15u) == 0;
+    const int64_t items = n_segments * (wide ? d / 8 : d);
+    const dim3 grid((unsigned)cdiv(items, 256));
+    switch (dtype) {
+        case FAD_F16:
+            if (wide) hipLaunchKernelGGL((segment_running_sums<raw_f16, true>), grid, dim3(256), 0, st, static_cast<const raw_f16*>(drows), dld, d, doff, n_segments, dout);
+            else hipLaunchKernelGGL((segment_running_sums<raw_f16, false>), grid, dim3(256), 0, st, static_cast<const raw_f16*>(drows), dld, d, doff, n_segments, dout);
+            break;
+        case FAD_BF16:
+            if (wide) hipLaunchKernelGGL((segment_running_sums<raw_bf16, true>), grid, dim3(256), 0, st, static_cast<const raw_bf16*>(drows), dld, d, doff, n_segments, dout);
+            else hipLaunchKernelGGL((segment_running_sums<raw_bf16, false>), grid, dim3(256), 0, st, static_cast<const raw_bf16*>(drows), dld, d, doff, n_segments, dout);
+            break;
+        case FAD_F32:
+            hipLaunchKernelGGL((segment_running_sums<float, false>), grid, dim3(256), 0, st, static_cast<const float*>(drows), dld, d, doff, n_segments, dout);
+            break;
+        default:
+            return set_error(FAD_ERR_INVALID, "running sums of float64 frames are the exact sums: pass seg_runsums = NULL");
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    return FAD_OK;
+}
+
 }  // namespace fad
 
 using namespace fad;
@@ -817,35 +843,12 @@ int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* co
     return update_device_multi(m, live_h, live_rows, live_n, live_ld, dtype, static_cast<hipStream_t>(stream));
 }
 
-// numpy's float32 running column sums of every segment (device rows) -> dout [n_segments x d] float32 (device)
 static int segment_running_sums_device(fad_moments* h, const void* drows, int64_t dld, int dtype, const int64_t* offsets, int64_t n_segments,
                                        float* dout, hipStream_t st) {
-    const int d = h->d;
     FAD_TRY(h->seg_off.reserve((size_t)(n_segments + 1) * sizeof(int64_t)));
     // (pageable source: the runtime stages it before the call returns)
     FAD_HIP_TRY(hipMemcpyAsync(h->seg_off.p, offsets, (size_t)(n_segments + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    const int64_t* doff = static_cast<const int64_t*>(h->seg_off.p);
-    const size_t es = dtype_size(dtype);
-    const bool wide = (dtype == FAD_F16 || dtype == FAD_BF16) && d % 8 == 0 && (dld * (int64_t)es) % 16 == 0 && (reinterpret_cast<uintptr_t>(drows) & 15u) == 0;
-    const int64_t items = n_segments * (wide ? d / 8 : d);
-    const dim3 grid((unsigned)cdiv(items, 256));
-    switch (dtype) {
-        case FAD_F16:
-            if (wide) hipLaunchKernelGGL((segment_running_sums<raw_f16, true>), grid, dim3(256), 0, st, static_cast<const raw_f16*>(drows), dld, d, doff, n_segments, dout);
-            else hipLaunchKernelGGL((segment_running_sums<raw_f16, false>), grid, dim3(256), 0, st, static_cast<const raw_f16*>(drows), dld, d, doff, n_segments, dout);
-            break;
-        case FAD_BF16:
-            if (wide) hipLaunchKernelGGL((segment_running_sums<raw_bf16, true>), grid, dim3(256), 0, st, static_cast<const raw_bf16*>(drows), dld, d, doff, n_segments, dout);
-            else hipLaunchKernelGGL((segment_running_sums<raw_bf16, false>), grid, dim3(256), 0, st, static_cast<const raw_bf16*>(drows), dld, d, doff, n_segments, dout);
-            break;
-        case FAD_F32:
-            hipLaunchKernelGGL((segment_running_sums<float, false>), grid, dim3(256), 0, st, static_cast<const float*>(drows), dld, d, doff, n_segments, dout);
-            break;
-        default:
-            return set_error(FAD_ERR_INVALID, "running sums of float64 frames are the exact sums: pass seg_runsums = NULL");
-    }
-    FAD_HIP_TRY(hipGetLastError());
-    return FAD_OK;
+    return segment_running_sums_launch(drows, dld, h->d, dtype, static_cast<const int64_t*>(h->seg_off.p), n_segments, dout, st);
 }
 
 static int update_segmented_impl(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,

@@ -1174,9 +1174,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int64_t ntiles = (j.n + kRsRows - 1) / kRsRows;
     auto rows_of = [&](int64_t t) { const int64_t left = j.n - t * kRsRows; return left < kRsRows ? (int)left : kRsRows; };
     // Two roles, two loops (wave-uniform branch; every wave passes the same barriers): the register sets of the loaders (four tiles in
-    // flight) and of the adding wave (32 rows of operands) never live side by side -- the kernel has to stay within 64 VGPRs
+    // flight) and of the adding wave (48 rows of operands) never live side by side -- the kernel has to stay within 64 VGPRs
     if (wave == 0) {
-        // ---- the adding wave: lanes 0..15 walk their column down the tile, 16 rows of reads ahead of the adds
+        // ---- the adding wave: lanes 0..15 walk their column down the tile, 32 rows of reads ahead of the adds
         const bool adder = lane < kRsCols;
         const bool col_ok = adder && c0 + lane < L.d;
         float s = (col_ok && !j.start_zero) ? j.run[c0 + lane] : 0.f;
@@ -1191,17 +1191,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 for (int u = 0; u < 4; ++u) { s = s + v[u].x; s = s + v[u].y; s = s + v[u].z; s = s + v[u].w; }
             };
             int r = 0;
-            // two register sets of 16 rows, read turn and turn about: the reads of one travel while the other is added (no copies)
-            float4 va[4], vb[4];
-            if (rows_here >= 16) ld4(va, 0);
-#pragma unroll 1
-            for (; r + 32 <= rows_here; r += 32) {
-                ld4(vb, r + 16);
-                add16(va);
-                if (r + 48 <= rows_here) ld4(va, r + 32);
-                add16(vb);
+            if (rows_here == kRsRows) {
+                // a whole tile, straight-line: three register sets of 16 rows, read turn and turn about, TWO sets ahead of the adds -- an LDS
+                // read takes ~130 cycles to come back, 16 dependent adds ~65 (one set ahead -- r05b -- left the adds waiting: 13 cycles per
+                // row).  The scheduling fences keep the order: reads of set k + 2, then the adds of set k.
+                float4 v[3][4];
+                ld4(v[0], 0);
+                ld4(v[1], 16);
+#pragma unroll
+                for (int k = 0; k < kRsRows / 16; ++k) {
+                    if (k + 2 < kRsRows / 16) ld4(v[(k + 2) % 3], 16 * (k + 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                    add16(v[k % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
             }
-            if (r + 16 <= rows_here) { add16(va); r += 16; }
+            // the last, partial tile: 16 rows at a time, then row by row
+            {
+                float4 w[4];
+#pragma unroll 1
+                for (; r + 16 <= rows_here; r += 16) { ld4(w, r); add16(w); }
+            }
             const float* colf = reinterpret_cast<const float*>(col);
 #pragma unroll 1
             for (; r < rows_here; ++r) s = s + colf[r];
@@ -1264,7 +1275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 // numpy's float32 running column sums PER FILE (utils.py:16: np.mean of every file; fad.py:377 per song): the rows of file f are
 // [offsets[f], offsets[f + 1]); one thread walks one column (WIDE: the eight columns of a 16-byte piece, 16-bit frames on 16-byte
-// aligned rows) down the file's rows in order, four rows of loads in flight; consecutive threads take consecutive columns of the same
+// aligned rows) down the file's rows in order, eight rows of loads in flight; consecutive threads take consecutive columns of the same
 // file, then the next file.  out: [n_files][d] float32.
 template <typename TIn, bool WIDE>
 __global__ __launch_bounds__(256) void segment_running_sums(const TIn* __restrict__ rows, int64_t ld, int d, const int64_t* __restrict__ offsets,
@@ -1294,12 +1305,12 @@ __global__ __launch_bounds__(256) void segment_running_sums(const TIn* __restric
         };
         const uint16_t* base = reinterpret_cast<const uint16_t*>(rows) + c0;
         int64_t r = r0;
-        for (; r + 4 <= r1; r += 4) {
-            uint4 v[4];
+        for (; r + 8 <= r1; r += 8) {                                  // (eight rows = 128 bytes per thread in flight: the walk is latency-bound per thread)
+            uint4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (r + u) * ld);
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (r + u) * ld);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) add8(v[u]);
+            for (int u = 0; u < 8; ++u) add8(v[u]);
         }
         for (; r < r1; ++r) add8(*reinterpret_cast<const uint4*>(base + r * ld));
     } else {

@@ -17,7 +17,7 @@ import numpy as np
 
 f32 = np.float32
 K_VER_SCALE = 4096.0
-L0_SCALE, L0_MIN, MAX_LOW = 2.0, 6e-4, 22
+L0_SCALE, L0_MIN, MAX_LOW = 3.0, 9e-4, 22
 
 
 def split16(x):

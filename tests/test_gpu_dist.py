@@ -203,3 +203,49 @@ def test_fused_stats_cli_under_torchrun_with_rccl(tmp_path):
         assert (tmp_path / name / "stats" / "encodec-emb" / "cov.npy").exists()
     ref = O.frechet_distance(*stats[0], *stats[1], run_sqrtm=False)
     assert abs(score - ref) / abs(ref) < 1e-4
+
+
+def _rccl_rank_main(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("FAD_DIST_BACKEND", None)                       # the default: nccl = RCCL over xGMI
+    import torch
+    from fadtk_amd import dist, hip
+    torch.cuda.set_device(rank)
+    assert dist.init()                                             # joins RANK / WORLD_SIZE / MASTER_* with the nccl (= RCCL) backend
+    x = torch.from_numpy(R.normal_rows(17, 40001, 512)).cuda(rank)
+    y = torch.from_numpy(R.normal_rows(18, 30003, 512, 1.05, 0.02)).cuda(rank)
+    sh = dist.SharedStats(512, 2, rank)                            # both sets' packed statistics in ONE device buffer on this rank's GPU
+    hip.Moments.update_multi(sh.moments, [x[rank::world].contiguous(), y[rank::world].contiguous()])
+    sh.allreduce()                                                 # ONE in-place all-reduce over RCCL
+    assert dist.world_size() == world and dist.rank() == rank
+    import torch.distributed as td
+    assert td.get_backend() == "nccl"
+    fad, diag = hip.frechet_from_moments(sh.moments[0], sh.moments[1], mean_dtype=0)     # replicas-only Frechet: every rank scores the union
+    packed = [m.export() for m in sh.moments]
+    sh.close()
+    np.savez(Path(tmp) / f"rank{rank}.npz", p0=packed[0], p1=packed[1], fad=fad)
+    dist.barrier()
+    td.destroy_process_group()
+
+
+def test_two_ranks_on_two_gpus_reduce_over_rccl(tmp_path):
+    """the two-rank moments path over RCCL itself -- one process per GPU, row shards, ONE in-place all-reduce of the
+    packed (n, sum x, sum xxT) of both sets, the Frechet distance replicated -- wherever the box has two GPUs (the driver's 8-GPU node;
+    skipped on the one-GPU boxes the round's own visits get).  Every rank must hold the union's statistics and the oracle's score."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: a one-GPU box cannot host a two-rank RCCL communicator")
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    x = R.normal_rows(17, 40001, 512); y = R.normal_rows(18, 30003, 512, 1.05, 0.02)
+    ref = O.fad_between(x, y)
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    for r in range(2):
+        for p, rows in ((z[r]["p0"], x.astype(np.float64)), (z[r]["p1"], y.astype(np.float64))):
+            assert p[0] == rows.shape[0]
+            np.testing.assert_allclose(p[1:513], rows.sum(0), rtol=1e-6, atol=1e-5)
+            np.testing.assert_allclose(p[513:].reshape(512, 512), rows.T @ rows, rtol=0, atol=2e-6 * np.abs(rows.T @ rows).max())
+        assert abs(float(z[r]["fad"]) - ref) <= 1e-5 * abs(ref)
+    assert np.array_equal(z[0]["p0"], z[1]["p0"]) and np.array_equal(z[0]["p1"], z[1]["p1"])      # an all-reduce leaves every rank the same sums
