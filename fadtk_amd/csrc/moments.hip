@@ -55,6 +55,8 @@ struct fad_moments {
     bool runsum_live = false;              // ... a running-sum kernel has written them since the handle was created / reset
     fad::DevBuf seg_run, seg_off;          // per-file running sums (fad_moments_update_segmented_ref) and the offsets they are walked by
     hipEvent_t rs_fork = nullptr, rs_join = nullptr;   // ... the walk runs on the device's side stream between these two (running_sums)
+    bool ref_detached = false;             // fad_moments_set_reference_mean(h, 2): the walk neither waits for the caller's stream nor holds it up
+    hipEvent_t rs_pending = nullptr;       // ... the library's event behind the handle's last detached walk: settle() makes a reader's stream wait for it
     int r256_sl = 0;                       // FAD_MOMENTS_R256_SL (read at creation; experiments): split lanes of moments_reduce256, 0 = by the split count
     int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
@@ -361,6 +363,19 @@ static hipStream_t runsum_side_stream(int device) {
     return side[device];
 }
 
+// Events behind DETACHED walks: a ring per device, owned by the library for the life of the process (a handle only borrows the pointer;
+// a re-recorded event stands for a LATER point of the in-order side stream, so waiting for it is still enough).
+static hipEvent_t runsum_ring_event(int device) {
+    static std::mutex mu;
+    static hipEvent_t ring[64][32] = {{nullptr}};
+    static unsigned next[64] = {0};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return nullptr;
+    hipEvent_t& e = ring[device][next[device]++ & 31u];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); }
+    return e;
+}
+
 // -> *joined: an event the caller's stream has to wait for before the update returns (the walk reads the caller's rows), or nullptr
 static int running_sums(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n, const int64_t* ld, int dtype,
                         hipStream_t st, hipEvent_t* joined) {
@@ -398,7 +413,16 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
     // so far (the rows may still be on their way), and the caller's stream waits for it before the update returns
     hipStream_t run_st = st;
     if (dtype == FAD_F16 && wide) {
-        if (hipStream_t side = runsum_side_stream(h0->device)) {
+        // DETACHED (every handle of the call asked for it: fad_moments_set_reference_mean(h, 2)): the caller vouches that the rows are
+        // complete now and stay as they are until the statistics are next read -- the walk starts at once, beside whatever the caller's
+        // stream still holds, and settle() orders the readers behind it
+        bool detached = true;
+        for (int i = 0; i < count; ++i) if (n[i] > 0 && hs[i]->ref_mean && hs[i]->runsum_covers && !hs[i]->ref_detached) detached = false;
+        hipStream_t side = runsum_side_stream(h0->device);
+        hipEvent_t pend = (side && detached) ? runsum_ring_event(h0->device) : nullptr;
+        if (side && detached && pend) {
+            run_st = side;
+        } else if (side) {
             if (!h0->rs_fork) {
                 FAD_HIP_TRY(hipEventCreateWithFlags(&h0->rs_fork, hipEventDisableTiming));
                 FAD_HIP_TRY(hipEventCreateWithFlags(&h0->rs_join, hipEventDisableTiming));
@@ -408,7 +432,12 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
             run_st = side;
         }
         hipLaunchKernelGGL(moments_running_colsum_h16, grid, dim3(256), kRsLds, run_st, L);
-        if (run_st != st) { FAD_HIP_TRY(hipEventRecord(h0->rs_join, run_st)); *joined = h0->rs_join; }
+        if (run_st != st && pend) {
+            FAD_HIP_TRY(hipEventRecord(pend, run_st));
+            for (int i = 0; i < count; ++i) if (n[i] > 0 && hs[i]->ref_mean && hs[i]->runsum_covers) hs[i]->rs_pending = pend;
+        } else if (run_st != st) {
+            FAD_HIP_TRY(hipEventRecord(h0->rs_join, run_st)); *joined = h0->rs_join;
+        }
     } else if (dtype == FAD_F16) {
         hipLaunchKernelGGL((moments_running_colsum<raw_f16, false>), grid, dim3(256), kRunLds, st, L);
     } else if (dtype == FAD_BF16) {
@@ -770,6 +799,10 @@ int fad_moments_destroy(fad_moments_t* h) {
 // every other reader settles the pending zeroing first.
 static int settle(const fad_moments* hc, hipStream_t st) {
     fad_moments* h = const_cast<fad_moments*>(hc);
+    if (h->rs_pending) {                           // a detached walk of numpy's running sums: whoever reads the statistics waits for it
+        FAD_HIP_TRY(hipStreamWaitEvent(st, h->rs_pending, 0));
+        h->rs_pending = nullptr;
+    }
     if (!h->fresh) return FAD_OK;
     FAD_HIP_TRY(hipMemsetAsync(h->acc, 0, (size_t)packed_len(h->d) * sizeof(double), st));
     h->fresh = false;
@@ -1204,6 +1237,7 @@ int fad_moments_trim(fad_moments_t* h, int64_t keep_bytes) {
 int fad_moments_set_reference_mean(fad_moments_t* h, int enabled) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
     h->ref_mean = enabled != 0;
+    h->ref_detached = enabled == 2;
     return FAD_OK;
 }
 

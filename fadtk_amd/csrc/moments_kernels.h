@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 // numpy's float32 running column sums PER FILE (utils.py:16: np.mean of every file; fad.py:377 per song): the rows of file f are
 // [offsets[f], offsets[f + 1]); one thread walks one column (WIDE: the eight columns of a 16-byte piece, 16-bit frames on 16-byte
-// aligned rows) down the file's rows in order, eight rows of loads in flight; consecutive threads take consecutive columns of the same
+// aligned rows) down the file's rows in order, 32 rows of loads in flight; consecutive threads take consecutive columns of the same
 // file, then the next file.  out: [n_files][d] float32.
 template <typename TIn, bool WIDE>
 __global__ __launch_bounds__(256) void segment_running_sums(const TIn* __restrict__ rows, int64_t ld, int d, const int64_t* __restrict__ offsets,
@@ -1305,12 +1305,21 @@ __global__ __launch_bounds__(256) void segment_running_sums(const TIn* __restric
         };
         const uint16_t* base = reinterpret_cast<const uint16_t*>(rows) + c0;
         int64_t r = r0;
-        for (; r + 8 <= r1; r += 8) {                                  // (eight rows = 128 bytes per thread in flight: the walk is latency-bound per thread)
-            uint4 v[8];
+        // 32 rows = 512 bytes per thread in flight: the walk is latency-bound per THREAD, and a call of 2000 songs x 16 column groups is
+        // 500 waves -- two per CU (eight rows in flight: 0.5 ms for 2000 x [2250 x 128], r05c)
+        for (; r + 32 <= r1; r += 32) {
+            uint4 v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (r + u) * ld);
+            for (int u = 0; u < 32; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (r + u) * ld);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) add8(v[u]);
+            for (int u = 0; u < 32; ++u) add8(v[u]);
+        }
+        for (; r + 4 <= r1; r += 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (r + u) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add8(v[u]);
         }
         for (; r < r1; ++r) add8(*reinterpret_cast<const uint4*>(base + r * ld));
     } else {

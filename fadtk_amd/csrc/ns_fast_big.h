@@ -253,14 +253,16 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
+            float ssf = 0.f;                                 // (the block's 16 squares in float32: a residual ESTIMATE, and 40 bytes of scratch less)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int q = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
                 const bool dg = (by == bx) && (q == r);
                 const float v = alpha * (acc0[i][j][reg] + acc1[i][j][reg] * kLoInv) + (dg ? beta : 0.f);
-                if constexpr (MODE == SP_T) { const double e = (double)v - (dg ? (double)gamma : 0.0); ss += e * e; }
+                if constexpr (MODE == SP_T) { const float e = v - (dg ? gamma : 0.f); ssf = __builtin_fmaf(e, e, ssf); }
                 fin[q * 33 + r] = v;
             }
+            ss += (double)ssf;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) store_tile_planes(fin, Cm, by, bx, d, pass * 64 + lane);

@@ -245,11 +245,13 @@ class Moments:
         return mu, cov, int(n.value)
 
     # -- timing of the dominant kernel (bench.py)
-    def set_reference_mean(self, on: bool = True) -> None:
+    def set_reference_mean(self, on: bool = True, detached: bool = False) -> None:
         """Carry numpy's float32 running column sums beside the exact ones (``fad_moments_set_reference_mean``): ``finalize`` then
         returns the mean ``np.mean(frames, axis=0)`` has (fadtk/fad.py:48) before its final cast -- bit for bit after the caller's
-        ``astype`` -- instead of the exact mean.  ~0.3 ms per 100 k rows."""
-        K.check(self._lib.fad_moments_set_reference_mean(self._h, 1 if on else 0))
+        ``astype`` -- instead of the exact mean.  The walk runs on a stream of its own beside the update's other kernels;
+        ``detached=True``: the caller vouches that the frames it feeds are complete at the call and stay unchanged until the statistics
+        are next read -- the walk then waits for nothing and holds nothing up (see include/fad_hip.h)."""
+        K.check(self._lib.fad_moments_set_reference_mean(self._h, (2 if detached else 1) if on else 0))
 
     def set_timing(self, on=True):
         """True / 1: events around the tile kernel and behind the reduce; 2: around the tile kernel only; False / 0: off."""

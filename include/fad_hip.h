@@ -88,7 +88,11 @@ int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld
  * (fad_moments_update / _multi, host or device rows, float16 / bfloat16 / float32) in the order they are fed; statistics that were imported,
  * all-reduced or fed while the switch was off have no row order: finalize then falls back to the exact mean.  The
  * fad_frechet_from_moments* entry points take the same mean for their mean term (then rounded as `mean_dtype` asks) from a handle whose
- * running sums cover its rows, the exact one otherwise. */
+ * running sums cover its rows, the exact one otherwise.
+ * enabled = 2 ("detached"): as 1, and the caller vouches that every frame matrix it feeds is COMPLETE when the update is called and stays
+ * unchanged until the handle's statistics are next read (finalize / export / merge / allreduce / fad_frechet_from_moments*): the walk
+ * then neither waits for the work queued on the caller's stream nor holds that stream up -- it runs beside everything and the readers
+ * wait for it.  With 1 the walk starts behind the caller's stream and the update does not return the stream before it is through. */
 int fad_moments_set_reference_mean(fad_moments_t* h, int enabled);
 
 /* Feed `count` (1..16) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""GPU probe for the occasional 30-70 ms stalls of a single blocking call: N blocking fad_frechet_from_moments calls on a
+decaying pair (float64 route) and on a flat pair (eight-launch chain), per-call wall time with the host clock at its start -- outliers
+(> 5 x the median) are printed with their index and start offset, so that a `rocprofv3 --hip-trace --kernel-trace` of this script can be
+searched for what the host / the device did at that moment (scripts/rocpd_long_calls.py)."""
+import gc, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from fadtk_amd import hip, _capi as K
+
+n_calls = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+rng = np.random.default_rng(0)
+d, n = 512, 20000
+t_origin = time.perf_counter()
+for decay, tag in ((2.0, "k^-2 (float64 route)"), (0.0, "flat (eight-launch chain)")):
+    lam = np.arange(1, d + 1) ** (-decay / 2.0)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    a = torch.from_numpy(((rng.standard_normal((n, d)) * lam) @ q.T).astype(np.float16)).cuda()
+    b = torch.from_numpy(((1.05 * rng.standard_normal((n, d)) * lam) @ q.T + 0.01).astype(np.float16)).cuda()
+    for gc_on in (True, False):
+        (gc.enable if gc_on else gc.disable)()
+        with hip.Moments(d) as ma, hip.Moments(d) as mb:
+            hip.Moments.update_multi([ma, mb], [a, b])
+            for _ in range(5): hip.frechet_from_moments(ma, mb, mean_dtype=K.FAD_F16)
+            ts, starts = [], []
+            for i in range(n_calls):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                hip.frechet_from_moments(ma, mb, mean_dtype=K.FAD_F16)
+                ts.append((time.perf_counter() - t0) * 1e3); starts.append((t0 - t_origin) * 1e3)
+        ts = np.array(ts); med = float(np.median(ts))
+        out = [(i, round(float(ts[i]), 3), round(starts[i], 1)) for i in np.nonzero(ts > 5 * med)[0]]
+        print(f"{tag}, python gc {'on ' if gc_on else 'off'}: median {med:.3f} ms, p99 {np.percentile(ts, 99):.3f}, max {ts.max():.3f}; "
+              f"outliers (> 5 x median) (index, ms, start offset ms): {out}", flush=True)
+gc.enable()

@@ -523,6 +523,29 @@ def test_frechet_from_moments_takes_numpys_mean_from_handles_that_carry_it(F, go
         both = hip.FrechetMultiJob([(ma, mb), (pa, pb), (ma, mb)], mean_dtype=hip.K.FAD_F16).result()
         assert abs(both[0][0] - want) / want < 1e-5 and abs(both[2][0] - want) / want < 1e-5, both
         assert abs(both[1][0] - fad_plain) <= 1e-9 * abs(fad_plain)
+        # round 5, detached walk (set_reference_mean(.., detached=True): the frames are resident and stay as they are): fed in two pieces
+        # while other work is queued on the stream -- the readers wait for the walk, the value is the attached one's bit for bit
+        mu_att = ma.finalize()[0]
+        ma.reset(); mb.reset()
+        ma.set_reference_mean(True, detached=True); mb.set_reference_mean(True, detached=True)
+        busy = torch.randn((4096, 4096), device="cuda")
+        for _ in range(4):
+            busy = busy @ busy * 1e-4                                   # something for the caller's stream to chew on meanwhile
+        hip.Moments.update_multi([ma, mb], [ta[:30001], tb[:30001]])
+        hip.Moments.update_multi([ma, mb], [ta[30001:], tb[30001:]])
+        fad_det, _ = hip.frechet_from_moments(ma, mb, mean_dtype=hip.K.FAD_F16)
+        assert fad_det == fad, (fad_det, fad)
+        assert np.array_equal(ma.finalize()[0], mu_att)
+        # a merge gives the row order up -- the handle falls back to the exact mean instead of dividing dst's running sums by
+        # the merged count
+        with hip.Moments(d) as half1, hip.Moments(d) as half2:
+            half1.set_reference_mean(True); half2.set_reference_mean(True)
+            half1.update(ta[:30000]); half2.update(ta[30000:])
+            half1.merge(half2)
+            mu_merged = half1.finalize()[0]
+        exact = a.astype(np.float64).mean(axis=0)
+        np.testing.assert_allclose(mu_merged, exact, rtol=1e-12)
+        del busy
 
 
 def test_frechet_identical_sets_is_zero(F, golden):
