@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""GPU probe, run under rocprofv3 --kernel-trace --stats: what bench.py's `value_realistic` loop launches -- 8 realistic scores per batch
+(k^-1 spectra, frames with an offset: bench.make_realistic_sets), two update_multi calls of 8 frame matrices each with numpy's running
+sums on (detached walk), then ONE chain for the 8 pairs (fad_frechet_from_moments_multi_begin: scaled steps on the 128 x 128-tile
+kernels, the exact correction, the verification products) -- a dozen batches, so that the kernel statistics show what a batch costs."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from fadtk_amd import hip, _capi as K
+
+dev = torch.device("cuda", 0)
+pairs = [bench.make_realistic_sets(torch, dev, k) for k in range(4)]
+hs = [(hip.Moments(bench.DIM), hip.Moments(bench.DIM)) for _ in range(8)]
+mode = sys.argv[1] if len(sys.argv) > 1 else "detached"
+for a, b in hs:
+    a.set_reference_mean(mode != "off", detached=(mode == "detached")); b.set_reference_mean(mode != "off", detached=(mode == "detached"))
+
+def batch():
+    for g in range(2):
+        grp = hs[4 * g:4 * g + 4]
+        for a, b in grp:
+            a.reset(); b.reset()
+        hip.Moments.update_multi([h for ab in grp for h in ab], [x for k in range(4) for x in pairs[k]])
+    return hip.FrechetMultiJob(hs, mean_dtype=K.FAD_F16).result()
+
+for _ in range(4):
+    res = batch()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = 12
+for _ in range(n):
+    res = batch()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(f"mode {mode}: {dt * 1e3:.3f} ms per batch of 8 scores = {8 / dt:.0f} scores/s; last batch: routes {[d['route'] for _, d in res]} iterations {[d['iters'] for _, d in res]}")
