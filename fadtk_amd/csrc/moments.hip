@@ -356,9 +356,14 @@ static hipStream_t runsum_side_stream(int device) {
     if (enabled < 0) { const char* e = getenv("FAD_MOMENTS_RUNSUM_SIDE"); enabled = (e && e[0] == '0') ? 0 : 1; }
     if (!enabled || device < 0 || device >= 64) return nullptr;
     if (!side[device]) {
+        // (a CU-masked stream -- hipExtStreamCreateWithCUMask -- would keep the walk off some CUs, but it is a BLOCKING stream: it would
+        //  synchronise with the legacy default stream most callers launch on.  The walk leaves CUs free by its grid instead: 16 workgroups
+        //  per matrix, moments_kernels.h.)
+        hipStream_t st = nullptr;
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
-        if (hipStreamCreateWithPriority(&side[device], hipStreamNonBlocking, hi) != hipSuccess) { side[device] = nullptr; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) { st = nullptr; (void)hipGetLastError(); }
+        side[device] = st;
     }
     return side[device];
 }
@@ -405,6 +410,7 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
     L.d = h0->d;
     FAD_TRY(ensure_kernel_attrs(h0->device));
     const dim3 grid((unsigned)cdiv(L.d, kRunCols), (unsigned)m);
+    const dim3 grid_h16((unsigned)cdiv(L.d, kRsCols), (unsigned)m);
     const size_t es = dtype_size(dtype);
     bool wide = (L.d % (int)(16 / es)) == 0;
     for (int i = 0; i < m && wide; ++i)
@@ -431,7 +437,7 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
             FAD_HIP_TRY(hipStreamWaitEvent(side, h0->rs_fork, 0));
             run_st = side;
         }
-        hipLaunchKernelGGL(moments_running_colsum_h16, grid, dim3(256), kRsLds, run_st, L);
+        hipLaunchKernelGGL(moments_running_colsum_h16, grid_h16, dim3(256), kRsLds, run_st, L);
         if (run_st != st && pend) {
             FAD_HIP_TRY(hipEventRecord(pend, run_st));
             for (int i = 0; i < count; ++i) if (n[i] > 0 && hs[i]->ref_mean && hs[i]->runsum_covers) hs[i]->rs_pending = pend;

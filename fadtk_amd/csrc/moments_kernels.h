@@ -1148,27 +1148,30 @@ __global__ __launch_bounds__(256) void moments_running_colsum(RunSumLaunch L) {
 // The same walk for float16 rows (the reference's storage type, model_loader.py:47-48) in a form that runs BESIDE the 256-column tile
 // kernel: 25 KiB of LDS and at most 64 VGPRs per wave -- what one CU has left next to a tile workgroup (128 KiB, 2 x 224 registers per
 // SIMD) -- so that update_device_multi can put it on a stream of its own (moments.hip: running_sums).  What sets its pace is the
-// instruction stream of the ONE wave that adds -- a wave issues an instruction every ~4-6 cycles, and every row costs a DEPENDENT add:
-//   * the tile in LDS as float32, column-major ([16 columns][192 rows + 4]): one ds_read_b128 brings FOUR consecutive rows of the lane's
-//     column (pitch 784 bytes: the 16 lanes' 16-byte pieces fall into 16 different bank groups), then four plain v_add_f32 -- 1.25
-//     instructions per row (the kernel above: a 4-byte LDS read and an add per row, ~11.5 cycles per row measured; a first version of
-//     this one kept float16 in LDS and added with v_fma_mix_f32: 21 cycles per row -- the compiler separates dependent mix
-//     instructions by s_nop, r05a);
-//   * waves 1..3 feed it: per tile a loader thread owns ONE row (32 bytes = two 16-byte loads, issued FOUR tiles ahead and held in
-//     registers meanwhile: 768 rows in flight), widens its 16 values and writes them down the 16 columns (conflict-free: the lanes of a
-//     wave write consecutive dwords of one column).
-// Workgroups whose columns share the rows' 128-byte lines (four column blocks) are dealt to ONE XCD (b % 8): a line crosses the fabric once.
-constexpr int kRsRows = 192, kRsPitch = kRsRows + 4, kRsCols = 16;      // pitch in floats
+// instruction stream of the ONE wave that adds -- a lone wave issues an instruction every ~5-6 cycles, and every row costs a DEPENDENT add:
+//   * the tile in LDS as float32, column-major ([32 columns][96 rows + 4]): one ds_read_b128 brings FOUR consecutive rows of the lane's
+//     column (pitch 400 bytes: the lanes' 16-byte pieces of a lane group fall into different bank groups), then four plain v_add_f32,
+//     three sets of 16 rows in rotation so that the reads are TWO sets ahead of the adds -- ~1.5 instructions per row, 9 cycles measured
+//     (the kernel above: a 4-byte LDS read and an add per row, ~11.5; float16 in LDS with v_fma_mix_f32: 21 -- the compiler separates
+//     dependent mix instructions by s_nop; float32 tiles with the reads one set ahead: 13 -- an LDS read takes ~130 cycles, r05a-c);
+//   * waves 1..3 feed it: per tile a loader thread owns 16 columns of ONE row (two 16-byte loads, issued FOUR tiles ahead and held in
+//     registers meanwhile), widens its 16 values and writes them down the columns (the lanes of a wave write consecutive dwords).
+// 32 columns per workgroup = d / 32 workgroups per matrix (16 at d = 512, 128 for the eight matrices of a launch): HALF the chip at most.
+// That is deliberate: a walk wave on a CU (64 registers) keeps every workgroup of 256-register waves OUT of that CU, and the gated second
+// pass of the shift guard (moments_tile256<.., true>) is such a kernel -- with a walk workgroup on every CU even the launch that only
+// reads its gate and exits could not be placed, and the caller's stream stood still for 170-300 us per update (r05d).
+// Workgroups whose columns share the rows' 128-byte lines (two column blocks) are dealt to ONE XCD (b % 8).
+constexpr int kRsRows = 96, kRsPitch = kRsRows + 4, kRsCols = 32;      // pitch in floats
 constexpr size_t kRsLds = (size_t)2 * kRsCols * kRsPitch * sizeof(float);
 typedef _Float16 rs_h2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void moments_running_colsum_h16(RunSumLaunch L) {
-    extern __shared__ __attribute__((aligned(16))) float rs_lds[];                          // [2][16][kRsPitch]
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];                          // [2][32][kRsPitch]
     const RunSumJob& j = L.job[blockIdx.y];
     if (j.n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int cb = blockIdx.x;
-    if ((gridDim.x & 31) == 0) { const int w = blockIdx.x & 31; cb = (blockIdx.x & ~31) + 4 * (w & 7) + (w >> 3); }
+    if ((gridDim.x & 15) == 0) { const int w = blockIdx.x & 15; cb = (blockIdx.x & ~15) + 2 * (w & 7) + (w >> 3); }
     const int c0 = cb * kRsCols;
     const uint16_t* base = static_cast<const uint16_t*>(j.rows);
     const int64_t ntiles = (j.n + kRsRows - 1) / kRsRows;
@@ -1176,12 +1179,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // Two roles, two loops (wave-uniform branch; every wave passes the same barriers): the register sets of the loaders (four tiles in
     // flight) and of the adding wave (48 rows of operands) never live side by side -- the kernel has to stay within 64 VGPRs
     if (wave == 0) {
-        // ---- the adding wave: lanes 0..15 walk their column down the tile, 32 rows of reads ahead of the adds
+        // ---- the adding wave: lanes 0..31 walk their column down the tile, 32 rows of reads ahead of the adds
         const bool adder = lane < kRsCols;
         const bool col_ok = adder && c0 + lane < L.d;
         float s = (col_ok && !j.start_zero) ? j.run[c0 + lane] : 0.f;
         auto walk = [&](int buf, int rows_here) {
-            const float4* col = reinterpret_cast<const float4*>(rs_lds + ((size_t)buf * kRsCols + lane) * kRsPitch);
+            const float4* col = reinterpret_cast<const float4*>(rs_lds + ((size_t)buf * kRsCols + (lane & (kRsCols - 1))) * kRsPitch);
             auto ld4 = [&](float4 (&v)[4], int r) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = col[(r >> 2) + u];
@@ -1192,9 +1195,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             };
             int r = 0;
             if (rows_here == kRsRows) {
-                // a whole tile, straight-line: three register sets of 16 rows, read turn and turn about, TWO sets ahead of the adds -- an LDS
-                // read takes ~130 cycles to come back, 16 dependent adds ~65 (one set ahead -- r05b -- left the adds waiting: 13 cycles per
-                // row).  The scheduling fences keep the order: reads of set k + 2, then the adds of set k.
+                // a whole tile, straight-line: three register sets of 16 rows, read turn and turn about, TWO sets ahead of the adds.  The
+                // scheduling fences keep the order: reads of set k + 2, then the adds of set k.
                 float4 v[3][4];
                 ld4(v[0], 0);
                 ld4(v[1], 16);
@@ -1224,18 +1226,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         if (col_ok) j.run[c0 + lane] = s;
     } else {
-        // ---- loaders (waves 1..3): thread lt owns row lt of a tile.  (Rows past the end and columns past d are never walked / written
-        // back: their addresses are clamped, their values do not matter.)
+        // ---- loaders (waves 1..3): thread lt owns 16 columns (`half`) of row lt % 96 of a tile.  (Rows past the end and columns past d are
+        // never walked / written back: their addresses are clamped, their values do not matter.)
         const int lt = tid - 64;
-        const int q1 = (c0 + 8 < L.d) ? 8 : 0;                          // (d is a multiple of 8, not necessarily of 16)
+        const int lrow = lt % kRsRows, half = lt / kRsRows;              // 192 threads = 96 rows x 2 halves
+        const int cbase = (c0 + 16 * half < L.d) ? 16 * half : 0;       // (d is a multiple of 8, not necessarily of 32)
+        const int q1 = (c0 + cbase + 8 < L.d) ? 8 : 0;
         auto issue = [&](uint4 (&r)[2], int64_t t) {
-            const int64_t row = t * kRsRows + lt;
-            const uint16_t* p = base + (row < j.n ? row : j.n - 1) * j.ld + c0;
+            const int64_t row = t * kRsRows + lrow;
+            const uint16_t* p = base + (row < j.n ? row : j.n - 1) * j.ld + c0 + cbase;
             r[0] = *reinterpret_cast<const uint4*>(p);
             r[1] = *reinterpret_cast<const uint4*>(p + q1);
         };
         auto dump = [&](const uint4 (&r)[2], int buf) {
-            float* dst = rs_lds + (size_t)buf * kRsCols * kRsPitch + lt;
+            float* dst = rs_lds + ((size_t)buf * kRsCols + 16 * half) * kRsPitch + lrow;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const uint32_t w[4] = {r[q].x, r[q].y, r[q].z, r[q].w};

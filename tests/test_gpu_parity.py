@@ -534,8 +534,8 @@ def test_frechet_from_moments_takes_numpys_mean_from_handles_that_carry_it(F, go
         hip.Moments.update_multi([ma, mb], [ta[:30001], tb[:30001]])
         hip.Moments.update_multi([ma, mb], [ta[30001:], tb[30001:]])
         fad_det, _ = hip.frechet_from_moments(ma, mb, mean_dtype=hip.K.FAD_F16)
-        assert fad_det == fad, (fad_det, fad)
-        assert np.array_equal(ma.finalize()[0], mu_att)
+        assert np.array_equal(ma.finalize()[0], mu_att)                 # the running sums carried across the two updates: numpy's mean bit for bit
+        assert abs(fad_det - fad) <= 2e-6 * abs(fad), (fad_det, fad)    # (two updates sum the partial tiles in another order: 1e-9 .. 1e-6 through the root)
         # a merge gives the row order up -- the handle falls back to the exact mean instead of dividing dst's running sums by
         # the merged count
         with hip.Moments(d) as half1, hip.Moments(d) as half2:
