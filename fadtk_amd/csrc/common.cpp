@@ -36,6 +36,7 @@ static int probe(int device) {
     return g_state[device];
 }
 
+static void warm_code_objects(int device);
 int check_device(int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -45,7 +46,34 @@ int check_device(int device) {
     if (probe(device) != 1)
         return set_error(FAD_ERR_NO_DEVICE, "device %d is '%s', this library is built for gfx950 only", device,
                          g_arch[device]);
+    warm_code_objects(device);
     return FAD_OK;
+}
+
+// The runtime loads a translation unit's code object at the FIRST launch of one of its kernels: ~75 ms each (rocprofv3 --hip-trace around
+// scripts/probe_stall.py: one hipLaunchKernel of 75 ms where a route ran a kernel of a unit nothing had touched yet -- the "30-70 ms stalls of
+// single blocking calls" of rounds 3-4).  Touching one kernel per unit when a device is first used moves all of that to one place.
+// FAD_WARM_KERNELS=0 leaves the loading lazy.
+const void* code_object_anchor_moments(); const void* code_object_anchor_gemm_f64(); const void* code_object_anchor_gemm_f32();
+const void* code_object_anchor_frechet_f64(); const void* code_object_anchor_frechet(); const void* code_object_anchor_frechet_songs();
+const void* code_object_anchor_logmel(); const void* code_object_anchor_resample();
+static void warm_code_objects(int device) {
+    static bool warm[kMaxDev] = {false};
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (warm[device]) return;
+        warm[device] = true;
+    }
+    const char* e = getenv("FAD_WARM_KERNELS");
+    if (e && e[0] == '0') return;
+    DeviceGuard g(device);
+    if (!g.ok) return;
+    const void* anchors[] = {code_object_anchor_moments(), code_object_anchor_gemm_f64(), code_object_anchor_gemm_f32(), code_object_anchor_frechet_f64(),
+                             code_object_anchor_frechet(), code_object_anchor_frechet_songs(), code_object_anchor_logmel(), code_object_anchor_resample()};
+    for (const void* a : anchors) {
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, a) != hipSuccess) (void)hipGetLastError();
+    }
 }
 
 int num_cus(int device) { return (device >= 0 && device < kMaxDev && g_cus[device] > 0) ? g_cus[device] : 256; }

@@ -63,16 +63,18 @@ struct DevBuf {
     void release();
 };
 
+// moments.hip: numpy's float32 running column sums of every segment [d_offsets[s], d_offsets[s + 1]) of DEVICE rows (float16 / bfloat16 /
+// float32) -> d_out [n_segments x d] float32 (segment_running_sums: per-file means of the online path, per-song means of --indiv)
+// (`jobs`: scratch for the job table of the LDS-staged walk -- float16 rows, 16-byte aligned, segments of a few hundred rows or more:
+//  one workgroup per (segment, 32 columns) -- else one thread walks eight columns of a segment with its loads in flight)
+int segment_running_sums_launch(const void* rows, int64_t ld, int d, int dtype, const int64_t* d_offsets, int64_t n_segments, float* d_out,
+                                hipStream_t st, DevBuf* jobs = nullptr, int64_t mean_rows = 0, int device = 0);
+
 // moments.hip: covariances of B songs of float16 frames on the moments tile kernels (for frechet.hip's batched per-song chain)
 bool song_cov_f16_ok(const void* rows, int64_t ld, int d);
 int song_cov_f16_launch(const void* rows, int64_t ld, int d, const int64_t* d_offsets, const int64_t* d_song_ids, int64_t B,
                         int64_t max_frames, const double* d_mean_exact, const double* d_var_exact, double* d_cov_out, DevBuf& scratch,
                         int device, hipStream_t st);
-
-// moments.hip: numpy's float32 running column sums of every segment [d_offsets[s], d_offsets[s + 1]) of DEVICE rows (float16 / bfloat16 /
-// float32) -> d_out [n_segments x d] float32 (segment_running_sums: per-file means of the online path, per-song means of --indiv)
-int segment_running_sums_launch(const void* rows, int64_t ld, int d, int dtype, const int64_t* d_offsets, int64_t n_segments, float* d_out,
-                                hipStream_t st);
 
 // Scratch buffers of the handle-less entry points: one set per (host thread, device), so callers in a thread pool
 // (fad.py:229, 387 use tmap) never share scratch memory, and the memory goes back to the device when the thread ends.

@@ -23,7 +23,7 @@ static inline int64_t stat_blocks(int d) { return cdiv(d, 32); }
 static inline size_t stat_doubles(int d) { const int64_t nb = stat_blocks(d); return (size_t)(2 * nb * d + kStatScal * nb * nb); }
 
 struct Workspace : NsWorkspace {
-    DevBuf rows, offs, songbuf, songmat, rows2, songrun;     // per-song path (songrun: numpy's float32 running column sums per song)
+    DevBuf rows, offs, songbuf, songmat, rows2, songrun, songjobs;     // per-song path (songrun: numpy's float32 running column sums per song)
     DevBuf base_root;                               // ... sqrt(Sigma_b) | I | zeros of the symmetric D x D route
     void* song_pin = nullptr; size_t song_pin_cap = 0;      // ... and its pinned staging: offsets going up, scores coming down
     DevBuf mats32;                                  // low-precision leg: Y32[2], Z32[2], T32 (floats)
@@ -53,7 +53,7 @@ struct Workspace : NsWorkspace {
     hipEvent_t done_ev = nullptr;
     struct Pool* pool = nullptr;
     void release_all() {
-        release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); songrun.release(); mats32.release(); base_root.release(); fast.release();
+        release(); rows.release(); offs.release(); songbuf.release(); songmat.release(); rows2.release(); songrun.release(); songjobs.release(); mats32.release(); base_root.release(); fast.release();
         fast_songs.release(); songcov.release(); fast_pairs.release();
         if (fast_pairs_pin) { (void)hipHostFree(fast_pairs_pin); fast_pairs_pin = nullptr; fast_pairs_pin_cap = 0; }
         if (fast_songs_pin) { (void)hipHostFree(fast_songs_pin); fast_songs_pin = nullptr; fast_songs_pin_cap = 0; }

@@ -665,7 +665,8 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         if (mean_mode && !std::is_same<TIn, double>::value && (h_off[n_songs] - h_off[0]) / n_songs >= 64) {
             FAD_TRY(ws.songrun.reserve((size_t)n_songs * d * sizeof(float)));
             const int code = std::is_same<TIn, r_f16>::value ? FAD_F16 : (std::is_same<TIn, r_bf16>::value ? FAD_BF16 : FAD_F32);
-            FAD_TRY(segment_running_sums_launch(drows, ld, d, code, d_off, n_songs, static_cast<float*>(ws.songrun.p), st));
+            FAD_TRY(segment_running_sums_launch(drows, ld, d, code, d_off, n_songs, static_cast<float*>(ws.songrun.p), st, &ws.songjobs,
+                                                (h_off[n_songs] - h_off[0]) / n_songs, device));
             runs = static_cast<const float*>(ws.songrun.p);
         }
         if (std::is_same<TIn, r_f16>::value && stats16_on && (h_off[n_songs] - h_off[0]) / n_songs >= 64 && song_cov_f16_ok(drows, ld, d)) {
@@ -1024,6 +1025,8 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
     return FAD_OK;
 }
 
+// (first-use warm-up, common.cpp: warm_code_objects -- loading this translation unit's code object costs ~75 ms at the first launch)
+const void* code_object_anchor_frechet_songs() { return reinterpret_cast<const void*>(&song_stats_f16); }
 }  // namespace fad
 
 extern "C" int fad_frechet_batched_vs_baseline(int d, const double* mu_b, const double* cov_b,

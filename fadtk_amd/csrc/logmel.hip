@@ -351,6 +351,8 @@ static int check_clips(const float* wav, const int64_t* offsets, int64_t n_clips
     return FAD_OK;
 }
 
+// (first-use warm-up, common.cpp: warm_code_objects -- loading this translation unit's code object costs ~75 ms at the first launch)
+const void* code_object_anchor_logmel() { return reinterpret_cast<const void*>(&whisper_normalize); }
 }  // namespace fad
 
 using namespace fad;

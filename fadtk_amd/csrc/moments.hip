@@ -53,7 +53,7 @@ struct fad_moments {
     fad::DevBuf runsum;                         // ... [d] floats
     bool runsum_covers = true;             // ... they cover exactly the rows the accumulator holds (an empty handle: trivially)
     bool runsum_live = false;              // ... a running-sum kernel has written them since the handle was created / reset
-    fad::DevBuf seg_run, seg_off;          // per-file running sums (fad_moments_update_segmented_ref) and the offsets they are walked by
+    fad::DevBuf seg_run, seg_off, seg_jobs;   // per-file running sums (fad_moments_update_segmented_ref), the offsets they are walked by, the walk's job table
     hipEvent_t rs_fork = nullptr, rs_join = nullptr;   // ... the walk runs on the device's side stream between these two (running_sums)
     bool ref_detached = false;             // fad_moments_set_reference_mean(h, 2): the walk neither waits for the caller's stream nor holds it up
     hipEvent_t rs_pending = nullptr;       // ... the library's event behind the handle's last detached walk: settle() makes a reader's stream wait for it
@@ -717,8 +717,25 @@ static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int
 
 // numpy's float32 running column sums of every segment (device rows, device offsets) -> dout [n_segments x d] float32 (device)
 int segment_running_sums_launch(const void* drows, int64_t dld, int d, int dtype, const int64_t* doff, int64_t n_segments, float* dout,
-                                hipStream_t st) {
+                                hipStream_t st, DevBuf* jobs, int64_t mean_rows, int device) {
     const size_t es = dtype_size(dtype);
+    // float16 rows on 16-byte aligned pitches, segments of some length: the LDS-staged walk of the plain update, one workgroup per
+    // (segment, 32 columns) -- the rows of a segment stream through coalesced, the adds cost ~9 cycles a row; one thread per 8 columns of
+    // a segment is latency-bound per THREAD (2.4 us per 16 rows in flight: 0.23 ms for 32 songs of [1500 x 768], r05d)
+    if (jobs && dtype == FAD_F16 && d % 8 == 0 && (dld * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(drows) & 15u) == 0 && mean_rows >= 256 &&
+        n_segments <= 65535) {
+        FAD_TRY(ensure_kernel_attrs(device));
+        FAD_TRY(jobs->reserve((size_t)n_segments * sizeof(RunSumJob)));
+        RunSumJob* table = static_cast<RunSumJob*>(jobs->p);
+        hipLaunchKernelGGL(runsum_segment_jobs, dim3((unsigned)cdiv(n_segments, 256)), dim3(256), 0, st, static_cast<const uint16_t*>(drows), dld, d,
+                           doff, n_segments, dout, table);
+        RunSumLaunch L;
+        memset(&L, 0, sizeof(L));
+        L.d = d; L.table = table;
+        hipLaunchKernelGGL(moments_running_colsum_h16, dim3((unsigned)cdiv(d, kRsCols), (unsigned)n_segments), dim3(256), kRsLds, st, L);
+        FAD_HIP_TRY(hipGetLastError());
+        return FAD_OK;
+    }
     const bool wide = (dtype == FAD_F16 || dtype == FAD_BF16) && d % 8 == 0 && (dld * (int64_t)es) % 16 == 0 && (reinterpret_cast<uintptr_t>(drows) & 15u) == 0;
     const int64_t items = n_segments * (wide ? d / 8 : d);
     const dim3 grid((unsigned)cdiv(items, 256));
@@ -792,6 +809,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     h->partials64.release(); h->colpart64.release(); h->cvec.release(); h->presum.release(); h->presum_col.release(); h->blocktab.release();
     h->partials.release(); h->colpart.release(); h->stage.release();
     h->seg_tab.release(); h->seg_piece.release(); h->seg_out.release(); h->scratch.release(); h->runsum.release();
+    h->seg_run.release(); h->seg_off.release(); h->seg_jobs.release();
     if (h->tab_host) (void)hipHostFree(h->tab_host);
     if (h->tab_ev) (void)hipEventDestroy(h->tab_ev);
     if (h->rs_fork) (void)hipEventDestroy(h->rs_fork);
@@ -887,7 +905,9 @@ static int segment_running_sums_device(fad_moments* h, const void* drows, int64_
     FAD_TRY(h->seg_off.reserve((size_t)(n_segments + 1) * sizeof(int64_t)));
     // (pageable source: the runtime stages it before the call returns)
     FAD_HIP_TRY(hipMemcpyAsync(h->seg_off.p, offsets, (size_t)(n_segments + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    return segment_running_sums_launch(drows, dld, h->d, dtype, static_cast<const int64_t*>(h->seg_off.p), n_segments, dout, st);
+    const int64_t total = n_segments > 0 ? offsets[n_segments] - offsets[0] : 0;
+    return segment_running_sums_launch(drows, dld, h->d, dtype, static_cast<const int64_t*>(h->seg_off.p), n_segments, dout, st, &h->seg_jobs,
+                                       n_segments > 0 ? total / n_segments : 0, h->device);
 }
 
 static int update_segmented_impl(fad_moments_t* h, const void* rows, int64_t n, int64_t ld, int dtype,
@@ -1343,4 +1363,6 @@ int song_cov_f16_launch(const void* rows, int64_t ld, int d, const int64_t* d_of
     FAD_HIP_TRY(hipGetLastError());
     return FAD_OK;
 }
+// (first-use warm-up, common.cpp: warm_code_objects -- loading this translation unit's code object costs ~75 ms at the first launch)
+const void* code_object_anchor_moments() { return reinterpret_cast<const void*>(&packed_axpy); }
 }  // namespace fad

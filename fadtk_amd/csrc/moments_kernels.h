@@ -1066,7 +1066,16 @@ __device__ __forceinline__ float load_as_float(const raw_f16* p) { return h16_to
 __device__ __forceinline__ float load_as_float(const raw_bf16* p) { return h16_to_f32<FAD_BF16>(p->b); }
 __device__ __forceinline__ float load_as_float(const float* p) { return *p; }
 struct RunSumJob { const void* rows; int64_t n, ld; float* run; int start_zero; };
-struct RunSumLaunch { RunSumJob job[kMaxSets]; int d; };
+struct RunSumLaunch { RunSumJob job[kMaxSets]; int d; const RunSumJob* table; };      // table != nullptr: job blockIdx.y is table[blockIdx.y] (device)
+// the jobs of a segmented walk (per-file / per-song running sums): segment s = rows [offsets[s], offsets[s + 1]) -> out + s * d
+__global__ __launch_bounds__(256) void runsum_segment_jobs(const uint16_t* __restrict__ rows, int64_t ld, int d, const int64_t* __restrict__ offsets,
+                                                           int64_t n_segments, float* __restrict__ out, RunSumJob* __restrict__ jobs) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_segments) return;
+    RunSumJob j;
+    j.rows = rows + offsets[s] * ld; j.n = offsets[s + 1] - offsets[s]; j.ld = ld; j.run = out + s * d; j.start_zero = 1;
+    jobs[s] = j;
+}
 // Workgroup = 16 columns (d / 16 workgroups per matrix: the walk is latency-bound per CU -- ~32 KB in flight against ~2 us -- so it
 // is spread over many CUs): waves 1..3 stage tiles of 1024 rows x 16 columns through LDS with 16-byte loads (two tiles: the next one travels
 // while this one is walked), lanes 0..15 of wave 0 walk their columns down the tile -- the dependent float32 adds are the critical path.
@@ -1166,8 +1175,11 @@ constexpr size_t kRsLds = (size_t)2 * kRsCols * kRsPitch * sizeof(float);
 typedef _Float16 rs_h2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void moments_running_colsum_h16(RunSumLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float rs_lds[];                          // [2][32][kRsPitch]
-    const RunSumJob& j = L.job[blockIdx.y];
-    if (j.n <= 0) return;
+    const RunSumJob j = L.table ? L.table[blockIdx.y] : L.job[blockIdx.y];
+    if (j.n <= 0) {                                                  // (an empty segment's sums are zero; an empty set has no buffer to write)
+        if (L.table && threadIdx.x < kRsCols && blockIdx.x * kRsCols + threadIdx.x < L.d) j.run[blockIdx.x * kRsCols + threadIdx.x] = 0.f;
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int cb = blockIdx.x;

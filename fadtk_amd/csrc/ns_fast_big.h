@@ -295,7 +295,9 @@ constexpr int kI8BigStage = 36 * 64;                               // uint4 per 
 constexpr int kI8BigStages = FAD_I8_BIG_STAGES;
 constexpr size_t kI8BigLds = (size_t)kI8BigStages * kI8BigStage * 16 + 256;
 
-template <int MODE>
+// WITHR (I8_G for pairs on the wide chain): the block's residual R stays in registers and leaves as kVerScale R planes (SP_V2 reads them);
+// the songs' launches use the instantiation without it (holding R across the epilogue cost the songs' correction 10 %: r05d)
+template <int MODE, bool WITHR = false>
 __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob_pad) {
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
     double* red = reinterpret_cast<double*>(ring + kI8BigStages * kI8BigStage);
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
         for (int reg = 0; reg < 16; ++reg) {
             const int q = (reg & 3) + 8 * (reg >> 2), gr = row0 + q + 4 * kg, gc = col0 + n;
             const double R = A64[(int64_t)q * d] * inv_c - gp[reg];
-            gp[reg] = R;                                           // (kept for the verification planes below)
+            if constexpr (WITHR) gp[reg] = R;                      // (kept for the verification planes below)
             int half;
             const size_t zi = fa_elem(gr, gc, 0, d, half);         // Z^T[gr][gc] = Z[gc][gr] pairs with R[gr][gc] in tr(Z R)
             const double z = (double)used16(reinterpret_cast<const _Float16*>(Zm.at + zi)[half], reinterpret_cast<const _Float16*>(Zm.at + zi + 64)[half]);
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
             zmax[0] = mrow; zmax[1] = mcol;
         }
     }
-    if constexpr (MODE == I8_G) {
+    if constexpr (MODE == I8_G && WITHR) {
         if (g.Rv.a) {                                              // kVerScale R of this wave's block, both orientations (ns_fast.h: SP_V2 reads them)
             __builtin_amdgcn_wave_barrier();                       // (the |Z| sums above have read the area)
 #pragma unroll
