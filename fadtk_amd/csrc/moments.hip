@@ -130,7 +130,8 @@ static int ensure_kernel_attrs(int device) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
         }
     }
-    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum_h16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsLds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum_h16<32, 96, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsLds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum_h16<16, 192, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsLds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_f16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_f16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum<raw_bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRunLds));
@@ -381,6 +382,29 @@ static hipEvent_t runsum_ring_event(int device) {
     return e;
 }
 
+// The float16 walk in one of its two shapes (moments_kernels.h); the 16-column shape in groups of four matrices, so that a launch never
+// holds more than half of the CUs (a walk wave on a CU keeps 256-register kernels out of it).
+static int runsum_cols() {
+    static int cols = 0;
+    if (!cols) { const char* e = getenv("FAD_MOMENTS_RUNSUM_COLS"); cols = (e && atoi(e) == 16) ? 16 : 32; }
+    return cols;
+}
+static void launch_runsum_h16(const RunSumLaunch& L, int jobs, hipStream_t st) {
+    if (runsum_cols() == 32 || L.table) {
+        if (runsum_cols() == 32)
+            hipLaunchKernelGGL((moments_running_colsum_h16<32, 96, 5>), dim3((unsigned)cdiv(L.d, 32), (unsigned)jobs), dim3(256), (RsShape<32, 96, 5>::lds), st, L);
+        else
+            hipLaunchKernelGGL((moments_running_colsum_h16<16, 192, 4>), dim3((unsigned)cdiv(L.d, 16), (unsigned)jobs), dim3(256), (RsShape<16, 192, 4>::lds), st, L);
+        return;
+    }
+    for (int j0 = 0; j0 < jobs; j0 += 4) {
+        RunSumLaunch P = L;
+        const int m = (jobs - j0 < 4) ? jobs - j0 : 4;
+        for (int q = 0; q < m; ++q) P.job[q] = L.job[j0 + q];
+        hipLaunchKernelGGL((moments_running_colsum_h16<16, 192, 4>), dim3((unsigned)cdiv(L.d, 16), (unsigned)m), dim3(256), (RsShape<16, 192, 4>::lds), st, P);
+    }
+}
+
 // -> *joined: an event the caller's stream has to wait for before the update returns (the walk reads the caller's rows), or nullptr
 static int running_sums(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n, const int64_t* ld, int dtype,
                         hipStream_t st, hipEvent_t* joined) {
@@ -410,7 +434,6 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
     L.d = h0->d;
     FAD_TRY(ensure_kernel_attrs(h0->device));
     const dim3 grid((unsigned)cdiv(L.d, kRunCols), (unsigned)m);
-    const dim3 grid_h16((unsigned)cdiv(L.d, kRsCols), (unsigned)m);
     const size_t es = dtype_size(dtype);
     bool wide = (L.d % (int)(16 / es)) == 0;
     for (int i = 0; i < m && wide; ++i)
@@ -437,7 +460,7 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
             FAD_HIP_TRY(hipStreamWaitEvent(side, h0->rs_fork, 0));
             run_st = side;
         }
-        hipLaunchKernelGGL(moments_running_colsum_h16, grid_h16, dim3(256), kRsLds, run_st, L);
+        launch_runsum_h16(L, m, run_st);
         if (run_st != st && pend) {
             FAD_HIP_TRY(hipEventRecord(pend, run_st));
             for (int i = 0; i < count; ++i) if (n[i] > 0 && hs[i]->ref_mean && hs[i]->runsum_covers) hs[i]->rs_pending = pend;
@@ -732,7 +755,7 @@ int segment_running_sums_launch(const void* drows, int64_t dld, int d, int dtype
         RunSumLaunch L;
         memset(&L, 0, sizeof(L));
         L.d = d; L.table = table;
-        hipLaunchKernelGGL(moments_running_colsum_h16, dim3((unsigned)cdiv(d, kRsCols), (unsigned)n_segments), dim3(256), kRsLds, st, L);
+        launch_runsum_h16(L, (int)n_segments, st);
         FAD_HIP_TRY(hipGetLastError());
         return FAD_OK;
     }

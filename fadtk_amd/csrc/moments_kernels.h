@@ -1163,32 +1163,42 @@ __global__ __launch_bounds__(256) void moments_running_colsum(RunSumLaunch L) {
 //     three sets of 16 rows in rotation so that the reads are TWO sets ahead of the adds -- ~1.5 instructions per row, 9 cycles measured
 //     (the kernel above: a 4-byte LDS read and an add per row, ~11.5; float16 in LDS with v_fma_mix_f32: 21 -- the compiler separates
 //     dependent mix instructions by s_nop; float32 tiles with the reads one set ahead: 13 -- an LDS read takes ~130 cycles, r05a-c);
-//   * waves 1..3 feed it: per tile a loader thread owns 16 columns of ONE row (two 16-byte loads, issued FOUR tiles ahead and held in
+//   * waves 1..3 feed it: per tile a loader thread owns 16 columns of ONE row (two 16-byte loads, issued FIVE tiles ahead and held in
 //     registers meanwhile), widens its 16 values and writes them down the columns (the lanes of a wave write consecutive dwords).
 // 32 columns per workgroup = d / 32 workgroups per matrix (16 at d = 512, 128 for the eight matrices of a launch): HALF the chip at most.
 // That is deliberate: a walk wave on a CU (64 registers) keeps every workgroup of 256-register waves OUT of that CU, and the gated second
 // pass of the shift guard (moments_tile256<.., true>) is such a kernel -- with a walk workgroup on every CU even the launch that only
 // reads its gate and exits could not be placed, and the caller's stream stood still for 170-300 us per update (r05d).
 // Workgroups whose columns share the rows' 128-byte lines (two column blocks) are dealt to ONE XCD (b % 8).
-constexpr int kRsRows = 96, kRsPitch = kRsRows + 4, kRsCols = 32;      // pitch in floats
-constexpr size_t kRsLds = (size_t)2 * kRsCols * kRsPitch * sizeof(float);
+// Two shapes of the same kernel (FAD_MOMENTS_RUNSUM_COLS, read once; default 32): <32 columns, 96-row tiles, five tiles in flight> and
+// <16 columns, 192-row tiles, four tiles in flight> -- the second has 768 rows in flight and walked at 9 cycles per row alone (r05c), but
+// needs d / 16 workgroups per matrix: eight matrices take the whole chip, so its launches are cut into groups of four matrices.
 typedef _Float16 rs_h2 __attribute__((ext_vector_type(2)));
+template <int kRsCols, int kRsRows, int RING> struct RsShape {
+    static constexpr int pitch = kRsRows + 4;                         // floats
+    static constexpr size_t lds = (size_t)2 * kRsCols * pitch * sizeof(float);
+};
+constexpr size_t kRsLds = 25600;                                      // the larger of the two shapes' LDS (25 088 / 25 600 bytes)
+template <int kRsCols, int kRsRows, int RING>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void moments_running_colsum_h16(RunSumLaunch L) {
+    constexpr int kRsPitch = RsShape<kRsCols, kRsRows, RING>::pitch;
+    static_assert(kRsRows * kRsCols == 192 * 16, "a loader thread owns two 16-byte pieces of a tile");
     extern __shared__ __attribute__((aligned(16))) float rs_lds[];                          // [2][32][kRsPitch]
     const RunSumJob j = L.table ? L.table[blockIdx.y] : L.job[blockIdx.y];
     if (j.n <= 0) {                                                  // (an empty segment's sums are zero; an empty set has no buffer to write)
-        if (L.table && threadIdx.x < kRsCols && blockIdx.x * kRsCols + threadIdx.x < L.d) j.run[blockIdx.x * kRsCols + threadIdx.x] = 0.f;
+        if (L.table && (int)threadIdx.x < kRsCols && blockIdx.x * kRsCols + threadIdx.x < L.d) j.run[blockIdx.x * kRsCols + threadIdx.x] = 0.f;
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int cb = blockIdx.x;
-    if ((gridDim.x & 15) == 0) { const int w = blockIdx.x & 15; cb = (blockIdx.x & ~15) + 2 * (w & 7) + (w >> 3); }
+    constexpr int G = 64 / kRsCols;                                  // column blocks per 128-byte line of the rows: dealt to one XCD (b % 8)
+    if ((gridDim.x % (8 * G)) == 0) { const int w = blockIdx.x % (8 * G); cb = (blockIdx.x - w) + G * (w & 7) + (w >> 3); }
     const int c0 = cb * kRsCols;
     const uint16_t* base = static_cast<const uint16_t*>(j.rows);
     const int64_t ntiles = (j.n + kRsRows - 1) / kRsRows;
     auto rows_of = [&](int64_t t) { const int64_t left = j.n - t * kRsRows; return left < kRsRows ? (int)left : kRsRows; };
-    // Two roles, two loops (wave-uniform branch; every wave passes the same barriers): the register sets of the loaders (four tiles in
+    // Two roles, two loops (wave-uniform branch; every wave passes the same barriers): the register sets of the loaders (five tiles in
     // flight) and of the adding wave (48 rows of operands) never live side by side -- the kernel has to stay within 64 VGPRs
     if (wave == 0) {
         // ---- the adding wave: lanes 0..31 walk their column down the tile, 32 rows of reads ahead of the adds
@@ -1241,7 +1251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // ---- loaders (waves 1..3): thread lt owns 16 columns (`half`) of row lt % 96 of a tile.  (Rows past the end and columns past d are
         // never walked / written back: their addresses are clamped, their values do not matter.)
         const int lt = tid - 64;
-        const int lrow = lt % kRsRows, half = lt / kRsRows;              // 192 threads = 96 rows x 2 halves
+        const int lrow = lt % kRsRows, half = lt / kRsRows;              // 192 threads = 96 rows x 2 halves (32 columns) / 192 rows (16 columns)
         const int cbase = (c0 + 16 * half < L.d) ? 16 * half : 0;       // (d is a multiple of 8, not necessarily of 32)
         const int q1 = (c0 + cbase + 8 < L.d) ? 8 : 0;
         auto issue = [&](uint4 (&r)[2], int64_t t) {
@@ -1263,28 +1273,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
         };
-        uint4 rg0[2], rg1[2], rg2[2], rg3[2];                            // tile t + 1 + k waits in set (t + 1 + k) & 3
-        issue(rg0, 0);
-        if (1 < ntiles) issue(rg1, 1);
-        if (2 < ntiles) issue(rg2, 2);
-        if (3 < ntiles) issue(rg3, 3);
-        dump(rg0, 0);
-        if (4 < ntiles) issue(rg0, 4);
+        // RING tiles in flight in registers (tile tau waits in set tau % RING), plus the tile in the other LDS buffer.  32 columns: five
+        // (480 rows; six spill; with four -- r05e -- the walk fell to 14 cycles per row: 384 rows are 1.5 us of adds, less than a load takes
+        // beside the tile kernel); 16 columns: four (768 rows).
+        constexpr int PERIOD = (RING & 1) ? 2 * RING : RING;
+        uint4 rg[RING][2];
+#pragma unroll
+        for (int q = 0; q < RING; ++q)
+            if (q < ntiles) issue(rg[q], q);
+        dump(rg[0], 0);
+        if (RING < ntiles) issue(rg[0], RING);
         __syncthreads();
-        // phase t: the adding wave walks tile t; tile t + 1 goes from its register set into the other buffer, tile t + 5 takes the set
-        for (int64_t t = 0; t < ntiles; t += 4) {
-            // (the scheduling fences keep a set's new loads behind the last use of its old values: without them the compiler holds both)
-            if (t + 1 < ntiles) { dump(rg1, 1); __builtin_amdgcn_sched_barrier(0); if (t + 5 < ntiles) issue(rg1, t + 5); }
-            __syncthreads();
-            if (t + 1 >= ntiles) break;
-            if (t + 2 < ntiles) { dump(rg2, 0); __builtin_amdgcn_sched_barrier(0); if (t + 6 < ntiles) issue(rg2, t + 6); }
-            __syncthreads();
-            if (t + 2 >= ntiles) break;
-            if (t + 3 < ntiles) { dump(rg3, 1); __builtin_amdgcn_sched_barrier(0); if (t + 7 < ntiles) issue(rg3, t + 7); }
-            __syncthreads();
-            if (t + 3 >= ntiles) break;
-            if (t + 4 < ntiles) { dump(rg0, 0); __builtin_amdgcn_sched_barrier(0); if (t + 8 < ntiles) issue(rg0, t + 8); }
-            __syncthreads();
+        // phase t: the adding wave walks tile t; tile t + 1 goes from its register set into the other buffer, tile t + 1 + RING takes the set
+        for (int64_t t = 0; t < ntiles; t += PERIOD) {
+            bool last = false;
+#pragma unroll
+            for (int k = 0; k < PERIOD; ++k) {
+                if (!last) {
+                    const int64_t tt = t + k;
+                    // (the scheduling fence keeps a set's new loads behind the last use of its old values: without it the compiler holds both)
+                    if (tt + 1 < ntiles) { dump(rg[(k + 1) % RING], (k + 1) & 1); __builtin_amdgcn_sched_barrier(0); if (tt + 1 + RING < ntiles) issue(rg[(k + 1) % RING], tt + 1 + RING); }
+                    __syncthreads();
+                    last = tt + 1 >= ntiles;
+                }
+            }
+            if (last) break;
         }
     }
 }
