@@ -382,27 +382,17 @@ static hipEvent_t runsum_ring_event(int device) {
     return e;
 }
 
-// The float16 walk in one of its two shapes (moments_kernels.h); the 16-column shape in groups of four matrices, so that a launch never
-// holds more than half of the CUs (a walk wave on a CU keeps 256-register kernels out of it).
+// The float16 walk in one of its two shapes (moments_kernels.h): 16 columns per workgroup by default (FAD_MOMENTS_RUNSUM_COLS=32: the other).
 static int runsum_cols() {
     static int cols = 0;
-    if (!cols) { const char* e = getenv("FAD_MOMENTS_RUNSUM_COLS"); cols = (e && atoi(e) == 16) ? 16 : 32; }
+    if (!cols) { const char* e = getenv("FAD_MOMENTS_RUNSUM_COLS"); cols = (e && atoi(e) == 32) ? 32 : 16; }
     return cols;
 }
 static void launch_runsum_h16(const RunSumLaunch& L, int jobs, hipStream_t st) {
-    if (runsum_cols() == 32 || L.table) {
-        if (runsum_cols() == 32)
-            hipLaunchKernelGGL((moments_running_colsum_h16<32, 96, 5>), dim3((unsigned)cdiv(L.d, 32), (unsigned)jobs), dim3(256), (RsShape<32, 96, 5>::lds), st, L);
-        else
-            hipLaunchKernelGGL((moments_running_colsum_h16<16, 192, 4>), dim3((unsigned)cdiv(L.d, 16), (unsigned)jobs), dim3(256), (RsShape<16, 192, 4>::lds), st, L);
-        return;
-    }
-    for (int j0 = 0; j0 < jobs; j0 += 4) {
-        RunSumLaunch P = L;
-        const int m = (jobs - j0 < 4) ? jobs - j0 : 4;
-        for (int q = 0; q < m; ++q) P.job[q] = L.job[j0 + q];
-        hipLaunchKernelGGL((moments_running_colsum_h16<16, 192, 4>), dim3((unsigned)cdiv(L.d, 16), (unsigned)m), dim3(256), (RsShape<16, 192, 4>::lds), st, P);
-    }
+    if (runsum_cols() == 32)
+        hipLaunchKernelGGL((moments_running_colsum_h16<32, 96, 5>), dim3((unsigned)cdiv(L.d, 32), (unsigned)jobs), dim3(256), (RsShape<32, 96, 5>::lds), st, L);
+    else
+        hipLaunchKernelGGL((moments_running_colsum_h16<16, 192, 4>), dim3((unsigned)cdiv(L.d, 16), (unsigned)jobs), dim3(256), (RsShape<16, 192, 4>::lds), st, L);
 }
 
 // -> *joined: an event the caller's stream has to wait for before the update returns (the walk reads the caller's rows), or nullptr

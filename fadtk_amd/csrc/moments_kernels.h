@@ -1158,21 +1158,21 @@ __global__ __launch_bounds__(256) void moments_running_colsum(RunSumLaunch L) {
 // kernel: 25 KiB of LDS and at most 64 VGPRs per wave -- what one CU has left next to a tile workgroup (128 KiB, 2 x 224 registers per
 // SIMD) -- so that update_device_multi can put it on a stream of its own (moments.hip: running_sums).  What sets its pace is the
 // instruction stream of the ONE wave that adds -- a lone wave issues an instruction every ~5-6 cycles, and every row costs a DEPENDENT add:
-//   * the tile in LDS as float32, column-major ([32 columns][96 rows + 4]): one ds_read_b128 brings FOUR consecutive rows of the lane's
-//     column (pitch 400 bytes: the lanes' 16-byte pieces of a lane group fall into different bank groups), then four plain v_add_f32,
+//   * the tile in LDS as float32, column-major ([16 columns][192 rows + 4]): one ds_read_b128 brings FOUR consecutive rows of the lane's
+//     column (pitch 784 bytes: the lanes' 16-byte pieces of a lane group fall into different bank groups), then four plain v_add_f32,
 //     three sets of 16 rows in rotation so that the reads are TWO sets ahead of the adds -- ~1.5 instructions per row, 9 cycles measured
 //     (the kernel above: a 4-byte LDS read and an add per row, ~11.5; float16 in LDS with v_fma_mix_f32: 21 -- the compiler separates
 //     dependent mix instructions by s_nop; float32 tiles with the reads one set ahead: 13 -- an LDS read takes ~130 cycles, r05a-c);
-//   * waves 1..3 feed it: per tile a loader thread owns 16 columns of ONE row (two 16-byte loads, issued FIVE tiles ahead and held in
+//   * waves 1..3 feed it: per tile a loader thread owns 16 columns of ONE row (two 16-byte loads, issued four tiles ahead (768 rows) and held in
 //     registers meanwhile), widens its 16 values and writes them down the columns (the lanes of a wave write consecutive dwords).
-// 32 columns per workgroup = d / 32 workgroups per matrix (16 at d = 512, 128 for the eight matrices of a launch): HALF the chip at most.
-// That is deliberate: a walk wave on a CU (64 registers) keeps every workgroup of 256-register waves OUT of that CU, and the gated second
-// pass of the shift guard (moments_tile256<.., true>) is such a kernel -- with a walk workgroup on every CU even the launch that only
-// reads its gate and exits could not be placed, and the caller's stream stood still for 170-300 us per update (r05d).
-// Workgroups whose columns share the rows' 128-byte lines (two column blocks) are dealt to ONE XCD (b % 8).
-// Two shapes of the same kernel (FAD_MOMENTS_RUNSUM_COLS, read once; default 32): <32 columns, 96-row tiles, five tiles in flight> and
-// <16 columns, 192-row tiles, four tiles in flight> -- the second has 768 rows in flight and walked at 9 cycles per row alone (r05c), but
-// needs d / 16 workgroups per matrix: eight matrices take the whole chip, so its launches are cut into groups of four matrices.
+// A walk wave on a CU (64 registers) keeps every workgroup of 256-register waves OUT of that CU: the gated second pass of the shift guard
+// (moments_tile256<.., true>) was such a kernel -- with a walk workgroup on every CU even the launch that only reads its gate and exits
+// could not be placed, and the caller's stream stood still for 170-300 us per update (r05d) -- and is now held to 224 registers
+// (moments_tile256.h).  Workgroups whose columns share the rows' 128-byte lines are dealt to ONE XCD (b % 8).
+// Two shapes of the same kernel (FAD_MOMENTS_RUNSUM_COLS, read once): <16 columns, 192-row tiles, four tiles in flight> -- the default:
+// 9 cycles per row alone, 0.37 ms per 100 000 rows for up to eight matrices (d / 16 workgroups each: eight matrices of d = 512 put a
+// workgroup on every CU) -- and <32 columns, 96-row tiles, five tiles in flight>, which leaves half the chip alone but pays its per-tile
+// costs (the barrier, the first LDS reads of a tile) twice as often: 16-21 cycles per row (r05e, r05f).
 typedef _Float16 rs_h2 __attribute__((ext_vector_type(2)));
 template <int kRsCols, int kRsRows, int RING> struct RsShape {
     static constexpr int pitch = kRsRows + 4;                         // floats

@@ -420,8 +420,13 @@ __device__ __forceinline__ void tile256_wave(
     }
 }
 
+// Both passes are held to 224 registers (amdgpu_num_vgpr counts HALF of the unified file: 112 -> 224, found on a toy kernel).  The
+// first pass needs 222 anyway; the SHIFT pass -- the gated second pass of the shift guard -- took 256 (+ 52 B/lane of scratch), and a
+// workgroup of 256-register waves fills its SIMDs: even the launch that only reads the gate and exits could not be PLACED on a CU while a
+// wave of the running-sum walk (moments_kernels.h: moments_running_colsum_h16, 64 registers, on a stream of its own) sat there -- r05d: the
+// caller's stream stood still for 170-300 us per update.  The pass itself runs for heavily shifted frames only; there it now spills more.
 template <int KIND, bool SHIFT>
-__global__ __launch_bounds__(512) void moments_tile256(T256Launch L) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112))) void moments_tile256(T256Launch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];
     const int w = xcd_contiguous(blockIdx.x, L.total);
     int si = 0;
