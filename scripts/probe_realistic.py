@@ -16,19 +16,36 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "detached"
 for a, b in hs:
     a.set_reference_mean(mode != "off", detached=(mode == "detached")); b.set_reference_mean(mode != "off", detached=(mode == "detached"))
 
-def batch():
+NB = 3 if (len(sys.argv) > 2 and sys.argv[2] == "pipelined") else 1      # batches in flight (bench.py keeps three)
+groups = [hs] + [[(hip.Moments(bench.DIM), hip.Moments(bench.DIM)) for _ in range(8)] for _ in range(NB - 1)]
+for grp in groups[1:]:
+    for a, b in grp:
+        a.set_reference_mean(mode != "off", detached=(mode == "detached")); b.set_reference_mean(mode != "off", detached=(mode == "detached"))
+jobs = [None] * NB
+
+def feed(q):
     for g in range(2):
-        grp = hs[4 * g:4 * g + 4]
+        grp = groups[q][4 * g:4 * g + 4]
         for a, b in grp:
             a.reset(); b.reset()
         hip.Moments.update_multi([h for ab in grp for h in ab], [x for k in range(4) for x in pairs[k]])
-    return hip.FrechetMultiJob(hs, mean_dtype=K.FAD_F16).result()
+    jobs[q] = hip.FrechetMultiJob(groups[q], mean_dtype=K.FAD_F16)
 
-for _ in range(4):
-    res = batch()
+def run(n):
+    res = None
+    for i in range(n):
+        q = i % NB
+        if jobs[q] is not None:
+            res = jobs[q].result(); jobs[q] = None
+        feed(q)
+    for q in range(NB):
+        if jobs[q] is not None:
+            res = jobs[q].result(); jobs[q] = None
+    return res
+
+run(6)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 12
-for _ in range(n):
-    res = batch()
+res = run(n)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"mode {mode}: {dt * 1e3:.3f} ms per batch of 8 scores = {8 / dt:.0f} scores/s; last batch: routes {[d['route'] for _, d in res]} iterations {[d['iters'] for _, d in res]}")
+print(f"mode {mode}, {NB} batch(es) in flight: {dt * 1e3:.3f} ms per batch of 8 scores = {8 / dt:.0f} scores/s; last batch: routes {[d['route'] for _, d in res]} iterations {[d['iters'] for _, d in res]}")
