@@ -735,8 +735,10 @@ int segment_running_sums_launch(const void* drows, int64_t dld, int d, int dtype
     // float16 rows on 16-byte aligned pitches, segments of some length: the LDS-staged walk of the plain update, one workgroup per
     // (segment, 32 columns) -- the rows of a segment stream through coalesced, the adds cost ~9 cycles a row; one thread per 8 columns of
     // a segment is latency-bound per THREAD (2.4 us per 16 rows in flight: 0.23 ms for 32 songs of [1500 x 768], r05d)
-    if (jobs && dtype == FAD_F16 && d % 8 == 0 && (dld * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(drows) & 15u) == 0 && mean_rows >= 256 &&
-        n_segments <= 65535) {
+    // (d >= 256: with fewer columns a row is one or two cache lines, the 16-column workgroups of a segment land on different XCDs and every
+    //  line crosses the fabric once per workgroup -- config 4's files, d = 128: 1.4 ms per group of 4096 against 0.4 with a thread per 8 columns)
+    if (jobs && dtype == FAD_F16 && d % 8 == 0 && d >= 256 && (dld * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(drows) & 15u) == 0 &&
+        mean_rows >= 256 && n_segments <= 65535) {
         FAD_TRY(ensure_kernel_attrs(device));
         FAD_TRY(jobs->reserve((size_t)n_segments * sizeof(RunSumJob)));
         RunSumJob* table = static_cast<RunSumJob*>(jobs->p);
