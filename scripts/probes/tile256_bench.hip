@@ -22,7 +22,10 @@ int main(int argc, char** argv) {
     const int sets = 2, npairs = (getenv("T2_SAME_PAIR") ? 1 : 3), n_cu = 256;
     const int nsb = (d + 255) / 256, dpad = nsb * 256;
     std::vector<uint16_t*> E(npairs * sets);
-    for (auto& p : E) { hipMalloc(&p, (size_t)n * d * 2 + 4096); fill<<<2048, 256>>>(p, (size_t)n * d, (uint32_t)(&p - E.data()) * 7919u); }
+    for (auto& p : E) {
+        hipMalloc(&p, (size_t)n * d * 2 + 4096); fill<<<2048, 256>>>(p, (size_t)n * d, (uint32_t)(&p - E.data()) * 7919u);
+        if (getenv("T2_ZERO")) hipMemset(p, 0, (size_t)n * d * 2);        // all-zero frames: the same instruction stream at the chip's lowest switching power
+    }
     T256Launch L; memset(&L, 0, sizeof(L));
     const int plan = getenv("T2_PLAN") ? atoi(getenv("T2_PLAN")) : 0;
     L.nsets = sets; L.d = d; L.nsb = nsb; L.plan = plan; L.NT = t256::item_types(nsb, L.type, L.sa, L.sb, plan);
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
         R.sl = sl;
         const int G = 256 / sl;
         const int blocks = (R.nblk * 256 + G - 1) / G + (d + 63) / 64;
-        double tk = 0, tr = 0, tr2 = 0; const int reps = 12;
+        double tk = 0, tr = 0, tr2 = 0; const int reps = getenv("T2_REPS") ? atoi(getenv("T2_REPS")) : 12;      // (T2_REPS: long runs for clock / power sampling)
         for (int it = -2; it < reps; ++it) {
             for (int i = 0; i < sets; ++i) L.set[i].E = E[((it + 2) % npairs) * sets + i];
             hipEventRecord(e[0]);
