@@ -70,6 +70,8 @@ struct DevBuf {
 int segment_running_sums_launch(const void* rows, int64_t ld, int d, int dtype, const int64_t* d_offsets, int64_t n_segments, float* d_out,
                                 hipStream_t st, DevBuf* jobs = nullptr, int64_t mean_rows = 0, int device = 0);
 
+// moments.hip: the library's side stream of a device (non-blocking, high priority; nullptr with FAD_MOMENTS_RUNSUM_SIDE=0): the running-sum walks
+hipStream_t moments_side_stream(int device);
 // moments.hip: covariances of B songs of float16 frames on the moments tile kernels (for frechet.hip's batched per-song chain)
 bool song_cov_f16_ok(const void* rows, int64_t ld, int d);
 int song_cov_f16_launch(const void* rows, int64_t ld, int d, const int64_t* d_offsets, const int64_t* d_song_ids, int64_t B,

@@ -48,8 +48,10 @@ template <> __device__ __forceinline__ double round_like_input<r_bf16>(double v)
 // frames carry an offset (rounds 1-4 returned the rounded EXACT mean for 16-bit frames; fixture g4.shifted holds the walk to the
 // reference's own scores).  One thread walks the column in that order, eight loads in flight; float64 frames: numpy's sum is the exact one.
 template <typename TIn> __device__ __forceinline__ float ld_f32(const TIn* p, int64_t i) { return (float)ld_f64<TIn>(p, i); }
-// (`run` != nullptr: the song's running sum of this column, walked by segment_running_sums_launch in front of the statistics kernel --
-//  songs of many frames: one thread per column walking 2250 rows inside the statistics kernel cost 0.5 ms of a 2.6 ms call)
+// (`run` != nullptr: the song's running sum of this column, walked by segment_running_sums_launch -- songs of many frames: one thread
+//  per column walking 2250 rows inside the statistics kernel cost 0.5 ms of a 2.6 ms call.  kMeanPlaceholder: the rounded exact mean for
+//  now; the walk runs on a stream of its own beside the covariances and the square roots, and batched_impl swaps the mean term at the end)
+#define kMeanPlaceholder (reinterpret_cast<const float*>(uintptr_t(1)))
 template <typename TIn>
 __device__ __forceinline__ double mean_like_reference(const TIn* __restrict__ rows, int64_t ld, int a, int64_t r0, int64_t r1, double m_exact,
                                                       const float* __restrict__ run = nullptr) {
@@ -57,6 +59,7 @@ __device__ __forceinline__ double mean_like_reference(const TIn* __restrict__ ro
         return m_exact;
     } else {
         if (r1 <= r0) return 0.0;
+        if (run == kMeanPlaceholder) return round_like_input<TIn>(m_exact);      // (the caller replaces the mean term afterwards: batched_impl)
         if (run) return round_like_input<TIn>(numpy_mean_of_f32_sum(*run, (double)(r1 - r0)));
         float acc = 0.f;
         int64_t r = r0;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void song_stats_long(const TIn* __restrict__ r
     psum[rl][cl] = sq;
     __syncthreads();
     if (rl == 0 && ok) {
-        const double mr = mean_mode ? mean_like_reference<TIn>(rows, ld, a, r0, r1, m, runs ? runs + s * d + a : nullptr) : m;
+        const double mr = mean_mode ? mean_like_reference<TIn>(rows, ld, a, r0, r1, m, runs == kMeanPlaceholder ? runs : (runs ? runs + s * d + a : nullptr)) : m;
         if (mean_exact) mean_exact[s * d + a] = m;
         ts = (psum[0][cl] + psum[1][cl]) + (psum[2][cl] + psum[3][cl]);
         const double df = mu_b[a] - mr;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict
             for (int l = 0; l < 16; ++l) { s1 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2]; s2 += sm[((l * 16 + (cl >> 3)) * 8 + (cl & 7)) * 2 + 1]; }
             const double first = (n > 0) ? ld_f64<r_f16>(reinterpret_cast<const r_f16*>(rows), r0 * ld + a) : 0.0;
             const double m = (n > 0) ? first + s1 / (double)n : 0.0;
-            const double mr = mean_mode ? mean_like_reference<r_f16>(reinterpret_cast<const r_f16*>(rows), ld, a, r0, r1, m, runs ? runs + s * d + a : nullptr) : m;
+            const double mr = mean_mode ? mean_like_reference<r_f16>(reinterpret_cast<const r_f16*>(rows), ld, a, r0, r1, m, runs == kMeanPlaceholder ? runs : (runs ? runs + s * d + a : nullptr)) : m;
             if (mean_exact) mean_exact[s * d + a] = m;
             const double df = mu_b[a] - mr;
             mt = df * df;
@@ -209,6 +212,23 @@ __global__ __launch_bounds__(256) void song_stats_f16(const uint16_t* __restrict
         double* o = out + 2 * (s * gridDim.y + blockIdx.y);
         o[0] = mt; o[1] = (n > 1) ? ts / (double)(n - 1) : 0.0;
     }
+}
+
+// ||mu_b - mean||^2 per song with the mean as np.mean forms it, from the song's float32 running column sums (segment_running_sums_launch)
+template <typename TIn>
+__global__ __launch_bounds__(256) void song_mean_terms_from_runs(const float* __restrict__ runs, const int64_t* __restrict__ offsets, int d,
+                                                                 const double* __restrict__ mu_b, double* __restrict__ mt_out) {
+    __shared__ double red[4];
+    const int64_t s = blockIdx.x;
+    const double n = (double)(offsets[s + 1] - offsets[s]);
+    double mt = 0.0;
+    if (n > 0.0)
+        for (int a = threadIdx.x; a < d; a += 256) {
+            const double df = mu_b[a] - round_like_input<TIn>(numpy_mean_of_f32_sum(runs[s * d + a], n));
+            mt += df * df;
+        }
+    mt = block_sum(mt, red);
+    if (threadIdx.x == 0) mt_out[s] = mt;
 }
 
 __global__ __launch_bounds__(256) void song_scal_sum(const double* __restrict__ part, int chunks, int64_t n_songs,
@@ -630,9 +650,9 @@ __global__ __launch_bounds__(256) void identity_and_zeros(double* __restrict__ e
 namespace fad {
 
 template <typename TIn>
-static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const TIn* drows, int64_t ld,
+static int batched_core(int d, const double* dmu_b, const double* dcov_b, const TIn* drows, int64_t ld,
                         const int64_t* h_off, const int64_t* d_off, int64_t n_songs, int mean_mode, int device,
-                        hipStream_t st, Workspace& ws, const SongKnobs& knobs, double* out_scores, int32_t* out_status) {
+                        hipStream_t st, Workspace& ws, const SongKnobs& knobs, double* out_scores, int32_t* out_status, bool defer_means) {
     const int64_t dd = (int64_t)d * d;
     std::vector<int64_t> pairs, gram, gram_ns, general;
     const bool gram_on = knobs.gram;
@@ -661,8 +681,9 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
     if (others) {                       // (two-frame songs get their scalars from pair_stats_diff)
         const bool stats16_on = knobs.stats16;
         // songs of many frames: numpy's float32 running sums per song in a kernel of their own (the reference's per-song mean, fad.py:377)
-        const float* runs = nullptr;
-        if (mean_mode && !std::is_same<TIn, double>::value && (h_off[n_songs] - h_off[0]) / n_songs >= 64) {
+        // -- on a stream of its own when the caller (batched_impl) defers the mean terms
+        const float* runs = defer_means ? kMeanPlaceholder : nullptr;
+        if (!defer_means && mean_mode && !std::is_same<TIn, double>::value && (h_off[n_songs] - h_off[0]) / n_songs >= 64) {
             FAD_TRY(ws.songrun.reserve((size_t)n_songs * d * sizeof(float)));
             const int code = std::is_same<TIn, r_f16>::value ? FAD_F16 : (std::is_same<TIn, r_bf16>::value ? FAD_BF16 : FAD_F32);
             FAD_TRY(segment_running_sums_launch(drows, ld, d, code, d_off, n_songs, static_cast<float*>(ws.songrun.p), st, &ws.songjobs,
@@ -1023,6 +1044,53 @@ static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const 
         }
     }
     return FAD_OK;
+}
+
+// Songs of many frames with the reference's own means (mean_mode = 1, 16-bit / float32 frames): the walk of numpy's running sums is a second
+// pass over all frames (0.4 ms for 2000 x [2250 x 128]) that nothing but the MEAN TERM of a score waits for -- and a score is linear in it.
+// So the walk and the mean terms run on the library's side stream beside the covariances and the square roots (MFMA work, the HBM idle), the
+// statistics kernels take the rounded exact mean as a placeholder, and the difference of the two mean terms is added to the scores at the end.
+template <typename TIn>
+static int batched_impl(int d, const double* dmu_b, const double* dcov_b, const TIn* drows, int64_t ld,
+                        const int64_t* h_off, const int64_t* d_off, int64_t n_songs, int mean_mode, int device,
+                        hipStream_t st, Workspace& ws, const SongKnobs& knobs, double* out_scores, int32_t* out_status) {
+    int64_t long_songs = 0;
+    for (int64_t s = 0; s < n_songs; ++s) long_songs += (h_off[s + 1] - h_off[s]) > 2;
+    hipStream_t side = moments_side_stream(device);
+    const bool defer = mean_mode == 1 && !std::is_same<TIn, double>::value && long_songs > 0 && side != nullptr &&
+                       (h_off[n_songs] - h_off[0]) / n_songs >= 64;
+    if (!defer) return batched_core<TIn>(d, dmu_b, dcov_b, drows, ld, h_off, d_off, n_songs, mean_mode, device, st, ws, knobs, out_scores, out_status, false);
+    FAD_TRY(ws.songrun.reserve((size_t)n_songs * d * sizeof(float) + (size_t)n_songs * sizeof(double) + 64));
+    float* runs = static_cast<float*>(ws.songrun.p);
+    double* mt_ref = reinterpret_cast<double*>(static_cast<char*>(ws.songrun.p) + (((size_t)n_songs * d * sizeof(float) + 63) & ~(size_t)63));
+    hipEvent_t fork = nullptr, join = nullptr;
+    FAD_HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    FAD_HIP_TRY(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    int rc = FAD_OK;
+    do {
+        if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess) { rc = set_error(FAD_ERR_HIP, "event fork failed"); break; }
+        const int code = std::is_same<TIn, r_f16>::value ? FAD_F16 : (std::is_same<TIn, r_bf16>::value ? FAD_BF16 : FAD_F32);
+        rc = segment_running_sums_launch(drows, ld, d, code, d_off, n_songs, runs, side, &ws.songjobs, (h_off[n_songs] - h_off[0]) / n_songs, device);
+        if (rc != FAD_OK) break;
+        hipLaunchKernelGGL((song_mean_terms_from_runs<TIn>), dim3((unsigned)n_songs), dim3(256), 0, side, runs, d_off, d, dmu_b, mt_ref);
+        if (hipEventRecord(join, side) != hipSuccess) { rc = set_error(FAD_ERR_HIP, "event join failed"); break; }
+        rc = batched_core<TIn>(d, dmu_b, dcov_b, drows, ld, h_off, d_off, n_songs, mean_mode, device, st, ws, knobs, out_scores, out_status, true);
+        // the swap: score += ||mu_b - numpy's mean||^2 - ||mu_b - rounded exact mean||^2   (songs of more than two frames; the placeholders are the
+        // statistics kernels' scal[2 s], still in the workspace)
+        if (hipStreamWaitEvent(st, join, 0) != hipSuccess) { if (rc == FAD_OK) rc = set_error(FAD_ERR_HIP, "event wait failed"); break; }
+        std::vector<double> h_ref((size_t)n_songs), h_scal((size_t)2 * n_songs);
+        if (hipMemcpyAsync(h_ref.data(), mt_ref, h_ref.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(h_scal.data(), ws.songbuf.p, h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { if (rc == FAD_OK) rc = set_error(FAD_ERR_HIP, "copy of the mean terms failed"); break; }
+        for (int64_t s = 0; s < n_songs; ++s) {
+            if (h_off[s + 1] - h_off[s] <= 2) continue;                 // (two-frame songs took numpy's mean inside pair_stats_diff)
+            if (!(out_scores[s] == out_scores[s])) continue;             // (not scored)
+            out_scores[s] += h_ref[s] - h_scal[2 * s];
+        }
+    } while (false);
+    if (rc != FAD_OK) (void)hipStreamSynchronize(side);                  // (nothing of this call may still be reading the frames when it returns an error)
+    (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
+    return rc;
 }
 
 // (first-use warm-up, common.cpp: warm_code_objects -- loading this translation unit's code object costs ~75 ms at the first launch)

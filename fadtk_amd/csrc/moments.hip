@@ -729,6 +729,7 @@ static int segment_sums_device(fad_moments* h, const void* rows, int64_t ld, int
 }
 
 // numpy's float32 running column sums of every segment (device rows, device offsets) -> dout [n_segments x d] float32 (device)
+hipStream_t moments_side_stream(int device) { return runsum_side_stream(device); }
 int segment_running_sums_launch(const void* drows, int64_t dld, int d, int dtype, const int64_t* doff, int64_t n_segments, float* dout,
                                 hipStream_t st, DevBuf* jobs, int64_t mean_rows, int device) {
     const size_t es = dtype_size(dtype);
