@@ -163,3 +163,91 @@ def test_fuzz_per_song_scores_fast_chain_against_float64_routes_and_oracle(monke
         # (frechet_songs.hip: mean_like_reference), so float32 frames meet the same bound as float16 ones
         assert (rel_o <= tol).all(), (what, rel_o)
         assert (rel_f <= tol).all(), (what, rel_f)
+
+
+def test_fuzz_wide_chain_decaying_pairs_against_oracle():
+    """Round 5's wide chain (scaled low-precision steps + a-posteriori verification) on the spectra it was built for, drawn at random:
+    D in {256, 384, 512, 768}, covariance spectra k^-p with p in [0.2, 1.7] (different exponents for the two sets, different random bases
+    for some pairs), sample sizes from 1.5 D to 60 D, overall scales 1e-3 .. 30, mean offsets -- single pairs through the blocking call,
+    then the same pairs as batches of up to eight through fad_frechet_from_moments_multi_begin.  Whatever route a pair takes (chain,
+    verified chain, float64), the distance must agree with the reference's eig formula (fad.py:91-92) to 1e-6 -- a hundredth of the
+    north star's tolerance -- and the batch with the single scores."""
+    import torch
+    from fadtk_amd import hip
+    rng = np.random.default_rng(505)
+    pairs, info = [], []
+    for case in range(24):
+        d = int(rng.choice([256, 384, 512, 512, 768]))
+        p1 = float(rng.uniform(0.2, 1.7)); p2 = p1 + float(rng.choice([0.0, 0.0, 0.1, -0.1]))
+        n1 = int(d * rng.choice([1.5, 4, 20, 60])); n2 = int(d * rng.choice([1.5, 4, 20]))
+        scale = float(rng.choice([1e-3, 1.0, 1.0, 30.0]))
+        q1, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        q2 = q1 if rng.random() < 0.7 else np.linalg.qr(q1 + 0.05 * rng.standard_normal((d, d)))[0]
+        lam1 = np.arange(1, d + 1) ** (-p1 / 2.0); lam2 = np.arange(1, d + 1) ** (-p2 / 2.0)
+        off = float(rng.choice([0.0, 0.01, 0.5]))
+        a = (((rng.standard_normal((n1, d)) * lam1) @ q1.T) * scale).astype(np.float16)
+        b = (((1.05 * rng.standard_normal((n2, d)) * lam2) @ q2.T + off * lam2.mean()) * scale).astype(np.float16)
+        pairs.append((a, b)); info.append(f"case {case}: d={d} p=({p1:.2f},{p2:.2f}) n=({n1},{n2}) scale={scale} off={off}")
+    worst, routes, by_d = 0.0, [], {}
+    for k, ((a, b), what) in enumerate(zip(pairs, info)):
+        d = a.shape[1]
+        ma, mb = hip.Moments(d), hip.Moments(d)
+        ma.update(torch.from_numpy(a).cuda()); mb.update(torch.from_numpy(b).cuda())
+        got, dg = hip.frechet_from_moments(ma, mb, mean_dtype=0)
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        want = O.frechet_distance(a64.mean(0), np.cov(a64, rowvar=False), b64.mean(0), np.cov(b64, rowvar=False), run_sqrtm=False)
+        err = abs(got - want) / abs(want)
+        routes.append(int(dg["route"]))
+        print(f"{what} want={want:.6e} got={got:.6e} rel={err:.1e} route={dg['route']} iterations={dg['iters']}")
+        assert err <= 1e-6, what
+        worst = max(worst, err)
+        by_d.setdefault(d, []).append((ma, mb, got))
+    assert 2 in routes, "none of the pairs stayed on the chain: the case list no longer exercises it"
+    for d, lst in by_d.items():                                       # the same pairs, batched
+        for lo in range(0, len(lst), 8):
+            grp = lst[lo:lo + 8]
+            res = hip.FrechetMultiJob([(ma, mb) for ma, mb, _ in grp], mean_dtype=0).result()
+            for (f, dg), (_, _, single) in zip(res, grp):
+                assert abs(f - single) <= 2e-6 * abs(single), (d, f, single, dg)
+    for lst in by_d.values():
+        for ma, mb, _ in lst:
+            ma.close(); mb.close()
+    print("worst relative error", worst)
+
+
+def test_fuzz_running_sum_mean_on_hostile_columns():
+    """np.mean's float32 running sum (fadtk/fad.py:48) bit for bit on columns built to break a re-ordered or wider sum: sums that hover
+    around a power of two (the rounding unit changes back and forth), exact ties (x an odd multiple of half the unit: round-to-even
+    depends on the running sum's last bit), cancellation of large values of both signs, a column that overflows float16's range in the
+    sum but not float32's, denormal-sized frames, and Inf / NaN entries (numpy propagates them: so must the walk).  Device rows and
+    host rows (the latter in pieces), one update and three."""
+    import torch
+    from fadtk_amd import hip
+    rng = np.random.default_rng(77)
+    n, d = 50000, 512
+    x = (rng.standard_normal((n, d)) * 0.5 + 0.25).astype(np.float32)
+    x[:, 0] = np.where(np.arange(n) % 2 == 0, 1024.0, -1023.5)                      # hovers around 2^k for ever larger k ... slowly upward
+    x[:, 1] = 0.0009765625 * (2 * rng.integers(0, 8, n) + 1)                        # odd multiples of 2^-10: ties once the sum passes 2^14
+    x[:, 2] = rng.choice([60000.0, -60000.0], n)                                    # cancellation at the top of float16's range
+    x[:, 3] = 60000.0                                                               # the sum reaches 3e9
+    x[:, 4] = 6e-8 * rng.integers(1, 5, n)                                          # float16 denormals
+    x[:, 5] = rng.standard_normal(n) * 1e-3 + 2048.0                                # |mean| / std = 2e6
+    x[:, 6] = np.where(rng.random(n) < 0.5, 0.5, -0.5) + 4096.0 * (np.arange(n) == 17)
+    x16 = x.astype(np.float16)
+    x16[40000, 7] = np.inf
+    x16[123, 8] = np.nan
+    x16[30000, 9] = np.inf; x16[30001, 9] = -np.inf                                 # Inf - Inf = NaN from then on
+    with np.errstate(all="ignore"):
+        want = np.mean(x16, axis=0)
+    assert want.dtype == np.float16 and np.isnan(want[8]) and np.isnan(want[9]) and np.isinf(want[7])
+    for rows, cuts in ((torch.from_numpy(x16).cuda(), (n,)), (torch.from_numpy(x16).cuda(), (7, 20001, n)), (x16, (n,)), (x16, (33333, n))):
+        with hip.Moments(d) as acc:
+            acc.set_reference_mean(True)
+            lo = 0
+            for hi in cuts:
+                acc.update(rows[lo:hi]); lo = hi
+            mu, _, cnt = acc.finalize()
+        assert cnt == n
+        with np.errstate(all="ignore"):
+            got = mu.astype(np.float32).astype(np.float16)
+        np.testing.assert_array_equal(got, want)                                    # (assert_array_equal treats NaN == NaN, Inf == Inf)
