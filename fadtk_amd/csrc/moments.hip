@@ -676,12 +676,13 @@ static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, i
     for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
         const int64_t m = (n - r0 < chunk_rows) ? n - r0 : chunk_rows;
         const char* src = static_cast<const char*>(rows) + r0 * ld * es;
-        // Pieces of ~12 MB, each copied and then accumulated; the copies on a stream of the handle's own, so that the copy of piece p + 1
+        // Pieces of ~24 MB, each copied and then accumulated; the copies on a stream of the handle's own, so that the copy of piece p + 1
         // (the host is inside the runtime's staged copy for its whole duration) runs while the device takes the moments -- and, for a
         // handle that carries numpy's running sums, the walk -- of piece p: only the last piece's kernels are left when the last byte has
         // crossed PCIe.  (One copy + one update: 2.04 ms of copy, then 0.07 + 0.37 ms of kernels for [100 000 x 512] float16.)
-        // FAD_H2D_PIECE_KB (default 12288; 0 = one piece, on the caller's stream).
-        static const int64_t piece_bytes = [] { const char* e = getenv("FAD_H2D_PIECE_KB"); return (int64_t)(e ? atoll(e) : 12288) * 1024; }();
+        // Measured (scripts/probe_host_pieces.py, r05l): one piece 2.40 ms per update, 12 MB pieces 2.36, 24 MB pieces 2.24 (the copy alone: 2.04).
+        // FAD_H2D_PIECE_KB (default 24576; 0 = one piece, on the caller's stream).
+        static const int64_t piece_bytes = [] { const char* e = getenv("FAD_H2D_PIECE_KB"); return (int64_t)(e ? atoll(e) : 24576) * 1024; }();
         int64_t piece_rows = (piece_bytes > 0) ? piece_bytes / (row_bytes > 0 ? row_bytes : 1) : m;
         piece_rows = (piece_rows / 256) * 256;
         if (piece_rows < 4096 || m < 2 * piece_rows) piece_rows = m;

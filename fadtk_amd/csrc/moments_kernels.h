@@ -1184,7 +1184,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     constexpr int kRsPitch = RsShape<kRsCols, kRsRows, RING>::pitch;
     static_assert(kRsRows * kRsCols == 192 * 16, "a loader thread owns two 16-byte pieces of a tile");
     extern __shared__ __attribute__((aligned(16))) float rs_lds[];                          // [2][32][kRsPitch]
-    const RunSumJob j = L.table ? L.table[blockIdx.y] : L.job[blockIdx.y];
+    // (the job comes through vector loads -- a table in global memory or a dynamically indexed kernel argument; its fields are the same for
+    //  every lane and are moved to scalar registers, or four of the kernel's 64 VGPRs hold them and the adding wave spills)
+    const RunSumJob jv = L.table ? L.table[blockIdx.y] : L.job[blockIdx.y];
+    auto uni64 = [](uint64_t v) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
+    RunSumJob j;
+    j.rows = reinterpret_cast<const void*>(uni64(reinterpret_cast<uint64_t>(jv.rows)));
+    j.run = reinterpret_cast<float*>(uni64(reinterpret_cast<uint64_t>(jv.run)));
+    j.n = (int64_t)uni64((uint64_t)jv.n); j.ld = (int64_t)uni64((uint64_t)jv.ld);
+    j.start_zero = __builtin_amdgcn_readfirstlane(jv.start_zero);
     if (j.n <= 0) {                                                  // (an empty segment's sums are zero; an empty set has no buffer to write)
         if (L.table && (int)threadIdx.x < kRsCols && blockIdx.x * kRsCols + threadIdx.x < L.d) j.run[blockIdx.x * kRsCols + threadIdx.x] = 0.f;
         return;
@@ -1204,7 +1213,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // ---- the adding wave: lanes 0..31 walk their column down the tile, 32 rows of reads ahead of the adds
         const bool adder = lane < kRsCols;
         const bool col_ok = adder && c0 + lane < L.d;
-        float s = (col_ok && !j.start_zero) ? j.run[c0 + lane] : 0.f;
+        typedef __attribute__((address_space(1))) const float g_f32;
+        float s = (col_ok && !j.start_zero) ? *(g_f32*)(uintptr_t)(j.run + c0 + lane) : 0.f;
         auto walk = [&](int buf, int rows_here) {
             const float4* col = reinterpret_cast<const float4*>(rs_lds + ((size_t)buf * kRsCols + (lane & (kRsCols - 1))) * kRsPitch);
             auto ld4 = [&](float4 (&v)[4], int r) {
@@ -1226,6 +1236,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 for (int k = 0; k < kRsRows / 16; ++k) {
                     if (k + 2 < kRsRows / 16) ld4(v[(k + 2) % 3], 16 * (k + 2));
                     __builtin_amdgcn_sched_barrier(0);
+                    // ONE wait for the four reads of set k (LDS returns in order: at most the 8 / 4 / 0 reads of the younger sets stay out) instead
+                    // of the compiler's one per read: a lone wave pays ~6 cycles for every instruction it issues, waits included
+                    // (scripts/probes/dep_add_rate.hip: 5.75 cycles per dependent v_add_f32).  simm16: lgkmcnt in bits 11:8, vmcnt / expcnt at maximum.
+                    if (k + 2 < kRsRows / 16) __builtin_amdgcn_s_waitcnt(0xC87F);
+                    else if (k + 1 < kRsRows / 16) __builtin_amdgcn_s_waitcnt(0xC47F);
+                    else __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);                       // (the adds are no memory operations: nothing else keeps them below the wait)
                     add16(v[k % 3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1256,9 +1273,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int q1 = (c0 + cbase + 8 < L.d) ? 8 : 0;
         auto issue = [&](uint4 (&r)[2], int64_t t) {
             const int64_t row = t * kRsRows + lrow;
+            // (global, not flat, loads: the pointer comes out of a structure in memory and the compiler cannot tell -- a flat load counts
+            //  on the LDS counter as well and forces full waits around the LDS traffic)
+            typedef __attribute__((address_space(1))) const uint4 g_u4;
             const uint16_t* p = base + (row < j.n ? row : j.n - 1) * j.ld + c0 + cbase;
-            r[0] = *reinterpret_cast<const uint4*>(p);
-            r[1] = *reinterpret_cast<const uint4*>(p + q1);
+            r[0] = *(g_u4*)(uintptr_t)p;
+            r[1] = *(g_u4*)(uintptr_t)(p + q1);
         };
         auto dump = [&](const uint4 (&r)[2], int buf) {
             float* dst = rs_lds + ((size_t)buf * kRsCols + 16 * half) * kRsPitch + lrow;

@@ -65,11 +65,13 @@ class Moments:
 
     def release_inputs(self, staging: bool = True):
         """Forget the last device tensor fed (kept alive for the enqueued kernels -- call this only after something synchronised,
-        e.g. finalize() or a collected score) and, with ``staging``, give back a host-input staging area above 64 MiB: a cached
-        handle must not pin the caller's frames or a frame-matrix-sized buffer in HBM between calls."""
+        e.g. finalize() or a collected score) and, with ``staging``, give back a host-input staging area above 256 MiB: a cached
+        handle must not pin the caller's frames in HBM between calls, nor a large share of it -- but freeing and re-allocating the
+        102 MB of a config-3 set on every call (hipFree synchronises, hipMalloc maps pages) cost ~0.5 ms of a 2.7 ms
+        calc_embd_statistics (round 5); 256 MiB is 0.1 % of this GPU's memory."""
         self._keep = None
         if staging:
-            K.check(self._lib.fad_moments_trim(self._h, 64 << 20), "fad_moments_trim")
+            K.check(self._lib.fad_moments_trim(self._h, 256 << 20), "fad_moments_trim")
 
     def settle(self):
         """Make a pending reset visible in the packed buffer (the zeroing is deferred until something reads it)."""

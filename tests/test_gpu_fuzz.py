@@ -173,7 +173,7 @@ def test_fuzz_wide_chain_decaying_pairs_against_oracle():
     verified chain, float64), the distance must agree with the reference's eig formula (fad.py:91-92) to 1e-6 -- a hundredth of the
     north star's tolerance -- and the batch with the single scores."""
     import torch
-    from fadtk_amd import hip
+    from fadtk_amd import hip, _capi as K
     rng = np.random.default_rng(505)
     pairs, info = [], []
     for case in range(24):
@@ -192,10 +192,11 @@ def test_fuzz_wide_chain_decaying_pairs_against_oracle():
     for k, ((a, b), what) in enumerate(zip(pairs, info)):
         d = a.shape[1]
         ma, mb = hip.Moments(d), hip.Moments(d)
+        ma.set_reference_mean(True); mb.set_reference_mean(True)      # numpy's own float16 means (fad.py:48), as calc_embd_statistics carries them
         ma.update(torch.from_numpy(a).cuda()); mb.update(torch.from_numpy(b).cuda())
-        got, dg = hip.frechet_from_moments(ma, mb, mean_dtype=0)
-        a64, b64 = a.astype(np.float64), b.astype(np.float64)
-        want = O.frechet_distance(a64.mean(0), np.cov(a64, rowvar=False), b64.mean(0), np.cov(b64, rowvar=False), run_sqrtm=False)
+        got, dg = hip.frechet_from_moments(ma, mb, mean_dtype=K.FAD_F16)   # ... and the reference's float16 mean term
+        mu_a, cov_a = O.embd_statistics(a); mu_b, cov_b = O.embd_statistics(b)
+        want = O.frechet_distance(mu_a, cov_a, mu_b, cov_b, run_sqrtm=False)
         err = abs(got - want) / abs(want)
         routes.append(int(dg["route"]))
         print(f"{what} want={want:.6e} got={got:.6e} rel={err:.1e} route={dg['route']} iterations={dg['iters']}")
@@ -206,7 +207,7 @@ def test_fuzz_wide_chain_decaying_pairs_against_oracle():
     for d, lst in by_d.items():                                       # the same pairs, batched
         for lo in range(0, len(lst), 8):
             grp = lst[lo:lo + 8]
-            res = hip.FrechetMultiJob([(ma, mb) for ma, mb, _ in grp], mean_dtype=0).result()
+            res = hip.FrechetMultiJob([(ma, mb) for ma, mb, _ in grp], mean_dtype=K.FAD_F16).result()
             for (f, dg), (_, _, single) in zip(res, grp):
                 assert abs(f - single) <= 2e-6 * abs(single), (d, f, single, dg)
     for lst in by_d.values():

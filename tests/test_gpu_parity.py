@@ -1364,7 +1364,7 @@ def test_songs_full_rank_route_on_the_matrix_pipes(F, monkeypatch, d, frames):
 
 
 @pytest.mark.parametrize("dtype,n,d,offset", [(np.float16, 60000, 256, 3.0), (np.float16, 20001, 128, 0.5), (np.float32, 30000, 96, 3.0), (np.float16, 513, 512, 10.0),
-                                              (np.float16, 70001, 512, 3.0)])      # (72 MB of host rows: copied and accumulated in ~12 MB pieces)
+                                              (np.float16, 70001, 512, 3.0)])      # (72 MB of host rows: copied and accumulated in ~24 MB pieces)
 def test_calc_embd_statistics_returns_numpys_own_mean_for_frames_with_an_offset(F, dtype, n, d, offset):
     """np.mean(embd_lst, axis=0) (fadtk/fad.py:48) adds the rows one after the other in float32: for frames with an offset the float16
     result is NOT the rounded exact mean in a few dimensions (worth 2e-5 .. 5e-4 of a small FAD at config-3 size).  calc_embd_statistics
