@@ -466,6 +466,8 @@ def main():
                          "batch's small launches take another batch's kernels -- but a dispatch's duration then includes the time it "
                          "waits for another stream's workgroups to leave the CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--realistic-only", action="store_true",
+                    help="profiling aid: the timed loop and the `value_realistic` block, nothing else (implies --timed-only for the other side blocks)")
     ap.add_argument("--no-realistic", action="store_true", help="skip the `value_realistic` block (k^-1 spectra, offset frames, reference-order means)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (used under rocprofv3 "
                                                              "so that the kernel statistics hold the config-3 launches only)")
@@ -492,6 +494,8 @@ def main():
     if int(args.batch) > 0 and not int(args.group) and not args.multi_stream:
         args.single_stream = True                                        # the batched schedule's default layout
     args.lane_streams = not args.single_stream
+    if args.realistic_only:
+        args.timed_only = True
     if args.timed_only:
         args.no_extras = True; args.no_cpu_baseline = True
     if (args.gpus > 1 or os.environ.get("FAD_BENCH_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -795,6 +799,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Python's cyclic collector stays out of the measured blocks, as `timeit` keeps it out: a generation-2 pass over the objects of torch +
+    # numpy + scipy takes ~70 ms here -- 30 x the timed region -- and falls wherever the allocation count says (r05p: a repeat block of 20
+    # steps at 283 scores/s; the "30-70 ms stalls of single blocking calls" that no HIP trace ever showed: DESIGN.md 6.4).  Nothing in the
+    # loops below creates reference cycles; the collector is switched on again before the line is printed.
+    import gc
+    gc.collect(); gc.disable()
     if os.environ.get("FAD_BENCH_PREWARM") == "1":       # diagnosis only: a block of K untimed steps in front of the warm-up
         run_steps(args.steps)
     if BATCH:
@@ -846,6 +856,7 @@ def main():
 
     kernel_ms, timed_launches_seen, launch_sets_mean, variant = collect_kernel_ms(timed_handles)   # (queried here: the side blocks record more launches)
 
+    side = args.steps > 0 and not args.timed_only
     # ---- side blocks, outside the timed region: the same K steps five more times (median: the timed region above is a few
     # milliseconds long, one outlier moves it), and K steps that re-feed ONE pair -- 204.8 MB, which fit the 256 MiB Infinity
     # Cache: what rounds 1-2 reported
@@ -855,66 +866,27 @@ def main():
         run_steps(args.steps, None, rotate)
         fence()
         return time.perf_counter() - t0
-    side = args.steps > 0 and not args.timed_only
-    repeat_s = [block(True) for _ in range(5)] if side else []
-    same_pair_s = [block(False) for _ in range(3)] if side else []
-    # ... and the same batches with ONE moments launch per step (--moments-group 1: what the line reported before the launches were grouped)
-    per_step_launch_s = []
-    if side and BATCH and MG > 1 and not distributed:
-        MGv[0] = 1
-        run_steps(BATCH)
-        per_step_launch_s = [block(True) for _ in range(3)]
-        MGv[0] = MG
-        run_steps(BATCH)
-    # ... and K steps in the other stream layout: by default that is ONE stream for all scores in flight -- no two kernels overlap, the
-    # tile kernel's duration there is the kernel alone
-    per_stream_s, per_stream_kernel_ms, per_stream_sets = [], None, SETS
-    if side and BATCH:
-        # batched schedule: the same batches, every one on the OTHER stream layout (ONE stream unless --single-stream was given)
-        other = ([torch.cuda.current_stream(device)] * NB_FLY if not args.single_stream else [torch.cuda.Stream(device=device) for _ in range(NB_FLY)])
-        saved = list(bstreams)
-        bstreams[:] = other
-        for q in range(NB_FLY):
-            for ln in blanes[q]:
-                ln.stream = ln.cstream = bstreams[q]
-        run_steps(min(args.steps, BATCH))
-        for rep in range(3):
-            if rep == 2:                                     # what the overlap does to the tile kernel itself (last block)
-                for hnd in timed_handles:
-                    hnd.set_timing(2)
-                launch_sets.clear()
-            fence(); t0 = time.perf_counter(); run_steps(args.steps); fence()
-            per_stream_s.append(time.perf_counter() - t0)
-        per_stream_kernel_ms, _, per_stream_sets, _ = collect_kernel_ms(timed_handles)
-        bstreams[:] = saved
-        for q in range(NB_FLY):
-            for ln in blanes[q]:
-                ln.stream = ln.cstream = bstreams[q]
-    elif side and n_lanes > 1 and not G:                    # the OTHER stream layout (one stream for all lanes / one per lane)
-        lanes_s = [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
-        run_steps_lanes(min(args.steps, 6), None, True, lanes_s)
-        for rep in range(3):
-            if rep == 2:
-                lanes_s[0].ma.set_timing(2)          # what the overlap does to the tile kernel itself (last block)
-            fence(); t0 = time.perf_counter(); run_steps_lanes(args.steps, None, True, lanes_s); fence()
-            per_stream_s.append(time.perf_counter() - t0)
-        per_stream_kernel_ms = lanes_s[0].ma.last_timing()[0]
-        lanes_s[0].ma.set_timing(False)
-        for ln in lanes_s:
-            ln.shared.close()
-
+    skip = set(os.environ.get("FAD_BENCH_SKIP", "").split(","))          # diagnostics: leave out side blocks (repeat, same, perstep, streams)
+    repeat_s = [block(True) for _ in range(5)] if side and "repeat" not in skip else []
+    same_pair_s = [block(False) for _ in range(3)] if side and "same" not in skip else []
     # ---- the REALISTIC score, same schedule: k^-1 spectra, frames with an offset, the reference's own float32 running-sum means ON
+    # (measured right behind the flat loop's repeats and BEFORE the other side blocks: behind the per-step-launch / other-stream-layout blocks the
+    #  same block ran at 4 150 / 2 830 scores/s (detached / attached walk) instead of 4 830 / 4 490 -- r05n against r05m, r05o, r05p; and the
+    #  repeats of the flat loop lose ~8 % when they run behind this block -- r05o, r05p.  Why a block is slower for a while behind a different
+    #  workload is not understood; the order keeps each of the two top-level numbers behind its own kind)
     realistic = None
-    if side and BATCH and rank == 0 and not distributed and not args.no_realistic:
+    saved_pairs = list(pairs)
+    if (side or args.realistic_only) and BATCH and rank == 0 and not distributed and not args.no_realistic:
         try:
             from oracle import fad_oracle as O
             rpairs = [make_realistic_sets(torch, device, k) for k in range(N_PAIRS)]
-            saved_pairs = list(pairs)
             all_h = [h for q in range(NB_FLY) for ln in blanes[q] for h in (ln.ma, ln.mb)]
 
-            # blocks of at least six batches: a block of K = 20 steps is two and a half batches, and the first batch of a block has nothing
-            # to hide its walks behind (the flat loop above pays the same fill and drain, but its batches are a third as long)
-            rsteps = max(args.steps, 6 * BATCH)
+            # blocks of at least twelve batches: a block of K = 20 steps is two and a half batches, and the first batch of a block has nothing
+            # to hide its walks behind -- its chain waits 1.2 ms for the two walks of its own moments (the flat loop above pays the same fill
+            # and drain, but its batches are a third as long); with six batches per block (r05i) the line showed 4 240 where the same loop
+            # run on (scripts/probe_realistic.py pipelined) gives 4 700-4 950
+            rsteps = max(args.steps, (int(os.environ.get("FAD_BENCH_REALISTIC_BATCHES", "12"))) * BATCH)
 
             def blocks(nb=5):
                 run_steps(3 * BATCH)                                     # (the thread's launch-count hints settle on this kind of pair)
@@ -975,6 +947,53 @@ def main():
             del rpairs
         except Exception as e:      # noqa: BLE001  a side block must never break the bench line
             realistic = {"error": repr(e)}
+        pairs[:] = saved_pairs
+        run_steps(6 * BATCH)            # (the flat pairs again: the thread's launch-count hints settle back before the side blocks below)
+
+    # ... and the same batches with ONE moments launch per step (--moments-group 1: what the line reported before the launches were grouped)
+    per_step_launch_s = []
+    if side and BATCH and MG > 1 and not distributed and "perstep" not in skip:
+        MGv[0] = 1
+        run_steps(BATCH)
+        per_step_launch_s = [block(True) for _ in range(3)]
+        MGv[0] = MG
+        run_steps(BATCH)
+    # ... and K steps in the other stream layout: by default that is ONE stream for all scores in flight -- no two kernels overlap, the
+    # tile kernel's duration there is the kernel alone
+    per_stream_s, per_stream_kernel_ms, per_stream_sets = [], None, SETS
+    if side and BATCH and "streams" not in skip:
+        # batched schedule: the same batches, every one on the OTHER stream layout (ONE stream unless --single-stream was given)
+        other = ([torch.cuda.current_stream(device)] * NB_FLY if not args.single_stream else [torch.cuda.Stream(device=device) for _ in range(NB_FLY)])
+        saved = list(bstreams)
+        bstreams[:] = other
+        for q in range(NB_FLY):
+            for ln in blanes[q]:
+                ln.stream = ln.cstream = bstreams[q]
+        run_steps(min(args.steps, BATCH))
+        for rep in range(3):
+            if rep == 2:                                     # what the overlap does to the tile kernel itself (last block)
+                for hnd in timed_handles:
+                    hnd.set_timing(2)
+                launch_sets.clear()
+            fence(); t0 = time.perf_counter(); run_steps(args.steps); fence()
+            per_stream_s.append(time.perf_counter() - t0)
+        per_stream_kernel_ms, _, per_stream_sets, _ = collect_kernel_ms(timed_handles)
+        bstreams[:] = saved
+        for q in range(NB_FLY):
+            for ln in blanes[q]:
+                ln.stream = ln.cstream = bstreams[q]
+    elif side and n_lanes > 1 and not G:                    # the OTHER stream layout (one stream for all lanes / one per lane)
+        lanes_s = [Lane(k, own=not args.lane_streams) for k in range(n_lanes)]
+        run_steps_lanes(min(args.steps, 6), None, True, lanes_s)
+        for rep in range(3):
+            if rep == 2:
+                lanes_s[0].ma.set_timing(2)          # what the overlap does to the tile kernel itself (last block)
+            fence(); t0 = time.perf_counter(); run_steps_lanes(args.steps, None, True, lanes_s); fence()
+            per_stream_s.append(time.perf_counter() - t0)
+        per_stream_kernel_ms = lanes_s[0].ma.last_timing()[0]
+        lanes_s[0].ma.set_timing(False)
+        for ln in lanes_s:
+            ln.shared.close()
 
     # launches of the tile kernel the events covered inside the timed region
     timed_launches = -(-args.steps // n_lanes)
@@ -1213,6 +1232,7 @@ def main():
         out["fad_cpu"] = fad_cpu
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
+    gc.enable()
     print(json.dumps(out), flush=True)
     os.dup2(2, 1)                       # whatever libraries say while the process winds down stays off stdout as well
 

@@ -9,6 +9,12 @@ import numpy as np, torch
 from fadtk_amd import hip, _capi as K
 
 n_calls = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+# every pass of Python's cyclic collector, timed (gc.callbacks): a long blocking call that coincides with one is the interpreter's, not the library's
+gc_log, _gc_t0 = [], [0.0]
+def _gc_cb(phase, info):
+    if phase == "start": _gc_t0[0] = time.perf_counter()
+    else: gc_log.append((info["generation"], (time.perf_counter() - _gc_t0[0]) * 1e3, time.perf_counter()))
+gc.callbacks.append(_gc_cb)
 rng = np.random.default_rng(0)
 d, n = 512, 20000
 t_origin = time.perf_counter()
@@ -32,3 +38,5 @@ for decay, tag in ((2.0, "k^-2 (float64 route)"), (0.0, "flat (eight-launch chai
         print(f"{tag}, python gc {'on ' if gc_on else 'off'}: median {med:.3f} ms, p99 {np.percentile(ts, 99):.3f}, max {ts.max():.3f}; "
               f"outliers (> 5 x median) (index, ms, start offset ms): {out}", flush=True)
 gc.enable()
+long_gc = [(g, round(ms, 1), round((t - t_origin) * 1e3, 1)) for g, ms, t in gc_log if ms > 2.0]
+print(f"collector passes: {len(gc_log)} in all; longer than 2 ms (generation, ms, end offset ms): {long_gc}")
