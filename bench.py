@@ -703,7 +703,7 @@ def main():
     if G:
         run_steps = run_steps_grouped
 
-    BATCH = 0 if G else max(0, min(int(args.batch), 8))
+    BATCH = 0 if G else max(0, min(int(args.batch), 16))
     MG = max(1, min(int(args.moments_group), 8, BATCH)) if BATCH else 1          # steps per moments launch (2 sets each, 16 at most)
     if BATCH:
         NB_FLY = 3

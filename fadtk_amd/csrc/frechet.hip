@@ -836,12 +836,12 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
     const PairBlock L = pair_block(d);
     const size_t hs = song_host_stride(d);
     void* const before = ws.fast_pairs.p;
-    FAD_TRY(ws.fast_pairs.reserve((size_t)(B > 4 ? 8 : 4) * L.stride + 256));      // (room for a full batch at once: no regrowth between calls)
+    FAD_TRY(ws.fast_pairs.reserve((size_t)(B > 8 ? kMaxMultiPairs : B > 4 ? 8 : 4) * L.stride + 256));      // (room for a full batch at once: no regrowth between calls)
     if (!ws.fast_pairs_pin || ws.fast_pairs_pin_cap < (size_t)B * hs) {
         if (ws.fast_pairs_pin) (void)hipHostFree(ws.fast_pairs_pin);
         ws.fast_pairs_pin = nullptr; ws.fast_pairs_pin_cap = 0;
-        FAD_HIP_TRY(hipHostMalloc(&ws.fast_pairs_pin, (size_t)8 * hs + 4096, hipHostMallocDefault));
-        ws.fast_pairs_pin_cap = (size_t)8 * hs + 4096;
+        FAD_HIP_TRY(hipHostMalloc(&ws.fast_pairs_pin, (size_t)kMaxMultiPairs * hs + 4096, hipHostMallocDefault));
+        ws.fast_pairs_pin_cap = (size_t)kMaxMultiPairs * hs + 4096;
     }
     char* blk = static_cast<char*>(ws.fast_pairs.p);
     char* hpin = static_cast<char*>(ws.fast_pairs_pin);
@@ -1224,7 +1224,7 @@ int fad_frechet_from_moments_multi_begin(int count, const fad_moments_t* const* 
                                          int mean_dtype, void* stream, fad_frechet_job_t** job) {
     if (!h1 || !h2 || !job) return set_error(FAD_ERR_INVALID, "NULL argument");
     *job = nullptr;
-    if (count < 1 || count > 8) return set_error(FAD_ERR_INVALID, "count=%d out of range [1, 8]", count);
+    if (count < 1 || count > kMaxMultiPairs) return set_error(FAD_ERR_INVALID, "count=%d out of range [1, %d]", count, kMaxMultiPairs);
     for (int b = 0; b < count; ++b) if (!h1[b] || !h2[b]) return set_error(FAD_ERR_INVALID, "pair %d: NULL handle", b);
     const int device = moments_device(h1[0]), d = moments_dim(h1[0]);
     for (int b = 0; b < count; ++b) {
@@ -1263,7 +1263,7 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
     const Workspace::Multi m = ws.multi;
     DeviceGuard g(j.device);
     const int d = j.d, nb = d / 32;
-    bool done[8] = {false};
+    bool done[kMaxMultiPairs] = {false};
     int rc = FAD_OK;
     if (m.enqueued) {
         const hipError_t e = hipEventSynchronize(ws.done_ev);

@@ -22,6 +22,10 @@ constexpr int kStatScal = 8;                         // doubles per tile: sumsq,
 static inline int64_t stat_blocks(int d) { return cdiv(d, 32); }
 static inline size_t stat_doubles(int d) { const int64_t nb = stat_blocks(d); return (size_t)(2 * nb * d + kStatScal * nb * nb); }
 
+// pairs of one batched chain (fad_frechet_from_moments_multi_begin): 8 until round 5 -- 128 workgroups per product, half the chip;
+// 16 pairs put a workgroup of the 128 x 128-tile kernels on every CU, and a launch of a dependent chain costs the same either way
+constexpr int kMaxMultiPairs = 16;
+
 struct Workspace : NsWorkspace {
     DevBuf rows, offs, songbuf, songmat, rows2, songrun, songjobs;     // per-song path (songrun: numpy's float32 running column sums per song)
     DevBuf base_root;                               // ... sqrt(Sigma_b) | I | zeros of the symmetric D x D route
@@ -37,7 +41,7 @@ struct Workspace : NsWorkspace {
     struct Multi {                                  // an in-flight batch of pairs
         int count = 0, gen = 0;
         bool enqueued = false;                      // the batched chain is on the stream (else: end() scores the pairs one by one)
-        const fad_moments_t* h1[8] = {nullptr}; const fad_moments_t* h2[8] = {nullptr};
+        const fad_moments_t* h1[kMaxMultiPairs] = {nullptr}; const fad_moments_t* h2[kMaxMultiPairs] = {nullptr};
     } multi;
     // an in-flight score (fad_frechet_from_moments_begin .. fad_frechet_end): everything the collecting side needs
     bool busy = false;

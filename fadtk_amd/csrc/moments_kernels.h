@@ -1275,10 +1275,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const int64_t row = t * kRsRows + lrow;
             // (global, not flat, loads: the pointer comes out of a structure in memory and the compiler cannot tell -- a flat load counts
             //  on the LDS counter as well and forces full waits around the LDS traffic)
-            typedef __attribute__((address_space(1))) const uint4 g_u4;
+            typedef unsigned int rs_u32x4 __attribute__((ext_vector_type(4)));       // (HIP's uint4 is a class: no address-space-qualified copies)
+            typedef __attribute__((address_space(1))) const rs_u32x4 g_u4;
             const uint16_t* p = base + (row < j.n ? row : j.n - 1) * j.ld + c0 + cbase;
-            r[0] = *(g_u4*)(uintptr_t)p;
-            r[1] = *(g_u4*)(uintptr_t)(p + q1);
+            const rs_u32x4 v0 = *(g_u4*)(uintptr_t)p, v1 = *(g_u4*)(uintptr_t)(p + q1);
+            r[0] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+            r[1] = make_uint4(v1.x, v1.y, v1.z, v1.w);
         };
         auto dump = [&](const uint4 (&r)[2], int buf) {
             float* dst = rs_lds + ((size_t)buf * kRsCols + 16 * half) * kRsPitch + lrow;

@@ -369,17 +369,19 @@ class FrechetJob:
 
 
 class FrechetMultiJob:
-    """Up to eight scores in flight as ONE batch (``fad_frechet_from_moments_multi_begin``): pair b = (pairs[b][0], pairs[b][1]);
+    """Up to MAX_PAIRS scores in flight as ONE batch (``fad_frechet_from_moments_multi_begin``): pair b = (pairs[b][0], pairs[b][1]);
     the eight launches of the square-root chain carry all of them.  ``result()`` -> [(fad, diag dict), ...] in order.  Thread
     rules as FrechetJob."""
+
+    MAX_PAIRS = 16                 # FAD_MULTI_MAX_PAIRS (include/fad_hip.h)
 
     def __init__(self, pairs, ddof: int = 1, eps: float = 1e-6, mean_dtype: int = -1):
         import threading
         self._lib = K.load_library()
         self._owner = threading.get_ident()
         self._n = len(pairs)
-        if not 1 <= self._n <= 8:
-            raise ValueError("a FrechetMultiJob holds 1..8 pairs")
+        if not 1 <= self._n <= self.MAX_PAIRS:
+            raise ValueError(f"a FrechetMultiJob holds 1..{self.MAX_PAIRS} pairs")
         a = (C.c_void_p * self._n)(*[p[0]._h for p in pairs])
         b = (C.c_void_p * self._n)(*[p[1]._h for p in pairs])
         job = C.c_void_p()

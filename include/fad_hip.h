@@ -221,12 +221,13 @@ int fad_frechet_from_moments_begin(const fad_moments_t* h1, const fad_moments_t*
 int fad_frechet_end(fad_frechet_job_t* job, double* out_fad, fad_diag_t* diag);
 int fad_frechet_cancel(fad_frechet_job_t* job);
 
-/* `count` (1..8) independent scores in ONE job: pair b = (h1[b], h2[b]).  The eight launches of the square-root chain carry all
+/* `count` (1..FAD_MULTI_MAX_PAIRS) independent scores in ONE job: pair b = (h1[b], h2[b]).  The eight launches of the square-root chain carry all
  * pairs (each launch costs ~4 us before it does anything and its workgroups are latency-bound: B chains as one batch take little
  * longer than one); multi_end() delivers out_fad[b] (and diag[b], or diag == NULL) exactly as fad_frechet_from_moments would for
  * that pair -- a pair the batch does not finish or accept goes through that very entry point.  Same stream / thread rules as
  * begin() / end(); one slot per job.  Used by bench.py for the scores it keeps in flight and by score_inf (fad.py:304-351: 25
  * independent scores against one baseline). */
+#define FAD_MULTI_MAX_PAIRS 16   /* (8 until round 5; 16 pairs put a workgroup of the batched kernels on every CU) */
 int fad_frechet_from_moments_multi_begin(int count, const fad_moments_t* const* h1, const fad_moments_t* const* h2, int ddof,
                                          double eps, int mean_dtype, void* stream, fad_frechet_job_t** job);
 int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fad_diag_t* diag);

@@ -10,6 +10,13 @@ import bench
 from fadtk_amd import hip, _capi as K
 
 dev = torch.device("cuda", 0)
+# EXTRA_STREAMS=N: N further torch streams, each used once and then left idle (bench.py's side blocks leave such streams behind: does their
+# mere existence slow this loop?  r05n)
+extra_streams = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("EXTRA_STREAMS", "0")))]
+for st_ in extra_streams:
+    with torch.cuda.stream(st_):
+        torch.zeros(16, device=dev).add_(1)
+torch.cuda.synchronize()
 pairs = [bench.make_realistic_sets(torch, dev, k) for k in range(4)]
 hs = [(hip.Moments(bench.DIM), hip.Moments(bench.DIM)) for _ in range(8)]
 mode = sys.argv[1] if len(sys.argv) > 1 else "detached"
@@ -48,4 +55,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 12
 res = run(n)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"mode {mode}, {NB} batch(es) in flight: {dt * 1e3:.3f} ms per batch of 8 scores = {8 / dt:.0f} scores/s; last batch: routes {[d['route'] for _, d in res]} iterations {[d['iters'] for _, d in res]}")
+print(f"extra streams {len(extra_streams)}: mode {mode}, {NB} batch(es) in flight: {dt * 1e3:.3f} ms per batch of 8 scores = {8 / dt:.0f} scores/s; last batch: routes {[d['route'] for _, d in res]} iterations {[d['iters'] for _, d in res]}")
