@@ -836,7 +836,7 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
     const PairBlock L = pair_block(d);
     const size_t hs = song_host_stride(d);
     void* const before = ws.fast_pairs.p;
-    FAD_TRY(ws.fast_pairs.reserve((size_t)(B > 8 ? kMaxMultiPairs : B > 4 ? 8 : 4) * L.stride + 256));      // (room for a full batch at once: no regrowth between calls)
+    FAD_TRY(ws.fast_pairs.reserve((size_t)(B > 16 ? kMaxMultiPairs : B > 8 ? 16 : B > 4 ? 8 : 4) * L.stride + 256));      // (room for a full batch at once: no regrowth between calls)
     if (!ws.fast_pairs_pin || ws.fast_pairs_pin_cap < (size_t)B * hs) {
         if (ws.fast_pairs_pin) (void)hipHostFree(ws.fast_pairs_pin);
         ws.fast_pairs_pin = nullptr; ws.fast_pairs_pin_cap = 0;
@@ -868,6 +868,7 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
     uint4* digY[2] = {reinterpret_cast<uint4*>(at(L.digY[0])), reinterpret_cast<uint4*>(at(L.digY[1]))};
     uint4* digYt[2] = {reinterpret_cast<uint4*>(at(L.digYt[0])), reinterpret_cast<uint4*>(at(L.digYt[1]))};
 
+    static_assert(2 * kMaxMultiPairs <= nsf::kPrepMaxSets, "PrepArgs holds two sets per pair of a batch");
     nsf::PrepArgs pa;
     memset(&pa, 0, sizeof(pa));
     for (int b = 0; b < B; ++b) {

@@ -23,8 +23,8 @@ static inline int64_t stat_blocks(int d) { return cdiv(d, 32); }
 static inline size_t stat_doubles(int d) { const int64_t nb = stat_blocks(d); return (size_t)(2 * nb * d + kStatScal * nb * nb); }
 
 // pairs of one batched chain (fad_frechet_from_moments_multi_begin): 8 until round 5 -- 128 workgroups per product, half the chip;
-// 16 pairs put a workgroup of the 128 x 128-tile kernels on every CU, and a launch of a dependent chain costs the same either way
-constexpr int kMaxMultiPairs = 16;
+// 16 pairs put a workgroup of the 128 x 128-tile kernels on every CU, 32 two; a launch of a dependent chain costs the same either way
+constexpr int kMaxMultiPairs = 32;
 
 struct Workspace : NsWorkspace {
     DevBuf rows, offs, songbuf, songmat, rows2, songrun, songjobs;     // per-song path (songrun: numpy's float32 running column sums per song)

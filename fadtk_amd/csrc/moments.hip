@@ -685,6 +685,7 @@ static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, i
         static const int64_t piece_bytes = [] { const char* e = getenv("FAD_H2D_PIECE_KB"); return (int64_t)(e ? atoll(e) : 24576) * 1024; }();
         int64_t piece_rows = (piece_bytes > 0) ? piece_bytes / (row_bytes > 0 ? row_bytes : 1) : m;
         piece_rows = (piece_rows / 256) * 256;
+        if (piece_rows < 16 * (int64_t)h->d) piece_rows = 16 * (int64_t)h->d;     // (a piece keeps the kernels a whole update of its rows would get: >= 16 rows per column)
         if (piece_rows < 4096 || m < 2 * piece_rows) piece_rows = m;
         if (piece_rows == m) {
             FAD_TRY(host_to_device_2d(h->stage.p, (size_t)row_bytes, src, (size_t)(ld * es), (size_t)row_bytes, (size_t)m, h->device, st));

@@ -172,6 +172,7 @@ __device__ __forceinline__ SplitMat adv(const SplitMat& m, int64_t bytes) { retu
 // K1: means, mean term, traces, scales and digit planes of both covariances from the packed moments (or the caller's matrices).
 // grid (d * d / 2048 + 1, 2), 512 threads: a thread owns 4 consecutive columns of one row = one dword of every digit plane;
 // the extra workgroup of set 0 forms both means and the mean term ||mu1 - mu2||^2 (the reference's dtype quirk included).
+constexpr int kPrepMaxSets = 64;      // two sets for each of the (at most 32) pairs of a batch: frechet_internal.h kMaxMultiPairs
 struct PrepArgs {
     const double* acc[2];            // packed moments [n | sum | sum xxT], or nullptr: the caller's (mu, Sigma) are used as they are
     const double* cov_in[2];         // ... then these (device)
@@ -187,10 +188,10 @@ struct PrepArgs {
     // accs[2 b + set]; EVERYTHING (mus, covs, dig, hdr, st) of pair b lives b * pstride bytes behind pair 0's; means, mean term and
     // the spare workgroup as for a single pair.
     int batch; int64_t pstride;
-    const double* accs[16];
+    const double* accs[kPrepMaxSets];
     // numpy's float32 running column sums of a set (fad_moments_set_reference_mean), or nullptr: then its mean is float32(float64(run) / n)
     // -- what np.mean returns before its final cast (fad.py:48) -- instead of the exact sum / n
-    const float* run[2]; const float* runs[16];
+    const float* run[2]; const float* runs[kPrepMaxSets];
 };
 
 __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {

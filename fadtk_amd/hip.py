@@ -373,7 +373,7 @@ class FrechetMultiJob:
     the eight launches of the square-root chain carry all of them.  ``result()`` -> [(fad, diag dict), ...] in order.  Thread
     rules as FrechetJob."""
 
-    MAX_PAIRS = 16                 # FAD_MULTI_MAX_PAIRS (include/fad_hip.h)
+    MAX_PAIRS = 32                 # FAD_MULTI_MAX_PAIRS (include/fad_hip.h)
 
     def __init__(self, pairs, ddof: int = 1, eps: float = 1e-6, mean_dtype: int = -1):
         import threading

@@ -227,7 +227,7 @@ int fad_frechet_cancel(fad_frechet_job_t* job);
  * that pair -- a pair the batch does not finish or accept goes through that very entry point.  Same stream / thread rules as
  * begin() / end(); one slot per job.  Used by bench.py for the scores it keeps in flight and by score_inf (fad.py:304-351: 25
  * independent scores against one baseline). */
-#define FAD_MULTI_MAX_PAIRS 16   /* (8 until round 5; 16 pairs put a workgroup of the batched kernels on every CU) */
+#define FAD_MULTI_MAX_PAIRS 32   /* (8 until round 5; 16 pairs put a workgroup of the batched kernels on every CU, 32 two) */
 int fad_frechet_from_moments_multi_begin(int count, const fad_moments_t* const* h1, const fad_moments_t* const* h2, int ddof,
                                          double eps, int mean_dtype, void* stream, fad_frechet_job_t** job);
 int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fad_diag_t* diag);

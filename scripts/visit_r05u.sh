@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 5, visit u: CPU-bandwidth cgroup of the box; batches of 8 vs 16 pairs per chain; the whole GPU suite on the rebuilt library
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+tag=${1:-r05u}; out=gpurun_out/$tag; mkdir -p $out
+{ echo "nproc $(nproc)"; for f in /sys/fs/cgroup/cpu.max /sys/fs/cgroup/cpu/cpu.cfs_quota_us /sys/fs/cgroup/cpu/cpu.cfs_period_us /sys/fs/cgroup/cpu.stat /sys/fs/cgroup/cpu/cpu.stat /sys/fs/cgroup/cpuset.cpus.effective /sys/fs/cgroup/cpuset/cpuset.cpus; do [ -r $f ] && echo "$f: $(cat $f | tr '\n' ' ')"; done; python -c "
+import os; print('sched_getaffinity', len(os.sched_getaffinity(0)))
+from threadpoolctl import threadpool_info; print([(d['internal_api'], d['num_threads']) for d in threadpool_info()])
+import numpy, scipy.linalg; from threadpoolctl import threadpool_info; print([(d['internal_api'], d['num_threads']) for d in threadpool_info()])"; } 2>&1 | tee $out/cpu_cgroup.txt
+strings fadtk_amd/lib/libfad_hip.so | grep "count=%d out of range"
+for b in 8 16; do
+  timeout 400 python bench.py --realistic-only --batch $b --steps 64 --warmup 16 > $out/bench_b$b.json 2> $out/bench_b$b.err
+  python - $out/bench_b$b.json $b <<'PY'
+import json, sys
+r = json.load(open(sys.argv[1])); x = r.get("realistic") or {}
+print("batch", sys.argv[2], "| value", round(r["value"]), "ms_per_step", round(r["ms_per_step"], 4), "| realistic", {k: (round(v) if isinstance(v, float) and v > 100 else v) for k, v in x.items() if k in ("value", "value_with_attached_walk", "value_with_rounded_exact_means", "error", "rel_err_vs_oracle")}, "| fad", r.get("fad"))
+PY
+done 2>&1 | tee $out/batch_ab.txt
+for b in 8 16; do
+  timeout 400 python bench.py --timed-only --batch $b --steps 20 --warmup 5 > $out/bench_k20_b$b.json 2> $out/bench_k20_b$b.err
+  python -c "
+import json; r=json.load(open('$out/bench_k20_b$b.json')); print('K=20 batch $b value', round(r['value']), 'ms_per_step', round(r['ms_per_step'],4))" | tee -a $out/batch_ab.txt
+done
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" $out/pytest_gpu.log | tail -8 | cut -c1-300
+echo "== done"

@@ -17,8 +17,37 @@ for p in (ROOT, ROOT / "tests" / "golden"):
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def _cpu_quota_cores():
+    """CPUs' worth of time per period the process's CPU-bandwidth cgroup grants (cgroup v2 cpu.max / v1 cfs_quota), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+_BLAS_LIMIT = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle is numpy / scipy on the host.  On the GPU boxes the process may use 16 CPUs' worth of time per 100 ms (cpu.max) while the
+    # BLAS pool starts 64 threads: most of every period the whole process -- the thread that launches kernels included -- is frozen.  The
+    # pool is held to what the cgroup grants (kept alive for the session in _BLAS_LIMIT).
+    global _BLAS_LIMIT
+    quota = _cpu_quota_cores()
+    if quota and quota >= 1:
+        try:
+            import numpy, scipy.linalg      # noqa: F401,E401  (the limit reaches the BLAS libraries that are loaded when it is set: numpy's and scipy's)
+            from threadpoolctl import threadpool_limits
+            _BLAS_LIMIT = threadpool_limits(limits=max(1, int(quota)), user_api="blas")
+        except Exception:
+            _BLAS_LIMIT = None
 
 
 def _gpu_present() -> bool:
