@@ -13,7 +13,7 @@ hot path over that batch -- one FAD score:
                        statistics (fadtk_amd.dist.SharedStats -- the same object the product's --gpus path uses)
     frechet(A, B)      finalise (mu, Sigma) x2, Newton-Schulz sqrt(S1 S2): split-float16 MFMA iterations + exact int8-MFMA products +
                        one float64-accurate correction (float64 throughout when the product is ill-conditioned), the reference's
-                       float16 mean term.  The chains of the scores in flight run as ONE batch of eight (--batch).
+                       float16 mean term.  The chains of the scores in flight run as ONE batch of 16 (--batch; the steps left at the end of a call join the last batch).
 
 i.e. exactly one FAD score over the union of all ranks' rows.  With N GPUs every rank holds its own
 100k-row shard of both sets (weak scaling: rows grow with N), so `value` is reported in
@@ -520,7 +520,7 @@ def main():
     ap.add_argument("--group", type=int, default=0,
                     help="grouped schedule: the moments of G consecutive steps back to back on ONE stream, then their G square-root chains "
                          "side by side on G streams (two groups in flight: 2 G scores); 0 = the lane schedule (one stream per score)")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="batched chains (the default schedule): the moments of B consecutive steps, then ONE square-root chain for the B "
                          "scores (fad_frechet_from_moments_multi_begin: nine launches carry all B); three such batches in flight, one stream "
                          "each; 0 = the lane schedule of round 3 (one stream and one chain per score, --inflight of them)")
@@ -753,8 +753,11 @@ def main():
         bstreams = [torch.cuda.current_stream(device)] * NB_FLY if args.single_stream else [torch.cuda.Stream(device=device) for _ in range(NB_FLY)]
         # the statistics of the steps that share a moments launch live in ONE device buffer (2 M packed accumulators): with several
         # ranks their exchange is ONE in-place all-reduce per launch (16.8 MB at M = 4) instead of one per step
-        gshared = [[fdist.SharedStats(DIM, SETS * MG, local_rank) for _ in range(-(-BATCH // MG))] for _ in range(NB_FLY)] if MG > 1 else None
-        blanes = [[Lane(k, own=False, shared=((gshared[q][k // MG], k % MG) if MG > 1 else None)) for k in range(BATCH)] for q in range(NB_FLY)]
+        # (a batch slot holds up to LCAP pairs: the LAST batch of a call takes the steps that are left when they are no more than that -- 20 steps
+        #  are one batch of 20, not 16 + 4: a chain of 4 pairs costs what a chain of 16 does)
+        LCAP = min(32, (3 * BATCH) // 2)
+        gshared = [[fdist.SharedStats(DIM, SETS * MG, local_rank) for _ in range(-(-LCAP // MG))] for _ in range(NB_FLY)] if MG > 1 else None
+        blanes = [[Lane(k, own=False, shared=((gshared[q][k // MG], k % MG) if MG > 1 else None)) for k in range(LCAP)] for q in range(NB_FLY)]
         for q in range(NB_FLY):
             for ln in blanes[q]:
                 ln.stream = ln.cstream = bstreams[q]
@@ -788,7 +791,7 @@ def main():
                 q = b % NB_FLY
                 if bjobs[q] is not None:
                     collect(q)
-                m = min(BATCH, count - i)
+                m = (count - i) if (count - i) <= LCAP else BATCH
                 t = pc()
                 MG = MGv[0]
                 if MG > 1:
@@ -853,6 +856,8 @@ def main():
         # set-up, not warm-up: every one of the three job slots allocates its batch workspace (8 x 28 MB) on first use, and a warm-up of
         # W < 3 B steps would leave that to the timed region (measured: 0.77 instead of 0.12 ms per step at W = 3).  One full round here.
         run_steps(3 * BATCH)
+        run_steps(LCAP)         # (... and the first slot the room of the largest batch a call can form: 1.3 GB for more than 16 pairs -- r05w: left
+                                #  to the timed region, 8 740-8 980 scores/s where the repeats of the same 20 steps gave 10 100-10 250)
     run_steps(max(args.warmup, 0))
     # The tile kernel is timed by HIP events the library records around it on the launch stream -- on ONE lane (every
     # n_lanes-th step of the timed region) and without the third event behind the reduce: a timed event record between two
