@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU probe, run under rocprofv3 --kernel-trace --stats: what bench.py's `value_realistic` loop launches -- 8 realistic scores per batch
+"""GPU probe, run under rocprofv3 --kernel-trace --stats: what bench.py's `value_realistic` loop launches -- PAIRS (16) realistic scores per batch
 (k^-1 spectra, frames with an offset: bench.make_realistic_sets), two update_multi calls of 8 frame matrices each with numpy's running
 sums on (detached walk), then ONE chain for the 8 pairs (fad_frechet_from_moments_multi_begin: scaled steps on the 128 x 128-tile
 kernels, the exact correction, the verification products) -- a dozen batches, so that the kernel statistics show what a batch costs."""
@@ -18,20 +18,21 @@ for st_ in extra_streams:
         torch.zeros(16, device=dev).add_(1)
 torch.cuda.synchronize()
 pairs = [bench.make_realistic_sets(torch, dev, k) for k in range(4)]
-hs = [(hip.Moments(bench.DIM), hip.Moments(bench.DIM)) for _ in range(8)]
+PAIRS = int(os.environ.get("PAIRS", "16"))          # pairs per batched chain (bench.py --batch: 16 since r05v; 8 before)
+hs = [(hip.Moments(bench.DIM), hip.Moments(bench.DIM)) for _ in range(PAIRS)]
 mode = sys.argv[1] if len(sys.argv) > 1 else "detached"
 for a, b in hs:
     a.set_reference_mean(mode != "off", detached=(mode == "detached")); b.set_reference_mean(mode != "off", detached=(mode == "detached"))
 
 NB = 3 if (len(sys.argv) > 2 and sys.argv[2] == "pipelined") else 1      # batches in flight (bench.py keeps three)
-groups = [hs] + [[(hip.Moments(bench.DIM), hip.Moments(bench.DIM)) for _ in range(8)] for _ in range(NB - 1)]
+groups = [hs] + [[(hip.Moments(bench.DIM), hip.Moments(bench.DIM)) for _ in range(PAIRS)] for _ in range(NB - 1)]
 for grp in groups[1:]:
     for a, b in grp:
         a.set_reference_mean(mode != "off", detached=(mode == "detached")); b.set_reference_mean(mode != "off", detached=(mode == "detached"))
 jobs = [None] * NB
 
 def feed(q):
-    for g in range(2):
+    for g in range(PAIRS // 4):
         grp = groups[q][4 * g:4 * g + 4]
         for a, b in grp:
             a.reset(); b.reset()
@@ -55,4 +56,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 12
 res = run(n)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"extra streams {len(extra_streams)}: mode {mode}, {NB} batch(es) in flight: {dt * 1e3:.3f} ms per batch of 8 scores = {8 / dt:.0f} scores/s; last batch: routes {[d['route'] for _, d in res]} iterations {[d['iters'] for _, d in res]}")
+print(f"extra streams {len(extra_streams)}: mode {mode}, {NB} batch(es) in flight: {dt * 1e3:.3f} ms per batch of {PAIRS} scores = {PAIRS / dt:.0f} scores/s; last batch: routes {[d['route'] for _, d in res]} iterations {[d['iters'] for _, d in res]}")
