@@ -450,12 +450,26 @@ def extra_decaying(torch, hip, device):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 fad, diag = hip.frechet_from_moments(ma, mb, mean_dtype=FAD_F16)
                 ms.append((time.perf_counter() - t0) * 1e3)
+            # the same pair sixteen times over as ONE batch (fad_frechet_from_moments_multi_begin): what a score of this kind costs among its like
+            batch = [(ma, mb)] * 16
+            for _ in range(2):
+                res = hip.FrechetMultiJob(batch, mean_dtype=FAD_F16).result()
+            msb = []
+            for _ in range(5):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                res = hip.FrechetMultiJob(batch, mean_dtype=FAD_F16).result()
+                msb.append((time.perf_counter() - t0) * 1e3)
+            fb, db = res[-1]
         t0 = time.perf_counter()
         ref = float(O.fad_between(a.cpu().numpy(), b.cpu().numpy()))
         out[f"k^-{p:g}"] = {"ms": float(np.median(ms)), "ms_spread": spread(ms), "route": int(diag.get("route", 0)) if diag["converged"] == 3 else 0,
                             "converged": int(diag["converged"]), "iterations": int(diag["iters"]), "fad": float(fad),
-                            "rel_err_vs_oracle": abs(float(fad) - ref) / abs(ref), "oracle_seconds": time.perf_counter() - t0}
+                            "rel_err_vs_oracle": abs(float(fad) - ref) / abs(ref),
+                            "ms_per_score_in_a_batch_of_16": float(np.median(msb)) / 16.0, "batch_ms_spread": spread(msb),
+                            "batch_route": int(db.get("route", 0)) if db["converged"] == 3 else 0, "batch_iterations": int(db["iters"]),
+                            "batch_rel_err_vs_oracle": abs(float(fb) - ref) / abs(ref), "oracle_seconds": time.perf_counter() - t0}
         del a, b
+        cpu_quiet()                 # (the oracle's BLAS burst must not reach into the next spectrum's timings)
     out["note"] = ("covariance spectra k^-p of both sets (product k^-2p); route 2 = eight-launch split-float16 chain, 1 = float32 chain, 0 = float64 "
                    "Newton-Schulz (scaled steps while the tracked lower bound of the spectrum is below 0.9)")
     return out

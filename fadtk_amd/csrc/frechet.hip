@@ -1315,6 +1315,55 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
         }
         if (learnt > 0 && ws.pool) ws.pool->lp_iters = learnt;
         if (ws.pool && wide) ws.pool->lp_verify = any_verified;
+
+        // ---- what the chain declined or did not finish: the float64 iteration over ALL of them as ONE batch (round 5; before, pair by
+        // pair through fad_frechet_from_moments: 0.7 ms each for k^-2 spectra -- three 512^3 float64 products per step on 256 and 512
+        // workgroups; sixteen problems per launch fill the chip: ~0.3 ms per pair).  K1 left every pair's (mu, Sigma) as the single route
+        // would form them (numpy's means where the handles carry them) in its block; the product Sigma_1 Sigma_2 is formed anew in
+        // float64 (fast_decide_one: why not the chain's).  Pairs the batch cannot close (no finite root: the eps fallback of fad.py:94-99;
+        // too few rows) stay for the single entry point below, which reports them as it always did.  FAD_PAIRS_F64_BATCH=0: pair by pair.
+        static const bool f64_batch = [] { const char* e = getenv("FAD_PAIRS_F64_BATCH"); return !(e && e[0] == '0'); }();
+        int undone = 0; bool all_recorded = true;
+        for (int b = 0; b < count; ++b)
+            if (!done[b]) { ++undone; if (reinterpret_cast<const int*>(hpin + (size_t)b * hs + off_words)[12] != m.gen) all_recorded = false; }
+        if (f64_batch && rc == FAD_OK && undone >= 2 && all_recorded) {
+            const PairBlock L = pair_block(d);
+            const size_t dd = (size_t)d * d;
+            char* blk = static_cast<char*>(ws.fast_pairs.p);
+            const int64_t stride = (int64_t)(L.stride / sizeof(double));
+            const double* mus = reinterpret_cast<const double*>(blk + L.mus);
+            const double* covs = reinterpret_cast<const double*>(blk + L.covs);
+            int r2 = ws.small.reserve(ns_small_bytes(d, count));
+            NsState* hst = nullptr;
+            if (r2 == FAD_OK) {
+                NsState* dstates = static_cast<NsState*>(ws.small.p);
+                enqueue_clear_states(dstates, count, j.stream);
+                uint32_t mask = 0;
+                for (int b = 0; b < count; ++b) if (done[b]) mask |= (1u << b);
+                if (mask) enqueue_mark_states_done(dstates, mask, count, j.stream);
+                NsProblem pb{d, count, covs, stride, covs + dd, stride, mus, stride, mus + d, stride, j.mean_dtype};
+                r2 = run_ns(pb, 0, 0.0, j.device, j.stream, ws, &hst, false, nullptr, (ws.pool && ws.pool->f64_iters_multi > 0) ? ws.pool->f64_iters_multi + 1 : 0);
+            }
+            if (r2 == FAD_OK && hst) {
+                int most = 0;
+                for (int b = 0; b < count; ++b) {
+                    if (done[b]) continue;
+                    const NsState& q = hst[b];
+                    if (q.nonfinite || q.conv == 0 || !q.finished || q.final_iter < 0) continue;          // -> the single entry point
+                    const double tr_sqrt = sqrt(q.c) * q.tr_last;
+                    out_fad[b] = q.mean_term + q.tr1 + q.tr2 - 2.0 * tr_sqrt;
+                    if (diag) {
+                        fad_diag_t& g2 = diag[b];
+                        memset(&g2, 0, sizeof(g2));
+                        g2.iters = q.final_iter + 1; g2.converged = q.conv; g2.used_eps = 0; g2.route = 0; g2.residual = q.res_last;
+                        g2.scale = q.c; g2.mean_term = q.mean_term; g2.tr1 = q.tr1; g2.tr2 = q.tr2; g2.tr_sqrt = tr_sqrt;
+                    }
+                    if (q.final_iter + 1 > most) most = q.final_iter + 1;
+                    done[b] = true;
+                }
+                if (most > 0 && ws.pool) ws.pool->f64_iters_multi = most;
+            }
+        }
     }
     ws.busy = false;                               // the slot is free again: the single route below takes any free one
     ws.multi = Workspace::Multi();

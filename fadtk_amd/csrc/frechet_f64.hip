@@ -270,7 +270,7 @@ __global__ void clear_states(NsState* st, int64_t B) {
 // reuse_prepared: A = C1 C2 (first matrix of ws.mats) and the armed state are those of a float32 attempt on the same problem
 // that just gave up (mixed_begin: same buffer, same ns_prepare) -- product, statistics and scale are not formed again.
 int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_t stream, Workspace& ws,
-           NsState** host_states, bool reuse_prepared, double** y_bufs) {
+           NsState** host_states, bool reuse_prepared, double** y_bufs, int first_chunk) {
     const int d = pb.d;
     const int64_t B = pb.B, dd = (int64_t)d * d;
     if (max_iter <= 0) max_iter = 64;
@@ -323,6 +323,7 @@ int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_
     // many launches end up skipped.
     int cur = 0, k = 0, chunk = 6;
     if (B == 1 && ws.pool && ws.pool->f64_iters > 0) chunk = ws.pool->f64_iters + 1;
+    if (first_chunk > 0) chunk = first_chunk;          // (a batch of pairs: what the thread's last such batch needed, frechet.hip)
     bool all_done = false;
     NsCheckArgs chk;
     chk.max_iter = max_iter; chk.st_all = dstates; chk.partials_all = partials; chk.pstride = pstride; chk.stride = dd;
@@ -359,6 +360,14 @@ int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_
     return FAD_OK;
 }
 
+// problems of a batch that need no iteration (bit b of `mask`): closed before the first launch looks at them
+__global__ void mark_states_done(NsState* st, uint32_t mask, int B) {
+    const int b = threadIdx.x;
+    if (b < B && ((mask >> b) & 1u)) { st[b].done = 1; st[b].finished = 1; st[b].upd_skip[0] = 1; st[b].upd_skip[1] = 1; st[b].conv = 1; st[b].final_iter = 0; }
+}
+void enqueue_mark_states_done(NsState* st, uint32_t mask, int B, hipStream_t stream) {
+    hipLaunchKernelGGL(mark_states_done, dim3(1), dim3(64), 0, stream, st, mask, B);
+}
 void enqueue_clear_states(NsState* st, int64_t B, hipStream_t stream) {
     hipLaunchKernelGGL(clear_states, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, stream, st, B);
 }

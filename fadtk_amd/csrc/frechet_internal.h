@@ -88,6 +88,7 @@ struct Pool {
                                                     // score enqueues them behind the correction at once instead of after a trip to the host
     int lp_wide = -1;                               // FAD_FRECHET_WIDE (read once): 0 = the chain only serves flat spectra, as in round 4
     int f64_iters = 0;                              // ... and the float64 iteration (single pair), 0 = not known yet
+    int f64_iters_multi = 0;                        // ... and the float64 iteration of a BATCH of pairs (fad_frechet_multi_end)
     int mixed = -1;                                 // FAD_FRECHET_MIXED (read once): 0 = always the fp64 iteration
     int fast = -1;                                  // FAD_FRECHET_FAST (read once): 0 = round 2's twelve-launch float32 chain
     double pred_thr = 0.0;                          // FAD_FRECHET_PRED_THR (read once; -1 = the built-in rule), see pred_threshold
@@ -139,7 +140,8 @@ constexpr int kSymMaxIter = 16;   // symmetric per-song route: iterates beyond t
 // reuse_prepared: A = C1 C2 (first matrix of ws.mats) and the armed state are those of a float32 attempt on the same problem
 // that just gave up (mixed_begin: same buffer, same ns_prepare) -- product, statistics and scale are not formed again.
 int run_ns(const NsProblem& pb, int max_iter, double tol, int device, hipStream_t stream, Workspace& ws,
-           NsState** host_states, bool reuse_prepared = false, double** y_bufs = nullptr);
+           NsState** host_states, bool reuse_prepared = false, double** y_bufs = nullptr, int first_chunk = 0);
+void enqueue_mark_states_done(NsState* st, uint32_t mask, int B, hipStream_t stream);   // B <= 32 problems: those of `mask` need no iteration
 // launches of that file's small kernels for the other two
 void enqueue_clear_states(NsState* st, int64_t B, hipStream_t stream);                 // per-call reset of B iteration states
 void enqueue_add_diag(double* M, int d, double eps, hipStream_t stream);               // M += eps I (fad.py:94-99)

@@ -1467,9 +1467,65 @@ def test_frechet_multi_job_matches_single_scores(F):
     for (a, b), (f, _) in zip(sets[:2] + sets[4:], got[:2] + got[4:]):                              # ... and against the oracle
         ref = O.fad_between(a, b)
         assert abs(f - ref) <= 2e-6 * abs(ref)
+    # the largest batch a job takes (FAD_MULTI_MAX_PAIRS = 32; 8 until round 5): the six pairs over and over -- flat, decaying and low-rank ones
+    # side by side in one chain -- and one pair more than that is refused
+    many = (handles * 6)[:hip.FrechetMultiJob.MAX_PAIRS]
+    got32 = hip.FrechetMultiJob(many, mean_dtype=0).result()
+    assert len(got32) == hip.FrechetMultiJob.MAX_PAIRS == 32
+    for k, (f, dg) in enumerate(got32):
+        fw = want[k % len(handles)][0]
+        assert abs(f - fw) <= (2e-9 if k % len(handles) != 4 else 2e-6) * abs(fw), (k, f, fw, dg)
+    with pytest.raises(ValueError):
+        hip.FrechetMultiJob((handles * 6)[:33], mean_dtype=0)
     two = hip.FrechetMultiJob(handles[1:3], mean_dtype=0).result()                                 # a smaller batch out of the same slot
     assert abs(two[0][0] - want[1][0]) <= 2e-9 * abs(want[1][0]) and abs(two[1][0] - want[2][0]) <= 2e-9 * abs(want[2][0])
     for ma, mb in handles:
+        ma.close(); mb.close()
+
+
+def test_frechet_multi_job_hands_declined_pairs_to_one_batched_float64_iteration(F):
+    """A batch whose pairs the low-precision chain declines (spectra k^-2 and steeper: condition 1e9 .. 1e13 of Sigma_1 Sigma_2) is closed by
+    ONE float64 Newton-Schulz iteration over all of them (round 5; fad_frechet_multi_end) instead of pair by pair: same distances as the
+    blocking call gives each pair (both are float64 iterations on the same (mu, Sigma): 1e-9), the reference's eig value (fad.py:91-92) to
+    1e-6, `route` 0 in the diagnostics -- for a batch of declined pairs only, and for one that mixes them with flat pairs the chain keeps."""
+    import torch
+    from fadtk_amd import hip
+    d = 256
+    rng = np.random.default_rng(909)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    def pair(power, n1, n2, scale=1.0):
+        lam = np.arange(1, d + 1) ** (-power / 2.0)
+        a = (((rng.standard_normal((n1, d)) * lam) @ q.T) * scale).astype(np.float16)
+        b = (((1.07 * rng.standard_normal((n2, d)) * lam) @ q.T + 0.01) * scale).astype(np.float16)
+        return a, b
+    steep = [pair(2.0, 9000, 8000), pair(2.5, 12000, 9000), pair(2.0, 7000, 7000, 30.0), pair(3.0, 20000, 15000), pair(2.2, 9000, 9000, 1e-2)]
+    flat = [pair(0.0, 6000, 6500), pair(0.0, 5000, 5000)]
+    def handles_of(sets):
+        out = []
+        for a, b in sets:
+            ma, mb = hip.Moments(d), hip.Moments(d)
+            ma.update(torch.from_numpy(a).cuda()); mb.update(torch.from_numpy(b).cuda())
+            out.append((ma, mb))
+        return out
+    hs, hf = handles_of(steep), handles_of(flat)
+    single = [hip.frechet_from_moments(ma, mb, mean_dtype=-1) for ma, mb in hs + hf]
+    assert all(dg["route"] == 0 for _, dg in single[:len(hs)]), [dg["route"] for _, dg in single]      # (the case list must stay declined)
+    for rep in range(2):                                                        # (the second batch runs on the learnt launch count)
+        got = hip.FrechetMultiJob(hs, mean_dtype=-1).result()
+        for k, ((f, dg), (fw, dw)) in enumerate(zip(got, single[:len(hs)])):
+            assert dg["route"] == 0 and dg["converged"] in (1, 2), (k, dg)
+            # (two float64 iterations on (mu, Sigma) that two kernels formed from the same sums: an ulp apart, and a k^-3 product -- condition
+            #  1e13 -- turns that into 2e-10 of the traces; seen 5.4e-10 absolute at tr Sigma_1 + tr Sigma_2 = 2.6)
+            assert abs(f - fw) <= 1e-9 * abs(fw) + 5e-10 * (dw["tr1"] + dw["tr2"]), (k, f, fw, dg, dw)
+    mixed = hip.FrechetMultiJob([hf[0], hs[0], hs[3], hf[1], hs[1]], mean_dtype=-1).result()
+    for (f, dg), (fw, dw), route in zip(mixed, [single[5], single[0], single[3], single[6], single[1]], [2, 0, 0, 2, 0]):
+        assert dg["route"] == route, (dg, route)
+        assert abs(f - fw) <= (1e-9 if route == 0 else 2e-9) * abs(fw) + 5e-10 * (dw["tr1"] + dw["tr2"]), (f, fw, dg)
+    for (a, b), (f, _) in zip(steep[:3], got[:3]):                              # ... and against the reference's formula
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        ref = O.frechet_distance(a64.mean(0), np.cov(a64, rowvar=False), b64.mean(0), np.cov(b64, rowvar=False), run_sqrtm=False)
+        assert abs(f - ref) <= 1e-6 * abs(ref), (f, ref)
+    for ma, mb in hs + hf:
         ma.close(); mb.close()
 
 
