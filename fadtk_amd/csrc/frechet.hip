@@ -1265,6 +1265,8 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
     DeviceGuard g(j.device);
     const int d = j.d, nb = d / 32;
     bool done[kMaxMultiPairs] = {false};
+    int chain_status[kMaxMultiPairs];                      // fast_decide_one's verdict on the pair (-1: no record)
+    for (int b = 0; b < kMaxMultiPairs; ++b) chain_status[b] = -1;
     int rc = FAD_OK;
     if (m.enqueued) {
         const hipError_t e = hipEventSynchronize(ws.done_ev);
@@ -1287,6 +1289,7 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
                 if (hw[12] != m.gen) continue;              // (no record: the single route decides)
                 MixedResult r;
                 fast_decide_one(hw, hv, hx, nb, &r, wide ? hvx : nullptr, m.gen, wide ? kMaxLowWide : kMaxLow);
+                chain_status[b] = r.status;
                 if (r.too_few0 || r.too_few1) {
                     if (rc == FAD_OK) rc = set_error(FAD_ERR_TOO_FEW_ROWS, "FAD requires at least two embedding window frames in each set");
                     out_fad[b] = NAN; done[b] = true;
@@ -1323,10 +1326,12 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
         // float64 (fast_decide_one: why not the chain's).  Pairs the batch cannot close (no finite root: the eps fallback of fad.py:94-99;
         // too few rows) stay for the single entry point below, which reports them as it always did.  FAD_PAIRS_F64_BATCH=0: pair by pair.
         static const bool f64_batch = [] { const char* e = getenv("FAD_PAIRS_F64_BATCH"); return !(e && e[0] == '0'); }();
-        int undone = 0; bool all_recorded = true;
-        for (int b = 0; b < count; ++b)
-            if (!done[b]) { ++undone; if (reinterpret_cast<const int*>(hpin + (size_t)b * hs + off_words)[12] != m.gen) all_recorded = false; }
-        if (f64_batch && rc == FAD_OK && undone >= 2 && all_recorded) {
+        // (only what the chain REJECTED or declined -- status 2: "the float64 route decides".  A pair the blind batch merely did not finish
+        //  -- status 0 / 4 -- goes to the single entry point as before: it tops the chain up by a few launches and teaches the thread the
+        //  launch count its kind needs; sent here instead, every batch of k^-1 pairs ran 21 float64 steps: r06b, 2 570 scores/s for 5 200)
+        int declined = 0;
+        for (int b = 0; b < count; ++b) if (!done[b] && chain_status[b] == 2) ++declined;
+        if (f64_batch && rc == FAD_OK && declined >= 2) {
             const PairBlock L = pair_block(d);
             const size_t dd = (size_t)d * d;
             char* blk = static_cast<char*>(ws.fast_pairs.p);
@@ -1339,7 +1344,7 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
                 NsState* dstates = static_cast<NsState*>(ws.small.p);
                 enqueue_clear_states(dstates, count, j.stream);
                 uint32_t mask = 0;
-                for (int b = 0; b < count; ++b) if (done[b]) mask |= (1u << b);
+                for (int b = 0; b < count; ++b) if (done[b] || chain_status[b] != 2) mask |= (1u << b);
                 if (mask) enqueue_mark_states_done(dstates, mask, count, j.stream);
                 NsProblem pb{d, count, covs, stride, covs + dd, stride, mus, stride, mus + d, stride, j.mean_dtype};
                 r2 = run_ns(pb, 0, 0.0, j.device, j.stream, ws, &hst, false, nullptr, (ws.pool && ws.pool->f64_iters_multi > 0) ? ws.pool->f64_iters_multi + 1 : 0);
@@ -1347,7 +1352,7 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
             if (r2 == FAD_OK && hst) {
                 int most = 0;
                 for (int b = 0; b < count; ++b) {
-                    if (done[b]) continue;
+                    if (done[b] || chain_status[b] != 2) continue;
                     const NsState& q = hst[b];
                     if (q.nonfinite || q.conv == 0 || !q.finished || q.final_iter < 0) continue;          // -> the single entry point
                     const double tr_sqrt = sqrt(q.c) * q.tr_last;
