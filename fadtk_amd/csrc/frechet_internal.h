@@ -23,7 +23,8 @@ static inline int64_t stat_blocks(int d) { return cdiv(d, 32); }
 static inline size_t stat_doubles(int d) { const int64_t nb = stat_blocks(d); return (size_t)(2 * nb * d + kStatScal * nb * nb); }
 
 // pairs of one batched chain (fad_frechet_from_moments_multi_begin): 8 until round 5 -- 128 workgroups per product, half the chip;
-// 16 pairs put a workgroup of the 128 x 128-tile kernels on every CU, 32 two; a launch of a dependent chain costs the same either way
+// 16 pairs put a workgroup of the 128 x 128-tile kernels on every CU (a chain of 16 costs little more than a chain of 8); beyond that the
+// chain's time grows with the pairs (16 / 24 / 32 measure alike per score, r05v)
 constexpr int kMaxMultiPairs = 32;
 
 struct Workspace : NsWorkspace {
