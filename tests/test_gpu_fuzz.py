@@ -53,7 +53,8 @@ def test_fuzz_moments_guard_second_pass(monkeypatch):
     sigma_i sigma_j for every entry -- raw second moments are 1e2..1e4 times larger here."""
     import torch
     from fadtk_amd.hip import Moments
-    rng = np.random.default_rng(2024)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FAD_FUZZ_SEED", "2024")))
     for case in range(18):
         d = int(rng.choice([64, 128, 200, 256, 512, 640]))
         n = int(rng.choice([16 * d, 16 * d + 7, 30000, 70001]))
