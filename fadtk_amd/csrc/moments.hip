@@ -48,7 +48,7 @@ struct fad_moments {
     fad::DevBuf cvec;                      // float16 rows: per-split column shifts for the guard's second pass
     fad::DevBuf presum, presum_col;        // stage-1 output of the two-level reduce
     fad::DevBuf blocktab;                  // 256-column-slab kernel: where every 32 x 32 block's partial sums sit (tile256_roles.h)
-    int blocktab_nsb = 0, blocktab_plan = -1;
+    int blocktab_nsb = 0;
     bool ref_mean = false;                 // fad_moments_set_reference_mean: keep numpy's float32 running column sums beside the exact ones
     fad::DevBuf runsum;                         // ... [d] floats
     bool runsum_covers = true;             // ... they cover exactly the rows the accumulator holds (an empty handle: trivially)
@@ -60,7 +60,6 @@ struct fad_moments {
     bool ref_detached = false;             // fad_moments_set_reference_mean(h, 2): the walk neither waits for the caller's stream nor holds it up
     hipEvent_t rs_pending = nullptr;       // ... the library's event behind the handle's last detached walk: settle() makes a reader's stream wait for it
     int r256_sl = 0;                       // FAD_MOMENTS_R256_SL (read at creation; experiments): split lanes of moments_reduce256, 0 = by the split count
-    int tile256_plan = -1;                 // FAD_MOMENTS_PLAN (read at creation): -1 auto, 0 = P/Q/X/Z items, 1 = combined ZC/XZ items
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
     // the segment tables of the last fused update_segmented call, kept on the host: a caller feeding groups of the SAME file sizes
     // (30-second clips: every file 2250 frames) finds them on the device already -- no H2D copy in front of the tile kernel
@@ -120,9 +119,9 @@ static int ensure_kernel_attrs(int device) {
     if (device < 0 || device >= 64) return set_error(FAD_ERR_INVALID, "device %d out of range", device);
     if (done[device]) return FAD_OK;
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256LdsCombined));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256LdsCombined));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
     for (int dt : {FAD_F16, FAD_BF16}) {
         for (bool fast : {false, true}) {
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
@@ -232,34 +231,36 @@ static int stage_tables(fad_moments* h, size_t bytes, char** host) {
 // D >= 512, float16 rows: the 256-column-slab kernel (moments_tile256.h).  Same three launches as the 128 x 128 path -- tile
 // kernel, gated second pass of the shift guard, reduce -- with ONE workgroup per CU and work items of 64-72 blocks.
 // ------------------------------------------------------------------------------------------
-static int block_table(fad_moments* h, int nsb, int plan, hipStream_t st) {
-    if (h->blocktab_nsb == nsb && h->blocktab_plan == plan) return FAD_OK;
+static int block_table(fad_moments* h, int nsb, hipStream_t st) {
+    if (h->blocktab_nsb == nsb) return FAD_OK;
     // host copies live for the life of the process: the upload below reads them asynchronously
     static std::mutex mu;
-    static std::vector<t256::BlockSrc>* cache[2][t256::MAX_SB + 1] = {{nullptr}};
+    static std::vector<t256::BlockSrc>* cache[t256::MAX_SB + 1] = {nullptr};
     const std::vector<t256::BlockSrc>* tab = nullptr;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!cache[plan][nsb]) {
+        if (!cache[nsb]) {
             auto* v = new (std::nothrow) std::vector<t256::BlockSrc>((size_t)t256::n_blocks(t256::NFR * nsb));
             if (!v) return set_error(FAD_ERR_ALLOC, "out of host memory");
-            if (!t256::build_block_table(nsb, v->data(), plan)) { delete v; return set_error(FAD_ERR_INVALID, "block table of %d superblocks is inconsistent", nsb); }
-            cache[plan][nsb] = v;
+            if (!t256::build_block_table(nsb, v->data())) { delete v; return set_error(FAD_ERR_INVALID, "block table of %d superblocks is inconsistent", nsb); }
+            cache[nsb] = v;
         }
-        tab = cache[plan][nsb];
+        tab = cache[nsb];
     }
     const size_t bytes = tab->size() * sizeof(t256::BlockSrc);
     FAD_TRY(h->blocktab.reserve(bytes));
     FAD_HIP_TRY(hipMemcpyAsync(h->blocktab.p, tab->data(), bytes, hipMemcpyHostToDevice, st));
-    h->blocktab_nsb = nsb; h->blocktab_plan = plan;
+    h->blocktab_nsb = nsb;
     return FAD_OK;
 }
 
-static bool tile256_eligible(const fad_moments* h0, int count, const int64_t* n, int dtype, bool aligned, bool seg) {
+static bool tile256_eligible(const fad_moments* h0, int count, const int64_t* n, const int64_t* ld, int dtype, bool aligned, bool seg) {
     const int d = h0->d;
     if (!h0->tile256 || !aligned || seg || dtype != FAD_F16 || h0->force_generic) return false;
     if (d < 2 * t256::SB || d > t256::MAX_SB * t256::SB) return false;
     for (int i = 0; i < count; ++i) if (n[i] < 16 * (int64_t)d) return false;      // (what the guard's second pass asks for as well)
+    // the kernel addresses the rows of a split (<= 8192 + 64) through a buffer resource with 32-bit offsets below 2^31
+    for (int i = 0; i < count; ++i) if (ld[i] >= ((int64_t)1 << 16)) return false;
     return true;
 }
 
@@ -271,26 +272,17 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
     T256Launch L;
     memset(&L, 0, sizeof(L));
     L.nsets = count; L.d = d; L.nsb = nsb;
-    // Which decomposition: the combined items (plan 1) halve the partial tiles -- 35 instead of 70 MB per launch, written here and
-    // read by the reduce -- at 2.5 instead of 2 slab reads per row; that pays while the partial tiles are a large part of the
-    // launch's traffic, i.e. for D = 512 with few rows per workgroup (config 3: a third).  Larger D keeps plan 0.
-    int64_t rows_total = 0;
-    for (int i = 0; i < count; ++i) rows_total += n[i];
-    int which = h0->tile256_plan;
-    if (which < 0) which = 0;       // (measured, profiles/r04c_plans.txt: at config 3 the 4 us the reduce gains the tile kernel loses; plan 1 is opt-in)
-    (void)rows_total;
-    L.plan = which;
-    L.NT = t256::item_types(nsb, L.type, L.sa, L.sb, which);
-    const bool has_z = which == 1 || (nsb & 1) != 0;
-    const size_t lds_bytes = which == 1 ? kT256LdsCombined : kT256Lds;
+    L.NT = t256::item_types(nsb, L.type, L.sa, L.sb);
+    const bool has_z = (nsb & 1) != 0;
+    const size_t lds_bytes = kT256Lds;
     SplitPlan plan[kMaxSets];
     plan_splits(count, n, d, t256::SB, has_z ? 2 * T2_KB : T2_KB, h0->n_cu, 1, 256, 8192, plan, L.NT);
-    FAD_TRY(block_table(h0, nsb, which, st));
+    FAD_TRY(block_table(h0, nsb, st));
     R256Launch R;
     memset(&R, 0, sizeof(R));
     R.table = static_cast<const t256::BlockSrc*>(h0->blocktab.p);
     R.d = d; R.nsb = nsb; R.NT = L.NT; R.nblk = t256::n_blocks(t256::NFR * nsb);
-    R.two_mask = which == 1 ? ((1u << nsb) - 1u) : ((nsb & 1) ? (1u << (nsb - 1)) : 0u);
+    R.two_mask = (nsb & 1) ? (1u << (nsb - 1)) : 0u;
     int item = 0, max_s = 0;
     bool any_guard = false;
     for (int i = 0; i < count; ++i) {
@@ -505,7 +497,7 @@ static int update_device_multi_impl(int count, fad_moments* const* hs, const voi
     hipEvent_t* ev = nullptr;
     FAD_TRY(timing_events(h0, &ev));
     h0->last_sets = count;
-    if (use_h16 && tile256_eligible(h0, count, n, dtype, aligned, seg != nullptr)) return update_tile256(count, hs, rows, n, ld, st, ev);
+    if (use_h16 && tile256_eligible(h0, count, n, ld, dtype, aligned, seg != nullptr)) return update_tile256(count, hs, rows, n, ld, st, ev);
     SplitPlan plan[kMaxSets];
     ReduceLaunch R;
     memset(&R, 0, sizeof(R));
@@ -843,7 +835,6 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     const char* t2 = getenv("FAD_MOMENTS_TILE256");
     h->tile256 = !(t2 && t2[0] == '0');
     const char* pl = getenv("FAD_MOMENTS_PLAN");
-    h->tile256_plan = (pl && (pl[0] == '0' || pl[0] == '1')) ? pl[0] - '0' : -1;
     const char* rs = getenv("FAD_MOMENTS_R256_SL");
     h->r256_sl = rs ? atoi(rs) : 0;
     const char* nc = getenv("FAD_MOMENTS_CUS");        // plan for fewer CUs than the device has (a CU-masked stream)

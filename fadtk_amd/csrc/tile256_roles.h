@@ -20,16 +20,6 @@
 // P and Q of a pair split the 136 blocks of "two triangles + the tile between them" evenly and read the SAME 64 KB of every
 // 32 rows, so that with both on one XCD the frames cross HBM once.  Every SIMD runs one triangle wave (18 MFMAs per stage) and
 // one XR wave (16).
-//
-// PLAN 1 ("combined", for few row-splits of many rows each -- config 3): every workgroup is Z-like -- both wave quartets hold
-// the SAME blocks, work on alternate 32-row stages and are summed through LDS before anything is stored, so that a CU leaves 36
-// (or 32) partial blocks instead of 68-72:
-//   ZC(a)        the triangle of superblock a, as Z, quartets combined                                       36 blocks
-//   XZ(a, b, h)  rows 128 h .. 128 h + 127 of the full tile (a, b): every wave XR on 4 A-side x 2 B-side fragments; a quartet
-//                streams 128 + 256 columns of its 32 rows (24 KiB; ring of three 48 KiB stages)             32 blocks
-// The partial tiles of a launch -- written once, read once by the reduce -- shrink from 70 to 35 MB at 256 workgroups, a third
-// of what the kernel moves at config 3; the price is 2.5 instead of 2 slab reads per frame row through L2 and 144 / 128 MFMAs
-// per 64 rows on ZC / XZ workgroups that share a split.
 #pragma once
 #include <cstdint>
 
@@ -43,11 +33,10 @@ constexpr int SLOTS = 72;          // partial-tile slots per work item: wave w, 
 constexpr int BLK = FR * FR;       // floats per 32 x 32 block
 constexpr int ITEM_STRIDE = SLOTS * BLK + 64;     // floats per work item's partials (+256 B: consecutive items do not alias one channel)
 constexpr int MAX_SB = 8;          // D <= 2048
-constexpr int MAX_TYPES = 64;      // work items per row-split at MAX_SB: plan 0: 4 pairs x 2 + 24 full tiles; plan 1: 8 + 56
+constexpr int MAX_TYPES = 32;      // work items per row-split at MAX_SB: 4 pairs x 2 + 24 full tiles
 
 enum Role : int { TRI_LO = 0, TRI_HI = 1, RECT_C = 2, RECT_D = 3, XR = 4 };
-enum Type : int { TYPE_P = 0, TYPE_Q = 1, TYPE_X = 2, TYPE_Z = 3, TYPE_ZC = 4, TYPE_XZ0 = 5, TYPE_XZ1 = 6 };
-inline constexpr bool combined_type(int type) { return type >= TYPE_ZC; }       // quartets hold the same blocks, summed in LDS
+enum Type : int { TYPE_P = 0, TYPE_Q = 1, TYPE_X = 2, TYPE_Z = 3 };
 
 // fragments a role loads per k-step (index into the wave's F[] array) and the blocks it owns: block b = F[fa[b]]^T F[fb[b]]
 template <int ROLE> struct RoleDef;
@@ -87,25 +76,15 @@ template <> struct RoleDef<XR> {           // F[0..3] = A-side fragments a0..a0+
 struct WaveJob { int role, slab, a0, b0; };
 inline constexpr WaveJob wave_job(int type, int wave) {
     if (type == TYPE_X) return WaveJob{XR, 0, 4 * (wave >> 2), 2 * (wave & 3)};
-    if (type == TYPE_Z || type == TYPE_ZC) return WaveJob{wave & 3, wave >> 2, 0, 0};
-    // XZ: `slab` = the quartet (its own three sub-slabs: A half, B, B), a0 = fragment 0 of the 128-column A half, b0 as X
-    if (type == TYPE_XZ0 || type == TYPE_XZ1) return WaveJob{XR, wave >> 2, 0, 2 * (wave & 3)};
+    if (type == TYPE_Z) return WaveJob{wave & 3, wave >> 2, 0, 0};
     if (wave < 4) return WaveJob{wave, type == TYPE_Q ? 1 : 0, 0, 0};
     return WaveJob{XR, 0, type == TYPE_Q ? 4 : 0, 2 * (wave - 4)};
 }
 
 // The work items of one row-split for `nsb` superblocks: pairs (2p, 2p+1) as P + Q, every other tile a < b as X, the last
 // superblock of an odd count as Z.  Returns the count; sa/sb = the superblocks behind slab A / slab B (Z: sb = sa).
-inline int item_types(int nsb, uint8_t* type, uint8_t* sa, uint8_t* sb, int plan = 0) {
+inline int item_types(int nsb, uint8_t* type, uint8_t* sa, uint8_t* sb) {
     int n = 0;
-    if (plan == 1) {
-        for (int a = 0; a < nsb; ++a) {
-            type[n] = TYPE_ZC; sa[n] = sb[n] = (uint8_t)a; ++n;
-            for (int b = a + 1; b < nsb; ++b)
-                for (int h = 0; h < 2; ++h) { type[n] = (uint8_t)(TYPE_XZ0 + h); sa[n] = (uint8_t)a; sb[n] = (uint8_t)b; ++n; }
-        }
-        return n;
-    }
     for (int p = 0; 2 * p + 1 < nsb; ++p) {
         type[n] = TYPE_P; sa[n] = (uint8_t)(2 * p); sb[n] = (uint8_t)(2 * p + 1); ++n;
         type[n] = TYPE_Q; sa[n] = (uint8_t)(2 * p); sb[n] = (uint8_t)(2 * p + 1); ++n;
@@ -123,18 +102,6 @@ inline int item_types(int nsb, uint8_t* type, uint8_t* sa, uint8_t* sb, int plan
 // an item (type, sa, sb); false for the unused ninth slot of an XR wave.
 inline bool slot_block(int type, int sa, int sb, int wave, int b, int* bi, int* bj) {
     const WaveJob j = wave_job(type, wave);
-    if (combined_type(type)) {                       // quartet 1 has no slots of its own: its sums join quartet 0's
-        if (wave >= 4) return false;
-        if (type == TYPE_ZC) {
-            int dummy_i, dummy_j;
-            (void)dummy_i; (void)dummy_j;
-            return slot_block(TYPE_Z, sa, sa, wave, b, bi, bj);
-        }
-        if (b >= 8) return false;
-        *bi = NFR * sa + 4 * (type - TYPE_XZ0) + RoleDef<XR>::fa[b];
-        *bj = NFR * sb + j.b0 + (RoleDef<XR>::fb[b] - 4);
-        return true;
-    }
     auto tri = [&](const int* frag, const int* fa, const int* fb, int nb) {
         if (b >= nb) return false;
         const int base = NFR * (j.slab == 0 ? sa : sb);
@@ -159,9 +126,9 @@ inline bool slot_block(int type, int sa, int sb, int wave, int b, int* bi, int* 
 struct BlockSrc { int16_t src[2]; };
 inline int block_index(int bi, int bj, int nb) { return bi * nb - bi * (bi - 1) / 2 + (bj - bi); }      // upper triangle, row major
 inline int n_blocks(int nb) { return nb * (nb + 1) / 2; }
-inline bool build_block_table(int nsb, BlockSrc* table /* n_blocks(8 nsb) */, int plan = 0) {
+inline bool build_block_table(int nsb, BlockSrc* table /* n_blocks(8 nsb) */) {
     uint8_t type[MAX_TYPES], sa[MAX_TYPES], sb[MAX_TYPES];
-    const int nt = item_types(nsb, type, sa, sb, plan), nb = NFR * nsb;
+    const int nt = item_types(nsb, type, sa, sb), nb = NFR * nsb;
     for (int i = 0; i < n_blocks(nb); ++i) table[i].src[0] = table[i].src[1] = -1;
     for (int t = 0; t < nt; ++t)
         for (int w = 0; w < 8; ++w)

@@ -19,7 +19,7 @@ __global__ void fill(uint16_t* E, size_t n, uint32_t seed) {
 int main(int argc, char** argv) {
     const int d = argc > 1 ? atoi(argv[1]) : 512;
     const int64_t n = argc > 2 ? atoll(argv[2]) : 100000;
-    const int sets = 2, npairs = (getenv("T2_SAME_PAIR") ? 1 : 3), n_cu = 256;
+    const int sets = getenv("T2_SETS") ? atoi(getenv("T2_SETS")) : 2, npairs = (getenv("T2_SAME_PAIR") ? 1 : 3), n_cu = 256;
     const int nsb = (d + 255) / 256, dpad = nsb * 256;
     std::vector<uint16_t*> E(npairs * sets);
     for (auto& p : E) {
@@ -27,21 +27,19 @@ int main(int argc, char** argv) {
         if (getenv("T2_ZERO")) hipMemset(p, 0, (size_t)n * d * 2);        // all-zero frames: the same instruction stream at the chip's lowest switching power
     }
     T256Launch L; memset(&L, 0, sizeof(L));
-    const int plan = getenv("T2_PLAN") ? atoi(getenv("T2_PLAN")) : 0;
-    L.nsets = sets; L.d = d; L.nsb = nsb; L.plan = plan; L.NT = t256::item_types(nsb, L.type, L.sa, L.sb, plan);
-    const int kb = (plan == 1 || (nsb & 1)) ? 64 : 32;
-    const size_t lds = plan == 1 ? kT256LdsCombined : kT256Lds;
+    L.nsets = sets; L.d = d; L.nsb = nsb; L.NT = t256::item_types(nsb, L.type, L.sa, L.sb);
+    const int kb = (nsb & 1) ? 64 : 32;
+    const size_t lds = kT256Lds;
     int64_t r = ((n * sets * L.NT + n_cu - 1) / n_cu + kb - 1) / kb * kb;
     while (sets * ((n + r - 1) / r) * L.NT > n_cu && r < 8192) r += kb;
     if (getenv("T2_ROWS")) r = atoll(getenv("T2_ROWS"));             // probe: rows per split that are NOT a multiple of the stage
     const int S = (int)((n + r - 1) / r);
-    printf("plan %d: ", plan);
     printf("d=%d n=%ld: %d item types, %d splits of %ld rows per set, %d workgroups\n", d, (long)n, L.NT, S, (long)r, sets * S * L.NT);
     std::vector<t256::BlockSrc> tab(t256::n_blocks(8 * nsb));
-    if (!t256::build_block_table(nsb, tab.data(), plan)) return 1;
+    if (!t256::build_block_table(nsb, tab.data())) return 1;
     t256::BlockSrc* dtab; hipMalloc(&dtab, tab.size() * sizeof(tab[0])); hipMemcpy(dtab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice);
     R256Launch R; memset(&R, 0, sizeof(R));
-    R.table = dtab; R.d = d; R.nsb = nsb; R.NT = L.NT; R.nblk = t256::n_blocks(8 * nsb); R.two_mask = plan == 1 ? ((1u << nsb) - 1u) : ((nsb & 1) ? (1u << (nsb - 1)) : 0u);
+    R.table = dtab; R.d = d; R.nsb = nsb; R.NT = L.NT; R.nblk = t256::n_blocks(8 * nsb); R.two_mask = (nsb & 1) ? (1u << (nsb - 1)) : 0u;
     int* flags; hipMalloc(&flags, 64); hipMemset(flags, 0, 64);
     int item = 0;
     for (int i = 0; i < sets; ++i) {
@@ -57,7 +55,7 @@ int main(int argc, char** argv) {
         j.n_add = (double)n; j.S = S; j.overwrite = 1; j.rows_per_split = r; j.n_rows = n;
     }
     L.total = item;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256LdsCombined);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds);
     hipEvent_t e[4]; for (auto& x : e) hipEventCreate(&x);
     for (int sl : {8, 4, 2, 1}) {
         R.sl = sl;
@@ -81,12 +79,14 @@ int main(int argc, char** argv) {
             float a, b; hipEventElapsedTime(&a, e[0], e[1]); hipEventElapsedTime(&b, e[1], e[2]);
             if (it >= 0) { tk += a; tr += b; }
         }
-        std::vector<double> h(1 + d + 8);
-        hipMemcpy(h.data(), R.job[1].acc, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> h(1 + d + (size_t)d * d);
+        hipMemcpy(h.data(), R.job[sets - 1].acc, h.size() * 8, hipMemcpyDeviceToHost);
+        double ck1 = 0, ck2 = 0;            // checksums over the whole accumulator of the last set (compare builds of the kernel with each other)
+        for (size_t i = 0; i < h.size(); ++i) { ck1 += h[i]; ck2 += h[i] * (double)((i * 2654435761u) % 1021); }
         const double fl = sets * 2.0 * n * d * d;
         if (tr2 > 0) printf("  (second reduce right behind the first: %6.1f us)\n", tr2 / reps * 1e3);
-        printf("  sl=%2d: tile %7.1f us (%5.1f %% of 2.5 PF algorithmic)   reduce %6.1f us (%d workgroups)   [n=%g sum0=%.6g M00=%.9g]\n", sl, tk / reps * 1e3,
-               fl / (tk / reps * 1e-3) / 2.5e15 * 100, tr / reps * 1e3, blocks * sets, h[0], h[1], h[1 + d]);
+        printf("  sl=%2d: tile %7.1f us (%5.1f %% of 2.5 PF algorithmic)   reduce %6.1f us (%d workgroups)   [n=%g sum0=%.6g M00=%.9g ck=%.12g %.12g]\n", sl, tk / reps * 1e3,
+               fl / (tk / reps * 1e-3) / 2.5e15 * 100, tr / reps * 1e3, blocks * sets, h[0], h[1], h[1 + d], ck1, ck2);
     }
     return 0;
 }

@@ -6,13 +6,12 @@
 #include <vector>
 using namespace fad::t256;
 int main() {
-    for (int plan = 0; plan < 2; ++plan)
     for (int nsb = 1; nsb <= MAX_SB; ++nsb) {
         const int nb = NFR * nsb;
         std::vector<BlockSrc> tab((size_t)n_blocks(nb));
-        if (!build_block_table(nsb, tab.data(), plan)) { printf("plan %d nsb=%d: table inconsistent\n", plan, nsb); return 1; }
+        if (!build_block_table(nsb, tab.data())) { printf("nsb=%d: table inconsistent\n", nsb); return 1; }
         uint8_t type[MAX_TYPES], sa[MAX_TYPES], sb[MAX_TYPES];
-        const int nt = item_types(nsb, type, sa, sb, plan);
+        const int nt = item_types(nsb, type, sa, sb);
         if (nt > MAX_TYPES) { printf("nsb=%d: %d item types\n", nsb, nt); return 1; }
         std::vector<int> count((size_t)nb * nb, 0);
         long blocks = 0;
@@ -29,7 +28,7 @@ int main() {
         }
         for (int i = 0; i < nb; ++i)
             for (int j = 0; j < nb; ++j) {
-                const bool z = plan == 0 && (nsb & 1) && i / NFR == nsb - 1 && j / NFR == nsb - 1;
+                const bool z = (nsb & 1) && i / NFR == nsb - 1 && j / NFR == nsb - 1;
                 const int want = (i <= j) ? (z ? 2 : 1) : 0;
                 if (count[(size_t)i * nb + j] != want) { printf("nsb=%d block (%d,%d): %d, want %d\n", nsb, i, j, count[(size_t)i * nb + j], want); return 1; }
             }
@@ -44,7 +43,7 @@ int main() {
                     if (!slot_block(type[t], sa[t], sb[t], slot / 9, slot % 9, &bi, &bj) || bi != i || bj != j) { printf("nsb=%d: table entry (%d,%d) wrong\n", nsb, i, j); return 1; }
                 }
             }
-        printf("%snsb=%d: %d item types, %ld blocks per split, %d output blocks ok\n", plan ? "plan 1 " : "", nsb, nt, blocks, n_blocks(nb));
+        printf("nsb=%d: %d item types, %ld blocks per split, %d output blocks ok\n", nsb, nt, blocks, n_blocks(nb));
     }
     return 0;
 }
