@@ -239,6 +239,141 @@ def extra_c4(torch, hip, device, local_rank):
             "cov_trace_per_dim": float(np.trace(cov)) / d}
 
 
+def extra_c2_vggish(torch, hip, device, local_rank, n_files=1000):
+    """Config 2 END TO END: two sets of `n_files` synthetic ten-second 16 kHz PCM16 wavs on disk -> normalised-audio cache
+    (fad.py:139-186) -> HIP log-mel front end + VGGish forward (seeded random weights: no checkpoint exists offline), 64 files per launch /
+    forward -> float16 embedding cache (.npy per file, written behind the loop) + statistics while the frames are in HBM (the online
+    path's per-file float16 means included) -> FAD from the cached statistics.  Checked against the oracle on the very same cached
+    embeddings.  Reference path: fadtk/fad_batch.py:15-48, fad.py:188-201, model_loader.py:99-108."""
+    import shutil
+    import tempfile
+    import fadtk_amd
+    from fadtk_amd import audio
+    from fadtk_amd.fad_batch import embed_and_accumulate
+    from fadtk_amd.model_loader import VGGishModel
+    from oracle import fad_oracle as O
+    os.environ["FADTK_AMD_RANDOM_WEIGHTS"] = "1"
+    root = Path(tempfile.mkdtemp(prefix="fad_c2_"))
+    sr, secs = 16000, 10
+    t = np.arange(sr * secs) / sr
+    try:
+        t0 = time.perf_counter()
+        for name, seed0, gain in (("base", 0, 1.0), ("eval", 100000, 0.8)):
+            (root / name).mkdir()
+            for i in range(n_files):
+                rng = np.random.default_rng(seed0 + i)
+                x = 0.1 * rng.standard_normal(sr * secs)
+                for f0, a in zip(rng.uniform(80.0, 4000.0, 3), rng.uniform(0.02, 0.15, 3)):
+                    x += a * np.sin(2.0 * np.pi * f0 * t + rng.uniform(0, 6.28))
+                audio.write_pcm16(root / name / f"clip{i:04d}.wav", gain * x, sr)
+        gen_s = time.perf_counter() - t0
+        ml = VGGishModel()
+        fad = fadtk_amd.FrechetAudioDistance(ml, audio_load_worker=8)          # loads the model once
+        torch.cuda.synchronize()
+        out = {}
+        t0 = time.perf_counter()
+        for name in ("base", "eval"):
+            t1 = time.perf_counter()
+            embed_and_accumulate(root / name, ml, workers=8)
+            torch.cuda.synchronize()
+            out[name + "_s"] = time.perf_counter() - t1
+        embed_s = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        score = float(fad.score(root / "base", root / "eval"))
+        score_s = time.perf_counter() - t1
+        # the same files once more from the normalised-audio cache, embeddings removed: the loop without the one-off PCM conversion
+        shutil.rmtree(root / "eval" / "embeddings"); shutil.rmtree(root / "eval" / "stats")
+        t1 = time.perf_counter()
+        embed_and_accumulate(root / "eval", ml, workers=8)
+        torch.cuda.synchronize()
+        warm_s = time.perf_counter() - t1
+        # ... and the reference's shape of the loop (one file per launch / forward) on a 100-file sample
+        shutil.rmtree(root / "eval" / "embeddings"); shutil.rmtree(root / "eval" / "stats")
+        some = sorted((root / "eval").glob("*.wav"))[:100]
+        sub = root / "sub"; sub.mkdir()
+        for pth in some:
+            shutil.copy(pth, sub / pth.name)
+        ml.batch_files = 1
+        t1 = time.perf_counter()
+        embed_and_accumulate(sub, ml, workers=8)
+        torch.cuda.synchronize()
+        per_file_s = time.perf_counter() - t1
+        del ml.batch_files
+        blocks = {name: [np.load(q) for q in sorted((root / name / "embeddings" / "vggish").glob("*.npy"))] for name in ("base",)}
+        shutil.rmtree(root / "eval" / "embeddings", ignore_errors=True)
+        embed_and_accumulate(root / "eval", ml, workers=8)
+        blocks["eval"] = [np.load(q) for q in sorted((root / "eval" / "embeddings" / "vggish").glob("*.npy"))]
+        t1 = time.perf_counter()
+        want = float(O.frechet_distance(*O.statistics_online(blocks["base"]), *O.statistics_online(blocks["eval"]), run_sqrtm=False))
+        oracle_s = time.perf_counter() - t1
+        frames = sum(b.shape[0] for v in blocks.values() for b in v)
+        return {"files": 2 * n_files, "seconds_per_file": secs, "frames": int(frames), "dim": 128, "files_per_forward": VGGishModel.batch_files,
+                "embed_and_accumulate_s": embed_s, "files_per_s": 2 * n_files / embed_s, "frames_per_s": frames / embed_s,
+                "files_per_s_from_the_audio_cache": n_files / warm_s,
+                "files_per_s_one_file_per_forward": 100 / per_file_s, "score_s": score_s, "fad": score, "fad_oracle_on_the_cached_embeddings": want,
+                "parity_rel_err_vs_oracle": abs(score - want) / abs(want), "oracle_s": oracle_s, "wav_generation_s": gen_s,
+                "includes": "wav decode + PCM16 normalisation cache + HIP log-mel + VGGish forward (random weights) + .npy cache + online statistics; "
+                            "host side: 8 decode threads, one writer thread"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def extra_c4_encodec(torch, hip, device, local_rank, clips_per_set=32):
+    """Config 4 WITH the embedder on a bounded sample: thirty-second 24 kHz clips generated on the device (72 GB of PCM for
+    the full 50k files would swamp any disk), Encodec's SEANet encoder (seeded random weights) over 8 clips per forward, the frames rounded
+    to float16 as model_loader.py:47-48 stores them and folded into the online statistics while still in HBM (one fad_moments_update_segmented
+    per group).  Two sets of `clips_per_set`; the FAD between them against the oracle on the same frames copied to the host."""
+    import fadtk_amd
+    from fadtk_amd.model_loader import EncodecEmbModel
+    from fadtk_amd.utils import OnlineStats
+    from oracle import fad_oracle as O
+    os.environ["FADTK_AMD_RANDOM_WEIGHTS"] = "1"
+    ml = EncodecEmbModel("24k"); ml.load_model()
+    sr, secs, B = 24000, 30, ml.batch_files
+    g = torch.Generator(device=device).manual_seed(4)
+    tt = torch.arange(sr * secs, device=device, dtype=torch.float32) / sr
+
+    def clips(n, gain):
+        x = 0.1 * torch.randn((n, 1, sr * secs), device=device, generator=g)
+        f0 = 100.0 + 3000.0 * torch.rand((n, 1, 1), device=device, generator=g)
+        return gain * (x + 0.1 * torch.sin(2.0 * np.pi * f0 * tt))
+
+    def run(gain, keep):
+        st = OnlineStats(128, local_rank, compat=True)
+        host = []
+        enc_s = 0.0
+        for o in range(0, clips_per_set, B):
+            wav = clips(min(B, clips_per_set - o), gain)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            embs = ml._get_embedding_batch(list(wav.split(1)))
+            rows = torch.cat([e.to(torch.float16) for e in embs], dim=0).contiguous()
+            torch.cuda.synchronize(); enc_s += time.perf_counter() - t1
+            st.add_group(rows, [int(e.shape[0]) for e in embs])
+            if keep:
+                host.extend(np.ascontiguousarray(e.to(torch.float16).cpu().numpy()) for e in embs)
+        mu, cov = st.finish()
+        n = st.frames.count
+        st.close()
+        return mu, cov, n, host, enc_s
+
+    run(1.0, False)                                  # warm-up: MIOpen picks its convolution algorithms on the first forward
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mu_a, cov_a, n_a, host_a, enc_a = run(1.0, True)
+    mu_b, cov_b, n_b, host_b, enc_b = run(0.8, True)
+    torch.cuda.synchronize()
+    total_s = time.perf_counter() - t0
+    score = float(fadtk_amd.calc_frechet_distance(mu_a, cov_a, mu_b, cov_b))
+    want = float(O.frechet_distance(*O.statistics_online(host_a), *O.statistics_online(host_b), run_sqrtm=False))
+    return {"clips": 2 * clips_per_set, "seconds_per_clip": secs, "frames": int(n_a + n_b), "dim": 128, "clips_per_forward": B,
+            "s": total_s, "clips_per_s": 2 * clips_per_set / total_s, "frames_per_s": (n_a + n_b) / total_s, "audio_seconds_per_s": 2 * clips_per_set * secs / total_s,
+            "encoder_forward_s": enc_a + enc_b, "statistics_and_copies_s": total_s - enc_a - enc_b,
+            "fad": score, "fad_oracle_on_the_same_frames": want, "parity_rel_err_vs_oracle": abs(score - want) / abs(want),
+            "full_config4_at_this_rate_s_per_gpu": 50000 / 8 / (2 * clips_per_set / total_s),
+            "includes": "device-generated clips -> SEANet encoder (random weights, PyTorch-ROCm / MIOpen) -> float16 frames -> fused online statistics (HIP); "
+                        "the host copies of the frames are for the oracle only"}
+
+
 def extra_c5(torch, hip, device):
     """Config 5 shape (Whisper-small): 10k two-frame songs at D=768 against one baseline, one batched
     call (seven calls timed, median); CPU baseline = 16 of the same songs through the oracle on a pool of 8 threads
@@ -538,9 +673,9 @@ def main():
                     help="batched chains (the default schedule): the moments of B consecutive steps, then ONE square-root chain for the B "
                          "scores (fad_frechet_from_moments_multi_begin: nine launches carry all B); three such batches in flight, one stream "
                          "each; 0 = the lane schedule of round 3 (one stream and one chain per score, --inflight of them)")
-    ap.add_argument("--moments-group", type=int, default=4,
+    ap.add_argument("--moments-group", type=int, default=16,
                     help="batched schedule: the moments of this many consecutive steps in ONE launch of the tile kernel and ONE reduce "
-                         "(fad_moments_update_multi over 2 x M frame matrices, 8 at most); 1 = one launch per step")
+                         "(fad_moments_update_multi over 2 x M frame matrices, 32 at most: a batch of 16 steps is one launch); 1 = one launch per step")
     ap.add_argument("--moments-stream", action="store_true",
                     help="batched schedule: every moments launch on ONE stream of its own, the chains on the batch streams (experiment)")
     ap.add_argument("--chain-cus", type=int, default=0,
@@ -760,7 +895,7 @@ def main():
         run_steps = run_steps_grouped
 
     BATCH = 0 if G else max(0, min(int(args.batch), 32))
-    MG = max(1, min(int(args.moments_group), 8, BATCH)) if BATCH else 1          # steps per moments launch (2 sets each, 16 at most)
+    MG = max(1, min(int(args.moments_group), 16, BATCH)) if BATCH else 1         # steps per moments launch (2 sets each, 32 at most)
     if BATCH:
         NB_FLY = 3
         # (--single-stream: all batches on ONE stream -- no two kernels ever overlap, the tile kernel's HIP-event time is the kernel alone)
@@ -809,7 +944,7 @@ def main():
                 t = pc()
                 MG = MGv[0]
                 if MG > 1:
-                    # the moments of MG steps in ONE launch of each kernel (fad_moments_update_multi takes up to 8 frame matrices): the
+                    # the moments of MG steps in ONE launch of each kernel (fad_moments_update_multi takes up to 32 frame matrices): the
                     # 256 workgroups of the tile kernel then hold MG x longer row ranges -- one set of partial tiles per LAUNCH, not per
                     # step -- and the reduce runs once (scripts/probe_sets.py: 108 / 75 / 70 / 68 us per pair at 1 / 2 / 3 / 4 pairs)
                     for k0 in range(0, m, MG):
@@ -1085,7 +1220,9 @@ def main():
     # ---- untimed side measurements (rank 0, single GPU)
     extra = {}
     if rank == 0 and not distributed and not args.no_extras:
-        for name, fn in (("c4_moments", lambda: extra_c4(torch, hip, device, local_rank)),
+        for name, fn in (("c2_vggish_e2e", lambda: extra_c2_vggish(torch, hip, device, local_rank)),
+                         ("c4_encodec_embed", lambda: extra_c4_encodec(torch, hip, device, local_rank)),
+                         ("c4_moments", lambda: extra_c4(torch, hip, device, local_rank)),
                          ("per_song_config5_shape", lambda: extra_c5(torch, hip, device)),
                          ("per_song_config5_encoder_frames", lambda: extra_c5_frames(torch, hip, device)),
                          ("per_song_config4_shape", lambda: extra_c4_songs(torch, hip, device)),
@@ -1207,7 +1344,7 @@ def main():
                            else "the same K steps with one HIP stream per score in flight: chains and moments kernels of consecutive scores overlap"))},
         "value_one_moments_launch_per_step": ({"median": float(np.median([n_gpus * args.steps / t for t in per_step_launch_s])), "blocks": len(per_step_launch_s),
                                                "note": "the same K steps with --moments-group 1: a tile-kernel launch, a guard launch and a reduce per step (2 frame "
-                                                       "matrices each) instead of one of each per 4 steps"} if per_step_launch_s else None),
+                                                       "matrices each) instead of one of each per batch of 16 steps"} if per_step_launch_s else None),
         "value_same_pair": {"median": float(np.median([n_gpus * args.steps / t for t in same_pair_s])) if same_pair_s else None,
                             "blocks": len(same_pair_s),
                             "note": "K steps that re-feed ONE pair (204.8 MB: Infinity-Cache resident) -- the loop rounds 1-2 timed"},

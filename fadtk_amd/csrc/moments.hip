@@ -275,7 +275,7 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
     L.NT = t256::item_types(nsb, L.type, L.sa, L.sb);
     const bool has_z = (nsb & 1) != 0;
     const size_t lds_bytes = kT256Lds;
-    SplitPlan plan[kMaxSets];
+    SplitPlan plan[kMaxSets256];
     plan_splits(count, n, d, t256::SB, has_z ? 2 * T2_KB : T2_KB, h0->n_cu, 1, 256, 8192, plan, L.NT);
     FAD_TRY(block_table(h0, nsb, st));
     R256Launch R;
@@ -922,10 +922,10 @@ int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld
 
 int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* const* rows, const int64_t* n,
                              const int64_t* ld, int dtype, void* stream) {
-    if (count < 1 || count > kMaxSets) return set_error(FAD_ERR_INVALID, "count=%d out of range [1, %d]", count, kMaxSets);
+    if (count < 1 || count > kMaxSets256) return set_error(FAD_ERR_INVALID, "count=%d out of range [1, %d]", count, kMaxSets256);
     if (!hs || !rows || !n || !ld) return set_error(FAD_ERR_INVALID, "NULL argument");
     if (dtype_size(dtype) == 0) return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
-    fad_moments* live_h[kMaxSets]; const void* live_rows[kMaxSets]; int64_t live_n[kMaxSets], live_ld[kMaxSets];
+    fad_moments* live_h[kMaxSets256]; const void* live_rows[kMaxSets256]; int64_t live_n[kMaxSets256], live_ld[kMaxSets256];
     int m = 0;
     for (int i = 0; i < count; ++i) {
         if (!hs[i]) return set_error(FAD_ERR_INVALID, "handle %d is NULL", i);
@@ -942,7 +942,24 @@ int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* co
     }
     if (m == 0) return FAD_OK;
     DeviceGuard g(live_h[0]->device);
-    return update_device_multi(m, live_h, live_rows, live_n, live_ld, dtype, static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (m > kMaxSets) {
+        // More than sixteen matrices share ONE launch of each kernel only on the 256-column-slab route (whose launch tables are that
+        // long) and only when no handle wants numpy's running sums beside it (the walk's tables are not); everything else goes
+        // sixteen at a time -- the same kernels, the same results, one more launch of each.
+        bool one = dtype == FAD_F16 && live_h[0]->d % 8 == 0;
+        for (int i = 0; i < m && one; ++i)
+            one = !live_h[i]->ref_mean && (live_ld[i] % 8 == 0) && ((reinterpret_cast<uintptr_t>(live_rows[i]) & 15u) == 0);
+        one = one && tile256_eligible(live_h[0], m, live_n, live_ld, dtype, true, false);
+        if (!one) {
+            for (int i0 = 0; i0 < m; i0 += kMaxSets) {
+                const int c = (m - i0 < kMaxSets) ? m - i0 : kMaxSets;
+                FAD_TRY(update_device_multi(c, live_h + i0, live_rows + i0, live_n + i0, live_ld + i0, dtype, st));
+            }
+            return FAD_OK;
+        }
+    }
+    return update_device_multi(m, live_h, live_rows, live_n, live_ld, dtype, st);
 }
 
 static int segment_running_sums_device(fad_moments* h, const void* drows, int64_t dld, int dtype, const int64_t* offsets, int64_t n_segments,

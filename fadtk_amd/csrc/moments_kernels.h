@@ -15,6 +15,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kXcd = 8;
 constexpr int kMaxSets = 16;      // frame matrices per launch
+constexpr int kMaxSets256 = 32;   // ... of the 256-column-slab kernel (moments_tile256.h): the statistics of sixteen scores in one launch
 
 // Workgroup id -> work item such that consecutive items land on the SAME XCD (block b runs on
 // XCD b % 8): the tiles of one row-split then share that XCD's L2 for their slabs of E.

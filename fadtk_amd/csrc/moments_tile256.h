@@ -47,7 +47,7 @@ struct T256Set {
     uint16_t* cvec;                         // [S][dpad] float16 shifts for the second pass (or nullptr)
 };
 struct T256Launch {
-    T256Set set[kMaxSets];
+    T256Set set[kMaxSets256];
     int nsets, d, nsb, NT, total;
     uint8_t type[t256::MAX_TYPES], sa[t256::MAX_TYPES], sb[t256::MAX_TYPES];
 };
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112))) void mom
     const int w = xcd_contiguous(blockIdx.x, L.total);
     int si = 0;
 #pragma unroll
-    for (int i = 1; i < kMaxSets; ++i)
+    for (int i = 1; i < kMaxSets256; ++i)
         if (i < L.nsets && w >= L.set[i].item0) si = i;
     const T256Set& s = L.set[si];
     if constexpr (SHIFT) {
@@ -455,7 +455,7 @@ struct R256Job {
     int64_t rows_per_split, n_rows;
 };
 struct R256Launch {
-    R256Job job[kMaxSets];
+    R256Job job[kMaxSets256];
     const t256::BlockSrc* table;             // device: n_blocks(8 nsb) entries
     int d, nsb, NT, nblk, sl;                // sl = split lanes per output group (1, 4 or 16)
     uint32_t two_mask;                       // bit a: superblock a's column sums have a second row (its triangle came from a Z / ZC item)

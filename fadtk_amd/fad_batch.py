@@ -53,52 +53,133 @@ class _DeviceFeeder:
         self.stats.add_group(rows.contiguous(), sizes)
 
 
+class _CacheWriter:
+    """The embedding cache files (fad.py:188-201: part of the contract) leave the GPU loop: ONE device-to-host copy per group of files
+    and the ``np.save`` calls run on a writer thread while the next group is embedded.  (The reference -- and rounds 1-5 here -- did a
+    synchronous copy and an ``np.save`` per file inside the loop.)"""
+
+    def __init__(self):
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.jobs = []
+
+    @staticmethod
+    def _write(items, host):
+        import numpy as np
+        o = 0
+        for cache, n in items:
+            cache.parent.mkdir(parents=True, exist_ok=True)
+            np.save(cache, host[o:o + n])
+            o += n
+
+    def submit(self, items, devs):
+        """items: [(cache path, frames)], devs: the float16 device tensors in the same order."""
+        import torch
+        rows = torch.cat(devs, dim=0) if len(devs) > 1 else devs[0]
+        host = torch.empty(rows.shape, dtype=rows.dtype, pin_memory=True)
+        host.copy_(rows, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def job():
+            done.synchronize()
+            self._write(items, host.numpy())
+        self.jobs.append(self.pool.submit(job))
+
+    def submit_host(self, cache, embd):
+        self.jobs.append(self.pool.submit(self._write, [(cache, embd.shape[0])], embd))
+
+    def close(self):
+        err = None
+        for j in self.jobs:
+            try:
+                j.result()
+            except Exception as e:      # noqa: BLE001
+                err = err or e
+        self.pool.shutdown()
+        if err is not None:
+            raise err
+
+
 def _cache_embedding_batch(fs, ml, workers: int = 8, feeder=None, **kwargs):
-    """Embed a list of files on this process's GPU; audio decode runs ``workers`` files ahead.
+    """Embed a list of files on this process's GPU; audio decode runs ``workers`` files ahead, ``ml.batch_files`` files share ONE
+    front-end launch and ONE forward (``ModelLoader._get_embedding_batch``), the cache files are written behind the loop.
     With ``feeder`` (a _DeviceFeeder) every embedding is also accumulated while it is still in HBM."""
     import numpy as np
     fad = FrechetAudioDistance(ml, audio_load_worker=workers, **kwargs)
     if not fs:
         return
-    depth = max(1, workers)
-    with ThreadPoolExecutor(max_workers=depth) as pool:
-        pending = []
-        it = iter(fs)
+    import torch
+    group_files = max(1, int(getattr(ml, "batch_files", 1)))
+    depth = max(1, workers, group_files)
+    on_gpu = torch.cuda.is_available() and getattr(ml, "device", None) is not None and ml.device.type == "cuda"
+    writer = _CacheWriter()
 
-        def submit():
-            f = next(it, None)
-            if f is not None:
-                pending.append((f, pool.submit(fad.load_audio, f)))
+    def embed_group(group):
+        """group: [(file, cache, audio)] -> [(file, cache, float16 frames or None)]; a failing group is retried file by file so that
+        only the file that fails is dropped (a bad file must not take the shard -- or its neighbours -- down)."""
+        try:
+            embs = ml._get_embedding_batch([a for _, _, a in group]) if len(group) > 1 else [ml._get_embedding(group[0][2])]
+        except Exception as e:      # noqa: BLE001
+            if len(group) == 1:
+                log.error(f"Embedding {group[0][0]} with {ml.name} failed: {e}")
+                return [(group[0][0], group[0][1], None)]
+            return [r for g in group for r in embed_group([g])]
+        out = []
+        for (f, cache, _), e in zip(group, embs):
+            e = e.detach()
+            out.append((f, cache, (e.to(torch.float16) if e.dtype == torch.float32 else e).contiguous()))   # (model_loader.py:47-48)
+        return out
 
-        for _ in range(depth):
-            submit()
-        while pending:
-            f, fut = pending.pop(0)
-            submit()
-            cache = get_cache_embedding_path(ml.name, f)
-            if cache.exists():
-                if feeder is not None:
-                    feeder.add_host(np.load(cache))
-                continue
-            log.info(f"Loading {f} using {ml.name}")
-            dev = None
-            try:                                 # only the embedding of THIS file is the file's own business
-                if feeder is not None:           # keep the frames on the device: fp16 exactly as stored, then moments
-                    import torch
-                    dev = ml._get_embedding(fut.result()).detach()
-                    dev = (dev.to(torch.float16) if dev.dtype == torch.float32 else dev).contiguous()
-                    embd = dev.cpu().numpy()     # the embedding cache file is part of the contract (fad.py:188-201)
-                else:
-                    embd = ml.get_embedding(fut.result())
-            except Exception as e:      # noqa: BLE001  a bad file must not take the shard down
-                log.error(f"Embedding {f} with {ml.name} failed: {e}")
-                continue
-            if dev is not None:
+    def flush(group):
+        if not group:
+            return
+        done = [(f, cache, e) for f, cache, e in embed_group(group) if e is not None]
+        if not done:
+            return
+        if on_gpu:
+            writer.submit([(cache, int(e.shape[0])) for _, cache, e in done], [e for _, _, e in done])
+        for _, cache, e in done:
+            if not on_gpu:
+                writer.submit_host(cache, e.cpu().numpy())
+            if feeder is not None:
                 # a GPU / library error of a group flush (64 files) is not this file's fault: it propagates, the shard
                 # stops at once instead of embedding everything that follows for nothing
-                feeder.add(dev)
-            cache.parent.mkdir(parents=True, exist_ok=True)
-            np.save(cache, embd)
+                feeder.add(e)
+
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            pending = []
+            it = iter(fs)
+
+            def submit():
+                f = next(it, None)
+                if f is not None:
+                    pending.append((f, pool.submit(fad.load_audio, f)))
+
+            for _ in range(depth):
+                submit()
+            group = []
+            while pending:
+                f, fut = pending.pop(0)
+                submit()
+                cache = get_cache_embedding_path(ml.name, f)
+                if cache.exists():
+                    if feeder is not None:
+                        flush(group); group = []                     # (the statistics take the files in order)
+                        feeder.add_host(np.load(cache))
+                    continue
+                log.info(f"Loading {f} using {ml.name}")
+                try:                                 # only the audio of THIS file is the file's own business
+                    audio = fut.result()
+                except Exception as e:      # noqa: BLE001  a bad file must not take the shard down
+                    log.error(f"Embedding {f} with {ml.name} failed: {e}")
+                    continue
+                group.append((f, cache, audio))
+                if len(group) >= group_files:
+                    flush(group); group = []
+            flush(group)
+    finally:
+        writer.close()
     if feeder is not None:
         feeder.flush()
 

@@ -134,9 +134,9 @@ class Moments:
 
     @staticmethod
     def update_multi(accs: Sequence["Moments"], blocks: Sequence) -> None:
-        """``accs[i].update(blocks[i])`` for up to 16 accumulators of one dimension with ONE launch of each kernel
+        """``accs[i].update(blocks[i])`` for up to 32 accumulators of one dimension with ONE launch of each kernel
         (``fad_moments_update_multi``); every block must be a device tensor of one common dtype."""
-        assert 1 <= len(accs) == len(blocks) <= 16
+        assert 1 <= len(accs) == len(blocks) <= 32
         views = [K.rows_view(b) for b in blocks]
         code = views[0][4]
         for a, v in zip(accs, views):

@@ -69,6 +69,16 @@ class ModelLoader(ABC):
         """Returns the embedding of the audio, shape (n_frames, n_features)."""
         pass
 
+    # How many files the batch driver (fad_batch.py) hands to ``_get_embedding_batch`` at once.  The reference's loop is one file per
+    # forward (fad_batch.py:18-22, fad.py:188-201); a loader that can do better says so here.  1 keeps that loop for third-party loaders.
+    batch_files = 1
+
+    def _get_embedding_batch(self, audios: list) -> list:
+        """Embeddings of several files: a list of (n_frames_i, n_features) tensors, one per input, each what ``_get_embedding`` returns
+        for that file alone.  Not part of the reference's plugin contract -- the default is the reference's own loop, so a loader written
+        for fadtk works unchanged; the loaders below override it with ONE front-end launch and ONE forward over all files."""
+        return [self._get_embedding(a) for a in audios]
+
     def load_wav(self, wav_file: Path):
         wav_data, _ = read_pcm16(wav_file)
         wav_data = wav_data / 32768.0                 # int16 -> [-1, 1) float64 (model_loader.py:64-65)
@@ -155,14 +165,27 @@ class VGGishModel(ModelLoader):
         self.model.eval().to(self.device)
 
     def _get_embedding(self, audio: np.ndarray):
-        wav = torch.as_tensor(np.asarray(audio, dtype=np.float32))
+        return self._get_embedding_batch([audio])[0]
+
+    batch_files = 64
+    _forward_examples = 1024                  # examples per forward: the first convolution keeps 1.5 MB of activations per example
+
+    def _get_embedding_batch(self, audios: list) -> list:
+        # all files' samples in ONE upload, all files' examples from ONE launch of the HIP front end, the network over them in slices
+        arrs = [np.asarray(a, dtype=np.float32).reshape(-1) for a in audios]
+        flat = torch.from_numpy(np.concatenate(arrs)) if len(arrs) > 1 else torch.from_numpy(np.ascontiguousarray(arrs[0]))
         if self.device.type == "cuda":
-            wav = wav.to(self.device)
-        examples, _ = hip.logmel_vggish([wav], device=self._device_index())       # HIP front end -> [E, 96, 64]
+            flat = flat.to(self.device)
+        lens = [len(a) for a in arrs]
+        wavs = list(torch.split(flat, lens))
+        examples, ex_off = hip.logmel_vggish(wavs, device=self._device_index())   # HIP front end -> [E, 96, 64], file i = examples ex_off[i] : ex_off[i + 1]
         if not torch.is_tensor(examples):
             examples = torch.from_numpy(examples).to(self.device)
         with torch.no_grad():
-            return self.model(examples.unsqueeze(1))
+            x = examples.unsqueeze(1)
+            out = torch.cat([self.model(x[o:o + self._forward_examples]) for o in range(0, x.shape[0], self._forward_examples)]) \
+                if x.shape[0] > self._forward_examples else self.model(x)
+        return [out[int(ex_off[i]):int(ex_off[i + 1])] for i in range(len(arrs))]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -199,6 +222,17 @@ class EncodecEmbModel(ModelLoader):
         with torch.no_grad():
             emb = self.model.encoder(audio.to(self.device))           # [1, 128, frames]
             return emb[0].transpose(0, 1)                             # [frames, 128]
+
+    batch_files = 8
+
+    def _get_embedding_batch(self, audios: list) -> list:
+        # 24 kHz: clips of ONE length go through the encoder as one [B, 1, T] batch (the convolutions are per clip: the frames of a clip
+        # do not depend on its neighbours); clips of different lengths -- and the segmented 48 kHz variant -- keep the per-file loop
+        if self.segment_length is None and len(audios) > 1 and all(torch.is_tensor(a) and a.shape == audios[0].shape for a in audios):
+            with torch.no_grad():
+                emb = self.model.encoder(torch.cat(list(audios), dim=0).to(self.device))      # [B, 128, frames]
+            return list(emb.transpose(1, 2).unbind(0))
+        return [self._get_embedding(a) for a in audios]
 
     def _get_embedding(self, audio):
         if self.segment_length is None:
@@ -377,14 +411,19 @@ class WhisperModel(ModelLoader):
         self.model.eval().to(self.device)
 
     def _get_embedding(self, audio: np.ndarray):
-        wav = torch.as_tensor(np.asarray(audio, dtype=np.float32).reshape(-1))
+        return self._get_embedding_batch([audio])[0]                                             # [2, D]
+
+    batch_files = 16
+
+    def _get_embedding_batch(self, audios: list) -> list:
+        wavs = [torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(-1)) for a in audios]
         if self.device.type == "cuda":
-            wav = wav.to(self.device)
-        feats = hip.logmel_whisper([wav], n_mels=self.n_mels, device=self._device_index())     # [1, n_mels, 3000]
+            wavs = [w.to(self.device) for w in wavs]
+        feats = hip.logmel_whisper(wavs, n_mels=self.n_mels, device=self._device_index())      # [B, n_mels, 3000]: one launch for all clips
         feats = feats if torch.is_tensor(feats) else torch.from_numpy(feats).to(self.device)
         with torch.no_grad():
-            out = self.model(feats, decoder_input_ids=self.decoder_input_ids).last_hidden_state
-        return out.squeeze(0)                                                                    # [2, D]
+            out = self.model(feats, decoder_input_ids=self.decoder_input_ids.expand(len(wavs), -1)).last_hidden_state
+        return list(out.unbind(0))                                                               # B x [2, D]
 
 
 class _HFLayerModel(ModelLoader):

@@ -95,8 +95,9 @@ int fad_moments_update(fad_moments_t* h, const void* rows, int64_t n, int64_t ld
  * wait for it.  With 1 the walk starts behind the caller's stream and the update does not return the stream before it is through. */
 int fad_moments_set_reference_mean(fad_moments_t* h, int enabled);
 
-/* Feed `count` (1..16) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE
- * launch of each kernel: rows[i] (a DEVICE pointer, n[i] frames, pitch ld[i]) goes to hs[i].  The two datasets of a
+/* Feed `count` (1..32) frame matrices to `count` DIFFERENT handles of one dimension, dtype and device with ONE
+ * launch of each kernel (more than 16: one launch on the 256-column-slab route -- float16, D >= 512, no running sums asked for --
+ * else sixteen at a time): rows[i] (a DEVICE pointer, n[i] frames, pitch ld[i]) goes to hs[i].  The two datasets of a
  * FAD score (fad.py:292-302 calls calc_embd_statistics / load_stats twice), the 25 resamples of score_inf
  * (fad.py:333-341) ...: the workgroup slots of the GPU are shared out over all sets in proportion to their rows,
  * so the fixed costs of a pass (one 64 KiB partial tile per workgroup, pipeline fill, launches) are paid once.

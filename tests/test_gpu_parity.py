@@ -920,6 +920,30 @@ def test_online_statistics_golden_g3(F, golden, golden_dir, tmp_path):
     np.testing.assert_allclose(mu_n, z["mu_nan"], rtol=1e-12)
 
 
+def test_online_statistics_at_config2_size(F, tmp_path):
+    """BASELINE config 2 at its stated size: 1 000 files of ten 128-dimensional float16 frames (VGGish on 1k ten-second wavs) for the
+    baseline and as many for the evaluation set, through ``calculate_embd_statistics_online`` (utils.py:19-46: per-file float16 means,
+    sequential merge) and ``calc_frechet_distance``, against the oracle on the same files.  Ten frames per file: every file's scatter has
+    rank 9, the float16 rounding of its mean is worth 1e-4 of the FAD -- the quirk has to be reproduced, not averaged away."""
+    sets = {}
+    for name, seed, gain, shift in (("base", 2000, 1.0, 0.0), ("eval", 3000, 1.05, 0.02)):
+        rng = np.random.default_rng(seed)
+        mix = rng.standard_normal((128, 128)) / np.sqrt(128.0)
+        files, blocks = [], []
+        for i in range(1000):
+            blk = (gain * (rng.standard_normal((10, 128)) @ mix + 0.3 * rng.standard_normal((1, 128))) + shift + 0.25).astype(np.float16)
+            np.save(tmp_path / f"{name}{i:04d}.npy", blk)
+            files.append(tmp_path / f"{name}{i:04d}.npy"); blocks.append(blk)
+        mu, cov = F.calculate_embd_statistics_online(files)
+        mu_o, cov_o = O.statistics_online(blocks)
+        np.testing.assert_allclose(mu, mu_o, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(cov, cov_o, rtol=0, atol=2e-6 * np.abs(cov_o).max())
+        sets[name] = (mu, cov, mu_o, cov_o)
+    got = F.calc_frechet_distance(sets["base"][0], sets["base"][1], sets["eval"][0], sets["eval"][1])
+    want = O.frechet_distance(sets["base"][2], sets["base"][3], sets["eval"][2], sets["eval"][3], run_sqrtm=False)
+    assert abs(got - want) / abs(want) < 1e-6
+
+
 def test_online_statistics_shifted_files_take_numpys_per_file_means(F, golden, golden_dir):
     """Round 5 fixture g3_shifted (the REFERENCE's calculate_embd_statistics_online on 12 float16 files of 9000-40000 frames with
     |mu| / sigma ~ 7): the per-file float16 means are np.mean's -- a float32 running sum per file (utils.py:16) -- which the online path

@@ -323,3 +323,61 @@ def test_config4_many_files_device_resident_matches_online_oracle():
     x = np.concatenate(blocks).astype(np.float64)
     plain = np.cov(x, rowvar=False)
     assert np.abs(cov - plain).max() > 10 * np.abs(cov - cov_o).max()
+
+
+def test_batched_loaders_give_each_file_what_it_gets_alone(monkeypatch):
+    """``ModelLoader._get_embedding_batch`` (round 6: ONE front-end launch and ONE forward for the files of a group, fad_batch.py)
+    returns, file by file, what ``_get_embedding`` returns for the file alone -- frame counts exactly, values to the accuracy a
+    convolution's choice of algorithm by batch size leaves (the embeddings are stored as float16)."""
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    import torch
+    from fadtk_amd.model_loader import EncodecEmbModel, VGGishModel, WhisperModel
+    ml = VGGishModel(); ml.load_model()
+    clips = [R.audio_clip(40 + i, int(s * 16000), 16000) for i, s in enumerate((10.0, 3.3, 1.0, 7.9, 10.0))]
+    both = ml._get_embedding_batch(clips)
+    assert [int(e.shape[0]) for e in both] == [10, 3, 1, 8, 10]
+    for c, e in zip(clips, both):
+        one = ml._get_embedding(c)
+        assert one.shape == e.shape
+        torch.testing.assert_close(e, one, rtol=2e-3, atol=2e-3 * float(one.abs().max()))
+    ml = WhisperModel("tiny"); ml.load_model()
+    clips = [R.audio_clip(50 + i, int(s * 16000), 16000) for i, s in enumerate((4.0, 31.0, 12.5))]
+    both = ml._get_embedding_batch(clips)
+    for c, e in zip(clips, both):
+        one = ml._get_embedding(c)
+        assert tuple(e.shape) == (2, 384)
+        torch.testing.assert_close(e, one, rtol=2e-3, atol=2e-3 * float(one.abs().max()))
+    ml = EncodecEmbModel("24k"); ml.load_model()
+    clips = [torch.from_numpy(R.audio_clip(60 + i, 2 * 24000, 24000).astype(np.float32))[None, None, :] for i in range(3)]
+    both = ml._get_embedding_batch(clips)
+    for c, e in zip(clips, both):
+        one = ml._get_embedding(c)
+        assert tuple(e.shape) == (150, 128)
+        torch.testing.assert_close(e, one, rtol=2e-3, atol=2e-3 * float(one.abs().max()))
+    ragged = clips[:2] + [clips[2][:, :, :30000]]                   # clips of different lengths: the per-file loop
+    assert [int(e.shape[0]) for e in ml._get_embedding_batch(ragged)] == [150, 150, 94]
+
+
+def test_batch_driver_drops_only_the_file_that_fails(tmp_path, monkeypatch):
+    """A group of files shares one forward; a file the loader cannot embed costs that file alone, the others of its group are embedded
+    one by one (the reference's loop loses only the failing file as well: fad_batch.py:18-22 catches per file)."""
+    monkeypatch.setenv("FADTK_AMD_RANDOM_WEIGHTS", "1")
+    from fadtk_amd.fad_batch import cache_embedding_files
+    from fadtk_amd.model_loader import VGGishModel
+    root = _make_set(tmp_path / "set", 7, 2.0, 16000, 900)
+
+    class Picky(VGGishModel):
+        def _get_embedding_batch(self, audios):
+            if any(abs(float(np.asarray(a)[0]) - self.bad) < 1e-12 for a in audios):
+                raise RuntimeError("cannot embed this one")
+            return super()._get_embedding_batch(audios)
+
+        def _get_embedding(self, audio):
+            return self._get_embedding_batch([audio])[0]
+
+    ml = Picky()
+    ml.bad = float(ml.load_wav(root / "clip003.wav")[0])            # (load_wav of the file as stored: what the loop will see)
+    cache_embedding_files(root, ml, workers=3)
+    got = sorted(p.stem for p in (root / "embeddings" / "vggish").glob("*.npy"))
+    assert got == [f"clip{i:03d}" for i in range(7) if i != 3]
+    assert np.load(root / "embeddings" / "vggish" / "clip000.npy").shape == (2, 128)
