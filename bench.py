@@ -57,9 +57,30 @@ N_PAIRS = 4                              # distinct (A, B) pairs rotated through
                                          # Infinity Cache, so every step streams its frames from HBM (a caller scores each set once)
 
 
+def golden_g7():
+    """The reference's own scalar for the C3 recipe (tests/golden/golden.json: g7, written by tests/golden/make_golden.py from the imported
+    reference) and the recipe's generator (tests/golden/recipes.py: numpy default_rng seeds 10 / 11) -- fixtures, not the oracle."""
+    try:
+        sys.path.insert(0, str(ROOT / "tests" / "golden"))
+        import recipes
+        g7 = json.loads((ROOT / "tests" / "golden" / "golden.json").read_text())["g7"]
+        return recipes, g7
+    except Exception:       # noqa: BLE001  (a checkout without tests/: the pair falls back to the device generator)
+        return None, None
+    finally:
+        if sys.path and sys.path[0].endswith("golden"):
+            sys.path.pop(0)
+
+
 def make_sets(torch, device, rank, pair=0):
-    """C3 recipe: A ~ N(0,1), B ~ 1.02 N(0,1) + 0.01, float16, generated on device.  Pair 0 of rank 0 is the
-    golden G7 pair (seeds 10 / 11); further pairs and ranks move the seeds."""
+    """C3 recipe: A ~ N(0,1), B ~ 1.02 N(0,1) + 0.01, float16.  Pair 0 of rank 0 is LITERALLY the golden G7 pair --
+    `recipes.c3_pair()` (numpy default_rng, seeds 10 / 11), generated on the host and uploaded once -- so that the line can hold the
+    reference's own scalar against the GPU's (`parity_rel_err_vs_golden_g7`); further pairs and ranks come from the device generator."""
+    if pair == 0 and rank == 0:
+        recipes, g7 = golden_g7()
+        if recipes is not None and (N_ROWS, DIM) == (int(g7["n"]), int(g7["d"])):
+            a, b = recipes.c3_pair()
+            return torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)
     g = torch.Generator(device=device)
     g.manual_seed(10 + 100 * pair + 1000 * rank)
     a = torch.randn((N_ROWS, DIM), generator=g, device=device, dtype=torch.float32).to(torch.float16)
@@ -1097,12 +1118,17 @@ def main():
             # the frames of this loop are resident and never change: the walk of numpy's running sums may run DETACHED (it waits for nothing
             # and holds nothing up; the chain of a batch waits for it).  `attached` = the default contract (any caller): the walk starts
             # behind the stream's earlier work and the update returns the stream only when it is through.
+            # (with the walk the moments go 8 matrices to a launch: the walk is paced per workgroup, 32 of them per matrix, and sixteen matrices'
+            #  worth of them crowd the CUs -- r06j: 5 120 / 4 750 / 4 270 scores/s at 4 / 8 / 16 steps per launch; without it, as the flat loop)
+            MG_walk = min(MGv[0], 4)
             for h in all_h:
                 h.set_reference_mean(True, detached=True)
+            MGv[0] = MG_walk
             ts_on, (fad_r, diag_r) = blocks()
             for h in all_h:
                 h.set_reference_mean(True, detached=False)
             ts_att, _ = blocks(3)
+            MGv[0] = MG
             for h in all_h:
                 h.set_reference_mean(False)
             ts_off, _ = blocks(3)
@@ -1324,7 +1350,9 @@ def main():
                    "sharding": ("rows sharded over ranks; ONE in-place all-reduce per moments launch over the buffer holding the packed "
                                 f"(n, sum x, sum xxT) fp64 of its {2 * MG if BATCH else 2} sets [{2 * MG if BATCH else 2} x {plen} doubles]") if distributed else "single GPU, no collective",
                    "collective_backend": coll_backend, "collective_ranks": coll_ranks},
-        "fad": fad0, "fad_pair": ("pair 0 (seeds 10 / 11: the golden G7 pair) on this rank's rows" if not args.timed_only else "last timed step"),
+        "fad": fad0, "fad_pair": ("pair 0 = the golden G7 pair (tests/golden/recipes.c3_pair, numpy seeds 10 / 11)" if not args.timed_only else "last timed step"),
+        "parity_rel_err_vs_golden_g7": ((abs(fad0 - float(golden_g7()[1]["fad"])) / float(golden_g7()[1]["fad"]))
+                                        if (not args.timed_only and not distributed and golden_g7()[1] is not None) else None),
         "fad_last_timed_step": fad, "timed_only": bool(args.timed_only), "chain_cus_per_xcd": int(args.chain_cus), "group": G, "batched_chains": BATCH,
         "newton_schulz_iters": diag["iters"], "ns_converged": diag["converged"],
         "frames_per_s": n_gpus * args.steps * 2 * N_ROWS / elapsed,

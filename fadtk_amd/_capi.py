@@ -134,6 +134,27 @@ def last_error() -> str:
     return load_library().fad_last_error().decode("utf-8", "replace")
 
 
+class FadOutOfMemory(RuntimeError):
+    """The library could not get memory: FAD_ERR_ALLOC, or a HIP call that failed with hipErrorOutOfMemory.  A RuntimeError like
+    torch's own out-of-memory error; callers that can fall back to a leaner route test for the TYPE, not for message wording."""
+
+
+def is_out_of_memory(e: BaseException) -> bool:
+    """This library's allocation failure, or torch's (torch.cuda.OutOfMemoryError / torch.OutOfMemoryError where torch has them)."""
+    if isinstance(e, FadOutOfMemory):
+        return True
+    try:
+        import torch
+        for name in ("OutOfMemoryError",):
+            for mod in (getattr(torch, "cuda", None), torch):
+                t = getattr(mod, name, None) if mod is not None else None
+                if isinstance(t, type) and isinstance(e, t):
+                    return True
+    except ImportError:
+        pass
+    return False
+
+
 def check(status: int, what: str = "libfad_hip"):
     """Map a fad_status to the exception type the reference raises for the same condition."""
     if status == FAD_OK:
@@ -148,6 +169,8 @@ def check(status: int, what: str = "libfad_hip"):
     if status == FAD_ERR_NOT_CONVERGED:
         log.warning(msg)
         return
+    if status == FAD_ERR_ALLOC or (status == FAD_ERR_HIP and ("hipErrorOutOfMemory" in msg or "out of memory" in msg.lower())):
+        raise FadOutOfMemory(msg)
     raise RuntimeError(msg)
 
 

@@ -1161,13 +1161,16 @@ static int stage_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, 
     ws.job.cov1 = s; ws.job.cov2 = s + dd; ws.job.mu1 = s + 2 * dd; ws.job.mu2 = s + 2 * dd + d;
     if (fast_eligible(ws, d, max_iter, tol)) {     // the eight-launch chain: its first kernel does this staging as well
         ws.job.fast = true;
-        return fast_prepare(ws, d, ddof, moments_packed(h1), moments_packed(h2), nullptr, nullptr, nullptr, nullptr, mean_dtype, s + 2 * dd, s, st,
-                            moments_runsum(h1), moments_runsum(h2));
+        FAD_TRY(fast_prepare(ws, d, ddof, moments_packed(h1), moments_packed(h2), nullptr, nullptr, nullptr, nullptr, mean_dtype, s + 2 * dd, s, st,
+                             moments_runsum(h1), moments_runsum(h2)));
+        FAD_TRY(moments_mark_read(h1, st));
+        return moments_mark_read(h2, st);
     }
     enqueue_finalize_for_frechet(moments_packed(h1), moments_packed(h2), d, ddof, s + 2 * dd, s, static_cast<NsState*>(ws.small.p), st,
                                  moments_runsum(h1), moments_runsum(h2));
     FAD_HIP_TRY(hipGetLastError());
-    return FAD_OK;
+    FAD_TRY(moments_mark_read(h1, st));
+    return moments_mark_read(h2, st);
 }
 
 int fad_frechet_from_moments(const fad_moments_t* h1, const fad_moments_t* h2, int ddof, double eps,
@@ -1248,6 +1251,7 @@ int fad_frechet_from_moments_multi_begin(int count, const fad_moments_t* const* 
     if (fast_eligible(ws, d, 0, 0.0)) {
         for (int b = 0; b < count; ++b) { FAD_TRY(moments_settle(h1[b], st)); FAD_TRY(moments_settle(h2[b], st)); }
         FAD_TRY(pairs_enqueue(ws, d, count, h1, h2, ddof, mean_dtype, st));
+        for (int b = 0; b < count; ++b) { FAD_TRY(moments_mark_read(h1[b], st)); FAD_TRY(moments_mark_read(h2[b], st)); }
         ws.multi.enqueued = true;
     }
     ws.busy = true;

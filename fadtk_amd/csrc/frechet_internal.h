@@ -14,6 +14,7 @@ struct fad_moments;
 namespace fad {
 const double* moments_packed(const fad_moments* h);
 int moments_settle(const fad_moments* h, hipStream_t st);      // pending reset -> zeros
+int moments_mark_read(const fad_moments* h, hipStream_t st);   // behind the launch of a kernel that reads the handle's statistics asynchronously
 int moments_device(const fad_moments* h);
 int moments_dim(const fad_moments* h);
 const float* moments_runsum(const fad_moments* h);          // numpy's running column sums when they cover the handle's rows, else nullptr

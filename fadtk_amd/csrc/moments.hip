@@ -59,6 +59,9 @@ struct fad_moments {
     hipEvent_t cp_enter = nullptr, cp_ev[8] = {};
     bool ref_detached = false;             // fad_moments_set_reference_mean(h, 2): the walk neither waits for the caller's stream nor holds it up
     hipEvent_t rs_pending = nullptr;       // ... the library's event behind the handle's last detached walk: settle() makes a reader's stream wait for it
+    hipEvent_t rs_reader = nullptr;        // ... and the handle's own event behind its last ASYNCHRONOUS reader (moments_mark_read): the next detached walk,
+    bool rs_reader_set = false;            //     which rewrites the running sums on the side stream, waits for it
+    bool staged_input = false;             // update_any is feeding host rows through the staging area: no detached walk over those
     int r256_sl = 0;                       // FAD_MOMENTS_R256_SL (read at creation; experiments): split lanes of moments_reduce256, 0 = by the split count
     int tile256 = 1;                       // 0: FAD_MOMENTS_TILE256=0 (read at creation) keeps D >= 512 on the 128 x 128 kernel
     // the segment tables of the last fused update_segmented call, kept on the host: a caller feeding groups of the SAME file sizes
@@ -430,10 +433,14 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
         // complete now and stay as they are until the statistics are next read -- the walk starts at once, beside whatever the caller's
         // stream still holds, and settle() orders the readers behind it
         bool detached = true;
-        for (int i = 0; i < count; ++i) if (n[i] > 0 && hs[i]->ref_mean && hs[i]->runsum_covers && !hs[i]->ref_detached) detached = false;
+        for (int i = 0; i < count; ++i) if (n[i] > 0 && hs[i]->ref_mean && hs[i]->runsum_covers && (!hs[i]->ref_detached || hs[i]->staged_input)) detached = false;
         hipStream_t side = runsum_side_stream(h0->device);
         hipEvent_t pend = (side && detached) ? runsum_ring_event(h0->device) : nullptr;
         if (side && detached && pend) {
+            // (it waits for nothing -- except a reader of these very running sums that is still on its way: a chain enqueued on the
+            //  caller's stream before the handle was reset would otherwise see the NEXT rows' sums)
+            for (int i = 0; i < count; ++i)
+                if (n[i] > 0 && hs[i]->rs_reader_set) { FAD_HIP_TRY(hipStreamWaitEvent(side, hs[i]->rs_reader, 0)); hs[i]->rs_reader_set = false; }
             run_st = side;
         } else if (side) {
             if (!h0->rs_fork) {
@@ -451,6 +458,12 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
         } else if (run_st != st) {
             FAD_HIP_TRY(hipEventRecord(h0->rs_join, run_st)); *joined = h0->rs_join;
         }
+    } else {
+        // walks on the caller's stream continue the carry of a detached walk that may still be running on the side stream
+        for (int i = 0; i < count; ++i)
+            if (n[i] > 0 && hs[i]->rs_pending) FAD_HIP_TRY(hipStreamWaitEvent(st, hs[i]->rs_pending, 0));
+    }
+    if (dtype == FAD_F16 && wide) {
     } else if (dtype == FAD_F16) {
         hipLaunchKernelGGL((moments_running_colsum<raw_f16, false>), grid, dim3(256), kRunLds, st, L);
     } else if (dtype == FAD_BF16) {
@@ -659,6 +672,11 @@ static int update_device(fad_moments* h, const void* rows, int64_t n, int64_t ld
 static int update_any(fad_moments* h, const void* rows, int64_t n, int64_t ld, int dtype, int on_device,
                       hipStream_t st) {
     if (on_device) return update_device(h, rows, n, ld, dtype, st);
+    // Host rows reach the kernels through the handle's staging area, block after block: a DETACHED walk of numpy's running sums
+    // (fad_moments_set_reference_mean(h, 2): "the rows are complete at the call and stay unchanged") would read that area before the
+    // copy has landed and while the next block overwrites it.  The caller's promise holds for ITS rows, not for the staging area:
+    // staged updates take the attached walk, which starts behind the copy and is waited for before the area is reused.
+    struct StagedScope { fad_moments* h; explicit StagedScope(fad_moments* p) : h(p) { h->staged_input = true; } ~StagedScope() { h->staged_input = false; } } staged_scope(h);
     const size_t es = dtype_size(dtype);
     const int64_t row_bytes = (int64_t)h->d * es;
     int64_t chunk_rows = ((int64_t)1 << 30) / (row_bytes > 0 ? row_bytes : 1);
@@ -860,6 +878,7 @@ int fad_moments_destroy(fad_moments_t* h) {
     if (h->cp_st) (void)hipStreamDestroy(h->cp_st);
     if (h->rs_join) (void)hipEventDestroy(h->rs_join);
     if (h->ev) { for (int i = 0; i < fad_moments::kRing * 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]); delete[] h->ev; }
+    if (h->rs_reader) (void)hipEventDestroy(h->rs_reader);
     delete h;
     return FAD_OK;
 }
@@ -868,10 +887,9 @@ int fad_moments_destroy(fad_moments_t* h) {
 // every other reader settles the pending zeroing first.
 static int settle(const fad_moments* hc, hipStream_t st) {
     fad_moments* h = const_cast<fad_moments*>(hc);
-    if (h->rs_pending) {                           // a detached walk of numpy's running sums: whoever reads the statistics waits for it
-        FAD_HIP_TRY(hipStreamWaitEvent(st, h->rs_pending, 0));
-        h->rs_pending = nullptr;
-    }
+    // a detached walk of numpy's running sums: whoever reads the statistics waits for it -- EVERY reader, on whatever stream (the
+    // event stays with the handle until the next walk replaces it; waiting twice costs nothing)
+    if (h->rs_pending) FAD_HIP_TRY(hipStreamWaitEvent(st, h->rs_pending, 0));
     if (!h->fresh) return FAD_OK;
     FAD_HIP_TRY(hipMemsetAsync(h->acc, 0, (size_t)packed_len(h->d) * sizeof(double), st));
     h->fresh = false;
@@ -965,8 +983,14 @@ int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* co
 static int segment_running_sums_device(fad_moments* h, const void* drows, int64_t dld, int dtype, const int64_t* offsets, int64_t n_segments,
                                        float* dout, hipStream_t st) {
     FAD_TRY(h->seg_off.reserve((size_t)(n_segments + 1) * sizeof(int64_t)));
-    // (pageable source: the runtime stages it before the call returns)
-    FAD_HIP_TRY(hipMemcpyAsync(h->seg_off.p, offsets, (size_t)(n_segments + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    // through the handle's pinned table area like every other table of this file (stage_tables waits for the previous upload's event;
+    // a pageable source would lean on the runtime staging it before the call returns -- the caller frees `offsets` right after)
+    char* pinned = nullptr;
+    const size_t off_bytes = (size_t)(n_segments + 1) * sizeof(int64_t);
+    FAD_TRY(stage_tables(h, off_bytes, &pinned));
+    memcpy(pinned, offsets, off_bytes);
+    FAD_HIP_TRY(hipMemcpyAsync(h->seg_off.p, pinned, off_bytes, hipMemcpyHostToDevice, st));
+    FAD_HIP_TRY(hipEventRecord(h->tab_ev, st));
     const int64_t total = n_segments > 0 ? offsets[n_segments] - offsets[0] : 0;
     return segment_running_sums_launch(drows, dld, h->d, dtype, static_cast<const int64_t*>(h->seg_off.p), n_segments, dout, st, &h->seg_jobs,
                                        n_segments > 0 ? total / n_segments : 0, h->device);
@@ -989,6 +1013,7 @@ static int update_segmented_impl(fad_moments_t* h, const void* rows, int64_t n, 
     const size_t es = dtype_size(dtype);
     const void* drows = rows;
     int64_t dld = ld;
+    struct StagedScope { fad_moments* h; bool on; StagedScope(fad_moments* p, bool o) : h(p), on(o) { if (on) h->staged_input = true; } ~StagedScope() { if (on) h->staged_input = false; } } staged_scope(h, !on_device);
     if (!on_device) {      // one staged copy serves both kernels (bounded by caller: host blocks are per-batch)
         const int64_t row_bytes = (int64_t)h->d * es;
         FAD_TRY(h->stage.reserve((size_t)n * row_bytes + 16));
@@ -1376,6 +1401,14 @@ int fad_moments_last_timing(fad_moments_t* h, float* ms_main, float* ms_reduce, 
 namespace fad {
 const double* moments_packed(const fad_moments* h) { return h->acc; }
 int moments_settle(const fad_moments* h, hipStream_t st) { return settle(h, st); }
+int moments_mark_read(const fad_moments* hc, hipStream_t st) {
+    fad_moments* h = const_cast<fad_moments*>(hc);
+    if (!h->ref_mean || !h->ref_detached) return FAD_OK;             // (everything else is ordered on the caller's stream already)
+    if (!h->rs_reader) FAD_HIP_TRY(hipEventCreateWithFlags(&h->rs_reader, hipEventDisableTiming));
+    FAD_HIP_TRY(hipEventRecord(h->rs_reader, st));
+    h->rs_reader_set = true;
+    return FAD_OK;
+}
 const float* moments_runsum(const fad_moments* h) {
     return (h->ref_mean && h->runsum_covers && h->runsum_live && !h->fresh) ? static_cast<const float*>(h->runsum.p) : nullptr;
 }

@@ -16,6 +16,7 @@ from typing import NamedTuple, Union
 
 import numpy as np
 
+from . import _capi as K
 from . import hip
 from .utils import PathLike, calculate_embd_statistics_online, find_sox_formats, get_cache_embedding_path, tmap, tq, write
 
@@ -265,8 +266,8 @@ class FrechetAudioDistance:
         except ImportError as e:                      # no torch to hold the frames in HBM: host arrays, one point at a time
             log.info(f"FAD-inf: device route not available ({type(e).__name__}), scoring point by point")
             values = None
-        except RuntimeError as e:                     # not enough HBM for frames + resamples (torch's OOM is a RuntimeError) -- and
-            if "out of memory" not in str(e).lower() and "hipMalloc" not in str(e):  # nothing else: a failure of the library itself must not be scored twice
+        except RuntimeError as e:                     # not enough HBM for frames + resamples: torch's OutOfMemoryError or the library's
+            if not K.is_out_of_memory(e):             # FadOutOfMemory, by TYPE -- nothing else: a failure of the library itself must not be scored twice
                 raise
             log.warning(f"FAD-inf: device route ran out of memory ({e}), scoring point by point")
             values = None

@@ -536,6 +536,19 @@ def test_frechet_from_moments_takes_numpys_mean_from_handles_that_carry_it(F, go
         fad_det, _ = hip.frechet_from_moments(ma, mb, mean_dtype=hip.K.FAD_F16)
         assert np.array_equal(ma.finalize()[0], mu_att)                 # the running sums carried across the two updates: numpy's mean bit for bit
         assert abs(fad_det - fad) <= 2e-6 * abs(fad), (fad_det, fad)    # (two updates sum the partial tiles in another order: 1e-9 .. 1e-6 through the root)
+        # detached handles fed HOST rows -- those go through the handle's staging area, which a walk that waits for nothing
+        # would read before the copy has landed (and while the next block overwrites it): staged updates take the attached walk.  Twice
+        # over, a reset in between (the second walk must not overtake the first chain's read of the running sums), readers on two streams.
+        for rep in range(2):
+            ma.reset(); mb.reset()
+            ma.update(a[:30001]); ma.update(a[30001:])
+            mb.update(b[:30001]); mb.update(b[30001:])
+            fad_host, _ = hip.frechet_from_moments(ma, mb, mean_dtype=hip.K.FAD_F16)
+            other = torch.cuda.Stream()
+            with torch.cuda.stream(other):
+                mu_other = ma.finalize()[0]
+            assert np.array_equal(mu_other, mu_att) and np.array_equal(ma.finalize()[0], mu_att), rep
+            assert abs(fad_host - fad) <= 2e-6 * abs(fad), (rep, fad_host, fad)
         # a merge gives the row order up -- the handle falls back to the exact mean instead of dividing dst's running sums by
         # the merged count
         with hip.Moments(d) as half1, hip.Moments(d) as half2:
@@ -892,9 +905,17 @@ def test_config3_full_size(F, golden):
     with hip.Moments(512) as ma, hip.Moments(512) as mb:
         ma.update(torch.from_numpy(a).cuda()); mb.update(torch.from_numpy(b).cuda())
         fad_dev, diag = hip.frechet_from_moments(ma, mb)
-    # this route keeps the means in float64 (no fp16 rounding of mu): compare the root, not the mean term
-    assert diag["tr_sqrt"] == pytest.approx(g["tr_sqrt"], rel=2e-7)
-    assert abs((fad_dev - diag["mean_term"]) - (g["fad"] - g["mean_term"])) / g["fad"] < FAD_BAR
+        # this route keeps the means in float64 (no fp16 rounding of mu): compare the root, not the mean term
+        assert diag["tr_sqrt"] == pytest.approx(g["tr_sqrt"], rel=2e-7)
+        assert abs((fad_dev - diag["mean_term"]) - (g["fad"] - g["mean_term"])) / g["fad"] < FAD_BAR
+        # ... and with the reference's float16 mean term (what bench.py's loop asks for: mean_dtype = float16 -- the means rounded to
+        # float16, their difference and its dot product in float16 like numpy's, fad.py:48 / :83-84): the whole scalar, single pair and batch
+        fad_h, diag_h = hip.frechet_from_moments(ma, mb, mean_dtype=0)
+        assert diag_h["mean_term"] == pytest.approx(g["mean_term"], rel=2e-3)
+        assert abs(fad_h - g["fad"]) / g["fad"] < FAD_BAR
+        res = hip.FrechetMultiJob([(ma, mb)] * 3, mean_dtype=0).result()
+        for fad_k, _ in res:
+            assert abs(fad_k - g["fad"]) / g["fad"] < FAD_BAR
 
 
 # --------------------------------------------------------------------------------- online statistics

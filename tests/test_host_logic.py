@@ -206,3 +206,19 @@ def test_wide_chain_acceptance_rule_emulated():
     assert k1["norm_bound_fad"] > 1e-3 and k1["iters"] <= 14, k1
     assert k1["fad_rel_err"] <= k1["verify_est_fad"] <= 1e-5, k1
     assert k2["route"] == "declined", k2
+
+
+def test_out_of_memory_is_a_type_not_a_wording():
+    """score_inf falls back to the point-by-point route on an out-of-memory error of the device route -- recognised by TYPE
+    (the library's FadOutOfMemory for FAD_ERR_ALLOC, torch's OutOfMemoryError), not by what the message happens to say."""
+    import torch
+    from fadtk_amd import _capi as K
+    with pytest.raises(K.FadOutOfMemory):
+        K.check(K.FAD_ERR_ALLOC, "somewhere")
+    assert issubclass(K.FadOutOfMemory, RuntimeError)
+    assert K.is_out_of_memory(K.FadOutOfMemory("any wording at all"))
+    assert K.is_out_of_memory(torch.cuda.OutOfMemoryError("x"))
+    assert not K.is_out_of_memory(RuntimeError("out of memory"))        # a RuntimeError that merely SAYS so is not one
+    with pytest.raises(RuntimeError) as ei:
+        K.check(K.FAD_ERR_HIP, "somewhere")
+    assert not isinstance(ei.value, K.FadOutOfMemory) or "memory" in str(ei.value).lower()

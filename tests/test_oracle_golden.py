@@ -196,6 +196,22 @@ def test_g6_score_inf(golden):
     assert res.r2 == pytest.approx(g["r2"], rel=1e-6)
 
 
+def test_g7_config3_scalar(golden):
+    """BASELINE config 3 at full size (N = 100 000, D = 512, float16; seeds 10 / 11): the ORACLE against the scalar the reference itself
+    returned for this recipe (round 6: rounds 1-5 held only the HIP path against it).  ~4 s of BLAS."""
+    g = golden["g7"]
+    a, b = R.c3_pair()
+    assert R.checksum(a) == pytest.approx(g["in_checksum"][0], rel=1e-12) and R.checksum(b) == pytest.approx(g["in_checksum"][1], rel=1e-12)
+    m1, c1 = O.embd_statistics(a)
+    m2, c2 = O.embd_statistics(b)
+    assert m1.dtype == np.float16 and str(m1.dtype) == g["mean_term_dtype"]
+    assert np.trace(c1) == pytest.approx(g["tr1"], rel=1e-12) and np.trace(c2) == pytest.approx(g["tr2"], rel=1e-12)
+    d = m1 - m2
+    assert float(d.dot(d)) == g["mean_term"]                    # a float16 scalar in the reference: bit for bit
+    fad = O.frechet_distance(m1, c1, m2, c2, run_sqrtm=False)
+    assert abs(fad - g["fad"]) / g["fad"] < 1e-10
+
+
 def test_g8_two_row_songs_subset(golden):
     g = golden["g8"]
     d = g["d"]
