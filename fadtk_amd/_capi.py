@@ -57,6 +57,7 @@ SIGNATURES = {
     "fad_moments_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "fad_moments_destroy": (C.c_int, [_P]),
     "fad_moments_reset": (C.c_int, [_P, _P]),
+    "fad_moments_reset_multi": (C.c_int, [C.c_int, C.POINTER(_P), _P]),
     "fad_moments_settle": (C.c_int, [_P, _P]),
     "fad_moments_dim": (C.c_int, [_P]),
     "fad_moments_packed_len": (_I64, [_P]),

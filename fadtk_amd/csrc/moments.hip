@@ -904,6 +904,12 @@ int fad_moments_reset(fad_moments_t* h, void* stream) {
     return FAD_OK;
 }
 
+int fad_moments_reset_multi(int count, fad_moments_t* const* hs, void* stream) {
+    if (count < 0 || (count > 0 && !hs)) return set_error(FAD_ERR_INVALID, "bad handle list");
+    for (int i = 0; i < count; ++i) FAD_TRY(fad_moments_reset(hs[i], stream));
+    return FAD_OK;
+}
+
 int fad_moments_settle(fad_moments_t* h, void* stream) {
     if (!h) return set_error(FAD_ERR_INVALID, "handle is NULL");
     DeviceGuard g(h->device);

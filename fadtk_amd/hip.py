@@ -154,6 +154,11 @@ class Moments:
             a._keep = v[6]
 
     @staticmethod
+    def prepared_update_multi(accs: Sequence["Moments"], blocks: Sequence) -> "PreparedMultiUpdate":
+        """``update_multi`` for a loop that feeds the SAME accumulators from the SAME device tensors again and again: see PreparedMultiUpdate."""
+        return PreparedMultiUpdate(accs, blocks)
+
+    @staticmethod
     def update_file_means(exact: "Moments", rounded: "Moments", weighted: "Moments", seg_sums, sizes, dtype_code: int, seg_runsums=None) -> None:
         """Accumulate the per-file mean rows of the online statistics (``fad_moments_update_file_means[_ref]``).
         ``seg_sums`` [F x D] float64 and ``sizes`` [F] int64: both numpy, or both torch CUDA tensors (sizes may stay on the host);
@@ -368,6 +373,38 @@ class FrechetJob:
             pass
 
 
+class PreparedMultiUpdate:
+    """``Moments.update_multi(accs, blocks)`` with the views and ctypes tables built ONCE: a loop that scores resident sets over and over
+    (bench.py's; a service that re-scores a fixed evaluation set against changing baselines) spends 5-6 us of Python per frame matrix in
+    ``update_multi`` -- 0.2 ms for the 32 matrices of a batch, during which the GPU waits for its first launch.  ``run()`` is one call into
+    the library (two with ``reset=True``: ``fad_moments_reset_multi`` first).  The tensors are kept alive by the object."""
+
+    def __init__(self, accs, blocks):
+        assert 1 <= len(accs) == len(blocks) <= 32
+        views = [K.rows_view(b) for b in blocks]
+        code = views[0][4]
+        for a, v in zip(accs, views):
+            if v[1] > 0 and v[2] != a.d:
+                raise AssertionError(f"frame matrix has {v[2]} features, accumulator has {a.d}")
+            if not v[5] or v[4] != code:
+                raise AssertionError("update_multi needs device tensors of one common dtype")
+        m = len(accs)
+        self._accs, self._keep, self._m, self._code = list(accs), [v[6] for v in views], m, code
+        self._hs = (C.c_void_p * m)(*[a._h for a in accs])
+        self._ptrs = (C.c_void_p * m)(*[v[0] for v in views])
+        self._ns = (C.c_int64 * m)(*[v[1] for v in views])
+        self._lds = (C.c_int64 * m)(*[max(v[3], a.d) for a, v in zip(accs, views)])
+        self._lib = accs[0]._lib
+
+    def run(self, reset: bool = False) -> None:
+        st = self._accs[0]._stream()
+        if reset:
+            K.check(self._lib.fad_moments_reset_multi(self._m, self._hs, st), "fad_moments_reset_multi")
+        K.check(self._lib.fad_moments_update_multi(self._m, self._hs, self._ptrs, self._ns, self._lds, self._code, st), "fad_moments_update_multi")
+        for a, k in zip(self._accs, self._keep):
+            a._keep = k
+
+
 class FrechetMultiJob:
     """Up to MAX_PAIRS scores in flight as ONE batch (``fad_frechet_from_moments_multi_begin``): pair b = (pairs[b][0], pairs[b][1]);
     the eight launches of the square-root chain carry all of them.  ``result()`` -> [(fad, diag dict), ...] in order.  Thread
@@ -401,6 +438,20 @@ class FrechetMultiJob:
         job, self._job = self._job, None
         K.check(self._lib.fad_frechet_multi_end(job, self._n, out, diag), "fad_frechet_multi_end")
         return [(float(out[i]), diag[i].as_dict()) for i in range(self._n)]
+
+    def result_arrays(self):
+        """``result()`` without the per-pair Python objects: (float64 array of the distances, the ctypes array of fad_diag_t records --
+        ``diags[i].as_dict()`` on demand).  Thirty-two dicts of diagnostics cost more host time than the library's own collection."""
+        import threading
+        if self._job is None:
+            raise RuntimeError("this job was collected already")
+        if threading.get_ident() != self._owner:
+            raise RuntimeError("a FrechetMultiJob must be collected by the thread that created it (its slot is thread-local)")
+        out = np.empty(self._n, dtype=np.float64)
+        diag = (K.FadDiag * self._n)()
+        job, self._job = self._job, None
+        K.check(self._lib.fad_frechet_multi_end(job, self._n, out.ctypes.data_as(C.POINTER(C.c_double)), diag), "fad_frechet_multi_end")
+        return out, diag
 
     def cancel(self):
         import threading

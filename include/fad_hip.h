@@ -63,6 +63,9 @@ typedef struct fad_moments fad_moments_t;
 int fad_moments_create(int d, int device, fad_moments_t** out);
 int fad_moments_destroy(fad_moments_t* h);
 int fad_moments_reset(fad_moments_t* h, void* stream);
+/* fad_moments_reset for `count` handles in one call (a scoring loop that re-feeds the accumulators of sixteen scores: one call into
+ * the library instead of thirty-two). */
+int fad_moments_reset_multi(int count, fad_moments_t* const* hs, void* stream);
 /* The zeroing of a reset (or bind) is deferred: an update right after it overwrites the accumulator instead.  Whoever
  * reads the packed buffer BEHIND the library's back (a collective over a bound buffer) calls this first so that a
  * handle that received no rows holds zeros. */

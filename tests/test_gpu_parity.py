@@ -5,6 +5,8 @@ tighter wherever the arithmetic allows, so a regression shows long before the ba
 """
 import logging
 
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -1595,3 +1597,35 @@ def test_frechet_fast_chain_forms_sigma1_sigma2_for_an_asymmetric_caller_matrix(
     assert abs(f_fast - f64) <= 1e-7 * abs(f64), (f_fast, f64, dg, dg64)
     f_t, _ = hip.frechet(mu, c1, mu, c2.T.copy())
     assert abs(f_t - f64) <= 1e-2 * abs(f64)                          # (sanity: the transposed matrix is a different, nearby problem)
+
+
+def test_prepared_multi_update_and_result_arrays_are_the_plain_calls(F):
+    """Round 6 host-side short cuts for loops over resident sets: ``hip.PreparedMultiUpdate`` (tables built once, ``fad_moments_reset_multi``)
+    feeds what ``Moments.update_multi`` feeds -- 20 handles: more than sixteen share ONE launch on the 256-column-slab route -- and
+    ``FrechetMultiJob.result_arrays`` returns what ``result`` returns."""
+    import torch
+    from fadtk_amd import hip
+    d, n = 512, 9000
+    xs = [torch.from_numpy(structured_rows(300 + i, n + 17 * i, d, np.float16)).cuda() for i in range(20)]
+    with contextlib.ExitStack() as es:
+        plain = [es.enter_context(hip.Moments(d)) for _ in xs]
+        prep = [es.enter_context(hip.Moments(d)) for _ in xs]
+        plain[0].set_timing(True)
+        hip.Moments.update_multi(plain, xs)
+        assert plain[0].last_timing()[2] == 2                         # one launch of the slab kernel for all twenty
+        pu = hip.Moments.prepared_update_multi(prep, xs)
+        pu.run()
+        pu.run(reset=True)                                            # (fed twice, reset in between: the second feed alone counts)
+        for a, b, x in zip(plain, prep, xs):
+            pa, pb = a.export(), b.export()
+            assert pa[0] == pb[0] == x.shape[0]
+            np.testing.assert_array_equal(pa, pb)
+        x64 = xs[3].cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(plain[3].export()[1 + d:].reshape(d, d), x64.T @ x64, rtol=0, atol=1e-6 * np.abs(x64.T @ x64).max())
+        pairs = [(plain[2 * k], plain[2 * k + 1]) for k in range(10)]
+        res = hip.FrechetMultiJob(pairs, mean_dtype=0).result()
+        vals, diags = hip.FrechetMultiJob(pairs, mean_dtype=0).result_arrays()
+        # (two runs of the chain: the thread's launch-count hints may give the second one an iteration more -- the values agree to 1e-9,
+        #  not to the bit)
+        np.testing.assert_allclose([r[0] for r in res], vals, rtol=1e-9)
+        assert set(res[4][1]) == set(diags[4].as_dict()) and res[4][1]["route"] == diags[4].as_dict()["route"]
