@@ -63,6 +63,7 @@ SIGNATURES = {
     "fad_moments_packed_len": (_I64, [_P]),
     "fad_moments_update": (C.c_int, [_P, _P, _I64, _I64, C.c_int, C.c_int, _P]),
     "fad_moments_update_multi": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I64), C.c_int, _P]),
+    "fad_moments_update_multi_indexed": (C.c_int, [C.c_int, C.POINTER(_P), _P, _I64, _I64, C.c_int, C.POINTER(_P), C.POINTER(_I64), _P]),
     "fad_moments_update_file_means": (C.c_int, [_P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "fad_moments_update_segmented": (C.c_int, [_P, _P, _I64, _I64, C.c_int, C.POINTER(_I64), _I64, _P, C.c_int, _P]),
     "fad_moments_update_segmented_ref": (C.c_int, [_P, _P, _I64, _I64, C.c_int, C.POINTER(_I64), _I64, _P, _P, C.c_int, _P]),

@@ -125,6 +125,11 @@ static int ensure_kernel_attrs(int device) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_tile256<FAD_F16, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT256Lds));
+    FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum_h16<16, 192, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsLds));
     for (int dt : {FAD_F16, FAD_BF16}) {
         for (bool fast : {false, true}) {
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
@@ -268,7 +273,7 @@ static bool tile256_eligible(const fad_moments* h0, int count, const int64_t* n,
 }
 
 static int update_tile256(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n, const int64_t* ld,
-                          hipStream_t st, hipEvent_t* ev) {
+                          hipStream_t st, hipEvent_t* ev, const int32_t* const* idx = nullptr, int64_t n_src = 0) {
     fad_moments* h0 = hs[0];
     const int d = h0->d, nsb = (int)cdiv(d, t256::SB), dpad = nsb * t256::SB;
     FAD_TRY(ensure_kernel_attrs(h0->device));
@@ -297,6 +302,7 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
         s.E = rows[i]; s.n = n[i]; s.ld = ld[i]; s.rows_per_split = p.rows_per_split; s.S = p.S; s.item0 = item;
         s.partials = static_cast<float*>(h->partials.p); s.colpart = static_cast<double*>(h->colpart.p);
         s.flag = nullptr; s.cvec = nullptr;
+        s.idx = idx ? idx[i] : nullptr; s.n_src = n_src;
         R256Job& j = R.job[i];
         if (h->guard) {
             FAD_TRY(h->cvec.reserve((size_t)p.S * dpad * sizeof(uint16_t)));
@@ -318,10 +324,16 @@ static int update_tile256(int count, fad_moments* const* hs, const void* const* 
     // timing: the two events take the dispatch's OWN begin / end stamps (what rocprofv3 reports for the kernel), not the stream's
     // idle-to-idle interval -- with several streams in flight an event recorded ahead of the launch also counts the time the
     // dispatch waits for another stream's workgroups to leave the CUs
+    if (idx) {           // gathered rows (fad_moments_update_multi_indexed): the same kernels, the row of every LDS-DMA piece from the index
+        if (ev) hipExtLaunchKernelGGL((moments_tile256<FAD_F16, false, true>), dim3((unsigned)L.total), dim3(512), (uint32_t)lds_bytes, st, ev[0], ev[1], 0u, L);
+        else hipLaunchKernelGGL((moments_tile256<FAD_F16, false, true>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
+        if (any_guard) hipLaunchKernelGGL((moments_tile256<FAD_F16, true, true>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
+    } else {
     if (ev) hipExtLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), (uint32_t)lds_bytes, st, ev[0], ev[1], 0u, L);
     else hipLaunchKernelGGL((moments_tile256<FAD_F16, false>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
     if (any_guard)       // second pass of the shift guard: same geometry, gated per set; rewrites the flagged sets' partials and column sums
         hipLaunchKernelGGL((moments_tile256<FAD_F16, true>), dim3((unsigned)L.total), dim3(512), lds_bytes, st, L);
+    }
     // split lanes per output group: one thread walks all splits of its four outputs with eight loads in flight.  Measured
     // (scripts/probe_reduce_sl.py, guard + reduce): 2 sets x 43 splits 22.2 / 22.8 / 22.3 / 23.3 / 26.1 us at 1 / 2 / 4 / 8 / 16 lanes,
     // 8 sets x 10 splits 26.5 / 28.3 / 32.3 / 37.6 / 58.9 us -- the LDS combine and the extra threads cost more than the shorter walks save.
@@ -385,8 +397,10 @@ static int runsum_cols() {
     if (!cols) { const char* e = getenv("FAD_MOMENTS_RUNSUM_COLS"); cols = (e && atoi(e) == 32) ? 32 : 16; }
     return cols;
 }
-static void launch_runsum_h16(const RunSumLaunch& L, int jobs, hipStream_t st) {
-    if (runsum_cols() == 32)
+static void launch_runsum_h16(const RunSumLaunch& L, int jobs, hipStream_t st, bool indexed = false) {
+    if (indexed)
+        hipLaunchKernelGGL((moments_running_colsum_h16<16, 192, 4, true>), dim3((unsigned)cdiv(L.d, 16), (unsigned)jobs), dim3(256), (RsShape<16, 192, 4>::lds), st, L);
+    else if (runsum_cols() == 32)
         hipLaunchKernelGGL((moments_running_colsum_h16<32, 96, 5>), dim3((unsigned)cdiv(L.d, 32), (unsigned)jobs), dim3(256), (RsShape<32, 96, 5>::lds), st, L);
     else
         hipLaunchKernelGGL((moments_running_colsum_h16<16, 192, 4>), dim3((unsigned)cdiv(L.d, 16), (unsigned)jobs), dim3(256), (RsShape<16, 192, 4>::lds), st, L);
@@ -394,7 +408,7 @@ static void launch_runsum_h16(const RunSumLaunch& L, int jobs, hipStream_t st) {
 
 // -> *joined: an event the caller's stream has to wait for before the update returns (the walk reads the caller's rows), or nullptr
 static int running_sums(int count, fad_moments* const* hs, const void* const* rows, const int64_t* n, const int64_t* ld, int dtype,
-                        hipStream_t st, hipEvent_t* joined) {
+                        hipStream_t st, hipEvent_t* joined, const int32_t* const* idx = nullptr) {
     *joined = nullptr;
     if (dtype == FAD_F64) {                                          // (numpy's float64 sum IS the exact one to 1e-16: finalize takes that)
         for (int i = 0; i < count; ++i)
@@ -413,6 +427,7 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
         FAD_TRY(h->runsum.reserve((size_t)h->d * sizeof(float)));
         RunSumJob& j = L.job[m++];
         j.rows = rows[i]; j.n = n[i]; j.ld = ld[i]; j.run = static_cast<float*>(h->runsum.p);
+        j.idx = idx ? idx[i] : nullptr;
         j.start_zero = (h->fresh || !h->runsum_live) ? 1 : 0;        // (a new handle is empty without having been reset: its buffer is not)
         h->runsum_live = true;
     }
@@ -451,7 +466,7 @@ static int running_sums(int count, fad_moments* const* hs, const void* const* ro
             FAD_HIP_TRY(hipStreamWaitEvent(side, h0->rs_fork, 0));
             run_st = side;
         }
-        launch_runsum_h16(L, m, run_st);
+        launch_runsum_h16(L, m, run_st, idx != nullptr);
         if (run_st != st && pend) {
             FAD_HIP_TRY(hipEventRecord(pend, run_st));
             for (int i = 0; i < count; ++i) if (n[i] > 0 && hs[i]->ref_mean && hs[i]->runsum_covers) hs[i]->rs_pending = pend;
@@ -852,7 +867,6 @@ int fad_moments_create(int d, int device, fad_moments_t** out) {
     h->force_generic = fg && fg[0] == '1';
     const char* t2 = getenv("FAD_MOMENTS_TILE256");
     h->tile256 = !(t2 && t2[0] == '0');
-    const char* pl = getenv("FAD_MOMENTS_PLAN");
     const char* rs = getenv("FAD_MOMENTS_R256_SL");
     h->r256_sl = rs ? atoi(rs) : 0;
     const char* nc = getenv("FAD_MOMENTS_CUS");        // plan for fewer CUs than the device has (a CU-masked stream)
@@ -984,6 +998,79 @@ int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* co
         }
     }
     return update_device_multi(m, live_h, live_rows, live_n, live_ld, dtype, st);
+}
+
+// rows[idx[r]] -> a dense matrix: the fallback of fad_moments_update_multi_indexed (16-byte chunks when everything is aligned, else bytes)
+__global__ void gather_rows_kernel(const char* __restrict__ src, int64_t src_pitch, const int32_t* __restrict__ idx, int64_t n, char* __restrict__ dst,
+                                   int row_bytes, int wide) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wide) {
+        const int per = row_bytes / 16;
+        if (t >= n * per) return;
+        const int64_t r = t / per; const int c = (int)(t - r * per);
+        reinterpret_cast<uint4*>(dst + r * row_bytes)[c] = reinterpret_cast<const uint4*>(src + (int64_t)idx[r] * src_pitch)[c];
+    } else {
+        if (t >= n * row_bytes) return;
+        const int64_t r = t / row_bytes; const int c = (int)(t - r * row_bytes);
+        dst[r * row_bytes + c] = src[(int64_t)idx[r] * src_pitch + c];
+    }
+}
+
+int fad_moments_update_multi_indexed(int count, fad_moments_t* const* hs, const void* rows, int64_t n_src, int64_t ld, int dtype,
+                                     const int32_t* const* idx, const int64_t* n_idx, void* stream) {
+    if (count < 1 || count > kMaxSets) return set_error(FAD_ERR_INVALID, "count=%d out of range [1, %d]", count, kMaxSets);
+    if (!hs || !rows || !idx || !n_idx) return set_error(FAD_ERR_INVALID, "NULL argument");
+    const size_t es = dtype_size(dtype);
+    if (es == 0) return set_error(FAD_ERR_INVALID, "unknown dtype %d", dtype);
+    if (n_src < 1 || n_src > INT32_MAX) return set_error(FAD_ERR_SHAPE, "n_src=%lld", (long long)n_src);
+    fad_moments* live_h[kMaxSets]; const int32_t* live_idx[kMaxSets]; int64_t live_n[kMaxSets], live_ld[kMaxSets]; const void* live_rows[kMaxSets];
+    int m = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!hs[i]) return set_error(FAD_ERR_INVALID, "handle %d is NULL", i);
+        if (hs[i]->d != hs[0]->d || hs[i]->device != hs[0]->device) return set_error(FAD_ERR_SHAPE, "handle %d: another dimension or device than handle 0", i);
+        for (int k = 0; k < i; ++k)
+            if (hs[k] == hs[i]) return set_error(FAD_ERR_INVALID, "handle %d appears twice", i);
+        if (n_idx[i] < 0 || ld < hs[i]->d) return set_error(FAD_ERR_SHAPE, "set %d: n=%lld ld=%lld d=%d", i, (long long)n_idx[i], (long long)ld, hs[i]->d);
+        if (n_idx[i] == 0) continue;
+        if (!idx[i]) return set_error(FAD_ERR_INVALID, "idx[%d] is NULL", i);
+        live_h[m] = hs[i]; live_idx[m] = idx[i]; live_n[m] = n_idx[i]; live_ld[m] = ld; live_rows[m] = rows; ++m;
+    }
+    if (m == 0) return FAD_OK;
+    fad_moments* h0 = live_h[0];
+    DeviceGuard g(h0->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int d = h0->d;
+    const bool aligned = dtype == FAD_F16 && d % 8 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15u) == 0;
+    // the gather rides on the slab kernel's row offsets (32-bit, range-checked against the WHOLE source: below 2^31 bytes) and on the
+    // walk's loads; everything else gathers into the handles' staging areas first and takes the ordinary route
+    if (aligned && !h0->force_generic && tile256_eligible(h0, m, live_n, live_ld, dtype, true, false) && n_src * ld * 2 < ((int64_t)1 << 31)) {
+        hipEvent_t joined = nullptr;
+        FAD_TRY(running_sums(m, live_h, live_rows, live_n, live_ld, dtype, st, &joined, live_idx));
+        hipEvent_t* ev = nullptr;
+        FAD_TRY(timing_events(h0, &ev));
+        h0->last_sets = m;
+        const int rc = update_tile256(m, live_h, live_rows, live_n, live_ld, st, ev, live_idx, n_src);
+        if (joined) {
+            const hipError_t e = hipStreamWaitEvent(st, joined, 0);
+            if (e != hipSuccess && rc == FAD_OK) return set_error(FAD_ERR_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+        }
+        return rc;
+    }
+    const int row_bytes = (int)((size_t)d * es);
+    const int wide = (row_bytes % 16 == 0) && ((ld * (int64_t)es) % 16 == 0) && ((reinterpret_cast<uintptr_t>(rows) & 15u) == 0);
+    for (int i = 0; i < m; ++i) {
+        fad_moments* h = live_h[i];
+        FAD_TRY(h->stage.reserve((size_t)live_n[i] * row_bytes + 16));
+        const int64_t items = wide ? live_n[i] * (row_bytes / 16) : live_n[i] * row_bytes;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, st, static_cast<const char*>(rows), ld * (int64_t)es,
+                           live_idx[i], live_n[i], static_cast<char*>(h->stage.p), row_bytes, wide);
+        live_rows[i] = h->stage.p; live_ld[i] = d;
+    }
+    FAD_HIP_TRY(hipGetLastError());
+    for (int i = 0; i < m; ++i) live_h[i]->staged_input = true;     // (the gathered copies are on their way: no detached walk over them)
+    const int rc = update_device_multi(m, live_h, live_rows, live_n, live_ld, dtype, st);
+    for (int i = 0; i < m; ++i) live_h[i]->staged_input = false;
+    return rc;
 }
 
 static int segment_running_sums_device(fad_moments* h, const void* drows, int64_t dld, int dtype, const int64_t* offsets, int64_t n_segments,

@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) void packed_axpy(double* __restrict__ dst, con
 __device__ __forceinline__ float load_as_float(const raw_f16* p) { return h16_to_f32<FAD_F16>(p->b); }
 __device__ __forceinline__ float load_as_float(const raw_bf16* p) { return h16_to_f32<FAD_BF16>(p->b); }
 __device__ __forceinline__ float load_as_float(const float* p) { return *p; }
-struct RunSumJob { const void* rows; int64_t n, ld; float* run; int start_zero; };
+struct RunSumJob { const void* rows; int64_t n, ld; float* run; int start_zero; const int32_t* idx; };      // idx != nullptr: frame r = row idx[r] of `rows` (IDX instantiation)
 struct RunSumLaunch { RunSumJob job[kMaxSets]; int d; const RunSumJob* table; };      // table != nullptr: job blockIdx.y is table[blockIdx.y] (device)
 // the jobs of a segmented walk (per-file / per-song running sums): segment s = rows [offsets[s], offsets[s + 1]) -> out + s * d
 __global__ __launch_bounds__(256) void runsum_segment_jobs(const uint16_t* __restrict__ rows, int64_t ld, int d, const int64_t* __restrict__ offsets,
@@ -1180,7 +1180,7 @@ template <int kRsCols, int kRsRows, int RING> struct RsShape {
     static constexpr size_t lds = (size_t)2 * kRsCols * pitch * sizeof(float);
 };
 constexpr size_t kRsLds = 25600;                                      // the larger of the two shapes' LDS (25 088 / 25 600 bytes)
-template <int kRsCols, int kRsRows, int RING>
+template <int kRsCols, int kRsRows, int RING, bool IDX = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void moments_running_colsum_h16(RunSumLaunch L) {
     constexpr int kRsPitch = RsShape<kRsCols, kRsRows, RING>::pitch;
     static_assert(kRsRows * kRsCols == 192 * 16, "a loader thread owns two 16-byte pieces of a tile");
@@ -1195,6 +1195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     j.run = reinterpret_cast<float*>(uni64(reinterpret_cast<uint64_t>(jv.run)));
     j.n = (int64_t)uni64((uint64_t)jv.n); j.ld = (int64_t)uni64((uint64_t)jv.ld);
     j.start_zero = __builtin_amdgcn_readfirstlane(jv.start_zero);
+    j.idx = IDX ? reinterpret_cast<const int32_t*>(uni64(reinterpret_cast<uint64_t>(jv.idx))) : nullptr;
     if (j.n <= 0) {                                                  // (an empty segment's sums are zero; an empty set has no buffer to write)
         if (L.table && (int)threadIdx.x < kRsCols && blockIdx.x * kRsCols + threadIdx.x < L.d) j.run[blockIdx.x * kRsCols + threadIdx.x] = 0.f;
         return;
@@ -1278,7 +1279,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             //  on the LDS counter as well and forces full waits around the LDS traffic)
             typedef unsigned int rs_u32x4 __attribute__((ext_vector_type(4)));       // (HIP's uint4 is a class: no address-space-qualified copies)
             typedef __attribute__((address_space(1))) const rs_u32x4 g_u4;
-            const uint16_t* p = base + (row < j.n ? row : j.n - 1) * j.ld + c0 + cbase;
+            int64_t src = row < j.n ? row : j.n - 1;
+            if constexpr (IDX) {                                         // (a dependent load per row; RING tiles in flight cover it)
+                typedef __attribute__((address_space(1))) const int32_t g_i32;
+                src = *(g_i32*)(uintptr_t)(j.idx + src);
+            }
+            const uint16_t* p = base + src * j.ld + c0 + cbase;
             // (plain loads: the four workgroups that share a row's 128-byte line meet in their XCD's L2 -- with the streaming hint `nt` on these
             //  loads the walk took 0.69 instead of 0.40 ms and the realistic loop 3 460 instead of 5 020 scores/s, r05y)
             const rs_u32x4 v0 = *(g_u4*)(uintptr_t)p, v1 = *(g_u4*)(uintptr_t)(p + q1);

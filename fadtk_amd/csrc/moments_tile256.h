@@ -45,6 +45,9 @@ struct T256Set {
     double* colpart;                        // [S][2][dpad]   (second row: the second wave quartet of a Z item)
     int* flag;                              // shift guard (or nullptr)
     uint16_t* cvec;                         // [S][dpad] float16 shifts for the second pass (or nullptr)
+    // IDX launches (fad_moments_update_multi_indexed: the resamples of FAD-inf, fad.py:333-337): frame r of this set is row idx[r] of E,
+    // a matrix of n_src rows -- the gather rides on the row offsets of the LDS-DMA pieces, nothing is materialised
+    const int32_t* idx; int64_t n_src;
 };
 struct T256Launch {
     T256Set set[kMaxSets256];
@@ -94,7 +97,7 @@ __device__ __forceinline__ void t2_split2(const uint4& f, uint32_t c2, int64_t r
 }
 
 // One wave's share of a work item.  Everything role-dependent is a compile-time constant.
-template <int KIND, int ROLE, bool SHIFT>
+template <int KIND, int ROLE, bool SHIFT, bool IDX>
 __device__ __forceinline__ void tile256_wave(
     const T256Launch& L, const T256Set& s, int split, int ti, int type, int sa, int sb, const t256::WaveJob job, char* smem) {
     using RD = t256::RoleDef<ROLE>;
@@ -130,30 +133,55 @@ __device__ __forceinline__ void tile256_wave(
     typedef int srd_t __attribute__((ext_vector_type(4)));
     srd_t srd;
     {
-        const uint64_t b = (uint64_t)(E + k_begin * ld);
-        const uint64_t nbytes = (uint64_t)((k_end - k_begin - 1) * ld + d) * 2;          // (update_tile256 keeps a split below 2^31 bytes)
+        // IDX: the resource covers the whole source matrix (the rows of a split come from anywhere in it)
+        const uint64_t b = (uint64_t)(IDX ? E : E + k_begin * ld);
+        const uint64_t nbytes = (uint64_t)(((IDX ? s.n_src : k_end - k_begin) - 1) * ld + d) * 2;   // (update_tile256 keeps it below 2^31 bytes)
         srd[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
         srd[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));     // stride 0: a raw buffer
         srd[2] = __builtin_amdgcn_readfirstlane((int)(uint32_t)nbytes);
         srd[3] = 0x00020000;                                                              // gfx9 raw buffer, 32-bit data format
     }
     uint32_t voff[LPS];
+    bool lane_in_b[LPS];
 #pragma unroll
     for (int p = 0; p < LPS; ++p) {
         const int c = lane ^ (p << 2);
         const bool in_b = c >= 32;
+        lane_in_b[p] = in_b;
         const int col = in_b ? colB + (c - 32) * 8 : colA + c * 8;                         // d % 8 == 0: a chunk is in or out as a whole
-        const int64_t row = LPS * wave + p + ((in_b && two_rows) ? T2_KB : 0);
+        const int64_t row = IDX ? 0 : LPS * wave + p + ((in_b && two_rows) ? T2_KB : 0);   // (IDX: the row's offset comes from the index)
         voff[p] = col < d ? (uint32_t)((row * ld + col) * 2) : 0x80000000u;
     }
     const uint32_t stage_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)rows_per_stage * ld * 2));
+    const uint32_t row_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ld * 2));
     const uint32_t smem_lds = (uint32_t)(size_t)(lptr_t)smem;
     const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(smem_lds + (uint32_t)(LPS * wave * T2_ROW));
-    auto piece = [&](int kb, int p) {
+    // IDX: the byte offsets of the source rows behind this wave's pieces of one stage (scalar loads; a frame past the end of the split
+    // gets 2^31: out of range, zeros).  `ro2`: the second row of a Z item's pieces (slab B = the frame 32 further down).
+    struct StageRows { uint32_t ro[LPS], ro2[LPS]; };
+    auto rows_of_stage = [&](int kb) -> StageRows {
+        StageRows r;
+        if constexpr (IDX) {
+            const int64_t p0 = k_begin + (int64_t)kb * rows_per_stage + LPS * wave;
+#pragma unroll
+            for (int p = 0; p < LPS; ++p) {
+                const int64_t q = p0 + p, q2 = q + T2_KB;
+                r.ro[p] = q < k_end ? (uint32_t)s.idx[q] * row_bytes : 0x80000000u;
+                r.ro2[p] = (two_rows && q2 < k_end) ? (uint32_t)s.idx[q2 < k_end ? q2 : q] * row_bytes : 0x80000000u;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < LPS; ++p) { r.ro[p] = (uint32_t)kb * stage_bytes; r.ro2[p] = r.ro[p]; }
+        }
+        return r;
+    };
+    auto piece = [&](int kb, int p, const StageRows& r) {
 #ifdef T2_ABL_NODMA                          // ablation: the ring is filled once and never refilled
         if (kb >= NSTG - 1) return;
 #endif
-        const uint32_t vo = voff[p] + (uint32_t)kb * stage_bytes;
+        uint32_t vo;
+        if constexpr (IDX) vo = voff[p] + ((two_rows && lane_in_b[p]) ? r.ro2[p] : r.ro[p]);
+        else vo = voff[p] + r.ro[p];
         const uint32_t m0v = wave_lds + (uint32_t)((kb % NSTG) * T2_STAGE + p * T2_ROW);
 #ifdef T2_NT
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds nt" ::"v"(vo), "s"(srd), "s"(m0v) : "memory");
@@ -162,8 +190,9 @@ __device__ __forceinline__ void tile256_wave(
 #endif
     };
     auto issue = [&](int kb) {
+        const StageRows r = rows_of_stage(kb);
 #pragma unroll
-        for (int p = 0; p < LPS; ++p) piece(kb, p);
+        for (int p = 0; p < LPS; ++p) piece(kb, p, r);
     };
     const int nwhole = (int)((k_end - k_begin) / rows_per_stage);                        // stages [0, nwhole) have all their rows
 
@@ -223,10 +252,10 @@ __device__ __forceinline__ void tile256_wave(
         for (int i = 0; i < NF; ++i) F[i] = t2_frag(base + foff[i]);
     };
     // The MFMAs of one k-step; `refill`: this wave's LDS-DMA pieces 2 ks, 2 ks + 1 of stage kb + NSTG - 1 go BETWEEN them.
-    auto half = [&](int kb, int ks, const uint4 (&F)[NF], auto refill, uint4 (&Fn)[NF], int nkb_, int nks_, bool nread) {
+    auto half = [&](int kb, int ks, const uint4 (&F)[NF], auto refill, uint4 (&Fn)[NF], int nkb_, int nks_, bool nread, const StageRows& rr) {
         constexpr int PH = LPS / 2;          // pieces per k-step: behind MFMA 1, 3
         if constexpr (SHIFT) {               // x - c = x' + e
-            if (decltype(refill)::value) { piece(kb + NSTG - 1, PH * ks); piece(kb + NSTG - 1, PH * ks + 1); }
+            if (decltype(refill)::value) { piece(kb + NSTG - 1, PH * ks, rr); piece(kb + NSTG - 1, PH * ks + 1, rr); }
             const bool full = kb < nwhole;
             uint4 X[NF], R[NF];
 #pragma unroll
@@ -246,7 +275,7 @@ __device__ __forceinline__ void tile256_wave(
 #ifdef T2_ABL_NOMMA                          // ablation: no MFMAs (the fragments stay live through a cheap VALU use)
 #pragma unroll
         for (int i = 0; i < NF; ++i) acc[0][i] += __uint_as_float((F[i].x ^ F[i].y ^ F[i].z ^ F[i].w) & 0x007fffffu);
-        if (decltype(refill)::value) { piece(kb + NSTG - 1, PH * ks); piece(kb + NSTG - 1, PH * ks + 1); }
+        if (decltype(refill)::value) { piece(kb + NSTG - 1, PH * ks, rr); piece(kb + NSTG - 1, PH * ks + 1, rr); }
         return;
 #endif
 #ifdef T2_ILV
@@ -259,7 +288,7 @@ __device__ __forceinline__ void tile256_wave(
             if (b < NF) { __builtin_amdgcn_sched_barrier(0); if (nread) Fn[b] = t2_frag(nbase + foff[b]); __builtin_amdgcn_sched_barrier(0); }
 #endif
             if (decltype(refill)::value && (b & 1) && (b >> 1) < PH) {
-                __builtin_amdgcn_sched_barrier(0); piece(kb + NSTG - 1, PH * ks + (b >> 1)); __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0); piece(kb + NSTG - 1, PH * ks + (b >> 1), rr); __builtin_amdgcn_sched_barrier(0);
             }
 #ifndef T2_OPT_NOCOLSUM
             if constexpr (CSUM) {
@@ -297,22 +326,24 @@ __device__ __forceinline__ void tile256_wave(
     constexpr bool kReadsFirst = true;
 #endif
     for (; kb < hot; ++kb) {                 // no branches: the refill rides between the MFMAs
+        const StageRows rr = rows_of_stage(kb + NSTG - 1);     // (IDX: four scalar loads, in flight while the k-step's reads are issued)
         if (kReadsFirst) load_half(kb, 1, F1);
         __builtin_amdgcn_sched_barrier(0);
-        half(kb, 0, F0, std::true_type{}, F1, kb, 1, true);
+        half(kb, 0, F0, std::true_type{}, F1, kb, 1, true, rr);
         __builtin_amdgcn_sched_barrier(0);
         // in flight at this point: stages kb + 1 .. kb + NSTG - 2 and half of kb + NSTG - 1; kb + 1 must have landed
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS * (NSTG - 3) + LPS / 2) : "memory");
         t2_phase_barrier();
         if (kReadsFirst) load_half(kb + 1, 0, F0);
         __builtin_amdgcn_sched_barrier(0);
-        half(kb, 1, F1, std::true_type{}, F0, kb + 1, 0, true);
+        half(kb, 1, F1, std::true_type{}, F0, kb + 1, 0, true, rr);
         __builtin_amdgcn_sched_barrier(0);
     }
+    const StageRows none = rows_of_stage(0);
     for (; kb < nkb; ++kb) {                 // the last NSTG - 1 stages: nothing left to fetch
         if (kReadsFirst) load_half(kb, 1, F1);
         __builtin_amdgcn_sched_barrier(0);
-        half(kb, 0, F0, std::false_type{}, F1, kb, 1, true);
+        half(kb, 0, F0, std::false_type{}, F1, kb, 1, true, none);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool more = kb + 1 < nkb;
@@ -322,7 +353,7 @@ __device__ __forceinline__ void tile256_wave(
             if (kReadsFirst) load_half(kb + 1, 0, F0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        half(kb, 1, F1, std::false_type{}, F0, kb + 1, 0, more);
+        half(kb, 1, F1, std::false_type{}, F0, kb + 1, 0, more, none);
         __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef T2_PRIO
@@ -416,7 +447,7 @@ __device__ __forceinline__ void tile256_wave(
 // workgroup of 256-register waves fills its SIMDs, and even the SHIFT launch that only reads the gate and exits could not be PLACED on a
 // CU while a wave of the running-sum walk (moments_kernels.h: moments_running_colsum_h16, 64 registers, on a stream of its own) sat
 // there -- r05d: the caller's stream stood still for 170-300 us per update.
-template <int KIND, bool SHIFT>
+template <int KIND, bool SHIFT, bool IDX = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112))) void moments_tile256(T256Launch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];
     char* const smem_bytes = reinterpret_cast<char*>(smem_dyn);
@@ -435,11 +466,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112))) void mom
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const t256::WaveJob job = t256::wave_job(type, wave);
     switch (job.role) {              // wave-uniform: every wave runs ONE of these loops, all with the same stage count and barriers
-        case t256::TRI_LO: tile256_wave<KIND, t256::TRI_LO, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
-        case t256::TRI_HI: tile256_wave<KIND, t256::TRI_HI, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
-        case t256::RECT_C: tile256_wave<KIND, t256::RECT_C, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
-        case t256::RECT_D: tile256_wave<KIND, t256::RECT_D, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
-        default: tile256_wave<KIND, t256::XR, SHIFT>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
+        case t256::TRI_LO: tile256_wave<KIND, t256::TRI_LO, SHIFT, IDX>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
+        case t256::TRI_HI: tile256_wave<KIND, t256::TRI_HI, SHIFT, IDX>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
+        case t256::RECT_C: tile256_wave<KIND, t256::RECT_C, SHIFT, IDX>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
+        case t256::RECT_D: tile256_wave<KIND, t256::RECT_D, SHIFT, IDX>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
+        default: tile256_wave<KIND, t256::XR, SHIFT, IDX>(L, s, split, ti, type, sa, sb, job, smem_bytes); break;
     }
 }
 

@@ -57,6 +57,24 @@ def _thread_accumulator(d: int, device: int):
     return acc
 
 
+def _thread_inf_accumulators(d: int, device: int, count: int, ref_mean: bool):
+    """The accumulators of FAD-inf's device route -- one for the baseline, `count` for the resamples of a launch -- kept per (host thread,
+    device, D) like ``_thread_accumulator``: creating and freeing a handle costs 0.27 ms (its packed statistics, partial tiles, workspaces;
+    hipFree waits for the device) and a call needs seventeen of them."""
+    pool = getattr(_tls, "inf", None)
+    if pool is None:
+        pool = _tls.inf = {}
+    ent = pool.get((device, d))
+    if ent is None:
+        if len(pool) >= 2:
+            for h in pool.pop(next(iter(pool))):
+                h.close()
+        ent = pool[(device, d)] = [hip.Moments(d, device) for _ in range(1 + count)]
+    for a in ent[1:]:
+        a.set_reference_mean(bool(ref_mean))            # the resamples' means as np.mean forms them (fad.py:48: a float32 running sum)
+    return ent[0], ent[1:]
+
+
 def calc_embd_statistics(embd_lst, device: int = 0):
     """Mean and covariance of a frame matrix [N x D] (fadtk/fad.py:42-48), computed on the GPU.
 
@@ -310,7 +328,6 @@ class FrechetAudioDistance:
         packed = np.concatenate([[2.0], 2.0 * mu_b, (cov_b + 2.0 * np.outer(mu_b, mu_b)).reshape(-1)])
         code = {np.dtype(np.float16): hip.K.FAD_F16, np.dtype(np.float32): hip.K.FAD_F32}.get(embeds.dtype)
         mean_dtype = -1 if code is None else (hip.K.FAD_MEAN_SECOND_ONLY | code)
-        budget = 2 << 30                             # bytes of gathered frames alive at once
         # Resamples of fewer than 16 rows per column have (nearly) rank-deficient covariances: the distance then moves with the
         # SQUARE ROOT of a perturbation of the moments, and the library sums such inputs exactly in float64 -- but it picks the
         # kernel per launch, by the launch's largest set.  So short and long resamples never share a launch.
@@ -318,37 +335,28 @@ class FrechetAudioDistance:
         n_short = sum(1 for idx in picks if idx.size < 16 * d)
         values = [None] * len(picks)
         with torch.cuda.device(dev):
-            base = hip.Moments(d, self.device_index).import_(packed)
-            # (groups of eight although a chain takes up to 32 pairs since round 5: every further accumulator costs 0.27 ms to create and
-            #  free per call -- 25 of them made this call 18.5 ms instead of 12.0, r05x -- and three chains fewer save less than that)
-            MAXP = 8
-            accs = [hip.Moments(d, self.device_index) for _ in range(MAXP)]
-            if code is not None:
-                for a in accs:                            # the resamples' means as np.mean forms them (fad.py:48: a float32 running sum)
-                    a.set_reference_mean(True)
-            try:
-                pos = 0
-                while pos < len(order):
-                    stop = n_short if pos < n_short else len(order)
-                    group, nbytes = [], 0
-                    while pos < stop and len(group) < MAXP and (not group or nbytes + picks[order[pos]].size * d * rows.element_size() <= budget):
-                        group.append(order[pos]); nbytes += picks[order[pos]].size * d * rows.element_size(); pos += 1
-                    gathered = [rows.index_select(0, torch.from_numpy(picks[k]).to(dev)) for k in group]
-                    for a in accs[:len(group)]:
-                        a.reset()
-                    for g0 in range(0, len(group), 8):                  # (a moments launch takes eight frame matrices)
-                        hip.Moments.update_multi(accs[g0:min(g0 + 8, len(group))], gathered[g0:g0 + 8])
-                    # the group's distances as ONE batch: the launches of the square-root chain carry all of them
-                    scores = hip.FrechetMultiJob([(base, a) for a in accs[:len(group)]], mean_dtype=mean_dtype).result()
-                    for k, (fad, _) in zip(group, scores):
-                        values[k] = np.float64(fad)
-                    for a in accs[:len(group)]:        # (the scores are in: the gathered frames need not outlive this group)
-                        a.release_inputs(staging=False)
-                    del gathered
-            finally:
-                base.close()
-                for a in accs:
-                    a.close()
+            # ONE upload of all points' indices (int32: 4 bytes per resampled frame); the gathers themselves are never materialised --
+            # fad_moments_update_multi_indexed reads rows[idx] straight into the moments kernels (round 5 built 1.3 GB of copies with
+            # index_select and read them again: 11.9 ms per call at config 3)
+            flat = torch.from_numpy(np.concatenate([np.asarray(p_, dtype=np.int32) for p_ in picks])).to(dev)
+            starts = np.concatenate([[0], np.cumsum([p_.size for p_ in picks])])
+            idx_dev = [flat[int(starts[k]):int(starts[k + 1])] for k in range(len(picks))]
+            base, accs = _thread_inf_accumulators(d, self.device_index, 16, ref_mean=code is not None)
+            base.reset(); base.import_(packed)
+            pos = 0
+            while pos < len(order):
+                stop = n_short if pos < n_short else len(order)
+                group = order[pos:min(pos + 16, stop)]                     # (a launch of the indexed update takes sixteen sets)
+                pos += len(group)
+                for a in accs[:len(group)]:
+                    a.reset()
+                hip.Moments.update_multi_indexed(accs[:len(group)], rows, [idx_dev[k] for k in group])
+                # the group's distances as ONE batch: the launches of the square-root chain carry all of them
+                vals, _ = hip.FrechetMultiJob([(base, a) for a in accs[:len(group)]], mean_dtype=mean_dtype).result_arrays()
+                for k, fad in zip(group, vals):
+                    values[k] = np.float64(fad)
+            for a in accs:                                 # (the scores are in: the frames need not outlive the call)
+                a.release_inputs(staging=False)
         return values
 
     def score_individual(self, baseline: PathLike, eval_dir: PathLike, csv_name: Union[Path, str]) -> Path:

@@ -154,6 +154,31 @@ class Moments:
             a._keep = v[6]
 
     @staticmethod
+    def update_multi_indexed(accs: Sequence["Moments"], rows, indices: Sequence) -> None:
+        """``accs[i].update(rows[indices[i]])`` for up to 16 accumulators WITHOUT materialising the gathered matrices
+        (``fad_moments_update_multi_indexed``): ``rows`` one resident device tensor [n_src x D], ``indices[i]`` int32 device tensors
+        (1-D, values in [0, n_src)).  The resamples with replacement of FAD-inf (fad.py:333-337)."""
+        import torch
+        assert 1 <= len(accs) == len(indices) <= 16
+        v = K.rows_view(rows)
+        if not v[5]:
+            raise AssertionError("update_multi_indexed needs a device tensor")
+        m = len(accs)
+        for a in accs:
+            if v[2] != a.d:
+                raise AssertionError(f"frame matrix has {v[2]} features, accumulator has {a.d}")
+        idx = [i if (i.dtype == torch.int32 and i.is_contiguous()) else i.to(torch.int32).contiguous() for i in indices]
+        for i in idx:
+            assert i.is_cuda and i.dim() == 1
+        hs = (C.c_void_p * m)(*[a._h for a in accs])
+        ips = (C.c_void_p * m)(*[i.data_ptr() for i in idx])
+        ns = (C.c_int64 * m)(*[int(i.numel()) for i in idx])
+        K.check(accs[0]._lib.fad_moments_update_multi_indexed(m, hs, v[0], int(v[1]), int(max(v[3], accs[0].d)), v[4], ips, ns, accs[0]._stream()),
+                "fad_moments_update_multi_indexed")
+        for a, i in zip(accs, idx):
+            a._keep = (v[6], i)
+
+    @staticmethod
     def prepared_update_multi(accs: Sequence["Moments"], blocks: Sequence) -> "PreparedMultiUpdate":
         """``update_multi`` for a loop that feeds the SAME accumulators from the SAME device tensors again and again: see PreparedMultiUpdate."""
         return PreparedMultiUpdate(accs, blocks)

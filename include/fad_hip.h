@@ -109,6 +109,14 @@ int fad_moments_set_reference_mean(fad_moments_t* h, int enabled);
 int fad_moments_update_multi(int count, fad_moments_t* const* hs, const void* const* rows, const int64_t* n,
                              const int64_t* ld, int dtype, void* stream);
 
+/* fad_moments_update_multi over GATHERED rows: set i is fed the n_idx[i] frames rows[idx[i][0]], rows[idx[i][1]], ... of ONE resident
+ * matrix `rows` [n_src x ld] (device; idx[i]: device, int32, 0 <= idx < n_src), in that order -- the resamples with replacement of
+ * score_inf (fad.py:333-337: np.random.choice + fancy indexing, 1.3 GB of copies at config 3) without materialising them: for float16
+ * frames of D >= 512 the gather rides on the row offsets of the slab kernel's LDS-DMA loads and of the running-sum walk; other inputs
+ * are gathered into the handles' staging areas first.  Results as fad_moments_update_multi on the materialised matrices (count <= 16). */
+int fad_moments_update_multi_indexed(int count, fad_moments_t* const* hs, const void* rows, int64_t n_src, int64_t ld, int dtype,
+                                     const int32_t* const* idx, const int64_t* n_idx, void* stream);
+
 /* Same, for `n_segments` files/songs stored back to back: segment s owns rows
  * [offsets[s], offsets[s+1]) (offsets is a HOST array of n_segments+1 entries).  If
  * seg_sums != NULL it receives the per-segment column sums, [n_segments x D] float64 (host or

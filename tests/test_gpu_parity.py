@@ -1629,3 +1629,40 @@ def test_prepared_multi_update_and_result_arrays_are_the_plain_calls(F):
         #  not to the bit)
         np.testing.assert_allclose([r[0] for r in res], vals, rtol=1e-9)
         assert set(res[4][1]) == set(diags[4].as_dict()) and res[4][1]["route"] == diags[4].as_dict()["route"]
+
+
+@pytest.mark.parametrize("d,n_src", [(512, 30000), (768, 20000), (640, 21000), (128, 9000), (256, 6000)])
+def test_update_multi_indexed_is_the_update_of_the_gathered_rows(F, d, n_src):
+    """``fad_moments_update_multi_indexed`` (round 6: FAD-inf's resamples, fad.py:333-337, without materialising them): the moments of
+    rows[idx] -- with replacement, unsorted, lengths that are no multiple of anything -- equal those of the gathered matrix: on the slab
+    kernel's indexed loads (D = 512; 768: a Z item, two rows per piece; 640: a ragged last superblock), on the fallback that gathers
+    first (D = 128 / 256), with numpy's running-sum means (the walk reads rows[idx] in the resample's order) and without."""
+    import torch
+    from fadtk_amd import hip
+    rng = np.random.default_rng(d)
+    x = structured_rows(77, n_src, d, np.float16)
+    x[:, 3:9] += np.float16(2.0)                                        # (an offset: the running-sum mean differs from the rounded exact one)
+    rows = torch.from_numpy(x).cuda()
+    sizes = [16 * d + 37, 16 * d + 1, 2 * n_src + 5, 16 * d + 4099]
+    idx = [rng.integers(0, n_src, size=s_) for s_ in sizes]
+    with contextlib.ExitStack() as es:
+        for ref in (False, True):
+            got = [es.enter_context(hip.Moments(d)) for _ in sizes]
+            want = [es.enter_context(hip.Moments(d)) for _ in sizes]
+            for h in got + want:
+                h.set_reference_mean(ref)
+            got[0].set_timing(True)
+            hip.Moments.update_multi_indexed(got, rows, [torch.from_numpy(i.astype(np.int32)).cuda() for i in idx])
+            if d >= 512:
+                assert got[0].last_timing()[2] == 2
+            hip.Moments.update_multi(want, [rows[torch.from_numpy(i).cuda()] for i in idx])
+            for g, w, i in zip(got, want, idx):
+                pg, pw = g.export(), w.export()
+                assert pg[0] == pw[0] == i.size
+                np.testing.assert_allclose(pg[1:1 + d], pw[1:1 + d], rtol=1e-12, atol=1e-9)
+                M = pw[1 + d:]
+                np.testing.assert_allclose(pg[1 + d:], M, rtol=0, atol=1e-9 * np.abs(M).max())
+                mg, mw = g.finalize()[0], w.finalize()[0]
+                assert np.array_equal(mg, mw)                           # the mean: bit for bit (the walk adds the same rows in the same order)
+                if ref:                                                 # ... and numpy's own float16 mean of the gathered matrix
+                    assert np.array_equal(mg.astype(np.float32).astype(np.float16), x[i].mean(axis=0))
