@@ -255,8 +255,10 @@ def extra_c4(torch, hip, device, local_rank):
             "one_update_of_all_files": ({"ms": one_ms, "frac_of_8TBps": nbytes / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if one_ms else None),
             "with_reference_order_file_means": ({"ms": ref_ms, "frac_of_8TBps_one_read": nbytes / (ref_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                  "frac_of_8TBps_two_reads": 2 * nbytes / (ref_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                 "note": "per-file means as np.mean forms them (utils.py:16: float32 running sum per file): a second walk "
-                                                         "over every group's rows (fad_moments_update_segmented_ref) -- what OnlineStats does by default"} if ref_ms else None),
+                                                 "note": "per-file means as np.mean forms them (utils.py:16: float32 running sum per file) -- what OnlineStats does by "
+                                                         "default.  Round 6: the tile kernel's diagonal workgroups walk them in the SAME pass (files of one run each, "
+                                                         "fad_moments_update_segmented_ref): the frames cross HBM once; `frac_of_8TBps_two_reads` is kept for comparison with "
+                                                         "round 5, when a second walk read every group again (4.1 ms)"} if ref_ms else None),
             "cov_trace_per_dim": float(np.trace(cov)) / d}
 
 

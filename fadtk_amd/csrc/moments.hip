@@ -110,6 +110,10 @@ typedef void (*tile_kernel_t)(TileLaunch);
 static tile_kernel_t tr_kernel_shift(bool fast) {          // second pass of the shift guard (float16 rows only)
     return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false, true>;
 }
+static tile_kernel_t tr_kernel_walk(int dtype, bool fast) {  // first pass + the per-file float32 running sums (file-aligned splits, one run per file)
+    if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true, false, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false, false, true>;
+    return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true, false, true> : &moments_tile_h16_tr<FAD_BF16, 2 * H_NST, false, false, true>;
+}
 static tile_kernel_t tr_kernel(int dtype, bool fast) {       // multi-tile: 4 stages of 16 KiB; single tile: 8 stages of 8 KiB
     if (dtype == FAD_F16) return fast ? &moments_tile_h16_tr<FAD_F16, H_NST, true> : &moments_tile_h16_tr<FAD_F16, 2 * H_NST, false>;
     return fast ? &moments_tile_h16_tr<FAD_BF16, H_NST, true> : &moments_tile_h16_tr<FAD_BF16, 2 * H_NST, false>;
@@ -132,6 +136,8 @@ static int ensure_kernel_attrs(int device) {
     FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_running_colsum_h16<16, 192, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsLds));
     for (int dt : {FAD_F16, FAD_BF16}) {
         for (bool fast : {false, true}) {
+            FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel_walk(dt, fast)),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
             FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_kernel(dt, fast)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLds));
             if (dt == FAD_F16)
@@ -217,6 +223,7 @@ struct SegPlan {
     const SegRun* runs; const int* split_first_run;   // device
     int n_runs, S;
     int64_t max_split_rows;
+    float* seg_runsum = nullptr;                      // device [n_segments][d]: the tile kernel walks numpy's per-file running sums as well
 };
 
 // Pinned host staging for the small tables update_segmented uploads (no pageable copy, no stream sync): the buffer is
@@ -554,7 +561,7 @@ static int update_device_multi_impl(int count, fad_moments* const* hs, const voi
             FAD_TRY(h->colpart.reserve((size_t)(seg ? seg->n_runs : p.S) * p.nt * H_BT * sizeof(double)));
             TileSet& s = L.set[i];
             s.E = rows[i]; s.n = n[i]; s.ld = ld[i]; s.rows_per_split = p.rows_per_split; s.S = p.S; s.item0 = item;
-            if (seg) { s.runs = seg->runs; s.split_first_run = seg->split_first_run; }
+            if (seg) { s.runs = seg->runs; s.split_first_run = seg->split_first_run; s.seg_runsum = seg->seg_runsum; }
             s.partials = h->partials.p; s.colpart = static_cast<double*>(h->colpart.p);
             s.flag = nullptr;
             if (h->guard && second_pass) {
@@ -570,7 +577,7 @@ static int update_device_multi_impl(int count, fad_moments* const* hs, const voi
         }
         L.total = item;
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(tr_kernel(dtype, L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
+        hipLaunchKernelGGL((seg && seg->seg_runsum) ? tr_kernel_walk(dtype, L.T > 1) : tr_kernel(dtype, L.T > 1), dim3((unsigned)L.total), dim3(256), kTrLds, st, L);
         if (ev) FAD_HIP_TRY(hipEventRecord(ev[1], st));
 
         // shift guard: exact fp64 redo of every flagged set, one gated launch for all of them
@@ -1125,7 +1132,7 @@ static int update_segmented_impl(fad_moments_t* h, const void* rows, int64_t n, 
     const int d = h->d;
     const bool is16 = (dtype == FAD_F16 || dtype == FAD_BF16);
     const bool aligned = is16 && (d % 8 == 0) && (dld % 8 == 0) && ((reinterpret_cast<uintptr_t>(drows) & 15u) == 0) && !h->force_generic;
-    bool fused = false;
+    bool fused = false, walked = false;
     if (want_sums && aligned) {
         constexpr int64_t kCap = 8192;             // rows one workgroup may sum in fp32 (see plan_splits)
         int64_t n_runs = 0, covered = 0;
@@ -1193,6 +1200,17 @@ static int update_segmented_impl(fad_moments_t* h, const void* rows, int64_t n, 
         }
         if (fused) {
             fad_moments* hh = h;
+            // every file one run (<= 8192 frames: config 4's 2250): the tile kernel's diagonal workgroups see a file's rows in order and
+            // walk numpy's float32 running sums beside their MFMAs -- the frames cross HBM once (round 5: a second pass, 4.1 instead of 2.3 ms)
+            if (seg_runsums && n_segments > 0 && sp.n_runs == n_segments && (dtype == FAD_F16 || dtype == FAD_BF16)) {
+                float* drun = seg_runsums;
+                if (!on_device) {
+                    FAD_TRY(h->seg_run.reserve((size_t)n_segments * h->d * sizeof(float)));
+                    drun = static_cast<float*>(h->seg_run.p);
+                }
+                sp.seg_runsum = drun;
+                walked = true;
+            }
             FAD_TRY(update_device_multi(1, &hh, &drows, &n, &dld, dtype, st, &sp));
             const int nt = (int)cdiv(d, H_BT);
             hipLaunchKernelGGL(segment_gather_sums, dim3((unsigned)n_segments, (unsigned)cdiv(d, 128)), dim3(128), 0, st,
@@ -1210,14 +1228,14 @@ static int update_segmented_impl(fad_moments_t* h, const void* rows, int64_t n, 
         }
     }
     if (seg_runsums && n_segments > 0) {
-        // the second walk over the rows the reference's per-file np.mean asks for (utils.py:16): they have just been read by the tile
-        // kernel -- a group of files that fits the Infinity Cache is served from there
+        // (files of more than one run, short segments, float32 frames:) the second walk over the rows the reference's per-file np.mean
+        // asks for (utils.py:16): they have just been read by the tile kernel -- a group of files that fits the Infinity Cache is served from there
         float* drun = seg_runsums;
         if (!on_device) {
             FAD_TRY(h->seg_run.reserve((size_t)n_segments * h->d * sizeof(float)));
             drun = static_cast<float*>(h->seg_run.p);
         }
-        FAD_TRY(segment_running_sums_device(h, drows, dld, dtype, offsets, n_segments, drun, st));
+        if (!walked) FAD_TRY(segment_running_sums_device(h, drows, dld, dtype, offsets, n_segments, drun, st));
         if (!on_device)
             FAD_HIP_TRY(hipMemcpyAsync(seg_runsums, drun, (size_t)n_segments * h->d * sizeof(float), hipMemcpyDeviceToHost, st));
     }

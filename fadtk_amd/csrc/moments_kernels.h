@@ -48,6 +48,9 @@ struct TileSet {
     // its own colpart row -- the per-file sums fall out of the one pass over E (moments_tile_h16_tr only).
     const SegRun* runs;
     const int* split_first_run;
+    // WALK launches (fad_moments_update_segmented_ref on files of one run each): numpy's float32 running column sums of every FILE
+    // (utils.py:16: np.mean of a float16 file adds its rows one after the other in float32) leave the same pass -- [n_segments][d]
+    float* seg_runsum;
 };
 struct SegRun { int64_t r0; int32_t rows; int32_t seg; };
 struct TileLaunch {
@@ -165,12 +168,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int outstanding
 // of every column, tripped or not.  moments_reduce restores the raw moments in float64: sum x_i x_j = S'_ij + c_i s'_j +
 // s'_i c_j + n c_i c_j with s' the column sums of x - c.  Two passes of this kernel + a few loads per split in the reduce
 // instead of the float64 kernel over the whole block: ~10x faster when the guard fires (scripts/probe_guard.py).
-template <int KIND, int NST, bool DIAG, bool FAST, bool SHIFT = false>
+template <int KIND, int NST, bool DIAG, bool FAST, bool SHIFT = false, bool WALK = false>
 __device__ __forceinline__ void tile_h16_tr_body(
     const uint16_t* __restrict__ E, int64_t k_begin0, int64_t k_end0, int64_t ld, int d, int nt, int T,
     int split, int tile, int ca, int cb, float* __restrict__ partials, double* __restrict__ colpart,
     uint4* smem, int* __restrict__ shift_flag, const SegRun* __restrict__ runs, int run_lo, int run_hi,
-    uint16_t* __restrict__ cvec = nullptr) {
+    uint16_t* __restrict__ cvec = nullptr, float* __restrict__ seg_runsum = nullptr) {
+    static_assert(!WALK || (DIAG && !SHIFT), "the per-file walk rides on the diagonal tiles of the first pass");
     static_assert(!SHIFT || KIND == FAD_F16, "the shifted pass is written for float16 rows");
     constexpr int LPS = DIAG ? 2 : 4;              // glds instructions per wave per stage
     // uint4 per stage: A slab + B slab; a launch whose only tile is the diagonal one (FAST = false: D <= 128, the
@@ -348,9 +352,31 @@ __device__ __forceinline__ void tile_h16_tr_body(
     // test inside one loop, hipcc kept the accumulators of the off-diagonal waves in a second register range and copied
     // all 64 of them back and forth around their four MFMAs -- 80 v_accvgpr_mov per stage (found in the ISA, round 2).
     const bool diag_wave = wr == wc;
+    // WALK: lane l of a diagonal wave walks column ca + 64 wr + l down the stage's 32 rows IN ORDER, one float32 add per row (what
+    // np.mean of the file does): eight transpose reads -- group g of the wave points at columns 16 g .. 16 g + 15 of rows 4 q .. 4 q + 3
+    // and every lane receives those four rows of ITS column -- then 32 dependent adds.  Rows past the end of the file are zeros in LDS
+    // (s + 0 = s).  ~250 cycles of a wave that waits for HBM at D = 128 anyway; the frames are not read a second time.
+    float walk_s = 0.f;
+    auto walk_stage = [&](const char* sA) {
+        if constexpr (WALK) {
+            const int wcol = 64 * wr + 16 * grp + 4 * (t16 & 3);
+            s16x4 h[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r0 = 4 * q + (t16 >> 2);
+                const int o = r0 * 256 + (((wcol >> 3) ^ ((r0 & 3) << 2)) << 4) + ((wcol >> 2) & 1) * 8;
+                h[q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sA + o));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) walk_s = walk_s + h16_to_f32<KIND>((uint32_t)(uint16_t)h[q][j]);
+        }
+    };
     auto stage_diag = [&](int kb, auto role_tag, bool full) {
         const char* sA = reinterpret_cast<const char*>(smem + (kb % NST) * STAGE);
         if constexpr (decltype(role_tag)::value) {
+            walk_stage(sA);
             uint4 A0[2], A1[2];
             A0[0] = frag(sA, 0, 64 * wr); A0[1] = frag(sA, 0, 64 * wr + 32);
             A1[0] = frag(sA, 1, 64 * wr); A1[1] = frag(sA, 1, 64 * wr + 32);
@@ -437,6 +463,13 @@ __device__ __forceinline__ void tile_h16_tr_body(
         };
         if (DIAG && diag_wave) run_stages(std::true_type{});
         else run_stages(std::false_type{});
+        if constexpr (WALK) {
+            if (diag_wave && runs) {               // this file's running sums (one run per file on WALK launches), then the next file's start
+                const int col = ca + 64 * wr + lane;
+                if (col < d) seg_runsum[(int64_t)runs[run_lo + ri].seg * d + col] = walk_s;
+                walk_s = 0.f;
+            }
+        }
         if (do_colsum) {
             csum[0] += __shfl_xor(csum[0], 32);
             csum[1] += __shfl_xor(csum[1], 32);
@@ -493,7 +526,7 @@ __device__ __forceinline__ void tile_h16_tr_body(
     }
 }
 
-template <int KIND, int NST, bool FAST, bool SHIFT = false>
+template <int KIND, int NST, bool FAST, bool SHIFT = false, bool WALK = false>
 __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_dyn[];     // the ONLY LDS object: NST x 16 KiB
     const int w = xcd_contiguous(blockIdx.x, L.total);
@@ -507,9 +540,9 @@ __global__ __launch_bounds__(256) void moments_tile_h16_tr(TileLaunch L) {
     float* partials = static_cast<float*>(s.partials);
     // (the second pass neither re-examines the columns nor rewrites the shifts: no flag, but the shifts to read)
     if (ta == tb)
-        tile_h16_tr_body<KIND, NST, true, FAST, SHIFT>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
-                                                       partials, s.colpart, smem_dyn, SHIFT ? nullptr : s.flag, s.runs, run_lo, run_hi,
-                                                       s.cvec);
+        tile_h16_tr_body<KIND, NST, true, FAST, SHIFT, WALK>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
+                                                             partials, s.colpart, smem_dyn, SHIFT ? nullptr : s.flag, s.runs, run_lo, run_hi,
+                                                             s.cvec, s.seg_runsum);
     else if constexpr (FAST)
         tile_h16_tr_body<KIND, NST, false, FAST, SHIFT>(E, k_begin, k_end, s.ld, L.d, L.nt, L.T, split, tile, ta * H_BT, tb * H_BT,
                                                         partials, s.colpart, smem_dyn, nullptr, s.runs, run_lo, run_hi, s.cvec);

@@ -347,6 +347,50 @@ def test_moments_segmented_sums_long_and_short_segments(F, d, sizes, dtype, wher
     assert p[0] == sum(sizes)
 
 
+@pytest.mark.parametrize("d,sizes,dtype", [(128, tuple([2250] * 40) + (700, 256, 8192, 1025, 5000, 2250), np.float16),      # config-4 shape: one run per file
+                                           (256, (2250, 3000, 4100, 600, 8000, 257), np.float16),                            # three tiles: the diagonal ones walk
+                                           (128, (2250, 900, 4097, 256, 3000), "bfloat16"),
+                                           (128, (2250, 9000, 2250, 300), np.float16)])                                      # one file of two runs: the separate walk
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_segmented_ref_running_sums_are_numpys_per_file_sums(F, d, sizes, dtype, where):
+    """``fad_moments_update_segmented_ref``: the per-file float32 running column sums are np.mean's own (utils.py:16: the rows of a
+    float16 file added one after the other in float32) BIT FOR BIT -- round 6: walked by the tile kernel's diagonal workgroups in the
+    same pass when every file is one run (frames with an offset of 7 sigma, where the order of the adds shows in the last bits)."""
+    import torch
+    from fadtk_amd.hip import Moments
+    rng = np.random.default_rng(sum(sizes) + d)
+    x32 = (rng.standard_normal((sum(sizes), d)) + 7.0).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    if dtype == "bfloat16":
+        xt = torch.from_numpy(x32).to(torch.bfloat16)
+        xf = xt.to(torch.float32).numpy()
+        rows = xt.cuda() if where == "device" else None
+        if where == "host":
+            pytest.skip("numpy has no bfloat16 host arrays")
+    else:
+        x = x32.astype(dtype)
+        xf = x.astype(np.float32)
+        rows = torch.from_numpy(x).cuda() if where == "device" else x
+    want = np.zeros((len(sizes), d), dtype=np.float32)
+    for f, (a, b) in enumerate(zip(offs[:-1], offs[1:])):
+        acc = np.zeros(d, dtype=np.float32)
+        for r in range(a, b):
+            acc = acc + xf[r]                       # float32, one row after the other
+        want[f] = acc
+    with Moments(d) as m:
+        sums, runs = m.update_segmented(rows, offs, want_runsums=True)
+        p = m.export()
+    runs = runs.cpu().numpy() if hasattr(runs, "cpu") else np.asarray(runs)
+    np.testing.assert_array_equal(runs, want)
+    if dtype != "bfloat16":                         # ... which is what np.mean divides: the float16 file means, bit for bit
+        for f, (a, b) in enumerate(zip(offs[:-1], offs[1:])):
+            np.testing.assert_array_equal((runs[f].astype(np.float64) / (b - a)).astype(np.float32).astype(np.float16), x[a:b].mean(axis=0))
+    x64 = xf.astype(np.float64)
+    np.testing.assert_allclose(np.asarray(sums.cpu() if hasattr(sums, "cpu") else sums), np.stack([x64[a:b].sum(0) for a, b in zip(offs[:-1], offs[1:])]), rtol=2e-7, atol=1e-4)
+    M = x64.T @ x64
+    np.testing.assert_allclose(p[1 + d:].reshape(d, d), M, rtol=0, atol=2e-6 * np.abs(M).max())
+
+
 @pytest.mark.parametrize("where", ["host", "device"])
 def test_moments_file_mean_terms_match_numpy(F, where):
     """fad_moments_update_file_means: rows sqrt(n_f) m_f / sqrt(n_f) m~_f / n_f m~_f from per-file sums, with the
