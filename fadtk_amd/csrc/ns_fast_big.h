@@ -375,16 +375,23 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
         else if (ahead == 1) { if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // stage ks is there for every wave; the slot of stage ks - 1 is free
-        if (ks + kI8BigStages - 1 < nks) issue(ks + kI8BigStages - 1);
+#ifndef FAD_I8_ABL_NODMA                                           // ablations (scripts/build_variant.sh + scripts/probe_chain16.py, r06p): 16 pairs of D = 512,
+        if (ks + kI8BigStages - 1 < nks) issue(ks + kI8BigStages - 1);   // nsf_i8_big<A> 66 us; without the MFMAs 42, without the loads 56: the int8 MFMAs bound it
+#endif
         const i32x4* st = reinterpret_cast<const i32x4*>(ring + (ks % kI8BigStages) * kI8BigStage) + lane;
         i32x4 a[kDigits], b[kDigits];
 #pragma unroll
         for (int p = 0; p < kDigits; ++p) { a[p] = st[(wr * 6 + p) * 64]; b[p] = st[(24 + wc * 6 + p) * 64]; }
+#ifdef FAD_I8_ABL_NOMMA
+#pragma unroll
+        for (int p = 0; p < kDigits; ++p) { acc[0][p] += a[p][0] ^ b[p][1]; acc[1][p] += a[p][2] ^ b[p][3]; }
+#else
 #pragma unroll
         for (int p = kDigits - 1; p >= 0; --p)
 #pragma unroll
             for (int q = kDigits - 1; q >= 0; --q)
                 if (p + q >= kUmin) acc[p + q - kUmin] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[q], acc[p + q - kUmin], 0, 0, 0);
+#endif
     }
     __syncthreads();                                               // the ring is scratch now: one [32][33] float area per wave
     double gp[16];
