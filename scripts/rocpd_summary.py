@@ -39,6 +39,20 @@ def main():
             gap = (st - prev_end) / 1e3 if prev_end is not None else 0.0
             print(f"\"{short(name)}\",{(en - st) / 1e3:.2f},{gap:.2f},{grid},{wg}")
             prev_end = en
+    elif mode == "schema":
+        for (name,) in cur.execute("select name from sqlite_master where type in ('table', 'view') and name like '%counter%'").fetchall():
+            print(name, [r[1] for r in cur.execute(f"pragma table_info('{name}')").fetchall()])
+    elif mode == "pmcgrid":
+        # counter means per (kernel, grid size): launches of one kernel that carry different numbers of frame matrices apart
+        cols = [r[1] for r in cur.execute("pragma table_info('counters_collection')").fetchall()]
+        grid = "grid_size" if "grid_size" in cols else ("grid_size_x" if "grid_size_x" in cols else ("grid_x" if "grid_x" in cols else None))
+        print("kernel,counter,grid,mean_per_dispatch,dispatches")
+        if grid is None:
+            print("# no grid column in counters_collection:", cols)
+            return
+        for r in cur.execute(f"select kernel_name, counter_name, {grid}, avg(value), count(*) from counters_collection "
+                             f"group by kernel_name, counter_name, {grid} order by kernel_name, counter_name, {grid}"):
+            print(f"\"{short(r[0])}\",{r[1]},{r[2]},{r[3]:.1f},{r[4]}")
     else:
         print("kernel,counter,mean_per_dispatch,dispatches")
         for r in cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "

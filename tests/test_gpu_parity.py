@@ -1686,6 +1686,8 @@ def test_update_multi_indexed_is_the_update_of_the_gathered_rows(F, d, n_src):
     rng = np.random.default_rng(d)
     x = structured_rows(77, n_src, d, np.float16)
     x[:, 3:9] += np.float16(2.0)                                        # (an offset: the running-sum mean differs from the rounded exact one)
+    if d == 768:                                                        # outlier columns: the shift guard's second pass on the indexed route
+        x[:, 600:640] = (30.0 + 0.04 * rng.standard_normal((n_src, 40))).astype(np.float16)
     rows = torch.from_numpy(x).cuda()
     sizes = [16 * d + 37, 16 * d + 1, 2 * n_src + 5, 16 * d + 4099]
     idx = [rng.integers(0, n_src, size=s_) for s_ in sizes]
