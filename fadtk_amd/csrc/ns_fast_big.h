@@ -338,7 +338,11 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob
     const bool alt = (MODE == I8_G) && g.sel && (*adv(g.sel, po) & 1);
     const uint4* Ad = (MODE == I8_A) ? adv(g.Adig, (int64_t)song * g.astride) : adv(alt ? g.Adig_alt : g.Adig, po);
     const uint4* Bd = adv(alt ? g.Bdig_alt : g.Bdig, po);
+#ifdef FAD_I8_ABL_G_NOLOOP                                       // ablation: the epilogue of the G product alone
+    const int nks = (MODE == I8_G) ? 0 : (d >> 5);
+#else
     const int nks = d >> 5;
+#endif
 
     // piece q of a stage: q < 24: A side, row block q / 6, digit q % 6; else B side, column block (q - 24) / 6.  Wave w moves pieces
     // w, w + 8, ... (waves 0..3: five, the others four)

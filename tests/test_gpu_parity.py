@@ -1712,3 +1712,34 @@ def test_update_multi_indexed_is_the_update_of_the_gathered_rows(F, d, n_src):
                 assert np.array_equal(mg, mw)                           # the mean: bit for bit (the walk adds the same rows in the same order)
                 if ref:                                                 # ... and numpy's own float16 mean of the gathered matrix
                     assert np.array_equal(mg.astype(np.float32).astype(np.float16), x[i].mean(axis=0))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_moments_tile256_fuzz_pitch_and_edges(F, seed):
+    """The slab kernel's loads are range-checked buffer loads (round 6): rows of a last, partial stage and columns of a ragged last superblock
+    come back as zeros by the hardware's bounds check, the row pitch may exceed D.  Random D (multiples of 8 in [512, 2048]), row counts that are
+    no multiple of anything, a pitch with NaN padding behind every row (never to be read), several matrices of different lengths per launch."""
+    import torch
+    from fadtk_amd.hip import Moments
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([512, 520, 600, 768, 776, 1024, 1536, 2040, 2048]))
+    pad = int(rng.choice([0, 8, 24, 264]))
+    ns = [16 * d + int(rng.integers(0, 3000)) for _ in range(int(rng.integers(1, 4)))]
+    mats, views = [], []
+    for k, n in enumerate(ns):
+        full = torch.full((n, d + pad), float("nan"), dtype=torch.float16, device="cuda")
+        x = (rng.standard_normal((n, d)) * (1.0 + 0.5 * k) + 0.1 * k).astype(np.float16)
+        full[:, :d] = torch.from_numpy(x).cuda()
+        mats.append(x); views.append(full[:, :d])                      # a strided view: pitch d + pad
+    with contextlib.ExitStack() as es:
+        hs = [es.enter_context(Moments(d)) for _ in ns]
+        hs[0].set_timing(True)
+        Moments.update_multi(hs, views)
+        assert hs[0].last_timing()[2] == 2
+        for h, x in zip(hs, mats):
+            p = h.export()
+            x64 = x.astype(np.float64)
+            M = x64.T @ x64
+            assert p[0] == x.shape[0] and np.isfinite(p).all()
+            np.testing.assert_allclose(p[1:1 + d], x64.sum(0), rtol=1e-7, atol=1e-5)
+            np.testing.assert_allclose(p[1 + d:].reshape(d, d), M, rtol=0, atol=1e-6 * np.abs(M).max())
