@@ -14,7 +14,7 @@ sc, pw = [], []
 for ln in open(sys.argv[1]):
     m = re.search(r"sclk clock level:\s*\d+:?\s*\(?(\d+)Mhz", ln) or re.search(r"sclk[^0-9]*(\d+)\s*Mhz", ln, re.I)
     if m: sc.append(int(m.group(1)))
-    m = re.search(r"Power[^0-9]*([0-9.]+)", ln)
+    m = re.search(r"Power \(W\):\s*([0-9.]+)", ln)
     if m: pw.append(float(m.group(1)))
 def st(v): return f"n={len(v)} min={min(v):.0f} median={sorted(v)[len(v)//2]:.0f} max={max(v):.0f}" if v else "no samples"
 print("   sclk MHz:", st(sc)); print("   power W :", st(pw))
