@@ -1743,3 +1743,44 @@ def test_moments_tile256_fuzz_pitch_and_edges(F, seed):
             assert p[0] == x.shape[0] and np.isfinite(p).all()
             np.testing.assert_allclose(p[1:1 + d], x64.sum(0), rtol=1e-7, atol=1e-5)
             np.testing.assert_allclose(p[1 + d:].reshape(d, d), M, rtol=0, atol=1e-6 * np.abs(M).max())
+
+
+@pytest.mark.parametrize("kind", ["two_cluster", "gapped", "low_rank_plus_floor", "rotated_bases", "one_dominant"])
+def test_frechet_chain_acceptance_on_spectra_outside_the_power_law_family(F, kind):
+    """the acceptance of a score on the chain's verification record is an ESTIMATE (4 x 1/8 |tr(Z P P)| + ||E||^2 ||P||,
+    csrc/frechet.hip), emulated and fuzzed on power-law spectra only.  Spectra outside that family -- two clusters three decades apart, a
+    gap in a k^-1 decay, rank 100 over a noise floor, the two sets in DIFFERENT bases (a strongly non-normal product), one dominant
+    direction -- through the moments handles (single pair and batch), whatever route the library picks: within 1e-5 of the oracle."""
+    import torch
+    from fadtk_amd import hip
+    d, n = 512, 24000
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    q2 = q
+    k = np.arange(1, d + 1, dtype=np.float64)
+    if kind == "two_cluster":
+        lam = np.where(k <= d // 2, 1.0, 1e-3)
+    elif kind == "gapped":
+        lam = k ** -1.0; lam[50:] *= 1e-2
+    elif kind == "low_rank_plus_floor":
+        lam = np.where(k <= 100, k ** -0.5, 1e-6)
+    elif kind == "one_dominant":
+        lam = np.where(k == 1, 100.0, k ** -0.5)
+    else:                                                           # rotated_bases: k^-0.75 in two bases 0.3 rad apart in random planes
+        lam = k ** -0.75
+        g, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        th = 0.3
+        rot = np.eye(d)
+        for i in range(0, d - 1, 2):
+            rot[i, i] = rot[i + 1, i + 1] = np.cos(th); rot[i, i + 1] = -np.sin(th); rot[i + 1, i] = np.sin(th)
+        q2 = q @ (g @ rot @ g.T)
+    a = ((rng.standard_normal((n, d)) * np.sqrt(lam)) @ q.T).astype(np.float16)
+    b = ((1.04 * rng.standard_normal((n, d)) * np.sqrt(lam)) @ q2.T + 0.003).astype(np.float16)
+    ref = O.fad_between(a, b)
+    with hip.Moments(d) as ma, hip.Moments(d) as mb:
+        hip.Moments.update_multi([ma, mb], [torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()])
+        one = hip.frechet_from_moments(ma, mb, mean_dtype=0)
+        again = hip.frechet_from_moments(ma, mb, mean_dtype=0)
+        batch = hip.FrechetMultiJob([(ma, mb)] * 3, mean_dtype=0).result()
+    for f, dg in (one, again, *batch):
+        assert abs(f - ref) <= 1e-5 * abs(ref), (kind, f, ref, dg)
