@@ -90,6 +90,22 @@ def resample_kaiser(x: np.ndarray, orig_sr: int, new_sr: int, quantize_pcm16: bo
 
 def convert_to_model_rate(src, dst, sr: int, device: int = 0):
     """Decode, mix to mono, resample to ``sr`` (on GPU ``device``) and store as PCM16 WAV (fad.py:148-160)."""
+    src = Path(src)
+    if src.suffix.lower() == ".wav":
+        # a mono 16-bit PCM WAV already at the model's rate: decode -> float -> quantise gives back the very samples (x / 32768 * 32768 is exact
+        # in float32), so the cache file is the input's frames under a fresh header -- no float round trip, no GPU call (config 2: every file)
+        try:
+            with wave.open(str(src), "rb") as w:
+                if w.getsampwidth() == 2 and w.getnchannels() == 1 and w.getframerate() == int(sr) and w.getcomptype() == "NONE":
+                    raw = w.readframes(w.getnframes())
+                    dst = Path(dst)
+                    dst.parent.mkdir(parents=True, exist_ok=True)
+                    with wave.open(str(dst), "wb") as o:
+                        o.setnchannels(1); o.setsampwidth(2); o.setframerate(int(sr))
+                        o.writeframes(raw)
+                    return
+        except (wave.Error, ValueError, EOFError):
+            pass
     x, fs = read_audio(src)
     mono = x.mean(axis=0)
     write_pcm16(dst, resample_kaiser(mono, fs, sr, device=device), sr)

@@ -222,3 +222,22 @@ def test_out_of_memory_is_a_type_not_a_wording():
     with pytest.raises(RuntimeError) as ei:
         K.check(K.FAD_ERR_HIP, "somewhere")
     assert not isinstance(ei.value, K.FadOutOfMemory) or "memory" in str(ei.value).lower()
+
+
+def test_convert_to_model_rate_copies_pcm16_mono_at_the_models_rate(tmp_path):
+    """fad.py:139-186 normalises every file to mono PCM16 at the model's rate; for a file that already is one the decode -> float -> quantise
+    round trip returns the very samples, so the cache file is written from the input's frames directly (no GPU needed: this runs on CPU).
+    Full-scale and odd values included: the copy must equal what the general path's arithmetic gives."""
+    from fadtk_amd import audio
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-32768, 32768, size=16000, dtype=np.int64).astype("<i2")
+    pcm[:4] = [-32768, 32767, 0, -1]
+    src = tmp_path / "in.wav"
+    with wave.open(str(src), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    audio.convert_to_model_rate(src, tmp_path / "convert" / "16000" / "in.wav", 16000)
+    got, sr = audio.read_pcm16(tmp_path / "convert" / "16000" / "in.wav")
+    assert sr == 16000 and np.array_equal(got, pcm)
+    x, _ = audio.read_audio(src)                                    # the general path's arithmetic on the same samples
+    q = np.clip(np.rint(x.mean(axis=0).astype(np.float64) * 32768.0), -32768, 32767).astype("<i2")
+    assert np.array_equal(q, pcm)
