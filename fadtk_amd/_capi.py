@@ -40,10 +40,10 @@ class FadHipUnavailable(RuntimeError):
 class FadDiag(C.Structure):
     _fields_ = [("iters", C.c_int32), ("converged", C.c_int32), ("used_eps", C.c_int32), ("route", C.c_int32),
                 ("residual", C.c_double), ("scale", C.c_double), ("mean_term", C.c_double),
-                ("tr1", C.c_double), ("tr2", C.c_double), ("tr_sqrt", C.c_double)]
+                ("tr1", C.c_double), ("tr2", C.c_double), ("tr_sqrt", C.c_double), ("verified", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
 _P = C.c_void_p

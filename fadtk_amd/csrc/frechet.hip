@@ -1050,7 +1050,7 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
             if (diag) {
                 diag->iters = r.iters + 1; diag->converged = 3; diag->used_eps = 0; diag->route = ws.job.fast ? 2 : 1;
                 diag->residual = r.res; diag->scale = r.c; diag->mean_term = r.mean_term; diag->tr1 = r.tr1; diag->tr2 = r.tr2;
-                diag->tr_sqrt = tr_sqrt;
+                diag->tr_sqrt = tr_sqrt; diag->verified = (ws.job.fast && r.pad == 1) ? 1 : 0; diag->reserved = 0;
             }
             return FAD_OK;
         }
@@ -1088,7 +1088,7 @@ static int frechet_single(int d, const double* cov1, const double* cov2, const d
     if (diag) {
         diag->iters = hs->final_iter + 1; diag->converged = hs->conv; diag->used_eps = used_eps ? 1 : 0;
         diag->route = 0; diag->residual = hs->res_last; diag->scale = hs->c;
-        diag->mean_term = hs->mean_term; diag->tr1 = tr1; diag->tr2 = tr2; diag->tr_sqrt = tr_sqrt;
+        diag->mean_term = hs->mean_term; diag->tr1 = tr1; diag->tr2 = tr2; diag->tr_sqrt = tr_sqrt; diag->verified = 0; diag->reserved = 0;
     }
     if (hs->conv == 0)
         return set_error(FAD_ERR_NOT_CONVERGED, "Newton-Schulz stopped at max_iter with residual %.3e", hs->res_last);
@@ -1308,6 +1308,7 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
                     memset(&q, 0, sizeof(q));
                     q.iters = r.iters + 1; q.converged = 3; q.used_eps = 0; q.route = 2;
                     q.residual = r.res; q.scale = r.c; q.mean_term = r.mean_term; q.tr1 = r.tr1; q.tr2 = r.tr2; q.tr_sqrt = tr_sqrt;
+                    q.verified = r.pad == 1 ? 1 : 0;
                 }
                 if (r.decided_at + 1 > learnt) learnt = r.decided_at + 1;
                 if (r.pad == 1) any_verified = true;

@@ -200,6 +200,10 @@ typedef struct fad_diag {
     double mean_term;       /* ||mu1 - mu2||^2 in float64                                        */
     double tr1, tr2;        /* tr C1, tr C2                                                      */
     double tr_sqrt;         /* tr sqrt(C1 C2)                                                    */
+    int32_t verified;       /* route 2 only: 1 = accepted on the MEASURED verification record (1/2 tr(EP) added, 4 x 1/8 |tr(ZPP)| +
+                               ||E||^2 ||P|| as the error estimate: csrc/frechet.hip) where the norm bound says nothing (decaying
+                               spectra); 0 = accepted on the norm bound, or another route                                  */
+    int32_t reserved;
 } fad_diag_t;
 
 int fad_frechet(int d, const double* mu1, const double* cov1, const double* mu2, const double* cov2,

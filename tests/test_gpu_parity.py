@@ -776,6 +776,9 @@ def test_frechet_wide_chain_takes_decaying_spectra(F, monkeypatch, power, on_cha
     assert second[0] == first[0], (first, second)                                   # the value is a function of the inputs alone
     for f, dg in (first, *multi, *multi2):
         assert abs(f - ref) <= 2e-6 * abs(ref), (power, f, ref, dg)
+    #  which acceptance let the score through is in the record: decaying spectra on the chain pass on the MEASURED verification
+    # products, not on the norm bound; the float64 route sets nothing
+    assert first[1]["verified"] == (1 if on_chain else 0) and all(dg["verified"] == (1 if on_chain else 0) for _, dg in multi2), (first, multi2)
     for f, dg in multi2:
         assert dg["route"] == (2 if on_chain else 0), dg
         assert abs(f - multi2[0][0]) == 0.0
