@@ -183,8 +183,11 @@ __device__ __forceinline__ void tile256_wave(
         if constexpr (IDX) vo = voff[p] + ((two_rows && lane_in_b[p]) ? r.ro2[p] : r.ro[p]);
         else vo = voff[p] + r.ro[p];
         const uint32_t m0v = wave_lds + (uint32_t)((kb % NSTG) * T2_STAGE + p * T2_ROW);
+        // (`nt`, the streaming hint, on these loads: 214 against 218 us per 8-matrix launch in the back-to-back harness at the power cap, nothing in
+        //  bench.py's loop -- 11 350-11 670 scores/s against 11 650-11 850 -- FETCH_SIZE + 0.2 %: not used.  `lds` has to be the LAST modifier: the
+        //  assembler rejects "offen lds nt".)
 #ifdef T2_NT
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds nt" ::"v"(vo), "s"(srd), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen nt lds" ::"v"(vo), "s"(srd), "s"(m0v) : "memory");
 #else
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(srd), "s"(m0v) : "memory");
 #endif
