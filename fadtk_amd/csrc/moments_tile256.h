@@ -12,10 +12,9 @@
 //   * fragments: ds_read_b64_tr_b16, two per fragment and 16-row k-step;
 //   * FREE-RUNNING waves, ONE barrier per stage.  Every wave runs the same software pipeline -- while it multiplies the fragments of
 //     one k-step it reads the next k-step's and issues its share of the refill between the MFMAs -- and the two waves of a SIMD are
-//     NOT phase-locked any more (rounds 4-5 ran the two wave quartets half a stage apart, two barriers per stage: the matrix pipe
-//     idled ~170 cycles at every hand-over; MFMA-only ablation 159 us per 8-matrix launch against the 136 the chip's power budget
-//     allows, r6_limits.hip A).  The barrier sits between the two k-steps of a stage: behind it stage k + 1 is in LDS for everybody
-//     and stage k's slot... is free once more behind the NEXT one (see the loop);
+//     NOT phase-locked any more (rounds 4-5 ran the two wave quartets half a stage apart, two barriers per stage).  The barrier sits
+//     between the two k-steps of a stage: behind it the next stage is in LDS for everybody and the slot of the stage before may be
+//     refilled (see the loop).  What bounds the kernel is the package's power budget: it runs at the 1400 W cap;
 //   * every wave has a compile-time ROLE (tile256_roles.h): the loop it runs updates a fixed set of accumulators (9 blocks = 144
 //     registers, or 8);
 //   * column sums (and sum x^2 for the shift guard) ride on the two waves per superblock that read fragments 0..3 / 4..7 anyway
@@ -255,7 +254,7 @@ __device__ __forceinline__ void tile256_wave(
         for (int i = 0; i < NF; ++i) F[i] = t2_frag(base + foff[i]);
     };
     // The MFMAs of one k-step; `refill`: this wave's LDS-DMA pieces 2 ks, 2 ks + 1 of stage kb + NSTG - 1 go BETWEEN them.
-    auto half = [&](int kb, int ks, const uint4 (&F)[NF], auto refill, uint4 (&Fn)[NF], int nkb_, int nks_, bool nread, const StageRows& rr) {
+    auto half = [&](int kb, int ks, const uint4 (&F)[NF], auto refill, const StageRows& rr) {
         constexpr int PH = LPS / 2;          // pieces per k-step: behind MFMA 1, 3
         if constexpr (SHIFT) {               // x - c = x' + e
             if (decltype(refill)::value) { piece(kb + NSTG - 1, PH * ks, rr); piece(kb + NSTG - 1, PH * ks + 1, rr); }
@@ -281,15 +280,9 @@ __device__ __forceinline__ void tile256_wave(
         if (decltype(refill)::value) { piece(kb + NSTG - 1, PH * ks, rr); piece(kb + NSTG - 1, PH * ks + 1, rr); }
         return;
 #endif
-#ifdef T2_ILV
-        const uint32_t nbase = smem_lds + (uint32_t)((nkb_ % NSTG) * T2_STAGE + nks_ * 16 * T2_ROW);
-#endif
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             acc[b] = mfma_h16<KIND>(F[RD::fa[b]], F[RD::fb[b]], acc[b]);
-#ifdef T2_ILV
-            if (b < NF) { __builtin_amdgcn_sched_barrier(0); if (nread) Fn[b] = t2_frag(nbase + foff[b]); __builtin_amdgcn_sched_barrier(0); }
-#endif
             if (decltype(refill)::value && (b & 1) && (b >> 1) < PH) {
                 __builtin_amdgcn_sched_barrier(0); piece(kb + NSTG - 1, PH * ks + (b >> 1), rr); __builtin_amdgcn_sched_barrier(0);
             }
@@ -320,52 +313,42 @@ __device__ __forceinline__ void tile256_wave(
     load_half(0, 0, F0);
     const int hot = nkb - (NSTG - 1) > 0 ? nkb - (NSTG - 1) : 0;                      // stages behind which a refill is due
     int kb = 0;
-#ifdef T2_PRIO
-    if (quartet == 1) __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef T2_ILV
-    constexpr bool kReadsFirst = SHIFT;      // (the shifted pass keeps its reads in front: its k-step is VALU-bound anyway)
-#else
-    constexpr bool kReadsFirst = true;
-#endif
+    // (static priority for waves 4..7 and the next k-step's reads spread one per MFMA were measured -- within the +-3 % of the harness,
+    //  profiles/r06b_tile256_variants.txt -- and are not in the code)
     for (; kb < hot; ++kb) {                 // no branches: the refill rides between the MFMAs
         const StageRows rr = rows_of_stage(kb + NSTG - 1);     // (IDX: four scalar loads, in flight while the k-step's reads are issued)
-        if (kReadsFirst) load_half(kb, 1, F1);
+        load_half(kb, 1, F1);
         __builtin_amdgcn_sched_barrier(0);
-        half(kb, 0, F0, std::true_type{}, F1, kb, 1, true, rr);
+        half(kb, 0, F0, std::true_type{}, rr);
         __builtin_amdgcn_sched_barrier(0);
         // in flight at this point: stages kb + 1 .. kb + NSTG - 2 and half of kb + NSTG - 1; kb + 1 must have landed
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS * (NSTG - 3) + LPS / 2) : "memory");
         t2_phase_barrier();
-        if (kReadsFirst) load_half(kb + 1, 0, F0);
+        load_half(kb + 1, 0, F0);
         __builtin_amdgcn_sched_barrier(0);
-        half(kb, 1, F1, std::true_type{}, F0, kb + 1, 0, true, rr);
+        half(kb, 1, F1, std::true_type{}, rr);
         __builtin_amdgcn_sched_barrier(0);
     }
     const StageRows none = rows_of_stage(0);
     for (; kb < nkb; ++kb) {                 // the last NSTG - 1 stages: nothing left to fetch
-        if (kReadsFirst) load_half(kb, 1, F1);
+        load_half(kb, 1, F1);
         __builtin_amdgcn_sched_barrier(0);
-        half(kb, 0, F0, std::false_type{}, F1, kb, 1, true, none);
+        half(kb, 0, F0, std::false_type{}, none);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool more = kb + 1 < nkb;
         if (more) {
             wait_next(kb);
             t2_phase_barrier();
-            if (kReadsFirst) load_half(kb + 1, 0, F0);
+            load_half(kb + 1, 0, F0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        half(kb, 1, F1, std::false_type{}, F0, kb + 1, 0, more, none);
+        half(kb, 1, F1, std::false_type{}, none);
         __builtin_amdgcn_sched_barrier(0);
     }
-#ifdef T2_PRIO
-    if (quartet == 1) __builtin_amdgcn_s_setprio(0);
-#endif
 
     // ---- epilogue: blocks, fragment major -- float4 (q, lane) of block b = registers 4q..4q+3 = rows 8q + 4 (lane >> 5) + 0..3
     // of column lane & 31
-#ifndef T2_DBG_NOEPI
     {
         float4* out = reinterpret_cast<float4*>(s.partials + ((int64_t)split * L.NT + ti) * t256::ITEM_STRIDE) + (size_t)(9 * wave) * 256;
 #pragma unroll
@@ -374,7 +357,6 @@ __device__ __forceinline__ void tile256_wave(
             for (int q = 0; q < 4; ++q)
                 out[(b * 4 + q) * 64 + lane] = make_float4(acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]);
     }
-#endif
 
     // ---- shift guard, first pass: sum x^2 of a column is the DIAGONAL of its 32 x 32 diagonal block -- it sits in the accumulators
     // of whichever triangle-family wave owns that block (rounds 4-5 summed it beside the column sums: 16 more v_dot2c per wave and
