@@ -350,11 +350,12 @@ static int fast_split_big(int d, int mode, nsf::SplitArgs g, hipStream_t st, uns
         FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_FIRST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
         ready.fetch_or(1u << device, std::memory_order_release);
     }
-    const unsigned t = (unsigned)(d / 128), Bp = (B + 7u) & ~7u;
-    g.nprob = (int)B; g.nprob_pad = (int)Bp;
-    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_FIRST>), dim3(t * t * Bp), dim3(256), nsf::kBigLds, st, g);
-    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(t * t * Bp), dim3(256), nsf::kBigLds, st, g);
-    else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U>), dim3(2 * t * t * Bp + B), dim3(256), nsf::kBigLds, st, g);
+    const int tt = (d / 128) * (d / 128);
+    g.nprob = (int)B;
+    const unsigned one = (unsigned)nsf::big_grid((int)B, tt), two = (unsigned)nsf::big_grid((int)B, 2 * tt);
+    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_FIRST>), dim3(one), dim3(256), nsf::kBigLds, st, g);
+    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(one), dim3(256), nsf::kBigLds, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U>), dim3(two + B), dim3(256), nsf::kBigLds, st, g);
     return FAD_OK;
 }
 static int fast_i8_big(int d, int mode, const nsf::I8Args& g, hipStream_t st, unsigned B, int device) {
@@ -365,10 +366,10 @@ static int fast_i8_big(int d, int mode, const nsf::I8Args& g, hipStream_t st, un
         FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_i8_big<nsf::I8_G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kI8BigLds));
         ready.fetch_or(1u << device, std::memory_order_release);
     }
-    const unsigned tiles = (unsigned)((d / 128) * (d / 64)), Bp = (B + 7u) & ~7u;
-    if (mode == nsf::I8_A) hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_A>), dim3(tiles * Bp), dim3(512), nsf::kI8BigLds, st, g, (int)B, (int)Bp);
-    else if (g.Rv.a) hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_G, true>), dim3(tiles * Bp), dim3(512), nsf::kI8BigLds, st, g, (int)B, (int)Bp);
-    else hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_G>), dim3(tiles * Bp), dim3(512), nsf::kI8BigLds, st, g, (int)B, (int)Bp);
+    const unsigned grid = (unsigned)nsf::big_grid((int)B, (d / 128) * (d / 64));
+    if (mode == nsf::I8_A) hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_A>), dim3(grid), dim3(512), nsf::kI8BigLds, st, g, (int)B);
+    else if (g.Rv.a) hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_G, true>), dim3(grid), dim3(512), nsf::kI8BigLds, st, g, (int)B);
+    else hipLaunchKernelGGL((nsf::nsf_i8_big<nsf::I8_G>), dim3(grid), dim3(512), nsf::kI8BigLds, st, g, (int)B);
     return FAD_OK;
 }
 template <int NS8> static void fast_launch_i8(int mode, unsigned t, unsigned B, const nsf::I8Args& g, hipStream_t st) {

@@ -599,7 +599,7 @@ struct SplitArgs {
     NsState* st; Ns32State* s32;
     // SP_U: the check of iteration k rides on the launch (blockIdx.z == 2)
     int k, max_low, nslots;
-    int nprob, nprob_pad;                // ns_fast_big.h: problems of the batch, and that rounded up to a multiple of 8
+    int nprob;                           // ns_fast_big.h: problems of the batch
     double l0_scale;                     // ... multiplier on the x_min estimate of ns_l0_from_participation
     int scaled;                          // ns_fast_big.h: scaled steps -- T_k = 1.5 mu I - 0.5 mu^3 Z Y with mu = st->mu[k] per problem (ns_check.h)
     double thr_pred;

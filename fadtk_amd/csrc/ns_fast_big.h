@@ -17,6 +17,7 @@
 // of the ring and runs the store_tile tasks over it in a few passes.
 #pragma once
 #include "ns_fast.h"
+#include "big_slots.h"
 
 namespace fad {
 namespace nsf {
@@ -37,24 +38,18 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
     double* red = reinterpret_cast<double*>(ring + kBigStages * kBigStage);
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
-    // ---- which (song, product, tile): a 1-D grid.  Workgroup L runs on XCD L % 8 and is that XCD's (L / 8)-th: the XCD takes songs
-    // xcd, xcd + 8, ... one after the other, product by product, tile by tile -- the t^2 tiles of a product run side by side on ONE
-    // XCD and walk the k range in step, so its L2 fetches every operand strip once for the 2 t tiles that read it.  (With z = song the
-    // tiles of a song were dealt round the eight XCDs and every L2 fetched everything: 885 MB per T launch at D = 768 x 32 songs through
-    // the fabric, 4.9 TB/s, a quarter of the matrix rate -- profiles/r03i_c5_kernel_stats.csv.)  The songs are padded to a multiple of
-    // eight (g.nprob_pad); after the product workgroups come the check workgroups of SP_U, one per song.
+    // ---- which (song, product, tile): a 1-D grid (big_slot above: one XCD per song, the last few songs cut over all eight); after the
+    // product workgroups come the check workgroups of SP_U, one per song.
     constexpr int ZP = (MODE == SP_U) ? 2 : 1;
     const int t = d >> 7, tt = t * t;
     const int L = blockIdx.x;
-    const int nprod = tt * ZP * g.nprob_pad;
+    const int nprod = big_grid(g.nprob, tt * ZP);
     if constexpr (MODE == SP_U) {
         if (L >= nprod) { nsf_check<256>(g, (int64_t)(L - nprod) * g.pstride, red); return; }
     }
-    const int xcd = L & 7, idx = L >> 3;
-    const int unit = idx / tt, tile = idx - unit * tt;
-    const int song = 8 * (unit / ZP) + xcd;
-    if (song >= g.nprob) return;
-    const int zi = unit % ZP;
+    const BigSlot slot = big_slot(L, g.nprob, tt * ZP);
+    if (!slot.live) return;
+    const int song = slot.song, zi = slot.item / tt, tile = slot.item - zi * tt;
     const int TY = tile / t, TX = tile - TY * t;
     const int64_t po = (int64_t)song * g.pstride;
     const MatHdr* hB = adv(g.hB, po);
@@ -298,19 +293,16 @@ constexpr size_t kI8BigLds = (size_t)kI8BigStages * kI8BigStage * 16 + 256;
 // WITHR (I8_G for pairs on the wide chain): the block's residual R stays in registers and leaves as kVerScale R planes (SP_V2 reads them);
 // the songs' launches use the instantiation without it (holding R across the epilogue cost the songs' correction 10 %: r05d)
 template <int MODE, bool WITHR = false>
-__global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob, int nprob_pad) {
+__global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob) {
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
     double* red = reinterpret_cast<double*>(ring + kI8BigStages * kI8BigStage);
     constexpr int kUmin = (MODE == I8_A) ? kUminA : kUminG;
     constexpr int kGroups = 2 * (kDigits - 1) - kUmin + 1;
     const int d = g.d, tid = threadIdx.x, lane = tid & 63;
     const int tr_ = d >> 7, tc_ = d >> 6, tt = tr_ * tc_;           // tiles per song: rows of 128, columns of 64
-    const int L = blockIdx.x;
-    const int xcd = L & 7, idx = L >> 3;
-    const int unit = idx / tt, tile = idx - unit * tt;
-    const int song = 8 * unit + xcd;
-    if (song >= nprob) return;
-    (void)nprob_pad;
+    const BigSlot slot = big_slot(blockIdx.x, nprob, tt);
+    if (!slot.live) return;
+    const int song = slot.song, tile = slot.item;
     const int TY = tile / tc_, TX = tile - TY * tc_;
     const int64_t po = (int64_t)song * g.pstride, ho = (int64_t)song * g.hstride;
     const MatHdr* hB = adv(g.hB, po);

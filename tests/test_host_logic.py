@@ -162,6 +162,19 @@ def test_tile256_role_tables_cover_the_upper_triangle(tmp_path):
     assert "nsb=3: 5 item types" in r.stdout and "nsb=8: 32 item types" in r.stdout
 
 
+def test_batched_chain_workgroups_take_every_tile_once_and_share_the_xcds(tmp_path):
+    """fadtk_amd/csrc/big_slots.h (the batched square-root chain's workgroup -> (problem, tile) map, shared with the host's grid sizes):
+    every tile of every problem once, a problem of a whole group of eight on one XCD, the leftover problems cut evenly over all eight
+    -- for 1..70 problems.  Plain C++, checked with g++ (no GPU)."""
+    exe = tmp_path / "big_slots_cover"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-o", str(exe), str(ROOT / "tests" / "native_cpu" / "big_slots_cover.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "20 problems x 16 items -> grid 320, 40 per XCD" in r.stdout
+
+
 def test_adaptive_step_scales_never_give_up_and_need_fewer_iterations_than_plain_steps():
     """The rule that sets the per-song step scale of the batched low-precision chain (csrc/ns_check.h, csrc/ns_fast.h: nsf_check), emulated
     on eigenvalues (scripts/ns_emulate_adaptive.py): from a thirtieth to three times the x_min estimate the capped rule closes every problem
