@@ -28,5 +28,10 @@ constexpr BigSlot big_slot(int L, int nprob, int per_song) {
     return BigSlot{(nprob & ~7) + w / per_song, w % per_song, true};
 }
 
+// The iteration products' tile: 128 x 64 NJ.  The narrow one (NJ = 1) when the wide one would leave CUs with a lone workgroup
+// (ns_fast_big.h: nsf_big) -- `products` = 1 (SP_T, SP_FIRST) or 2 (SP_U) per problem.
+constexpr int big_nj(int d, int products, int nprob) { return (products * (d / 128) * (d / 128) * nprob < 512) ? 1 : 2; }
+constexpr int big_tiles(int d, int nj) { return (d / 128) * (d / (64 * nj)); }
+
 }  // namespace nsf
 }  // namespace fad

@@ -342,20 +342,30 @@ static void fast_split(int d, int mode, const nsf::SplitArgs& g, hipStream_t st,
     }
 }
 // the batched form of SP_T / SP_U on 128 x 128 tiles (ns_fast_big.h); 64 KiB + of dynamic LDS: the attribute is set once per device
+template <int NJ> static void fast_big_attrs() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_T, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_U, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_FIRST, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds);
+}
+template <int NJ> static void fast_big_launch(int d, int mode, const nsf::SplitArgs& g, hipStream_t st, unsigned B) {
+    const int tt = nsf::big_tiles(d, NJ);
+    const unsigned one = (unsigned)nsf::big_grid((int)B, tt), two = (unsigned)nsf::big_grid((int)B, 2 * tt);
+    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_FIRST, NJ>), dim3(one), dim3(256), nsf::kBigLds, st, g);
+    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T, NJ>), dim3(one), dim3(256), nsf::kBigLds, st, g);
+    else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U, NJ>), dim3(two + B), dim3(256), nsf::kBigLds, st, g);
+}
+// the residual partials an SP_T launch of the batch leaves per problem (the check riding on the SP_U launch sums them: g.nslots)
+static int fast_big_t_slots(int d, unsigned B) { return nsf::big_tiles(d, nsf::big_nj(d, 1, (int)B)); }
 static int fast_split_big(int d, int mode, nsf::SplitArgs g, hipStream_t st, unsigned B, int device) {
     static std::atomic<unsigned> ready{0};
     if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
-        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
-        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
-        FAD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nsf::nsf_big<nsf::SP_FIRST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsf::kBigLds));
+        fast_big_attrs<1>(); fast_big_attrs<2>();
+        FAD_HIP_TRY(hipGetLastError());
         ready.fetch_or(1u << device, std::memory_order_release);
     }
-    const int tt = (d / 128) * (d / 128);
     g.nprob = (int)B;
-    const unsigned one = (unsigned)nsf::big_grid((int)B, tt), two = (unsigned)nsf::big_grid((int)B, 2 * tt);
-    if (mode == nsf::SP_FIRST) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_FIRST>), dim3(one), dim3(256), nsf::kBigLds, st, g);
-    else if (mode == nsf::SP_T) hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_T>), dim3(one), dim3(256), nsf::kBigLds, st, g);
-    else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U>), dim3(two + B), dim3(256), nsf::kBigLds, st, g);
+    if (nsf::big_nj(d, mode == nsf::SP_U ? 2 : 1, (int)B) == 1) fast_big_launch<1>(d, mode, g, st, B);
+    else fast_big_launch<2>(d, mode, g, st, B);
     return FAD_OK;
 }
 static int fast_i8_big(int d, int mode, const nsf::I8Args& g, hipStream_t st, unsigned B, int device) {
@@ -718,7 +728,7 @@ int fast_songs(int d, int64_t B, const double* dcov_b, const double* covs, hipSt
             g = split_args();
             g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1];
             g.skip = &s32_0->upd_skip[k & 1];
-            g.k = k; g.max_low = kMaxLow; g.nslots = big ? (d / 128) * (d / 128) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
+            g.k = k; g.max_low = kMaxLow; g.nslots = big ? fast_big_t_slots(d, (unsigned)B) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
             if (big) FAD_TRY(fast_split_big(d, nsf::SP_U, g, st, (unsigned)B, device));
             else fast_split(d, nsf::SP_U, g, st, (unsigned)B);
         }
@@ -881,7 +891,7 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
     pa.mus = reinterpret_cast<double*>(at(L.mus)); pa.covs = reinterpret_cast<double*>(at(L.covs));
     pa.dig[0] = reinterpret_cast<uint4*>(at(L.digA)); pa.dig[1] = reinterpret_cast<uint4*>(at(L.digB));
     pa.st = st0; pa.hdr[0] = hA; pa.hdr[1] = hB;
-    pa.batch = 2; pa.pstride = (int64_t)L.stride;
+    pa.batch = 2; pa.pstride = (int64_t)L.stride; pa.no_covs = 1;
     hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)(dd / 2048 + 1), (unsigned)(2 * B)), dim3(512), 0, st, pa);
 
     auto split_args = [&]() {
@@ -918,7 +928,7 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
         g.A[0] = Y[cur]; g.B[0] = T; g.C[0] = Y[cur ^ 1]; g.A[1] = T; g.B[1] = Z[cur]; g.C[1] = Z[cur ^ 1];
         if (!big) { g.Cdig[0] = digY[cur ^ 1]; g.Cdig_t[0] = digYt[cur ^ 1]; }
         g.skip = &s32_0->upd_skip[k & 1];
-        g.k = k; g.max_low = max_low; g.nslots = big ? (d / 128) * (d / 128) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
+        g.k = k; g.max_low = max_low; g.nslots = big ? fast_big_t_slots(d, (unsigned)B) : nb * nb; g.chk_partials = partials; g.thr_pred = pred_threshold(ws.pool, d);
         if (big) FAD_TRY(fast_split_big(d, nsf::SP_U, g, st, (unsigned)B, device));
         else fast_split(d, nsf::SP_U, g, st, (unsigned)B);
     }
@@ -1352,6 +1362,13 @@ int fad_frechet_multi_end(fad_frechet_job_t* job, int count, double* out_fad, fa
                 uint32_t mask = 0;
                 for (int b = 0; b < count; ++b) if (done[b] || chain_status[b] != 2) mask |= (1u << b);
                 if (mask) enqueue_mark_states_done(dstates, mask, count, j.stream);
+                // (K1 of a batch leaves the covariances out: formed here, element for element as it would have)
+                nsf::PrepArgs pc;
+                memset(&pc, 0, sizeof(pc));
+                for (int b = 0; b < count; ++b) { pc.accs[2 * b] = moments_packed(m.h1[b]); pc.accs[2 * b + 1] = moments_packed(m.h2[b]); }
+                pc.d = d; pc.ddof = j.ddof; pc.batch = 2; pc.pstride = (int64_t)L.stride;
+                pc.covs = reinterpret_cast<double*>(blk + L.covs);
+                hipLaunchKernelGGL(nsf::nsf_pairs_covs, dim3((unsigned)(dd / 2048), (unsigned)(2 * count)), dim3(512), 0, j.stream, pc);
                 NsProblem pb{d, count, covs, stride, covs + dd, stride, mus, stride, mus + d, stride, j.mean_dtype};
                 r2 = run_ns(pb, 0, 0.0, j.device, j.stream, ws, &hst, false, nullptr, (ws.pool && ws.pool->f64_iters_multi > 0) ? ws.pool->f64_iters_multi + 1 : 0);
             }

@@ -192,7 +192,13 @@ struct PrepArgs {
     // numpy's float32 running column sums of a set (fad_moments_set_reference_mean), or nullptr: then its mean is float32(float64(run) / n)
     // -- what np.mean returns before its final cast (fad.py:48) -- instead of the exact sum / n
     const float* run[2]; const float* runs[kPrepMaxSets];
+    // batch = 2: leave `covs` unwritten (a third of the launch's bytes; the float64 route of a batch fills them with nsf_pairs_covs if
+    // it has to take pairs over -- frechet.hip: fad_frechet_multi_end)
+    int no_covs;
 };
+
+// Sigma[row][k] from the packed moments: the expression of moments_finalize_kernel up to the reciprocals (symmetric bit for bit)
+__device__ __forceinline__ double prep_cov(double m, double sr, double sk, double inv_n, double inv_nd) { return (m - (sr * sk) * inv_n) * inv_nd; }
 
 __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     __shared__ double red[8 * 2];
@@ -280,9 +286,8 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     double* cov_out = acc ? adv(a.covs, po) + (int64_t)set * d * d + (int64_t)row * d + k0 : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        // Sigma[row][k0 + q]: the expression of moments_finalize_kernel up to the reciprocals (symmetric bit for bit)
-        const double c0 = acc ? (m[q] - (sr * sk[q]) * inv_n) * inv_nd : m[q];
-        if (acc) cov_out[q] = c0;
+        const double c0 = acc ? prep_cov(m[q], sr, sk[q], inv_n, inv_nd) : m[q];
+        if (acc && !a.no_covs) cov_out[q] = c0;
         const double v = c0 * s;
         const bool fits = fabs(v) <= 1.9375;             // false for NaN / Inf, or |Sigma_ij| > max diagonal (not a covariance)
         off_grid = off_grid || !fits;
@@ -295,6 +300,24 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     uint4* out = adv(a.dig[set], po);
 #pragma unroll
     for (int p = 0; p < kDigits; ++p) reinterpret_cast<uint32_t*>(out + dg_idx(rb, ks, p, 32 * g + r, d))[qd] = w[p];
+}
+
+// The covariances nsf_prepare left out (no_covs) for the pairs of a batch, element for element what it would have written.
+// grid (d * d / 2048, 2 B), 512 threads: a thread owns 4 consecutive columns of one row.
+__global__ __launch_bounds__(512) void nsf_pairs_covs(PrepArgs a) {
+    const int d = a.d, set = (int)(blockIdx.y & 1);
+    const int64_t po = (int64_t)(blockIdx.y >> 1) * a.pstride;
+    const double* acc = a.accs[blockIdx.y];
+    const double n = acc[0];
+    const double* sum = acc + 1;
+    const double* M = acc + 1 + d;
+    const double inv_n = 1.0 / n, inv_nd = 1.0 / (n - (double)a.ddof);
+    const int64_t e = ((int64_t)blockIdx.x * 512 + threadIdx.x) * 4;
+    const int row = (int)(e / d), k0 = (int)(e - (int64_t)row * d);
+    const double sr = sum[row];
+    double* cov_out = adv(a.covs, po) + (int64_t)set * d * d + (int64_t)row * d + k0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cov_out[q] = prep_cov(M[(int64_t)row * d + k0 + q], sr, sum[k0 + q], inv_n, inv_nd);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -32,7 +32,12 @@ constexpr int kBigStages = FAD_BIG_STAGES;
 constexpr int kBigStage = 1024;                                   // uint4 per stage: A pieces [4 rb][2 planes][64 lanes], then B pieces
 constexpr size_t kBigLds = (size_t)kBigStages * kBigStage * 16 + 256;   // + the reduction scratch
 
-template <int MODE>
+// NJ = 2: the 128 x 128 tile.  NJ = 1: a 128 x 64 tile (a wave 64 x 32) for launches that would put fewer than two workgroups on a
+// CU (big_nj, big_slots.h): a lone workgroup's four waves are one to a SIMD and each pays its LDS-DMA issue, its LDS reads and its
+// MFMAs one after the other -- 544 ns per k-step at 16 pairs of D = 512 where the MFMAs need 160 and the L2 -> LDS path 138
+// (scripts/probes/r6_l2_paths.hip: 119-131 GB/s per CU from L2) -- while two workgroups per CU fill each other's gaps (SP_U, always two
+// products: 182 ns).  Half the tile costs 12 instead of 16 pieces for half the MFMAs (1.5 x the operand traffic per flop).
+template <int MODE, int NJ = 2>
 __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <= 4) ? 2 : 1)) void nsf_big(SplitArgs g) {
     static_assert(MODE == SP_T || MODE == SP_U || MODE == SP_FIRST, "SP_FIRST: iteration 0 (scale from nsf_i8<A>'s statistics, Y1, Z1)");
     extern __shared__ __attribute__((aligned(16))) uint4 ring[];
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     // ---- which (song, product, tile): a 1-D grid (big_slot above: one XCD per song, the last few songs cut over all eight); after the
     // product workgroups come the check workgroups of SP_U, one per song.
     constexpr int ZP = (MODE == SP_U) ? 2 : 1;
-    const int t = d >> 7, tt = t * t;
+    const int t = d >> 7, tx_n = (NJ == 2) ? t : 2 * t, tt = t * tx_n;   // tiles of a product: t rows of 128 x tx_n columns of 64 NJ
     const int L = blockIdx.x;
     const int nprod = big_grid(g.nprob, tt * ZP);
     if constexpr (MODE == SP_U) {
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     const BigSlot slot = big_slot(L, g.nprob, tt * ZP);
     if (!slot.live) return;
     const int song = slot.song, zi = slot.item / tt, tile = slot.item - zi * tt;
-    const int TY = tile / t, TX = tile - TY * t;
+    const int TY = tile / tx_n, TX = tile - TY * tx_n;
     const int64_t po = (int64_t)song * g.pstride;
     const MatHdr* hB = adv(g.hB, po);
     const MatHdr* hA = adv(g.hA, (int64_t)song * g.astride);        // (astride = 0: the songs' shared baseline; pairs: per problem)
@@ -137,13 +142,13 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     const int nks = d >> 4;
 #endif
 
-    // ---- loads: wave w moves pieces 4 w .. 4 w + 3 of a stage (waves 0, 1: the A side, row blocks 2 (w & 1) + {0, 1}; waves 2, 3: the
-    // B side), hi and lo plane of a block being 2 KiB in a row.  Wave-uniform 64-bit base in SGPRs + the lane's 16-byte offset (the
-    // form that overlaps with the MFMAs, moments_kernels.h: issue_fast).
+    // ---- loads: the pieces of a stage are A's four row blocks (hi, lo plane: 2 KiB in a row) and then B's 2 NJ column blocks, 16 or 12
+    // of them; wave w moves pieces PP w .. PP w + PP - 1 (NJ = 2: waves 0, 1 the A side, waves 2, 3 the B side).  Wave-uniform 64-bit
+    // base in SGPRs + the lane's 16-byte offset (the form that overlaps with the MFMAs, moments_kernels.h: issue_fast).
     const SplitMat Am = adv(g.A[zi], po), Bm = adv(g.B[zi], po);
-    const int side = wave >> 1, blk0 = 2 * (wave & 1);
-    const uint4* src_mat = side ? Bm.at : Am.a;
-    const int blk_global0 = 4 * (side ? TX : TY) + blk0;
+    constexpr int PP = 2 + NJ;                                       // pieces per wave and stage
+    // (the narrow tile's stages are 12 KiB and FOUR of them would fit where the wide tile has three: measured, no gain -- r06p)
+    constexpr int STG = kBigStage, NST = kBigStages;
     const uint32_t voff = (uint32_t)lane * 16u;
     const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)ring;
     // (all tiles of a product walk k from 0 in step -- letting tile (TY, TX) start (TY t + TX) s k-steps in, s = 1 .. 13, so that they do
@@ -151,50 +156,59 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     auto issue = [&](int ks) {
         const int kk = ks;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int blk = q >> 1, plane = q & 1;
-            const uint64_t sb = (uint64_t)(src_mat + fa_idx(blk_global0 + blk, kk, plane, 0, d));
+        for (int q = 0; q < PP; ++q) {
+            const int piece = wave * PP + q;                         // (wave-uniform)
+            const bool bside = piece >= 8;
+            const int blk = (bside ? piece - 8 : piece) >> 1, plane = piece & 1;
+            const uint4* src_mat = bside ? Bm.at : Am.a;
+            const int blk_global = bside ? 2 * NJ * TX + blk : 4 * TY + blk;
+            const uint64_t sb = (uint64_t)(src_mat + fa_idx(blk_global, kk, plane, 0, d));
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
             const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
             const uint64_t ub = ((uint64_t)hi << 32) | lo;
-            const uint32_t dst = ring_lds + (uint32_t)(((ks % kBigStages) * kBigStage + (side * 8 + (blk0 + blk) * 2 + plane) * 64) * 16);
+            const uint32_t dst = ring_lds + (uint32_t)(((ks % NST) * STG + piece * 64) * 16);
             const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ub), "s"(m0v) : "memory", "m0");
         }
     };
-    f32x16 acc0[2][2], acc1[2][2];
+    f32x16 acc0[2][NJ], acc1[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc0[i][j][q] = 0.f; acc1[i][j][q] = 0.f; }
 
-    for (int ks = 0; ks < kBigStages - 1 && ks < nks; ++ks) issue(ks);
+    for (int ks = 0; ks < NST - 1 && ks < nks; ++ks) issue(ks);
     for (int ks = 0; ks < nks; ++ks) {
         // stage ks must have landed; up to two younger stages stay in flight (the count has to be an immediate)
-        const int ahead = (nks - 1 - ks < kBigStages - 2) ? (nks - 1 - ks) : (kBigStages - 2);
-        switch (ahead) {
-            case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        const int ahead = (nks - 1 - ks < NST - 2) ? (nks - 1 - ks) : (NST - 2);
+        switch (ahead * PP) {
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
         __builtin_amdgcn_s_barrier();                          // stage ks is in LDS for every wave; the slot of stage ks - 1 is free
-        if (ks + kBigStages - 1 < nks) issue(ks + kBigStages - 1);
-        const f16x8* st = reinterpret_cast<const f16x8*>(ring + (ks % kBigStages) * kBigStage) + lane;
-        f16x8 ah[2], al[2], bh[2], bl[2];
+        if (ks + NST - 1 < nks) issue(ks + NST - 1);
+        const f16x8* st = reinterpret_cast<const f16x8*>(ring + (ks % NST) * STG) + lane;
+        f16x8 ah[2], al[2], bh[NJ], bl[NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { ah[i] = st[((2 * wr + i) * 2) * 64]; al[i] = st[((2 * wr + i) * 2 + 1) * 64]; }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { bh[j] = st[(8 + (2 * wc + j) * 2) * 64]; bl[j] = st[(8 + (2 * wc + j) * 2 + 1) * 64]; }
+        for (int j = 0; j < NJ; ++j) { bh[j] = st[(8 + (NJ * wc + j) * 2) * 64]; bl[j] = st[(8 + (NJ * wc + j) * 2 + 1) * 64]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
                 acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
                 acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
     if (acc0[0][0][0] != 12345.678f) return;
 #endif
 
-    // ---- epilogue, per wave: its four 32 x 32 blocks one after the other through a [32][33] float area of its own
+    // ---- epilogue, per wave: its 2 NJ 32 x 32 blocks one after the other through a [32][33] float area of its own
     float* fin = reinterpret_cast<float*>(ring) + wave * (32 * 33 + 32);
     const int kg = lane >> 5, r = lane & 31;
     float alpha = (MODE == SP_T) ? g.alpha : 1.f, beta = (MODE == SP_T) ? g.beta_eye : 0.f, gamma = g.gamma;
@@ -221,8 +235,8 @@ __global__ __launch_bounds__(256, (FAD_BIG_STAGES <= 3) ? 3 : ((FAD_BIG_STAGES <
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int by = 4 * TY + 2 * wr + i, bx = 4 * TX + 2 * wc + j;
+        for (int j = 0; j < NJ; ++j) {
+            const int by = 4 * TY + 2 * wr + i, bx = 2 * NJ * TX + NJ * wc + j;
             if constexpr (MODE == SP_FIRST) {
                 // Y0 = A/c; the product is P P = (c Y0)^2 in normalised units: Y1 = Y0 T0 = 1.5 Y0 - 0.5 Y0^2, Z1 = T0 = 1.5 I - 0.5 Y0
                 const double* A64 = adv(g.A64, po) + (int64_t)(32 * by + 4 * kg) * d + 32 * bx + r;
