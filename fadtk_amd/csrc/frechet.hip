@@ -355,7 +355,13 @@ template <int NJ> static void fast_big_launch(int d, int mode, const nsf::SplitA
     else hipLaunchKernelGGL((nsf::nsf_big<nsf::SP_U, NJ>), dim3(two + B), dim3(256), nsf::kBigLds, st, g);
 }
 // the residual partials an SP_T launch of the batch leaves per problem (the check riding on the SP_U launch sums them: g.nslots)
-static int fast_big_t_slots(int d, unsigned B) { return nsf::big_tiles(d, nsf::big_nj(d, 1, (int)B)); }
+// FAD_BIG_NARROW_BELOW (probe switch): narrow tiles for launches of fewer than that many wide-tile workgroups (default: big_nj's 512)
+static int fast_big_nj(int d, int products, unsigned B) {
+    static const int below = [] { const char* e = getenv("FAD_BIG_NARROW_BELOW"); return e ? atoi(e) : 0; }();
+    if (below > 0) return (products * (d / 128) * (d / 128) * (int)B < below) ? 1 : 2;
+    return nsf::big_nj(d, products, (int)B);
+}
+static int fast_big_t_slots(int d, unsigned B) { return nsf::big_tiles(d, fast_big_nj(d, 1, B)); }
 static int fast_split_big(int d, int mode, nsf::SplitArgs g, hipStream_t st, unsigned B, int device) {
     static std::atomic<unsigned> ready{0};
     if (device >= 0 && device < 32 && !(ready.load(std::memory_order_acquire) & (1u << device))) {
@@ -364,7 +370,7 @@ static int fast_split_big(int d, int mode, nsf::SplitArgs g, hipStream_t st, uns
         ready.fetch_or(1u << device, std::memory_order_release);
     }
     g.nprob = (int)B;
-    if (nsf::big_nj(d, mode == nsf::SP_U ? 2 : 1, (int)B) == 1) fast_big_launch<1>(d, mode, g, st, B);
+    if (fast_big_nj(d, mode == nsf::SP_U ? 2 : 1, B) == 1) fast_big_launch<1>(d, mode, g, st, B);
     else fast_big_launch<2>(d, mode, g, st, B);
     return FAD_OK;
 }
