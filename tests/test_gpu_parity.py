@@ -1577,6 +1577,36 @@ def test_frechet_multi_job_matches_single_scores(F):
         ma.close(); mb.close()
 
 
+@pytest.mark.parametrize("d, counts", [(256, (5, 11)), (768, (3, 9, 15)), (1024, (3, 5, 9))])
+def test_frechet_multi_job_tile_shapes_and_leftover_pairs(F, d, counts):
+    """The batched chain picks its workgroup tile by the launch's size (csrc/big_slots.h: 128 x 64 tiles while the wide ones would leave CUs
+    with a lone workgroup -- T / FIRST and U cross that line at different batch sizes) and cuts the pairs left over after the groups of eight
+    over all XCDs: batches on either side of both lines, with and without leftovers, give what the single route gives pair by pair, all of
+    them on the chain."""
+    import torch
+    from fadtk_amd import hip
+    rng = np.random.default_rng(31 + d)
+    n = 4 * d
+    handles = []
+    for k in range(max(counts)):
+        a = rng.standard_normal((n, d)).astype(np.float16)
+        b = ((1.0 + 0.02 * (k % 7)) * rng.standard_normal((n + 64 * (k % 3), d)) + 0.01 * (k % 5)).astype(np.float16)
+        ma, mb = hip.Moments(d), hip.Moments(d)
+        ma.update(torch.from_numpy(a).cuda()); mb.update(torch.from_numpy(b).cuda())
+        handles.append((ma, mb))
+    want = [hip.frechet_from_moments(ma, mb, mean_dtype=0) for ma, mb in handles]
+    assert all(dw["route"] == 2 for _, dw in want)
+    for count in counts:
+        got = hip.FrechetMultiJob(handles[:count], mean_dtype=0).result()
+        assert len(got) == count
+        for k, ((f, dg), (fw, dw)) in enumerate(zip(got, want)):
+            assert dg["route"] == 2, (d, count, k, dg)
+            assert abs(f - fw) <= 2e-9 * abs(fw), (d, count, k, f, fw)
+            assert abs(dg["tr_sqrt"] - dw["tr_sqrt"]) <= 1e-9 * abs(dw["tr_sqrt"])
+    for ma, mb in handles:
+        ma.close(); mb.close()
+
+
 def test_frechet_multi_job_hands_declined_pairs_to_one_batched_float64_iteration(F):
     """A batch whose pairs the low-precision chain declines (spectra k^-2 and steeper: condition 1e9 .. 1e13 of Sigma_1 Sigma_2) is closed by
     ONE float64 Newton-Schulz iteration over all of them (round 5; fad_frechet_multi_end) instead of pair by pair: same distances as the
