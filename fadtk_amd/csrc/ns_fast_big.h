@@ -440,14 +440,23 @@ __global__ __launch_bounds__(512) void nsf_i8_big(I8Args g, int nprob) {
         const SplitMat Ym = adv(g.Y[alt ? 1 : 0], po);
         const double inv_c = 1.0 / st_p->c;
         const double* A64 = adv(g.A64in, po) + (int64_t)(row0 + 4 * kg) * d + col0 + n;
+        // Z[gc][gr] pairs with R[gr][gc] in tr(Z R): the lane's 16 rows gr = row0 + 8 j + 4 kg + i are four runs of four consecutive k of ROW gc
+        // of Z -- 8 bytes of one piece of the A-layout planes each (until round 6: 32 two-byte loads from the transposed planes)
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 zh[4], zl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int half;
+            const size_t zi = fa_elem(col0 + n, row0 + 8 * j + 4 * kg, 0, d, half);
+            zh[j] = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(Zm.a + zi) + half);
+            zl[j] = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(Zm.a + zi + 64) + half);
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int q = (reg & 3) + 8 * (reg >> 2), gr = row0 + q + 4 * kg, gc = col0 + n;
             const double R = A64[(int64_t)q * d] * inv_c - gp[reg];
             if constexpr (WITHR) gp[reg] = R;                      // (kept for the verification planes below)
-            int half;
-            const size_t zi = fa_elem(gr, gc, 0, d, half);         // Z^T[gr][gc] = Z[gc][gr] pairs with R[gr][gc] in tr(Z R)
-            const double z = (double)used16(reinterpret_cast<const _Float16*>(Zm.at + zi)[half], reinterpret_cast<const _Float16*>(Zm.at + zi + 64)[half]);
+            const double z = (double)used16(zh[reg >> 2][reg & 3], zl[reg >> 2][reg & 3]);
             v3[0] += z * R; v3[1] += R * R;
             if (by == bx && gr == gc) {
                 int hy;
