@@ -898,7 +898,8 @@ static int pairs_enqueue(Workspace& ws, int d, int B, const fad_moments_t* const
     pa.dig[0] = reinterpret_cast<uint4*>(at(L.digA)); pa.dig[1] = reinterpret_cast<uint4*>(at(L.digB));
     pa.st = st0; pa.hdr[0] = hA; pa.hdr[1] = hB;
     pa.batch = 2; pa.pstride = (int64_t)L.stride; pa.no_covs = 1;
-    hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)(dd / 2048 + 1), (unsigned)(2 * B)), dim3(512), 0, st, pa);
+    pa.per = ((dd / 2048) % 4 == 0) ? 4 : 2;              // (d a multiple of 64: d * d / 2048 is even)
+    hipLaunchKernelGGL(nsf::nsf_prepare, dim3((unsigned)(dd / 2048 / pa.per + 1), (unsigned)(2 * B)), dim3(512), 0, st, pa);
 
     auto split_args = [&]() {
         nsf::SplitArgs g;

@@ -195,6 +195,8 @@ struct PrepArgs {
     // batch = 2: leave `covs` unwritten (a third of the launch's bytes; the float64 route of a batch fills them with nsf_pairs_covs if
     // it has to take pairs over -- frechet.hip: fad_frechet_multi_end)
     int no_covs;
+    // runs of 2048 elements per workgroup (0 / 1: one; the grid's x is d * d / (2048 per) [+ 1 for the spare workgroup])
+    int per;
 };
 
 // Sigma[row][k] from the packed moments: the expression of moments_finalize_kernel up to the reciprocals (symmetric bit for bit)
@@ -235,26 +237,31 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
     NsState* st = adv(a.st, po);
     const double inv_n = 1.0 / n, inv_nd = 1.0 / (n - (double)a.ddof);
     // this thread's dword: quarter qd of the piece of lane (r, g), k-step ks, row block rb -- consecutive threads write
-    // consecutive dwords of consecutive pieces
-    const int T = blockIdx.x * 512 + tid;
-    const int qd = T & 3, piece = T >> 2;
-    const int r = piece & 31, g = (piece >> 5) & 1, ksrb = piece >> 6, ks = ksrb % (d >> 5), rb = ksrb / (d >> 5);
-    const int row = 32 * rb + r, k0 = 32 * ks + 16 * g + 4 * qd;
-    // its elements are requested first; the scale is found while they travel.  (The packed moments start at an odd double:
-    // 8-byte loads.)
+    // consecutive dwords of consecutive pieces.  A workgroup takes `per` runs of 2048 elements (a.per; the pairs of a batch: each
+    // workgroup finds the scale for itself -- 512 strided diagonal reads and two reductions -- which for ONE run is more L2 traffic than the run).
+    const int per = a.per > 1 ? a.per : 1;
+    int T = blockIdx.x * per * 512 + tid;
+    int qd = T & 3, piece = T >> 2;
+    int r = piece & 31, g = (piece >> 5) & 1, ksrb = piece >> 6, ks = ksrb % (d >> 5), rb = ksrb / (d >> 5);
+    int row = 32 * rb + r, k0 = 32 * ks + 16 * g + 4 * qd;
+    // its (first run's) elements are requested first; the scale is found while they travel.  (The packed moments start at an odd
+    // double: 8-byte loads.)
     double m[4], sk[4], sr = 0.0;
-    const double* Mrow = M + (int64_t)row * d + k0;
     // the B operand is Sigma_2^T: the moments give a bit-for-bit symmetric matrix (read it row-wise), a CALLER's Sigma_2 need
     // not be (fad_frechet on host arrays): its planes are filled from the transposed read, so that the product is Sigma_1 Sigma_2
     // on every route (the float64 routes and the reference form sigma1.dot(sigma2), fad.py:88)
     const bool transposed = !acc && set == 1;
+    auto fetch = [&]() {
+        const double* Mrow = M + (int64_t)row * d + k0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) m[q] = transposed ? M[(int64_t)(k0 + q) * d + row] : Mrow[q];
-    if (acc) {
-        sr = sum[row];
+        for (int q = 0; q < 4; ++q) m[q] = transposed ? M[(int64_t)(k0 + q) * d + row] : Mrow[q];
+        if (acc) {
+            sr = sum[row];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sk[q] = sum[k0 + q];
-    }
+            for (int q = 0; q < 4; ++q) sk[q] = sum[k0 + q];
+        }
+    };
+    fetch();
     // every workgroup finds the scale itself: trace and largest diagonal entry (a NaN / Inf on the diagonal shows in the trace)
     double tr1[1] = {0.0}, mx = 0.0;
     for (int i = tid; i < d; i += 512) {
@@ -279,27 +286,36 @@ __global__ __launch_bounds__(512) void nsf_prepare(PrepArgs a) {
             if (songs) { st->too_few[0] = 0; st->too_few[1] = 0; st->mean_term = 0.0; }
         }
     }
-    uint32_t w[kDigits];
-#pragma unroll
-    for (int p = 0; p < kDigits; ++p) w[p] = 0u;
     bool off_grid = false;
-    double* cov_out = acc ? adv(a.covs, po) + (int64_t)set * d * d + (int64_t)row * d + k0 : nullptr;
+    uint4* out = adv(a.dig[set], po);
+    for (int it = 0; it < per; ++it) {
+        if (it > 0) {
+            T += 512;
+            qd = T & 3; piece = T >> 2;
+            r = piece & 31; g = (piece >> 5) & 1; ksrb = piece >> 6; ks = ksrb % (d >> 5); rb = ksrb / (d >> 5);
+            row = 32 * rb + r; k0 = 32 * ks + 16 * g + 4 * qd;
+            fetch();
+        }
+        uint32_t w[kDigits];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const double c0 = acc ? prep_cov(m[q], sr, sk[q], inv_n, inv_nd) : m[q];
-        if (acc && !a.no_covs) cov_out[q] = c0;
-        const double v = c0 * s;
-        const bool fits = fabs(v) <= 1.9375;             // false for NaN / Inf, or |Sigma_ij| > max diagonal (not a covariance)
-        off_grid = off_grid || !fits;
-        int dg[kDigits];
-        digits_of<double>((bad || !fits) ? 0.0 : v, dg);
+        for (int p = 0; p < kDigits; ++p) w[p] = 0u;
+        double* cov_out = acc ? adv(a.covs, po) + (int64_t)set * d * d + (int64_t)row * d + k0 : nullptr;
 #pragma unroll
-        for (int p = 0; p < kDigits; ++p) w[p] |= ((uint32_t)dg[p] & 0xffu) << (8 * q);
+        for (int q = 0; q < 4; ++q) {
+            const double c0 = acc ? prep_cov(m[q], sr, sk[q], inv_n, inv_nd) : m[q];
+            if (acc && !a.no_covs) cov_out[q] = c0;
+            const double v = c0 * s;
+            const bool fits = fabs(v) <= 1.9375;             // false for NaN / Inf, or |Sigma_ij| > max diagonal (not a covariance)
+            off_grid = off_grid || !fits;
+            int dg[kDigits];
+            digits_of<double>((bad || !fits) ? 0.0 : v, dg);
+#pragma unroll
+            for (int p = 0; p < kDigits; ++p) w[p] |= ((uint32_t)dg[p] & 0xffu) << (8 * q);
+        }
+#pragma unroll
+        for (int p = 0; p < kDigits; ++p) reinterpret_cast<uint32_t*>(out + dg_idx(rb, ks, p, 32 * g + r, d))[qd] = w[p];
     }
     if (off_grid) hdr->flag_gen = a.gen;                 // (every raiser writes the same value)
-    uint4* out = adv(a.dig[set], po);
-#pragma unroll
-    for (int p = 0; p < kDigits; ++p) reinterpret_cast<uint32_t*>(out + dg_idx(rb, ks, p, 32 * g + r, d))[qd] = w[p];
 }
 
 // The covariances nsf_prepare left out (no_covs) for the pairs of a batch, element for element what it would have written.
