@@ -11,7 +11,8 @@
 // global_load_lds_dwordx4 per piece moves it into LDS verbatim (no swizzle, no transpose read: the 64 lanes' 16-byte operands back to
 // back) and one ds_read_b128 per lane brings it to the MFMA.  A ring of three stages of one k-step; 12 MFMAs (2 x 2 blocks x hi hi,
 // hi lo, lo hi) against 8 ds_read_b128 and 4 LDS-DMA instructions per wave and k-step; operand traffic per tile is a quarter of
-// the small-tile kernels'.  48 KiB of LDS: three workgroups per CU.
+// the small-tile kernels'.  48 KiB of LDS: three workgroups per CU.  Launches that would leave CUs with ONE such workgroup take
+// 128 x 64 tiles instead (nsf_big<MODE, 1>, below); which (problem, tile) a workgroup takes: big_slots.h.
 //
 // The epilogue is ns_fast.h's, a 32 x 32 block at a time: each wave parks a block of its 64 x 64 result in its own (now free) part
 // of the ring and runs the store_tile tasks over it in a few passes.
